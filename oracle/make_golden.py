@@ -1,0 +1,410 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference (naver/pasero,
+imported read-only from /root/reference) on its PyTorch-CPU fp32 path.
+
+Test infrastructure only. Runs in the build container (the reference never travels to the GPU box; only
+the .npz files written here do).  The reference has no tests / golden vectors of its own, so
+these fixtures are what pins the oracle (oracle/ref_cpu.py) and, through it, the HIP path.
+
+Two third-party imports of the reference are absent from this image and irrelevant to the model path;
+they are stubbed in sys.modules exactly as SURVEY §8c describes: `sacrebleu` (pasero/evaluation.py:8,18)
+and `stopes...text_normalizer` (pasero/preprocessing.py:20).
+
+Usage:  python oracle/make_golden.py [--only NAME ...]
+"""
+import os
+import sys
+import types
+import argparse
+import numpy as np
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(REPO, 'tests', 'golden')
+sys.path.insert(0, OUT)
+import paramgen  # noqa: E402
+
+
+def import_reference():
+    sb = types.ModuleType('sacrebleu')
+    sbm = types.ModuleType('sacrebleu.metrics')
+
+    class _B:
+        TOKENIZERS = {}
+    sbm.METRICS = {'BLEU': _B}
+    sb.metrics = sbm
+    sys.modules['sacrebleu'] = sb
+    sys.modules['sacrebleu.metrics'] = sbm
+    names = ['stopes', 'stopes.pipelines', 'stopes.pipelines.monolingual',
+             'stopes.pipelines.monolingual.utils', 'stopes.pipelines.monolingual.utils.text_normalizer']
+    for n in names:
+        sys.modules[n] = types.ModuleType(n)
+    tn = sys.modules[names[-1]]
+    tn.remove_non_printing_char = lambda s: s
+    tn.replace_unicode_punct = lambda s: s
+    sys.path.insert(0, '/root/reference')
+    import torch
+    from pasero.models import transformer, modules
+    from pasero import config, decoding, optimization
+    return torch, transformer, modules, config, decoding, optimization
+
+
+torch, transformer, modules, config, decoding, optimization = import_reference()
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+class FakeTask:
+    freeze_encoder_embed_mask = None
+
+    def __init__(self, V):
+        self.encoder_num_embeddings = V
+        self.decoder_num_embeddings = V
+
+
+def build_model(V, **overrides):
+    cfg = config.TransformerConfig(**overrides)
+    # task-dependent defaults (config.py:1146-1153,1241-1248,1265-1272) set by hand as in SURVEY §8c
+    if cfg.label_smoothing is None:
+        cfg.label_smoothing = 0.1
+    cfg.model_type = cfg.model_type or 'encoder_decoder'
+    cfg.decoder_max_len = cfg.decoder_max_len or 256
+    model = transformer.Transformer(cfg, config.DistributedConfig(), FakeTask(V))
+    return cfg, model
+
+
+def load_params(model, seed):
+    sd = model.state_dict()
+    names_shapes = [(k, tuple(v.shape)) for k, v in sd.items()]
+    new = paramgen.make_state_dict(seed, names_shapes)
+    # tied tensors appear under several names (e.g. encoder./decoder.embed_tokens.weight when
+    # shared_embeddings, transformer.py:151-153): every alias gets the value generated for its FIRST name
+    first = {}
+    for k, v in sd.items():
+        new[k] = new[first.setdefault(v.data_ptr(), k)]
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()})
+    return names_shapes
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def npy(x):
+    return x.detach().cpu().numpy().copy()  # copy: in-place updates (optimizer) must not alias saved arrays
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez(path, **arrays)
+    print(f'wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB')
+
+
+def names_shapes_arrays(names_shapes):
+    return {
+        'param_names': np.array([n for n, _ in names_shapes]),
+        'param_shapes': np.array([','.join(map(str, s)) for _, s in names_shapes]),
+    }
+
+
+CFG_KEYS = [
+    'encoder_layers', 'decoder_layers', 'embed_dim', 'encoder_ffn_dim', 'decoder_ffn_dim',
+    'encoder_attention_heads', 'decoder_attention_heads', 'dropout', 'attention_dropout', 'activation_dropout',
+    'label_smoothing', 'activation_fn', 'encoder_prenorm', 'decoder_prenorm', 'encoder_embed_norm',
+    'decoder_embed_norm', 'encoder_positional_encoding', 'decoder_positional_encoding',
+    'positional_encoding_shift', 'scale_embed', 'encoder_max_len', 'decoder_max_len', 'shared_embeddings',
+    'tied_output_projection', 'input_dim', 'conv_input_dim', 'conv_channels', 'conv_kernel_sizes',
+    'conv_strides', 'conv_activation', 'norm_eps', 'padding_idx', 'eos_idx', 'bos_idx',
+]
+
+
+def cfg_json(cfg):
+    import json
+    return np.array(json.dumps({k: getattr(cfg, k) for k in CFG_KEYS}))
+
+
+# ----------------------------------------------------------------------------------------------------------
+def gen_encdec(name, V, B, S, T, seed, store_grads='full', **overrides):
+    """Whole Transformer.forward + backward (transformer.py:227-380), encoder (698-752), decoder (831-898)"""
+    cfg, model = build_model(V, **overrides)
+    names_shapes = load_params(model, seed)
+    model.train()  # dropout probabilities are 0 in every fixture config, so train() == eval() numerically
+    batch = paramgen.make_text_batch(seed, B, S, T, V)
+    tb = {k: t(v) for k, v in batch.items()}
+    loss, logs = model(**tb)
+    loss.backward()
+    out = {
+        'cfg': cfg_json(cfg), 'V': V, 'B': B, 'S': S, 'T': T, 'seed': seed,
+        'loss': npy(loss), 'logs_loss': logs['loss'], 'logs_nll_loss': logs['nll_loss'],
+        'logs_num_tokens': logs['num_tokens'], 'logs_num_lines': logs['num_lines'],
+        **names_shapes_arrays(names_shapes),
+    }
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    out['grad_names'] = np.array(list(grads))
+    out['grad_norms'] = np.array([g.norm().item() for g in grads.values()])
+    out['grad_sums'] = np.array([g.double().sum().item() for g in grads.values()])
+    if store_grads == 'full':
+        for k, g in grads.items():
+            out['grad:' + k] = npy(g)
+    else:  # strided sample only (large models)
+        for k, g in grads.items():
+            out['gradsample:' + k] = npy(g.reshape(-1)[::store_grads])
+    with torch.no_grad():
+        model.eval()
+        enc_out, enc_mask, _ = model.encoder(tb['encoder_input'], tb['encoder_input_length'])
+        logits, _ = model.decoder(enc_out, enc_mask, tb['decoder_input'][:, :-1])
+    if store_grads == 'full':
+        out['encoder_out'] = npy(enc_out)
+        out['encoder_mask'] = npy(enc_mask)
+        out['logits'] = npy(logits)
+    else:
+        out['encoder_out_sample'] = npy(enc_out.reshape(-1)[::store_grads])
+        out['logits_sample'] = npy(logits.reshape(-1)[::store_grads])
+    out['argmax'] = npy(logits.argmax(-1))
+    save(name, **out)
+    return cfg, model, tb
+
+
+def gen_tiny_post():
+    gen_encdec('tiny_encdec_post', V=101, B=3, S=7, T=5, seed=11,
+               embed_dim=128, encoder_ffn_dim=192, decoder_ffn_dim=192, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=2, decoder_layers=2, dropout=0.0)
+
+
+def gen_tiny_pre():
+    # whisper/NLLB-like variant: pre-norm, GELU(erf), learned positions, no embed scaling, embed layer norms
+    gen_encdec('tiny_encdec_pre', V=67, B=4, S=9, T=6, seed=12,
+               embed_dim=128, encoder_ffn_dim=160, decoder_ffn_dim=160, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=1, decoder_layers=1, dropout=0.0,
+               encoder_prenorm=True, decoder_prenorm=True, activation_fn='gelu',
+               encoder_positional_encoding='learned', decoder_positional_encoding='learned',
+               positional_encoding_shift=0, scale_embed=False, encoder_embed_norm=True,
+               decoder_embed_norm=True, label_smoothing=0.2, encoder_max_len=32, decoder_max_len=32)
+
+
+def gen_base_c1():
+    """BASELINE config C1: `transformer` base 6+6 d=512 H=8 f=2048 V=8032, batch 8x(64,64), ragged.
+    Weights are regenerated from the seed (193 MB), so only scalars / samples are stored."""
+    gen_encdec('base_c1', V=8032, B=8, S=64, T=64, seed=21, store_grads=4099, dropout=0.0)
+
+
+# ----------------------------------------------------------------------------------------------------------
+def gen_mha():
+    """modules.MultiheadAttention.forward (modules.py:579-739): self w/ key-padding mask, causal self where a
+    2-D mask is dropped (modules.py:602-605), cross attention with ragged source; plus return_attn weights."""
+    d, H, B, T, S = 128, 2, 3, 10, 13
+    out = {}
+    for variant in ('self_pad', 'self_causal', 'cross'):
+        causal = variant == 'self_causal'
+        mha = modules.MultiheadAttention(d, H, dropout=0.0, causal=causal)
+        sd = mha.state_dict()
+        ns = [(k, tuple(v.shape)) for k, v in sd.items()]
+        mha.load_state_dict({k: t(v) for k, v in paramgen.make_state_dict(31, ns).items()})
+        q = t(paramgen.make_array(31, variant + '.q', (B, T, d))).requires_grad_()
+        if variant == 'cross':
+            kv = t(paramgen.make_array(31, variant + '.kv', (B, S, d))).requires_grad_()
+            lens = torch.tensor([S, 7, 1])
+            src = S
+        else:
+            kv = q
+            lens = torch.tensor([T, 6, 3])
+            src = T
+        mask = torch.arange(src)[None] >= lens[:, None]
+        y, w = mha(query=q, key=kv, value=kv, attn_mask=mask)
+        assert w is None
+        dy = t(paramgen.make_array(31, variant + '.dy', (B, T, d)))
+        y.backward(dy)
+        out[variant + ':y'] = npy(y)
+        out[variant + ':lens'] = npy(lens)
+        out[variant + ':dq'] = npy(q.grad)
+        if variant == 'cross':
+            out[variant + ':dkv'] = npy(kv.grad)
+        for k, p in mha.named_parameters():
+            out[variant + ':grad:' + k] = npy(p.grad)
+        with torch.no_grad():
+            y2, w2 = mha(query=q, key=kv, value=kv, attn_mask=mask, return_attn=True)
+        out[variant + ':attn_weights'] = npy(w2)  # (B, T, H, S)
+        out[variant + ':y_return_attn'] = npy(y2)
+        out[variant + ':param_names'] = np.array([n for n, _ in ns])
+        out[variant + ':param_shapes'] = np.array([','.join(map(str, s)) for _, s in ns])
+    save('mha', d=d, H=H, B=B, T=T, S=S, **out)
+
+
+def gen_ce():
+    """Transformer.compute_loss (transformer.py:324-380): label-smoothed CE, sum reduction, pad ignored,
+    logs in bits"""
+    cfg, model = build_model(37, embed_dim=64, encoder_ffn_dim=64, decoder_ffn_dim=64, encoder_layers=1,
+                             decoder_layers=1, encoder_attention_heads=1, decoder_attention_heads=1)
+    B, T, V = 4, 16, 8032
+    logits_np = paramgen.make_array(41, 'ce.logits', (B, T, V), scale=2.0)
+    rs = np.random.RandomState(41)
+    target = rs.randint(4, V, size=(B, T)).astype(np.int64)
+    target[0, 10:] = 1
+    target[2, 3:] = 1
+    target[3, :] = 1  # a fully padded row
+    out = {'B': B, 'T': T, 'V': V, 'target': target}
+    for eps in (0.0, 0.1, 0.2):
+        cfg.label_smoothing = eps
+        logits = t(logits_np).requires_grad_()
+        loss, logs = model.compute_loss(logits, t(target), {})
+        loss.backward()
+        tag = f'eps{eps}'
+        out[tag + ':loss'] = npy(loss)
+        out[tag + ':logs_loss'] = logs['loss']
+        out[tag + ':logs_nll_loss'] = logs['nll_loss']
+        out[tag + ':num_tokens'] = logs['num_tokens']
+        out[tag + ':num_lines'] = logs['num_lines']
+        out[tag + ':dlogits_rows'] = npy(logits.grad[:, :2])  # (B, 2, V) sample; rest checked by sums
+        out[tag + ':dlogits_rowsum'] = npy(logits.grad.sum(-1))
+        out[tag + ':dlogits_abs_rowsum'] = npy(logits.grad.abs().sum(-1))
+    save('ce_ls', **out)
+
+
+def gen_sinpos():
+    """modules.SinusoidalPositionalEmbedding (modules.py:415-457)"""
+    out = {}
+    for d in (128, 512, 1024):
+        pe = modules.SinusoidalPositionalEmbedding(300, d, shift=2)
+        out[f'd{d}'] = npy(pe(40))[0]          # (40, d): positions 2..41
+        out[f'd{d}_off'] = npy(pe(3, offset=17))[0]
+        out[f'd{d}_rows'] = npy(pe.weight[[0, 1, 2, 150, 301]])
+    save('sinpos', **out)
+
+
+def gen_speech():
+    """Speech path of TransformerEncoder.forward (transformer.py:731-744): in_linear (+ReLU) ->
+    ConvolutionSubsampler (modules.py:774-834) -> scale -> positions -> layers"""
+    for name, ov in (
+        ('speech_whisper', dict(input_dim=80, conv_input_dim=80, conv_channels=128, conv_kernel_sizes=[3, 3],
+                                conv_strides=[1, 2], conv_activation='gelu', encoder_prenorm=True,
+                                decoder_prenorm=True, activation_fn='gelu', scale_embed=False,
+                                encoder_positional_encoding='learned', decoder_positional_encoding='learned',
+                                positional_encoding_shift=0, encoder_max_len=64, decoder_max_len=32)),
+        ('speech_iwslt', dict(input_dim=96, conv_input_dim=80, conv_channels=256, conv_kernel_sizes=[5],
+                              conv_strides=[2], conv_activation='glu', encoder_prenorm=True,
+                              decoder_prenorm=True, encoder_max_len=64, decoder_max_len=32)),
+    ):
+        V, B, S, T, seed = 53, 3, 37, 6, 51
+        cfg, model = build_model(V, embed_dim=128, encoder_ffn_dim=128, decoder_ffn_dim=128,
+                                 encoder_attention_heads=2, decoder_attention_heads=2, encoder_layers=1,
+                                 decoder_layers=1, dropout=0.0, **ov)
+        names_shapes = load_params(model, seed)
+        model.train()
+        feats = t(paramgen.make_array(seed, name + '.feats', (B, S, cfg.input_dim)))
+        lens = torch.tensor([S, 20, 9])
+        for b in range(B):
+            feats[b, lens[b]:] = 0
+        tb = paramgen.make_text_batch(seed, B, 4, T, V)
+        feats.requires_grad_()
+        loss, logs = model(encoder_input=feats, encoder_input_length=lens,
+                           decoder_input=t(tb['decoder_input']), prompt_mask=t(tb['prompt_mask']))
+        loss.backward()
+        out = {'cfg': cfg_json(cfg), 'V': V, 'B': B, 'S': S, 'T': T, 'seed': seed, 'lens': npy(lens),
+               'loss': npy(loss), 'logs_loss': logs['loss'], 'logs_nll_loss': logs['nll_loss'],
+               'logs_num_tokens': logs['num_tokens'], 'dfeats': npy(feats.grad),
+               **names_shapes_arrays(names_shapes)}
+        for k, p in model.named_parameters():
+            if 'subsample' in k or 'in_linear' in k:
+                out['grad:' + k] = npy(p.grad)
+        out['grad_names'] = np.array([k for k, _ in model.named_parameters()])
+        out['grad_norms'] = np.array([p.grad.norm().item() for _, p in model.named_parameters()])
+        with torch.no_grad():
+            x = feats.detach()
+            if model.encoder.in_linear is not None:
+                x = model.encoder.in_linear(x)
+            sub, new_len = model.encoder.subsample(x, lens)
+            enc_out, enc_mask, _ = model.encoder(feats.detach(), lens)
+        out['subsample_out'] = npy(sub)
+        out['new_len'] = npy(new_len)
+        out['encoder_out'] = npy(enc_out)
+        out['encoder_mask'] = npy(enc_mask)
+        save(name, **out)
+
+
+def gen_greedy():
+    """decoding.sample_on_the_fly greedy path (decoding.py:1005-1221) with the decoder's incremental `state`
+    (transformer.py:869-872,1263-1289; modules.py:625-641)"""
+    V, B, S, seed = 101, 3, 7, 11
+    cfg, model = build_model(V, embed_dim=128, encoder_ffn_dim=192, decoder_ffn_dim=192,
+                             encoder_attention_heads=2, decoder_attention_heads=2, encoder_layers=2,
+                             decoder_layers=2, dropout=0.0)
+    names_shapes = load_params(model, seed)
+    model.eval()
+    batch = paramgen.make_text_batch(seed, B, S, 5, V)
+    with torch.no_grad():
+        enc_out, enc_mask, _ = model.encoder(t(batch['encoder_input']), t(batch['encoder_input_length']))
+        steps = []
+        # decoder_input given explicitly: EnsembleDecoder has no `bos_idx` (decoding.py:1068 would raise)
+        bos = torch.full((B, 1), cfg.bos_idx, dtype=torch.long)
+        for o in decoding.sample_on_the_fly(model.decoder, enc_out, enc_mask, 12, {}, decoder_input=bos,
+                                            sampling_temperature=0):
+            steps.append(npy(o['tokens']).copy())
+    tokens = np.concatenate(steps, axis=1)
+    save('greedy_decode', cfg=cfg_json(cfg), V=V, B=B, S=S, seed=seed, max_output_len=12, tokens=tokens,
+         n_steps=len(steps), **names_shapes_arrays(names_shapes))
+
+
+def gen_optim():
+    """K9 ("next" row): optimization.Adam.step (optimization.py:56-149), clip_grad_norm_ (390-427),
+    LRScheduler inverse-sqrt (21-52)"""
+    rs = np.random.RandomState(61)
+    shapes = [(33, 17), (129,), (8, 8, 3)]
+    params = [torch.nn.Parameter(t(rs.standard_normal(s).astype(np.float32))) for s in shapes]
+    grads = [[rs.standard_normal(s).astype(np.float32) for s in shapes] for _ in range(3)]
+    out = {'n': len(shapes), 'steps': 3}
+    for i, p in enumerate(params):
+        out[f'p0:{i}'] = npy(p)
+    opt = optimization.Adam(params, lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    for step in range(3):
+        for i, p in enumerate(params):
+            p.grad = t(grads[step][i]).clone()
+            out[f'g{step}:{i}'] = grads[step][i]
+        gnorm = optimization.clip_grad_norm_(params, 1.0)
+        out[f'gnorm{step}'] = float(gnorm)
+        opt.step()
+        for i, p in enumerate(params):
+            out[f'p{step + 1}:{i}'] = npy(p)
+    save('adam_step', **out)
+
+
+def gen_logmel():
+    """K8: third-party arithmetic — transformers.WhisperFeatureExtractor as called from
+    examples/Whisper/extract-features.py:107-117 (pinned to the transformers version installed here)"""
+    import transformers
+    from transformers import WhisperFeatureExtractor
+    fe = WhisperFeatureExtractor()  # defaults: 80 mel, 16 kHz, n_fft 400, hop 160, chunk 30 s
+    rs = np.random.RandomState(0)
+    n = 32000
+    wav0 = (0.1 * rs.standard_normal(n)).astype(np.float32)
+    tt = np.arange(n) / 16000.0
+    wav1 = (0.5 * np.sin(2 * np.pi * 1000.0 * tt)).astype(np.float32)
+    feats = fe([wav0, wav1], sampling_rate=16000, return_tensors='np')['input_features']  # (2, 80, 3000)
+    feats = np.ascontiguousarray(feats.transpose(0, 2, 1))  # extract-features.py:116 -> (3000, 80)
+    save('logmel', wav0=wav0, wav1=wav1, feats=feats.astype(np.float32)[:, :240],  # first 240 frames (rest = pad)
+         feats_tail=feats.astype(np.float32)[:, -4:],
+         mel_filters=np.asarray(fe.mel_filters, dtype=np.float64),
+         transformers_version=np.array(transformers.__version__))
+
+
+GENERATORS = {
+    'tiny_encdec_post': gen_tiny_post,
+    'tiny_encdec_pre': gen_tiny_pre,
+    'base_c1': gen_base_c1,
+    'mha': gen_mha,
+    'ce_ls': gen_ce,
+    'sinpos': gen_sinpos,
+    'speech': gen_speech,
+    'greedy_decode': gen_greedy,
+    'adam_step': gen_optim,
+    'logmel': gen_logmel,
+}
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', nargs='*')
+    args = ap.parse_args()
+    for name, fn in GENERATORS.items():
+        if args.only and name not in args.only:
+            continue
+        print('==', name)
+        fn()

@@ -1,0 +1,210 @@
+"""Pins the CPU oracle (oracle/ref_cpu.py) against golden vectors produced by the real reference
+(oracle/make_golden.py, PyTorch-CPU fp32).  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+import paramgen
+from conftest import load_golden, golden_cfg, golden_names_shapes
+from oracle import ref_cpu as O
+
+RTOL = 2e-5  # fp32 round-off between two orderings of the same sums
+
+
+def close(a, b, rtol=RTOL, atol=1e-6):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-30) if b.size else 1.0
+    err = np.abs(a - b).max() if b.size else 0.0
+    assert err <= atol + rtol * scale, f'max abs err {err:.3e} vs scale {scale:.3e}'
+
+
+def _state(g, seed):
+    ns = golden_names_shapes(g)
+    return O.to_torch_state(paramgen.make_state_dict(seed, ns))
+
+
+def _run_encdec(name, full=True):
+    g = load_golden(name)
+    cfg = golden_cfg(g)
+    seed = int(g['seed'])
+    P = {k: v.requires_grad_() for k, v in _state(g, seed).items()}
+    if cfg.shared_embeddings:  # one tensor under two names (transformer.py:151-153)
+        P['decoder.embed_tokens.weight'] = P['encoder.embed_tokens.weight']
+    batch = paramgen.make_text_batch(seed, int(g['B']), int(g['S']), int(g['T']), int(g['V']))
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    loss, logs = O.transformer_forward(P, cfg, **tb)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    assert abs(logs['loss'] - float(g['logs_loss'])) <= 1e-5 * abs(float(g['logs_loss']))
+    assert abs(logs['nll_loss'] - float(g['logs_nll_loss'])) <= 1e-5 * abs(float(g['logs_nll_loss']))
+    assert logs['num_tokens'] == int(g['logs_num_tokens'])
+    assert logs['num_lines'] == int(g['logs_num_lines'])
+    names = [str(n) for n in g['grad_names']]
+    norms = g['grad_norms']
+    for n, ref_norm in zip(names, norms):
+        gr = P[n].grad
+        assert gr is not None, n
+        # (k_proj.bias gradients are mathematically zero: softmax is shift-invariant -> pure round-off)
+        assert abs(gr.norm().item() - ref_norm) <= 1e-4 * ref_norm + 2e-6, n
+        if full:
+            close(gr.numpy(), g['grad:' + n], rtol=1e-4)
+        else:
+            stride = 4099  # 12 layers deep: fp32 summation-order noise grows to a few 1e-4 relative
+            close(gr.reshape(-1)[::stride].numpy(), g['gradsample:' + n], rtol=1e-3)
+    with torch.no_grad():
+        enc_out, enc_mask = O.encoder(P, cfg, tb['encoder_input'], tb['encoder_input_length'])
+        logits = O.decoder(P, cfg, enc_out, enc_mask, tb['decoder_input'][:, :-1])
+    if full:
+        close(enc_out.numpy(), g['encoder_out'])
+        assert (enc_mask.numpy() == g['encoder_mask']).all()
+        close(logits.numpy(), g['logits'])
+    else:
+        close(logits.reshape(-1)[::4099].numpy(), g['logits_sample'], rtol=1e-4)
+    assert (logits.argmax(-1).numpy() == g['argmax']).all()  # bit-exact token argmax
+
+
+def test_tiny_encdec_postnorm():
+    _run_encdec('tiny_encdec_post')
+
+
+def test_tiny_encdec_prenorm_gelu_learned():
+    _run_encdec('tiny_encdec_pre')
+
+
+def test_base_c1():
+    _run_encdec('base_c1', full=False)
+
+
+@pytest.mark.parametrize('variant', ['self_pad', 'self_causal', 'cross'])
+def test_mha(variant):
+    g = load_golden('mha')
+    d, H, B, T, S = (int(g[k]) for k in 'dHBTS')
+    names = [str(n) for n in g[variant + ':param_names']]
+    shapes = [tuple(int(x) for x in str(s).split(',')) for s in g[variant + ':param_shapes']]
+    P = {'a.' + k: v.requires_grad_() for k, v in
+         O.to_torch_state(paramgen.make_state_dict(31, list(zip(names, shapes)))).items()}
+    q = torch.from_numpy(paramgen.make_array(31, variant + '.q', (B, T, d))).requires_grad_()
+    if variant == 'cross':
+        kv = torch.from_numpy(paramgen.make_array(31, variant + '.kv', (B, S, d))).requires_grad_()
+        src = S
+    else:
+        kv, src = q, T
+    lens = torch.from_numpy(g[variant + ':lens'])
+    mask = O.len_to_mask(lens, src)
+    y, w = O.multihead_attention(P, 'a', q, kv, kv, H, mask, causal=(variant == 'self_causal'))
+    y.backward(torch.from_numpy(paramgen.make_array(31, variant + '.dy', (B, T, d))))
+    close(y.detach().numpy(), g[variant + ':y'])
+    close(y.detach().numpy(), g[variant + ':y_return_attn'])
+    close(w.detach().numpy(), g[variant + ':attn_weights'])
+    close(q.grad.numpy(), g[variant + ':dq'], rtol=1e-4)
+    if variant == 'cross':
+        close(kv.grad.numpy(), g[variant + ':dkv'], rtol=1e-4)
+    for n in names:
+        close(P['a.' + n].grad.numpy(), g[variant + ':grad:' + n], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('eps', [0.0, 0.1, 0.2])
+def test_label_smoothed_ce(eps):
+    g = load_golden('ce_ls')
+    B, T, V = int(g['B']), int(g['T']), int(g['V'])
+    logits = torch.from_numpy(paramgen.make_array(41, 'ce.logits', (B, T, V), scale=2.0)).requires_grad_()
+    target = torch.from_numpy(g['target'])
+    loss, nll, ntok = O.label_smoothed_ce(logits.view(-1, V), target.view(-1), 1, eps)
+    loss.backward()
+    tag = f'eps{eps}'
+    assert abs(loss.item() - float(g[tag + ':loss'])) <= 1e-5 * abs(float(g[tag + ':loss']))
+    assert abs(loss.item() / O.LN2 - float(g[tag + ':logs_loss'])) <= 1e-5 * abs(float(g[tag + ':logs_loss']))
+    assert abs(nll.item() / O.LN2 - float(g[tag + ':logs_nll_loss'])) <= 1e-5 * abs(float(g[tag + ':logs_nll_loss']))
+    assert int(ntok) == int(g[tag + ':num_tokens'])
+    close(logits.grad[:, :2].numpy(), g[tag + ':dlogits_rows'], rtol=1e-4)
+    close(logits.grad.sum(-1).numpy(), g[tag + ':dlogits_rowsum'], rtol=1e-4, atol=1e-5)
+    close(logits.grad.abs().sum(-1).numpy(), g[tag + ':dlogits_abs_rowsum'], rtol=1e-4)
+
+
+@pytest.mark.parametrize('d', [128, 512, 1024])
+def test_sinusoidal_positions(d):
+    g = load_golden('sinpos')
+    table = O.sinusoidal_table(300, d, shift=2)
+    close(table[2:42].numpy(), g[f'd{d}'], rtol=1e-6)
+    close(table[19:22].numpy(), g[f'd{d}_off'], rtol=1e-6)
+    close(table[[0, 1, 2, 150, 301]].numpy(), g[f'd{d}_rows'], rtol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['speech_whisper', 'speech_iwslt'])
+def test_speech_frontend(name):
+    g = load_golden(name)
+    cfg = golden_cfg(g)
+    seed, B, S, T, V = (int(g[k]) for k in ('seed', 'B', 'S', 'T', 'V'))
+    P = {k: v.requires_grad_() for k, v in _state(g, seed).items()}
+    if cfg.shared_embeddings:
+        P['decoder.embed_tokens.weight'] = P['encoder.embed_tokens.weight']
+    feats = torch.from_numpy(paramgen.make_array(seed, name + '.feats', (B, S, cfg.input_dim)))
+    lens = torch.from_numpy(g['lens'])
+    for b in range(B):
+        feats[b, lens[b]:] = 0
+    feats.requires_grad_()
+    tb = paramgen.make_text_batch(seed, B, 4, T, V)
+    loss, logs = O.transformer_forward(P, cfg, feats, lens, torch.from_numpy(tb['decoder_input']))
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    assert logs['num_tokens'] == int(g['logs_num_tokens'])
+    close(feats.grad.numpy(), g['dfeats'], rtol=1e-4)
+    for n, ref_norm in zip(g['grad_names'], g['grad_norms']):
+        n = str(n)
+        assert abs(P[n].grad.norm().item() - ref_norm) <= 1e-4 * ref_norm + 2e-6, n
+        if 'grad:' + n in g:
+            close(P[n].grad.numpy(), g['grad:' + n], rtol=1e-4)
+    with torch.no_grad():
+        x = feats.detach()
+        if 'encoder.in_linear.0.weight' in P:
+            x = torch.clamp(O.linear(x, P['encoder.in_linear.0.weight'], P['encoder.in_linear.0.bias']), min=0)
+        sub, new_len = O.conv_subsampler(P, 'encoder.subsample', x, lens, cfg.conv_kernel_sizes,
+                                         cfg.conv_strides, cfg.conv_activation)
+        enc_out, enc_mask = O.encoder(P, cfg, feats.detach(), lens)
+    close(sub.numpy(), g['subsample_out'])
+    assert (new_len.numpy() == g['new_len']).all()
+    close(enc_out.numpy(), g['encoder_out'])
+    assert (enc_mask.numpy() == g['encoder_mask']).all()
+
+
+def test_greedy_decode_incremental_state():
+    g = load_golden('greedy_decode')
+    cfg = golden_cfg(g)
+    seed, B, S, V = (int(g[k]) for k in ('seed', 'B', 'S', 'V'))
+    P = _state(g, seed)
+    if cfg.shared_embeddings:
+        P['decoder.embed_tokens.weight'] = P['encoder.embed_tokens.weight']
+    batch = paramgen.make_text_batch(seed, B, S, 5, V)
+    with torch.no_grad():
+        enc_out, enc_mask = O.encoder(P, cfg, torch.from_numpy(batch['encoder_input']),
+                                      torch.from_numpy(batch['encoder_input_length']))
+        tokens = O.greedy_decode(P, cfg, enc_out, enc_mask, int(g['max_output_len']))
+    assert tokens.shape == g['tokens'].shape
+    assert (tokens.numpy() == g['tokens']).all()
+
+
+def test_adam_and_clip():
+    g = load_golden('adam_step')
+    n, steps = int(g['n']), int(g['steps'])
+    ps = [torch.from_numpy(g[f'p0:{i}']) for i in range(n)]
+    ms = [torch.zeros_like(p) for p in ps]
+    vs = [torch.zeros_like(p) for p in ps]
+    for s in range(steps):
+        grads = [torch.from_numpy(g[f'g{s}:{i}']) for i in range(n)]
+        gnorm, grads = O.clip_grad_norm(grads, 1.0)
+        assert abs(gnorm.item() - float(g[f'gnorm{s}'])) <= 1e-5 * float(g[f'gnorm{s}'])
+        for i in range(n):
+            ps[i], ms[i], vs[i] = O.adam_step(ps[i], grads[i], ms[i], vs[i], s + 1, 1e-3, 0.9, 0.98, 1e-8, 0.01)
+            close(ps[i].numpy(), g[f'p{s + 1}:{i}'], rtol=1e-5)
+
+
+def test_log_mel():
+    g = load_golden('logmel')
+    close(O.mel_filter_bank(), g['mel_filters'], rtol=1e-6, atol=1e-9)
+    for i, key in enumerate(('wav0', 'wav1')):
+        f = O.log_mel(g[key])
+        assert f.shape == (3000, 80)
+        # fp32-vs-fp64 STFT round-off on a log scale; features are O(1)
+        assert np.abs(f[:240] - g['feats'][i]).max() < 2e-4
+        assert np.abs(f[-4:] - g['feats_tail'][i]).max() < 2e-4
