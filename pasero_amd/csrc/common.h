@@ -1,0 +1,168 @@
+// Shared device/host helpers for the pasero_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#define PK_F32 0
+#define PK_BF16 1
+
+// activation ids (pasero/models/modules.py:220-228)
+#define PK_ACT_NONE 0
+#define PK_ACT_RELU 1
+#define PK_ACT_GELU 2       // erf
+#define PK_ACT_GELU_TANH 3
+#define PK_ACT_SILU 4
+
+typedef __hip_bfloat16 bf16;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA bf16 A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+extern "C" void pk_set_error(const char* fmt, ...);
+
+#define PK_CHECK_ARG(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            pk_set_error(__VA_ARGS__);          \
+            return -1;                          \
+        }                                       \
+    } while (0)
+
+#define PK_LAUNCH_CHECK()                                                        \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            pk_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return (int)e_;                                                      \
+        }                                                                        \
+    } while (0)
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+// round-to-nearest-even f32 -> bf16 through the compiler's cast (keeps NaN a NaN, v_cvt_pk_bf16_f32 at -O3)
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    bf16 b = __float2bfloat16(f);
+    return *reinterpret_cast<unsigned short*>(&b);
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return __bfloat162float(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return __float2bfloat16(v); }
+
+// ---- 16-byte vector access: VEC<T> elements per 16 B ----
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    float4 raw;
+    __device__ __forceinline__ float get(int i) const { return (&raw.x)[i]; }
+    __device__ __forceinline__ void set(int i, float v) { (&raw.x)[i] = v; }
+};
+template <> struct Vec16<bf16> {
+    static constexpr int N = 8;
+    uint4 raw;
+    __device__ __forceinline__ float get(int i) const {
+        unsigned w = (&raw.x)[i >> 1];
+        return bf2f((unsigned short)((i & 1) ? (w >> 16) : (w & 0xffff)));
+    }
+    __device__ __forceinline__ void set(int i, float v) {
+        unsigned& w = (&raw.x)[i >> 1];
+        unsigned b = f2bf(v);
+        w = (i & 1) ? ((w & 0x0000ffffu) | (b << 16)) : ((w & 0xffff0000u) | b);
+    }
+};
+template <typename T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
+    Vec16<T> v;
+    v.raw = *reinterpret_cast<const decltype(v.raw)*>(p);
+    return v;
+}
+template <typename T> __device__ __forceinline__ void store16(T* p, const Vec16<T>& v) {
+    *reinterpret_cast<decltype(v.raw)*>(p) = v.raw;
+}
+
+// ---- wave (64 lanes) reductions ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- activations ----
+__device__ __forceinline__ float act_fwd(int act, float x) {
+    switch (act) {
+        case PK_ACT_RELU: return fmaxf(x, 0.f);
+        case PK_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+        case PK_ACT_GELU_TANH: {
+            float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+            return 0.5f * x * (1.f + tanhf(u));
+        }
+        case PK_ACT_SILU: return x / (1.f + __expf(-x));
+        default: return x;
+    }
+}
+// derivative w.r.t. the pre-activation x (for RELU `x` may also be the post-activation: sign is the same)
+__device__ __forceinline__ float act_bwd(int act, float x) {
+    switch (act) {
+        case PK_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case PK_ACT_GELU: {
+            float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+            float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+            return cdf + x * pdf;
+        }
+        case PK_ACT_GELU_TANH: {
+            float x2 = x * x;
+            float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
+            float t = tanhf(u);
+            float du = 0.7978845608028654f * (1.f + 3.f * 0.044715f * x2);
+            return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+        }
+        case PK_ACT_SILU: {
+            float s = 1.f / (1.f + __expf(-x));
+            return s * (1.f + x * (1.f - s));
+        }
+        default: return 1.f;
+    }
+}
+
+// ---- Philox4x32-10 counter RNG for dropout: mask is a pure function of (seed, offset, element index), so the
+// backward pass regenerates it instead of storing it ----
+struct Philox4 {
+    unsigned x, y, z, w;
+};
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsigned long long offset,
+                                                 unsigned long long idx) {
+    unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = (unsigned)offset, c3 = (unsigned)(offset >> 32);
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+        unsigned n1 = (unsigned)p1;
+        unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        unsigned n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+// keep-threshold for drop probability p: element kept iff rnd >= thr
+__host__ __device__ __forceinline__ unsigned dropout_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
+}
+// 4 keep flags for elements [4*q, 4*q+4) of a flat tensor
+__device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned long long offset,
+                                              unsigned long long q, unsigned thr, bool keep[4]) {
+    Philox4 r = philox4x32_10(seed, offset, q);
+    keep[0] = r.x >= thr; keep[1] = r.y >= thr; keep[2] = r.z >= thr; keep[3] = r.w >= thr;
+}

@@ -1,0 +1,346 @@
+// Residual + dropout + LayerNorm, forward and backward (K4 of SURVEY §2c).
+//   reference: x = residual + dropout(x); x = LayerNorm(x)      pasero/models/transformer.py:1043-1054,1073-1086
+//              nn.LayerNorm(eps=1e-5, affine)                    pasero/models/transformer.py:941-947
+// HBM-bound: one wave (64 lanes) owns one row, each lane keeps its 16-byte chunks of the row in registers, so a row
+// is read exactly once; mean / variance are wave-shuffle reductions in fp32 (two-pass variance, like aten).
+// The dropout mask is regenerated from (seed, offset, element index) in the backward pass, never stored.
+// dgamma / dbeta: per-workgroup partial column sums in fp32 -> second kernel (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;  // one wave per row, 256 threads
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ residual, const T* __restrict__ gamma,
+    const T* __restrict__ beta, T* __restrict__ z_out, T* __restrict__ y_out, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, long long rows, int d, float eps, unsigned thr, float drop_scale,
+    unsigned long long seed, unsigned long long offset) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = d / EPV;
+    const float inv_d = 1.f / (float)d;
+    for (long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + wave; row < rows;
+         row += (long long)gridDim.x * ROWS_PER_BLOCK) {
+        float v[NCH][EPV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int ch = lane + 64 * i;
+            if (ch < nchunks) {
+                long long off = row * d + (long long)ch * EPV;
+                Vec16<T> xv = load16<T>(x + off);
+                bool keep[EPV];
+                if (thr) {
+#pragma unroll
+                    for (int e = 0; e < EPV; e += 4) dropout_keep4(seed, offset, (unsigned long long)(off + e) >> 2, thr, keep + e);
+                }
+                Vec16<T> rv;
+                if (residual) rv = load16<T>(residual + off);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    float a = xv.get(e);
+                    if (thr) a = keep[e] ? a * drop_scale : 0.f;
+                    if (residual) a += rv.get(e);
+                    v[i][e] = a;
+                    sum += a;
+                }
+                if (z_out) {
+                    Vec16<T> zv;
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) zv.set(e, v[i][e]);
+                    store16<T>(z_out + off, zv);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) v[i][e] = 0.f;
+            }
+        }
+        if (!gamma) continue;  // residual-only mode (pre-norm blocks)
+        // z is a tensor of dtype T in the reference (and is what the backward pass re-reads): take the statistics
+        // on the rounded values
+        if ((residual || thr) && sizeof(T) == 2) {
+            sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    v[i][e] = bf2f(f2bf(v[i][e]));
+                    sum += v[i][e];
+                }
+        }
+        float mu = wave_sum(sum) * inv_d;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int ch = lane + 64 * i;
+            if (ch < nchunks) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    float c = v[i][e] - mu;
+                    sq += c * c;
+                }
+            }
+        }
+        float rstd = rsqrtf(wave_sum(sq) * inv_d + eps);
+        if (lane == 0) {
+            mean_out[row] = mu;
+            rstd_out[row] = rstd;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int ch = lane + 64 * i;
+            if (ch < nchunks) {
+                Vec16<T> gv = load16<T>(gamma + ch * EPV), bv, yv;
+                if (beta) bv = load16<T>(beta + ch * EPV);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    float y = (v[i][e] - mu) * rstd * gv.get(e);
+                    if (beta) y += bv.get(e);
+                    yv.set(e, y);
+                }
+                store16<T>(y_out + row * d + (long long)ch * EPV, yv);
+            }
+        }
+    }
+}
+
+// dz = LN_bwd(dy) (+ dz_extra);  dres_out = dz;  dx_out = dz * keep * scale;  partial dgamma/dbeta per block
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
+    const T* __restrict__ dy, const T* __restrict__ dz_extra, const T* __restrict__ z, const T* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dres_out, T* __restrict__ dx_out,
+    float* __restrict__ partials /* [gridDim.x][2][d] */, long long rows, int d, unsigned thr, float drop_scale,
+    unsigned long long seed, unsigned long long offset) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = d / EPV;
+    const float inv_d = 1.f / (float)d;
+    float dg[NCH][EPV], db[NCH][EPV], gm[NCH][EPV];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        int ch = lane + 64 * i;
+        Vec16<T> gv;
+        if (gamma && ch < nchunks) gv = load16<T>(gamma + ch * EPV);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            dg[i][e] = 0.f;
+            db[i][e] = 0.f;
+            gm[i][e] = (gamma && ch < nchunks) ? gv.get(e) : 0.f;
+        }
+    }
+    for (long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + wave; row < rows;
+         row += (long long)gridDim.x * ROWS_PER_BLOCK) {
+        float g[NCH][EPV], xh[NCH][EPV];
+        float s1 = 0.f, s2 = 0.f;
+        float mu = 0.f, rs = 0.f;
+        if (gamma) {
+            mu = mean[row];
+            rs = rstd[row];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                int ch = lane + 64 * i;
+                if (ch < nchunks) {
+                    long long off = row * d + (long long)ch * EPV;
+                    Vec16<T> dv = load16<T>(dy + off), zv = load16<T>(z + off);
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) {
+                        float dyv = dv.get(e);
+                        float xhat = (zv.get(e) - mu) * rs;
+                        float gg = dyv * gm[i][e];
+                        g[i][e] = gg;
+                        xh[i][e] = xhat;
+                        s1 += gg;
+                        s2 += gg * xhat;
+                        dg[i][e] += dyv * xhat;
+                        db[i][e] += dyv;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) g[i][e] = xh[i][e] = 0.f;
+                }
+            }
+            s1 = wave_sum(s1) * inv_d;
+            s2 = wave_sum(s2) * inv_d;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int ch = lane + 64 * i;
+            if (ch < nchunks) {
+                long long off = row * d + (long long)ch * EPV;
+                float dz[EPV];
+                Vec16<T> ev;
+                if (dz_extra) ev = load16<T>(dz_extra + off);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    float t = gamma ? rs * (g[i][e] - s1 - xh[i][e] * s2) : 0.f;
+                    if (dz_extra) t += ev.get(e);
+                    dz[e] = t;
+                }
+                if (dres_out) {
+                    Vec16<T> o;
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) o.set(e, dz[e]);
+                    store16<T>(dres_out + off, o);
+                }
+                if (dx_out) {
+                    bool keep[EPV];
+                    if (thr) {
+#pragma unroll
+                        for (int e = 0; e < EPV; e += 4)
+                            dropout_keep4(seed, offset, (unsigned long long)(off + e) >> 2, thr, keep + e);
+                    }
+                    Vec16<T> o;
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) o.set(e, thr ? (keep[e] ? dz[e] * drop_scale : 0.f) : dz[e]);
+                    store16<T>(dx_out + off, o);
+                }
+            }
+        }
+    }
+    if (!partials) return;
+    // 4 waves -> one partial row per block
+    __shared__ float red[ROWS_PER_BLOCK][2][64 * EPV];  // per wave, one chunk-column set at a time
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            red[wave][0][lane * EPV + e] = dg[i][e];
+            red[wave][1][lane * EPV + e] = db[i][e];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * 64 * EPV; c += 256) {
+            int which = c / (64 * EPV), col = c % (64 * EPV);
+            int gcol = i * 64 * EPV + col;
+            if (gcol < d) {
+                float s = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+                partials[((long long)blockIdx.x * 2 + which) * d + gcol] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// out[which][col] = sum_b partials[b][which][col]   (which = 0: dgamma, 1: dbeta)
+template <typename T>
+__global__ void ln_param_grad_kernel(const float* __restrict__ partials, T* __restrict__ dgamma, T* __restrict__ dbeta,
+                                     int nblocks, int d) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= d) return;
+    float sg = 0.f, sb = 0.f;
+    for (int b = 0; b < nblocks; ++b) {
+        sg += partials[((long long)b * 2 + 0) * d + col];
+        sb += partials[((long long)b * 2 + 1) * d + col];
+    }
+    if (dgamma) dgamma[col] = from_f32<T>(sg);
+    if (dbeta) dbeta[col] = from_f32<T>(sb);
+}
+
+inline int ln_grid(long long rows) {
+    long long blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+}
+
+template <typename T>
+int launch_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* z, void* y, float* mean,
+               float* rstd, long long rows, int d, float eps, float p, unsigned long long seed,
+               unsigned long long offset, hipStream_t s) {
+    constexpr int EPV = 16 / sizeof(T);
+    PK_CHECK_ARG(d % EPV == 0 && d <= 64 * EPV * 16, "pk_residual_ln_fwd: d=%d unsupported", d);
+    unsigned thr = p > 0.f ? dropout_threshold(p) : 0u;
+    float scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    int nch = (d / EPV + 63) / 64;
+    dim3 grid(ln_grid(rows)), block(256);
+#define PK_L(N)                                                                                                   \
+    hipLaunchKernelGGL((residual_ln_fwd_kernel<T, N>), grid, block, 0, s, (const T*)x, (const T*)res,             \
+                       (const T*)gamma, (const T*)beta, (T*)z, (T*)y, mean, rstd, rows, d, eps, thr, scale, seed, \
+                       offset)
+    if (nch <= 1) PK_L(1);
+    else if (nch <= 2) PK_L(2);
+    else if (nch <= 4) PK_L(4);
+    else if (nch <= 8) PK_L(8);
+    else PK_L(16);
+#undef PK_L
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int launch_bwd(const void* dy, const void* dz_extra, const void* z, const void* gamma, const float* mean,
+               const float* rstd, void* dres, void* dx, void* dgamma, void* dbeta, float* ws, size_t ws_bytes,
+               long long rows, int d, float p, unsigned long long seed, unsigned long long offset, hipStream_t s) {
+    constexpr int EPV = 16 / sizeof(T);
+    PK_CHECK_ARG(d % EPV == 0 && d <= 64 * EPV * 8, "pk_residual_ln_bwd: d=%d unsupported", d);
+    unsigned thr = p > 0.f ? dropout_threshold(p) : 0u;
+    float scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    int nch = (d / EPV + 63) / 64;
+    int nblocks = ln_grid(rows);
+    if (nblocks > 512) nblocks = 512;
+    bool want_pg = gamma && (dgamma || dbeta);
+    if (want_pg) {
+        size_t need = (size_t)nblocks * 2 * d * sizeof(float);
+        PK_CHECK_ARG(ws && ws_bytes >= need, "pk_residual_ln_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
+    }
+    dim3 grid(nblocks), block(256);
+#define PK_L(N)                                                                                                  \
+    hipLaunchKernelGGL((residual_ln_bwd_kernel<T, N>), grid, block, 0, s, (const T*)dy, (const T*)dz_extra,      \
+                       (const T*)z, (const T*)gamma, mean, rstd, (T*)dres, (T*)dx, want_pg ? ws : nullptr, rows, \
+                       d, thr, scale, seed, offset)
+    if (nch <= 1) PK_L(1);
+    else if (nch <= 2) PK_L(2);
+    else if (nch <= 4) PK_L(4);
+    else PK_L(8);
+#undef PK_L
+    PK_LAUNCH_CHECK();
+    if (want_pg) {
+        hipLaunchKernelGGL((ln_param_grad_kernel<T>), dim3((d + 255) / 256), dim3(256), 0, s, ws, (T*)dgamma,
+                           (T*)dbeta, nblocks, d);
+        PK_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pk_residual_ln_fwd(const void* x, const void* residual, const void* gamma, const void* beta,
+                                  void* z_out, void* y_out, float* mean, float* rstd, long long rows, int d,
+                                  float eps, float drop_p, unsigned long long seed, unsigned long long offset,
+                                  int dtype, void* stream) {
+    PK_CHECK_ARG(x, "pk_residual_ln_fwd: x is null");
+    PK_CHECK_ARG(!gamma || (y_out && mean && rstd), "pk_residual_ln_fwd: gamma given but y/mean/rstd missing");
+    PK_CHECK_ARG(gamma || z_out, "pk_residual_ln_fwd: nothing to compute");
+    PK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pk_residual_ln_fwd: bad dropout %f", drop_p);
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PK_BF16)
+        return launch_fwd<bf16>(x, residual, gamma, beta, z_out, y_out, mean, rstd, rows, d, eps, drop_p, seed, offset, s);
+    if (dtype == PK_F32)
+        return launch_fwd<float>(x, residual, gamma, beta, z_out, y_out, mean, rstd, rows, d, eps, drop_p, seed, offset, s);
+    PK_CHECK_ARG(false, "pk_residual_ln_fwd: dtype %d not supported", dtype);
+}
+
+extern "C" size_t pk_residual_ln_bwd_workspace(long long rows, int d) {
+    int nblocks = ln_grid(rows);
+    if (nblocks > 512) nblocks = 512;
+    return (size_t)nblocks * 2 * d * sizeof(float);
+}
+
+extern "C" int pk_residual_ln_bwd(const void* dy, const void* dz_extra, const void* z, const void* gamma,
+                                  const float* mean, const float* rstd, void* dres_out, void* dx_out,
+                                  void* dgamma, void* dbeta, void* workspace, size_t ws_bytes, long long rows,
+                                  int d, float drop_p, unsigned long long seed, unsigned long long offset,
+                                  int dtype, void* stream) {
+    PK_CHECK_ARG(!gamma || (dy && z && mean && rstd), "pk_residual_ln_bwd: LN inputs missing");
+    PK_CHECK_ARG(gamma || dz_extra, "pk_residual_ln_bwd: nothing to compute");
+    PK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pk_residual_ln_bwd: bad dropout %f", drop_p);
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PK_BF16)
+        return launch_bwd<bf16>(dy, dz_extra, z, gamma, mean, rstd, dres_out, dx_out, dgamma, dbeta, (float*)workspace,
+                                ws_bytes, rows, d, drop_p, seed, offset, s);
+    if (dtype == PK_F32)
+        return launch_bwd<float>(dy, dz_extra, z, gamma, mean, rstd, dres_out, dx_out, dgamma, dbeta,
+                                 (float*)workspace, ws_bytes, rows, d, drop_p, seed, offset, s);
+    PK_CHECK_ARG(false, "pk_residual_ln_bwd: dtype %d not supported", dtype);
+}

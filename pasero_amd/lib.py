@@ -1,0 +1,90 @@
+"""ctypes binding of libpasero_hip.so (the C ABI declared in include/pasero_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, this raises.  The product
+path never routes through PyTorch eager ops or the CPU oracle for the work these kernels do.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_float, c_longlong, c_size_t, c_ulonglong, c_void_p, c_char_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpasero_hip.so')
+
+PK_F32, PK_BF16 = 0, 1
+ACT = {'none': 0, None: 0, 'relu': 1, 'gelu': 2, 'gelu_tanh': 3, 'geglu': 3, 'swiglu': 4, 'silu': 4}
+
+P, I, F, LL, SZ, ULL = c_void_p, c_int, c_float, c_longlong, c_size_t, c_ulonglong
+
+# name -> (restype, argtypes); must stay in sync with include/pasero_hip.h (tests/test_abi.py checks the symbols)
+SIGNATURES = {
+    'pk_version': (I, []),
+    'pk_last_error': (c_char_p, []),
+    'pk_gemm': (I, [P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, SZ, P]),
+    'pk_residual_ln_fwd': (I, [P, P, P, P, P, P, P, P, LL, I, F, F, ULL, ULL, I, P]),
+    'pk_residual_ln_bwd_workspace': (SZ, [LL, I]),
+    'pk_residual_ln_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, SZ, LL, I, F, ULL, ULL, I, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Raises ImportError with the build command if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, "csrc")}` '
+            '(or `python -c "import __graft_entry__ as g; g.build()"`). pasero_amd has no fallback path.'
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().pk_last_error().decode(errors='replace')
+        raise RuntimeError(f'{what} failed (code {rc}): {msg}')
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return PK_F32
+    if t.dtype == torch.bfloat16:
+        return PK_BF16
+    raise TypeError(f'pasero_amd kernels support float32 and bfloat16, got {t.dtype}')
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('pasero_amd kernels need CUDA/HIP tensors (no CPU fallback); got a CPU tensor')
+
+
+_workspaces = {}
+
+
+def workspace(nbytes: int, device, tag: str = 'default') -> torch.Tensor:
+    """Grow-only per-(device, tag) scratch buffer; kernels on one stream use it in order, so sharing is safe."""
+    key = (str(device), tag)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
