@@ -62,6 +62,58 @@ int pk_residual_ln_bwd(const void* dy, const void* dz_extra, const void* z, cons
                        size_t ws_bytes, long long rows, int d, float drop_p, unsigned long long seed,
                        unsigned long long offset, int dtype, void* stream);
 
+/* ---- Scaled-dot-product attention, head_dim 64 (K3): replaces F.scaled_dot_product_attention and the mask
+ * assembly around it, pasero/models/modules.py:654-677,707-720 (fallback :742-771).
+ *   q (B,T,H,64), k/v (B,S,H,64), o (B,T,H,64): element strides *_bs (batch) and *_rs (row), head stride 64.
+ *   key_pad: the reference's bool (B,S) key-padding mask, 1 byte per key, or NULL.  causal: query t attends keys
+ *   s <= t + (S - T).  A query with every key masked outputs 0.  lse [B,H,T] fp32 (natural log, scaled scores). */
+int pk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const unsigned char* key_pad,
+                int B, int H, int T, int S, int hd, long long q_bs, long long q_rs, long long k_bs, long long k_rs,
+                long long v_bs, long long v_rs, long long o_bs, long long o_rs, int causal, float scale, int dtype,
+                void* stream);
+/*   dq, dk, dv from d_o; `delta` [B,H,T] fp32 is scratch (rowsum(dO*O), produced and consumed inside the call) */
+int pk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                float* delta, void* dq, void* dk, void* dv, const unsigned char* key_pad, int B, int H, int T, int S,
+                int hd, long long q_bs, long long q_rs, long long k_bs, long long k_rs, long long v_bs,
+                long long v_rs, long long o_bs, long long o_rs, long long do_bs, long long do_rs, long long dq_bs,
+                long long dq_rs, long long dk_bs, long long dk_rs, long long dv_bs, long long dv_rs, int causal,
+                float scale, int dtype, void* stream);
+
+/* ---- Token + positional embedding (K1): replaces Embedding.forward, `*= embed_scale`, `+= positions`, Dropout,
+ * pasero/models/modules.py:916-933,435-457,467-484; pasero/models/transformer.py:727-744,866-878.
+ *   out[tok] = dropout( E[clip(ids[tok])] * scale + pos[pos_start + tok % Tlen] )      (pos may be NULL) */
+int pk_embed_fwd(const long long* ids, const void* E, const void* pos, void* out, long long ntok, int Tlen, int d,
+                 long long V, float scale, int pos_start, float drop_p, unsigned long long seed,
+                 unsigned long long offset, int dtype, void* stream);
+/*   dE[V,d] = scatter-add over tokens of dout * keep/(1-p) * scale, row pad_idx excluded (nn.Embedding padding_idx);
+ *   bf16: accumulated in fp32 in `workspace` (>= V*d*4 bytes) and rounded once */
+int pk_embed_bwd(const long long* ids, const void* dout, void* dE, void* workspace, size_t ws_bytes, long long ntok,
+                 int d, long long V, long long pad_idx, float scale, float drop_p, unsigned long long seed,
+                 unsigned long long offset, int dtype, void* stream);
+
+/* ---- Label-smoothed cross-entropy (K6): replaces logits.float() + 2x F.cross_entropy(ignore_index=pad,
+ * reduction='sum', label_smoothing) + 3 .item() syncs, pasero/models/transformer.py:354-380.
+ *   per row i with target != pad:  nll_i = lse_i - x_i[y_i];  loss_i = (1-eps) nll_i + eps (lse_i - mean_c x_i[c])
+ *   dlogits (optional, may alias logits) = softmax - eps/V - (1-eps) onehot, zero on pad rows. */
+int pk_ce_rows(const void* logits, long long ld, const long long* target, void* dlogits, long long ldd,
+               float* row_loss, float* row_nll, float* row_lse, long long rows, long long V, long long pad_idx,
+               float eps, int dtype, void* stream);
+/*   sums3 = { sum loss_i, sum nll_i, #(target != pad) } (fp32, accumulated in fp64, deterministic) */
+int pk_ce_finalize(const float* row_loss, const float* row_nll, const long long* target, long long rows,
+                   long long pad_idx, float* sums3, void* stream);
+
+/* ---- small reductions / elementwise helpers of the autograd glue ---- */
+/*   out[n] = sum_m x[m][n]   (bias gradients of nn.Linear, learned-position gradients) */
+size_t pk_colsum_workspace(long long M, long long N);
+int pk_colsum(const void* x, long long ld, void* out, long long M, long long N, void* workspace, size_t ws_bytes,
+              int dtype, void* stream);
+/*   out = x * keep/(1-p)  (nn.Dropout fwd; the same call with the same seed/offset is its backward) */
+int pk_dropout(const void* x, void* out, long long n, float drop_p, unsigned long long seed,
+               unsigned long long offset, int dtype, void* stream);
+/*   out = x * (*dev_scalar) * host_scalar   (dev_scalar: device fp32 scalar or NULL) */
+int pk_scale(const void* x, void* out, long long n, const float* dev_scalar, float host_scalar, int dtype,
+             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

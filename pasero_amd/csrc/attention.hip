@@ -1,0 +1,581 @@
+// Scaled-dot-product attention, forward + backward, head_dim = 64 (K3 of SURVEY §2c).
+//   reference: F.scaled_dot_product_attention(q, k, v, attn_mask, is_causal, scale)  pasero/models/modules.py:707-720
+//              mask assembly (bool (B,S) key-padding -> -inf, causal triu)            pasero/models/modules.py:654-677
+//              custom fallback with fp32 softmax + nan_to_num                         pasero/models/modules.py:742-771
+// q (B,T,H,64), k/v (B,S,H,64) are read in place from the projection outputs (row strides given), o is written in
+// the (B,T,H,64) layout out_proj consumes: no transposes, no mask tensor, no (B,H,T,S) score matrix.
+// Masks: key_pad[b][s] != 0 -> key masked (the bool tensor of the reference is passed as is); causal -> query t sees
+// keys s <= t + (S - T).  A query whose keys are all masked outputs 0 (the reference's nan_to_num behaviour).
+//
+// bf16 path (MFMA 32x32x16, flash-style, online softmax in fp32, exp2 domain):
+//   fwd / bwd_dq : one wave owns 32 queries, the QUERY sits on the MFMA lane (Sᵀ = K·Qᵀ), so row max / sum / lse are
+//                  per-lane scalars and the probability tile feeds the next MFMA as its B operand straight from the
+//                  accumulator registers (no LDS round trip); K rows are read with ds_read_b128, Vᵀ / Kᵀ operands with
+//                  ds_read_b64_tr_b16 from the same row-major LDS tile.
+//   bwd_dkv      : one wave owns 32 keys, the KEY sits on the lane (S = Q·Kᵀ, dP = dO·Vᵀ), so P and dS feed
+//                  dVᵀ += dOᵀ·P and dKᵀ += Qᵀ·dS from registers and dK/dV need no cross-workgroup sum (no atomics).
+// fp32 path: one thread per query (or key) row with broadcast LDS reads — exact fp32 arithmetic for parity runs.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s4;
+
+namespace {
+
+constexpr int HD = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnParams {
+    int B, H, T, S;
+    long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;  // batch / row strides in elements (head stride = 64)
+    long long do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    const unsigned char* key_pad;  // [B][S] or null
+    int causal;
+    float scale;
+};
+
+__device__ __forceinline__ bool key_masked(const AttnParams& p, int b, int t, int s) {
+    if (s >= p.S) return true;
+    if (p.key_pad && p.key_pad[(long long)b * p.S + s]) return true;
+    if (p.causal && s > t + (p.S - p.T)) return true;
+    return false;
+}
+
+// =====================================================================================================
+// fp32 path
+// =====================================================================================================
+constexpr int F32_TILE = 32;
+
+__global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, float* __restrict__ o,
+                                                           float* __restrict__ lse, AttnParams p) {
+    __shared__ float ks[F32_TILE][HD], vs[F32_TILE][HD];
+    const int b = blockIdx.z, h = blockIdx.y, t = blockIdx.x * 128 + threadIdx.x;
+    const bool valid = t < p.T;
+    float qr[HD], acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        qr[d] = valid ? q[b * p.q_bs + (long long)t * p.q_rs + h * HD + d] : 0.f;
+        acc[d] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    const float c = p.scale * LOG2E;
+    for (int s0 = 0; s0 < p.S; s0 += F32_TILE) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < F32_TILE * HD; i += 128) {
+            int r = i / HD, d = i % HD, s = s0 + r;
+            ks[r][d] = s < p.S ? k[b * p.k_bs + (long long)s * p.k_rs + h * HD + d] : 0.f;
+            vs[r][d] = s < p.S ? v[b * p.v_bs + (long long)s * p.v_rs + h * HD + d] : 0.f;
+        }
+        __syncthreads();
+        for (int r = 0; r < F32_TILE; ++r) {
+            int s = s0 + r;
+            if (!valid || key_masked(p, b, t, s)) continue;
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dot += qr[d] * ks[r][d];
+            float s2 = dot * c;
+            float mn = fmaxf(m, s2);
+            float alpha = exp2f(m - mn), pw = exp2f(s2 - mn);
+            l = l * alpha + pw;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = acc[d] * alpha + pw * vs[r][d];
+            m = mn;
+        }
+    }
+    if (!valid) return;
+    float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[b * p.o_bs + (long long)t * p.o_rs + h * HD + d] = acc[d] * inv;
+    lse[((long long)b * p.H + h) * p.T + t] = l > 0.f ? (m + log2f(l)) * LN2 : 0.f;
+}
+
+// dQ (thread per query) + delta = rowsum(dO * O)
+__global__ __launch_bounds__(128) void attn_bwd_dq_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, const float* __restrict__ o,
+                                                              const float* __restrict__ d_o,
+                                                              const float* __restrict__ lse, float* __restrict__ delta,
+                                                              float* __restrict__ dq, AttnParams p) {
+    __shared__ float ks[F32_TILE][HD], vs[F32_TILE][HD];
+    const int b = blockIdx.z, h = blockIdx.y, t = blockIdx.x * 128 + threadIdx.x;
+    const bool valid = t < p.T;
+    float qr[HD], dor[HD], acc[HD];
+    float dl = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        qr[d] = valid ? q[b * p.q_bs + (long long)t * p.q_rs + h * HD + d] : 0.f;
+        dor[d] = valid ? d_o[b * p.do_bs + (long long)t * p.do_rs + h * HD + d] : 0.f;
+        float ov = valid ? o[b * p.o_bs + (long long)t * p.o_rs + h * HD + d] : 0.f;
+        dl += dor[d] * ov;
+        acc[d] = 0.f;
+    }
+    const long long row = ((long long)b * p.H + h) * p.T + t;
+    const float L2 = valid ? lse[row] * LOG2E : 0.f;
+    if (valid) delta[row] = dl;
+    const float c = p.scale * LOG2E;
+    for (int s0 = 0; s0 < p.S; s0 += F32_TILE) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < F32_TILE * HD; i += 128) {
+            int r = i / HD, d = i % HD, s = s0 + r;
+            ks[r][d] = s < p.S ? k[b * p.k_bs + (long long)s * p.k_rs + h * HD + d] : 0.f;
+            vs[r][d] = s < p.S ? v[b * p.v_bs + (long long)s * p.v_rs + h * HD + d] : 0.f;
+        }
+        __syncthreads();
+        for (int r = 0; r < F32_TILE; ++r) {
+            int s = s0 + r;
+            if (!valid || key_masked(p, b, t, s)) continue;
+            float dot = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                dot += qr[d] * ks[r][d];
+                dp += dor[d] * vs[r][d];
+            }
+            float pw = exp2f(dot * c - L2);
+            float ds = pw * (dp - dl) * p.scale;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] += ds * ks[r][d];
+        }
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dq[b * p.dq_bs + (long long)t * p.dq_rs + h * HD + d] = acc[d];
+}
+
+// dK, dV (thread per key)
+__global__ __launch_bounds__(128) void attn_bwd_dkv_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v,
+                                                               const float* __restrict__ d_o,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta, float* __restrict__ dk,
+                                                               float* __restrict__ dv, AttnParams p) {
+    __shared__ float qs[F32_TILE][HD], dos[F32_TILE][HD], ls[F32_TILE], dls[F32_TILE];
+    const int b = blockIdx.z, h = blockIdx.y, s = blockIdx.x * 128 + threadIdx.x;
+    const bool valid = s < p.S;
+    float kr[HD], vr[HD], dka[HD], dva[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        kr[d] = valid ? k[b * p.k_bs + (long long)s * p.k_rs + h * HD + d] : 0.f;
+        vr[d] = valid ? v[b * p.v_bs + (long long)s * p.v_rs + h * HD + d] : 0.f;
+        dka[d] = 0.f;
+        dva[d] = 0.f;
+    }
+    const float c = p.scale * LOG2E;
+    for (int t0 = 0; t0 < p.T; t0 += F32_TILE) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < F32_TILE * HD; i += 128) {
+            int r = i / HD, d = i % HD, t = t0 + r;
+            qs[r][d] = t < p.T ? q[b * p.q_bs + (long long)t * p.q_rs + h * HD + d] : 0.f;
+            dos[r][d] = t < p.T ? d_o[b * p.do_bs + (long long)t * p.do_rs + h * HD + d] : 0.f;
+        }
+        if (threadIdx.x < F32_TILE) {
+            int t = t0 + threadIdx.x;
+            long long row = ((long long)b * p.H + h) * p.T + t;
+            ls[threadIdx.x] = t < p.T ? lse[row] * LOG2E : 0.f;
+            dls[threadIdx.x] = t < p.T ? delta[row] : 0.f;
+        }
+        __syncthreads();
+        for (int r = 0; r < F32_TILE; ++r) {
+            int t = t0 + r;
+            if (!valid || t >= p.T || key_masked(p, b, t, s)) continue;
+            float dot = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                dot += qs[r][d] * kr[d];
+                dp += dos[r][d] * vr[d];
+            }
+            float pw = exp2f(dot * c - ls[r]);
+            float ds = pw * (dp - dls[r]) * p.scale;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                dva[d] += pw * dos[r][d];
+                dka[d] += ds * qs[r][d];
+            }
+        }
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        dk[b * p.dk_bs + (long long)s * p.dk_rs + h * HD + d] = dka[d];
+        dv[b * p.dv_bs + (long long)s * p.dv_rs + h * HD + d] = dva[d];
+    }
+}
+
+// =====================================================================================================
+// bf16 MFMA path
+// =====================================================================================================
+constexpr int PITCH = 144;   // bytes per 64-element bf16 row in LDS (+16 B: ds_read_b128 row reads conflict-free)
+constexpr int VPITCH = 192;  // V tile of the forward pass: only transposed reads (4 key rows on distinct bank quarters)
+constexpr int KT = 64;       // rows (keys or queries) staged per LDS tile
+
+// stage a [64 rows][64 cols] bf16 tile (rows r0.., row limit `lim`, zero fill) into LDS with the given pitch
+__device__ __forceinline__ void stage_tile(char* lds, int pitch, const bf16* __restrict__ base, long long rs, int r0,
+                                           int lim, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int c = tid + i * 256;  // 512 chunks of 16 B
+        int r = c >> 3, cc = (c & 7) * 8;
+        uint4 val = {0, 0, 0, 0};
+        if (r0 + r < lim) val = *reinterpret_cast<const uint4*>(base + (long long)(r0 + r) * rs + cc);
+        *reinterpret_cast<uint4*>(lds + r * pitch + cc * 2) = val;
+    }
+}
+
+// row fragment: lane (r = l&31, h = l>>5) gets row row0 + r, elements d = 16*kk + 8*h .. +7
+__device__ __forceinline__ bf16x8_t row_frag(const char* lds, int pitch, int row0, int kk, int lane) {
+    return *reinterpret_cast<const bf16x8_t*>(lds + (row0 + (lane & 31)) * pitch + (kk * 16 + 8 * (lane >> 5)) * 2);
+}
+// transposed fragment for "accumulator tile as next operand" products (cdna guide §3): lane (r, h) gets column
+// c0 + r of rows  row0 + 16*s + 8*(j>>2) + 4*h + (j&3),  j = 0..7
+__device__ __forceinline__ bf16x8_t tr_frag(const char* lds, int pitch, int row0, int s, int c0, int lane) {
+    int q = (lane & 15) >> 2, p4 = lane & 3;
+    int col = c0 + 16 * ((lane >> 4) & 1) + 4 * p4;
+    int row = row0 + 16 * s + 4 * (lane >> 5) + q;
+    const char* ptr = lds + row * pitch + col * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)ptr);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(ptr + 8 * pitch));
+    s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, f);
+}
+// accumulator registers 8s..8s+7 of a 32x32 tile -> bf16 B/A operand of k-step s
+__device__ __forceinline__ bf16x8_t acc_frag(const f32x16& a, int s) {
+    s16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (short)f2bf(a[8 * s + j]);
+    return __builtin_bit_cast(bf16x8_t, f);
+}
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// global row fragment (rows beyond `lim` read as zero): lane (r, h) row row0 + r, d = 16kk + 8h .. +7
+__device__ __forceinline__ void load_row_frags(bf16x8_t (&f)[4], const bf16* __restrict__ base, long long rs, int row,
+                                               bool valid, int lane) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        uint4 val = {0, 0, 0, 0};
+        if (valid) val = *reinterpret_cast<const uint4*>(base + (long long)row * rs + kk * 16 + 8 * (lane >> 5));
+        f[kk] = __builtin_bit_cast(bf16x8_t, val);
+    }
+}
+
+__device__ __forceinline__ float frag_dot(const bf16x8_t& a, const bf16x8_t& b) {
+    s16x8 x = __builtin_bit_cast(s16x8, a), y = __builtin_bit_cast(s16x8, b);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += bf2f((unsigned short)x[j]) * bf2f((unsigned short)y[j]);
+    return s;
+}
+
+// write a transposed accumulator pair Xᵀ[d][row-on-lane] (2 d-tiles) as bf16 rows: lane (r, h) owns row `row`
+__device__ __forceinline__ void store_rowT(bf16* __restrict__ base, long long rs, int row, bool valid,
+                                           const f32x16 (&acc)[2], float mul, int lane) {
+    if (!valid) return;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int d = dt * 32 + 8 * g + 4 * (lane >> 5);
+            unsigned lo = (unsigned)f2bf(acc[dt][4 * g] * mul) | ((unsigned)f2bf(acc[dt][4 * g + 1] * mul) << 16);
+            unsigned hi = (unsigned)f2bf(acc[dt][4 * g + 2] * mul) | ((unsigned)f2bf(acc[dt][4 * g + 3] * mul) << 16);
+            *reinterpret_cast<uint2*>(base + (long long)row * rs + d) = make_uint2(lo, hi);
+        }
+}
+
+// ---- forward (MODE 0) and dQ backward (MODE 1): query on the lane ----
+template <int MODE>
+__global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                     const bf16* __restrict__ v, bf16* __restrict__ o,
+                                                     const bf16* __restrict__ d_o, float* __restrict__ lse,
+                                                     float* __restrict__ delta, bf16* __restrict__ dq, AttnParams p) {
+    constexpr int VP = MODE == 0 ? VPITCH : PITCH;
+    __shared__ __attribute__((aligned(16))) char k_lds[KT * PITCH];
+    __shared__ __attribute__((aligned(16))) char v_lds[KT * VP];
+    __shared__ unsigned char pad_lds[KT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int t = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool valid = t < p.T;
+    const float c = p.scale * LOG2E;
+
+    bf16x8_t qf[4], dof[4];
+    load_row_frags(qf, q + b * p.q_bs + h * HD, p.q_rs, t, valid, lane);
+    float m = -INFINITY, l = 0.f, L2 = 0.f, dl = 0.f;
+    f32x16 acc[2];  // Oᵀ (MODE 0) or dQᵀ (MODE 1): [d-tile][d rows] x query lane
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    if constexpr (MODE == 1) {
+        load_row_frags(dof, d_o + b * p.do_bs + h * HD, p.do_rs, t, valid, lane);
+        bf16x8_t of[4];
+        load_row_frags(of, o + b * p.o_bs + h * HD, p.o_rs, t, valid, lane);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) dl += frag_dot(dof[kk], of[kk]);
+        dl += __shfl_xor(dl, 32, 64);
+        const long long row = ((long long)b * p.H + h) * p.T + t;
+        if (valid) {
+            L2 = lse[row] * LOG2E;
+            if (lane < 32) delta[row] = dl;
+        }
+    }
+
+    // causal: keys beyond the last query of this workgroup are never visible
+    int s_end = p.S;
+    if (p.causal) s_end = min(p.S, blockIdx.x * 128 + 128 + (p.S - p.T));
+    for (int s0 = 0; s0 < s_end; s0 += KT) {
+        __syncthreads();
+        stage_tile(k_lds, PITCH, k + b * p.k_bs + h * HD, p.k_rs, s0, p.S, tid);
+        stage_tile(v_lds, VP, v + b * p.v_bs + h * HD, p.v_rs, s0, p.S, tid);
+        if (tid < KT) pad_lds[tid] = (p.key_pad && s0 + tid < p.S) ? p.key_pad[(long long)b * p.S + s0 + tid] : 0;
+        __syncthreads();
+
+        f32x16 sc[2];  // Sᵀ[key][query] for the two 32-key blocks of the tile
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(k_lds, PITCH, kb * 32, kk, lane), qf[kk],
+                                                                 sc[kb], 0, 0, 0);
+        }
+        // scale + mask (exp2 domain)
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int kl = kb * 32 + acc_row(r, lane), s = s0 + kl;
+                bool masked = s >= p.S || pad_lds[kl] || (p.causal && s > t + (p.S - p.T));
+                float x = masked ? -INFINITY : sc[kb][r] * c;
+                sc[kb][r] = x;
+                tmax = fmaxf(tmax, x);
+            }
+        if constexpr (MODE == 0) {
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            float mn = fmaxf(m, tmax);
+            float alpha = mn == -INFINITY ? 1.f : exp2f(m - mn);
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pw = mn == -INFINITY ? 0.f : exp2f(sc[kb][r] - mn);
+                    sc[kb][r] = pw;
+                    psum += pw;
+                }
+            l = l * alpha + psum;
+            m = mn;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+            // Oᵀ[d][query] += Vᵀ[d][key] · P[key][query]
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8_t pf = acc_frag(sc[kb], s);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(v_lds, VP, kb * 32, s, dt * 32, lane),
+                                                                          pf, acc[dt], 0, 0, 0);
+                }
+        } else {
+            // dPᵀ[key][query] = V[key][:] · dO[query][:]
+            f32x16 dp[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[kb][r] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(v_lds, VP, kb * 32, kk, lane), dof[kk],
+                                                                     dp[kb], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pw = (sc[kb][r] == -INFINITY || !valid) ? 0.f : exp2f(sc[kb][r] - L2);
+                    sc[kb][r] = pw * (dp[kb][r] - dl);  // dSᵀ
+                }
+            }
+            // dQᵀ[d][query] += Kᵀ[d][key] · dSᵀ[key][query]
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8_t pf = acc_frag(sc[kb], s);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            tr_frag(k_lds, PITCH, kb * 32, s, dt * 32, lane), pf, acc[dt], 0, 0, 0);
+                }
+        }
+    }
+    if constexpr (MODE == 0) {
+        l += __shfl_xor(l, 32, 64);
+        float inv = l > 0.f ? 1.f / l : 0.f;
+        store_rowT(o + b * p.o_bs + h * HD, p.o_rs, t, valid, acc, inv, lane);
+        if (valid && lane < 32) lse[((long long)b * p.H + h) * p.T + t] = l > 0.f ? (m + log2f(l)) * LN2 : 0.f;
+    } else {
+        store_rowT(dq + b * p.dq_bs + h * HD, p.dq_rs, t, valid, acc, p.scale, lane);
+    }
+}
+
+// ---- dK / dV backward: key on the lane ----
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                           const bf16* __restrict__ v, const bf16* __restrict__ d_o,
+                                                           const float* __restrict__ lse,
+                                                           const float* __restrict__ delta, bf16* __restrict__ dk,
+                                                           bf16* __restrict__ dv, AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char q_lds[KT * PITCH];
+    __shared__ __attribute__((aligned(16))) char do_lds[KT * PITCH];
+    __shared__ float l2_lds[KT], dl_lds[KT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int s = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool kvalid = s < p.S && !(p.key_pad && p.key_pad[(long long)b * p.S + min(s, p.S - 1)]);
+    const float c = p.scale * LOG2E;
+
+    bf16x8_t kf[4], vf[4];
+    load_row_frags(kf, k + b * p.k_bs + h * HD, p.k_rs, s, s < p.S, lane);
+    load_row_frags(vf, v + b * p.v_bs + h * HD, p.v_rs, s, s < p.S, lane);
+    f32x16 dka[2], dva[2];  // dKᵀ, dVᵀ: [d-tile][d rows] x key lane
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dka[dt][r] = dva[dt][r] = 0.f;
+
+    // causal: queries before the first key of this workgroup (minus the offset) never see it
+    int t_begin = 0;
+    if (p.causal) t_begin = max(0, (int)(blockIdx.x * 128) - (p.S - p.T)) / KT * KT;
+    for (int t0 = t_begin; t0 < p.T; t0 += KT) {
+        __syncthreads();
+        stage_tile(q_lds, PITCH, q + b * p.q_bs + h * HD, p.q_rs, t0, p.T, tid);
+        stage_tile(do_lds, PITCH, d_o + b * p.do_bs + h * HD, p.do_rs, t0, p.T, tid);
+        if (tid < KT) {
+            int t = t0 + tid;
+            long long row = ((long long)b * p.H + h) * p.T + t;
+            l2_lds[tid] = t < p.T ? lse[row] * LOG2E : INFINITY;  // +inf -> p = 0 for rows past T
+            dl_lds[tid] = t < p.T ? delta[row] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 sc, dp;  // S[query][key], dP[query][key]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(q_lds, PITCH, qb * 32, kk, lane), kf[kk], sc, 0,
+                                                             0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(do_lds, PITCH, qb * 32, kk, lane), vf[kk], dp,
+                                                             0, 0, 0);
+            }
+            f32x16 ds;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int tl = qb * 32 + acc_row(r, lane), t = t0 + tl;
+                bool masked = !kvalid || (p.causal && s > t + (p.S - p.T));
+                float pw = masked ? 0.f : exp2f(sc[r] * c - l2_lds[tl]);
+                sc[r] = pw;
+                ds[r] = pw * (dp[r] - dl_lds[tl]);
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8_t pf = acc_frag(sc, st), dsf = acc_frag(ds, st);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    // dVᵀ[d][key] += dOᵀ[d][query] · P[query][key] ;  dKᵀ[d][key] += Qᵀ[d][query] · dS[query][key]
+                    dva[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_frag(do_lds, PITCH, qb * 32, st, dt * 32, lane), pf, dva[dt], 0, 0, 0);
+                    dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_frag(q_lds, PITCH, qb * 32, st, dt * 32, lane), dsf, dka[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    store_rowT(dk + b * p.dk_bs + h * HD, p.dk_rs, s, s < p.S, dka, p.scale, lane);
+    store_rowT(dv + b * p.dv_bs + h * HD, p.dv_rs, s, s < p.S, dva, 1.f, lane);
+}
+
+int check_common(const AttnParams& p, int hd, int dtype, const char* who) {
+    PK_CHECK_ARG(hd == HD, "%s: head_dim %d not supported (64 only)", who, hd);
+    PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16, "%s: dtype %d not supported", who, dtype);
+    PK_CHECK_ARG(p.B >= 0 && p.H > 0 && p.T >= 0 && p.S >= 0, "%s: bad sizes", who);
+    PK_CHECK_ARG(p.B <= 65535 && p.H <= 65535, "%s: B and H must be <= 65535", who);
+    if (dtype == PK_BF16) {
+        PK_CHECK_ARG(p.q_rs % 8 == 0 && p.k_rs % 8 == 0 && p.v_rs % 8 == 0 && p.o_rs % 8 == 0 && p.q_bs % 8 == 0 &&
+                         p.k_bs % 8 == 0 && p.v_bs % 8 == 0 && p.o_bs % 8 == 0,
+                     "%s: bf16 strides must be multiples of 8 elements", who);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                           const unsigned char* key_pad, int B, int H, int T, int S, int hd, long long q_bs,
+                           long long q_rs, long long k_bs, long long k_rs, long long v_bs, long long v_rs,
+                           long long o_bs, long long o_rs, int causal, float scale, int dtype, void* stream) {
+    AttnParams p = {};
+    p.B = B; p.H = H; p.T = T; p.S = S;
+    p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
+    p.key_pad = key_pad; p.causal = causal; p.scale = scale;
+    if (int rc = check_common(p, hd, dtype, "pk_attn_fwd")) return rc;
+    PK_CHECK_ARG(q && k && v && o && lse, "pk_attn_fwd: null tensor");
+    if (B == 0 || T == 0) return 0;
+    dim3 grid((T + 127) / 128, H, B);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PK_BF16)
+        hipLaunchKernelGGL((attn_q_kernel<0>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v,
+                           (bf16*)o, (const bf16*)nullptr, lse, (float*)nullptr, (bf16*)nullptr, p);
+    else
+        hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(128), 0, s, (const float*)q, (const float*)k,
+                           (const float*)v, (float*)o, lse, p);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                           const float* lse, float* delta, void* dq, void* dk, void* dv,
+                           const unsigned char* key_pad, int B, int H, int T, int S, int hd, long long q_bs,
+                           long long q_rs, long long k_bs, long long k_rs, long long v_bs, long long v_rs,
+                           long long o_bs, long long o_rs, long long do_bs, long long do_rs, long long dq_bs,
+                           long long dq_rs, long long dk_bs, long long dk_rs, long long dv_bs, long long dv_rs,
+                           int causal, float scale, int dtype, void* stream) {
+    AttnParams p = {};
+    p.B = B; p.H = H; p.T = T; p.S = S;
+    p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
+    p.do_bs = do_bs; p.do_rs = do_rs; p.dq_bs = dq_bs; p.dq_rs = dq_rs; p.dk_bs = dk_bs; p.dk_rs = dk_rs;
+    p.dv_bs = dv_bs; p.dv_rs = dv_rs;
+    p.key_pad = key_pad; p.causal = causal; p.scale = scale;
+    if (int rc = check_common(p, hd, dtype, "pk_attn_bwd")) return rc;
+    PK_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv, "pk_attn_bwd: null tensor");
+    if (dtype == PK_BF16)
+        PK_CHECK_ARG(do_rs % 8 == 0 && dq_rs % 8 == 0 && dk_rs % 8 == 0 && dv_rs % 8 == 0 && do_bs % 8 == 0 &&
+                         dq_bs % 8 == 0 && dk_bs % 8 == 0 && dv_bs % 8 == 0,
+                     "pk_attn_bwd: bf16 strides must be multiples of 8 elements");
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 gq((T + 127) / 128, H, B), gk((S + 127) / 128, H, B);
+    if (dtype == PK_BF16) {
+        if (T > 0)
+            hipLaunchKernelGGL((attn_q_kernel<1>), gq, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v,
+                               (bf16*)const_cast<void*>(o), (const bf16*)d_o, const_cast<float*>(lse), delta, (bf16*)dq, p);
+        PK_LAUNCH_CHECK();
+        if (S > 0)
+            hipLaunchKernelGGL(attn_bwd_dkv_kernel, gk, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,
+                               (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dk, (bf16*)dv, p);
+    } else {
+        if (T > 0)
+            hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, gq, dim3(128), 0, s, (const float*)q, (const float*)k,
+                               (const float*)v, (const float*)o, (const float*)d_o, lse, delta, (float*)dq, p);
+        PK_LAUNCH_CHECK();
+        if (S > 0)
+            hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, gk, dim3(128), 0, s, (const float*)q, (const float*)k,
+                               (const float*)v, (const float*)d_o, lse, (const float*)delta, (float*)dk, (float*)dv, p);
+    }
+    PK_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,449 @@
+// HBM-bound kernels at the two ends of the Transformer hot path:
+//   K1  token embedding * sqrt(d) + positional embedding (+dropout), and its scatter-add backward
+//         pasero/models/modules.py:916-933 (Embedding.forward), :435-457 / :467-484 (positions),
+//         pasero/models/transformer.py:727-744, :866-878
+//   K6  label-smoothed cross-entropy over a (rows, V) chunk of logits, loss and dlogits in one launch
+//         pasero/models/transformer.py:354-380 (compute_loss; F.cross_entropy sum-reduced, ignore_index = pad)
+//   plus the small reductions / elementwise helpers the autograd glue needs (column sums for bias gradients,
+//   dropout, multiply by a device-resident scalar).
+// All are written for coalesced 16-byte accesses, wave-shuffle reductions and >= 1024 workgroups per launch.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// embedding
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ ids, const T* __restrict__ E,
+                                                        const T* __restrict__ pos, T* __restrict__ out,
+                                                        long long ntok, int Tlen, int d, long long V, float scale,
+                                                        int pos_start, unsigned thr, float drop_scale,
+                                                        unsigned long long seed, unsigned long long offset) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = d / EPV;
+    for (long long tok = (long long)blockIdx.x * 4 + wave; tok < ntok; tok += (long long)gridDim.x * 4) {
+        long long id = ids[tok];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);  // modules.py:923 clip(min=0); upper clamp keeps the read in bounds
+        const T* erow = E + id * d;
+        const T* prow = pos ? pos + (long long)(pos_start + (int)(tok % Tlen)) * d : nullptr;
+        for (int ch = lane; ch < nchunks; ch += 64) {
+            Vec16<T> ev = load16<T>(erow + ch * EPV), pv, ov;
+            if (prow) pv = load16<T>(prow + ch * EPV);
+            long long off = tok * d + (long long)ch * EPV;
+            bool keep[EPV];
+            if (thr) {
+#pragma unroll
+                for (int e = 0; e < EPV; e += 4) dropout_keep4(seed, offset, (unsigned long long)(off + e) >> 2, thr, keep + e);
+            }
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float x = ev.get(e) * scale;
+                if (prow) x += pv.get(e);
+                if (thr) x = keep[e] ? x * drop_scale : 0.f;
+                ov.set(e, x);
+            }
+            store16<T>(out + off, ov);
+        }
+    }
+}
+
+// dE32[id] += dout * keep * drop_scale * scale  (fp32 atomics: one 256-byte wave-instruction per 64 floats of a row)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ ids, const T* __restrict__ dout,
+                                                        float* __restrict__ dE32, long long ntok, int d, long long V,
+                                                        long long pad_idx, float scale, unsigned thr,
+                                                        float drop_scale, unsigned long long seed,
+                                                        unsigned long long offset) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long tok = (long long)blockIdx.x * 4 + wave; tok < ntok; tok += (long long)gridDim.x * 4) {
+        long long id = ids[tok];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        if (id == pad_idx) continue;  // nn.Embedding(padding_idx): that row never receives gradient
+        float* grow = dE32 + id * d;
+        for (int c = lane; c < d; c += 64) {
+            long long off = tok * d + c;
+            float g = to_f32<T>(dout[off]) * scale;
+            if (thr) {
+                Philox4 r = philox4x32_10(seed, offset, (unsigned long long)off >> 2);
+                unsigned rv = (off & 3) == 0 ? r.x : (off & 3) == 1 ? r.y : (off & 3) == 2 ? r.z : r.w;
+                g = rv >= thr ? g * drop_scale : 0.f;
+            }
+            atomicAdd(grow + c, g);
+        }
+    }
+}
+
+template <typename T> __global__ void f32_to_T_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = from_f32<T>(src[i]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// label-smoothed cross entropy: one workgroup per row
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
+    float mn = fmaxf(m, m2);
+    if (mn == -INFINITY) { m = mn; s = 0.f; return; }
+    s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, long long ld,
+                                                 const long long* __restrict__ target, T* __restrict__ dlogits,
+                                                 long long ldd, float* __restrict__ row_loss,
+                                                 float* __restrict__ row_nll, float* __restrict__ row_lse, long long V,
+                                                 long long pad_idx, float eps, bool vec_ok) {
+    constexpr int EPV = 16 / sizeof(T);
+    __shared__ float red_m[4], red_s[4], red_t[4];
+    __shared__ float bc[2];
+    const long long row = blockIdx.x;
+    const T* x = logits + row * ld;
+    const long long tgt = target[row];
+    const bool active = tgt != pad_idx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float lse = 0.f;
+    if (active || row_lse) {
+        float m = -INFINITY, s = 0.f, tot = 0.f;
+        const long long nvec = vec_ok ? V / EPV : 0;
+        for (long long ch = tid; ch < nvec; ch += 256) {
+            Vec16<T> v = load16<T>(x + ch * EPV);
+            float cm = v.get(0);
+#pragma unroll
+            for (int e = 1; e < EPV; ++e) cm = fmaxf(cm, v.get(e));
+            float cs = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float a = v.get(e);
+                cs += __expf(a - cm);
+                tot += a;
+            }
+            online_merge(m, s, cm, cs);
+        }
+        for (long long c = nvec * EPV + tid; c < V; c += 256) {
+            float a = to_f32<T>(x[c]);
+            tot += a;
+            online_merge(m, s, a, 1.f);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+            online_merge(m, s, m2, s2);
+            tot += __shfl_xor(tot, o, 64);
+        }
+        if (lane == 0) { red_m[wave] = m; red_s[wave] = s; red_t[wave] = tot; }
+        __syncthreads();
+        if (tid == 0) {
+            float M = red_m[0], S = red_s[0], Tt = red_t[0];
+            for (int w = 1; w < 4; ++w) { online_merge(M, S, red_m[w], red_s[w]); Tt += red_t[w]; }
+            bc[0] = M + __logf(S);
+            bc[1] = Tt;
+        }
+        __syncthreads();
+        lse = bc[0];
+        if (tid == 0) {
+            if (row_lse) row_lse[row] = lse;
+            if (active) {
+                long long tc = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
+                float nll = lse - to_f32<T>(x[tc]);
+                float smooth = lse - bc[1] / (float)V;
+                row_nll[row] = nll;
+                row_loss[row] = eps > 0.f ? (1.f - eps) * nll + eps * smooth : nll;
+            }
+        }
+    }
+    if (!active && tid == 0) { row_loss[row] = 0.f; row_nll[row] = 0.f; }
+    if (!dlogits) return;
+    T* dx = dlogits + row * ldd;
+    const float uni = eps / (float)V;
+    const long long nvec = vec_ok ? V / EPV : 0;
+    for (long long ch = tid; ch < nvec; ch += 256) {
+        Vec16<T> o;
+        if (active) {
+            Vec16<T> v = load16<T>(x + ch * EPV);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                long long c = ch * EPV + e;
+                float g = __expf(v.get(e) - lse) - uni - (c == tgt ? 1.f - eps : 0.f);
+                o.set(e, g);
+            }
+        } else {
+            o.raw = {0, 0, 0, 0};
+        }
+        store16<T>(dx + ch * EPV, o);
+    }
+    for (long long c = nvec * EPV + tid; c < V; c += 256) {
+        float g = active ? __expf(to_f32<T>(x[c]) - lse) - uni - (c == tgt ? 1.f - eps : 0.f) : 0.f;
+        dx[c] = from_f32<T>(g);
+    }
+}
+
+// sums[0] = sum(row_loss), sums[1] = sum(row_nll), sums[2] = #(target != pad); one workgroup, fp64 accumulation
+__global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* __restrict__ row_loss,
+                                                           const float* __restrict__ row_nll,
+                                                           const long long* __restrict__ target, long long rows,
+                                                           long long pad_idx, float* __restrict__ sums) {
+    __shared__ double sh[3][16];
+    double a = 0, b = 0, c = 0;
+    for (long long i = threadIdx.x; i < rows; i += 1024) {
+        a += row_loss[i];
+        b += row_nll[i];
+        c += target[i] != pad_idx ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+        c += __shfl_xor(c, o, 64);
+    }
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wave] = a; sh[1][wave] = b; sh[2][wave] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double A = 0, Bv = 0, C = 0;
+        for (int w = 0; w < 16; ++w) { A += sh[0][w]; Bv += sh[1][w]; C += sh[2][w]; }
+        sums[0] = (float)A; sums[1] = (float)Bv; sums[2] = (float)C;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// column sums (bias gradients, learned-position gradients): out[n] = sum_m x[m][n]
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long long ld, long long M,
+                                                             long long N, float* __restrict__ partials, bool vec_ok) {
+    constexpr int EPV = 16 / sizeof(T);
+    __shared__ float red[4][64 * EPV];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long col0 = ((long long)blockIdx.x * 64 + tx) * EPV;
+    float acc[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) acc[e] = 0.f;
+    if (col0 < N) {
+        const bool full = vec_ok && col0 + EPV <= N;
+        for (long long r = (long long)blockIdx.y * 4 + ty; r < M; r += (long long)gridDim.y * 4) {
+            if (full) {
+                Vec16<T> v = load16<T>(x + r * ld + col0);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) acc[e] += v.get(e);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e)
+                    if (col0 + e < N) acc[e] += to_f32<T>(x[r * ld + col0 + e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) red[ty][tx * EPV + e] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 64 * EPV; c += 256) {
+        long long col = (long long)blockIdx.x * 64 * EPV + c;
+        if (col < N) partials[(long long)blockIdx.y * N + col] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    }
+}
+template <typename T>
+__global__ void colsum_final_kernel(const float* __restrict__ partials, T* __restrict__ out, int nparts, long long N) {
+    long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partials[(long long)p * N + col];
+    out[col] = from_f32<T>(s);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// elementwise
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, long long n,
+                                                      unsigned thr, float drop_scale, unsigned long long seed,
+                                                      unsigned long long offset) {
+    constexpr int EPV = 16 / sizeof(T);
+    const long long nvec = n / EPV;
+    for (long long ch = (long long)blockIdx.x * 256 + threadIdx.x; ch < nvec; ch += (long long)gridDim.x * 256) {
+        Vec16<T> v = load16<T>(x + ch * EPV), o;
+        bool keep[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; e += 4) dropout_keep4(seed, offset, (unsigned long long)(ch * EPV + e) >> 2, thr, keep + e);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) o.set(e, keep[e] ? v.get(e) * drop_scale : 0.f);
+        store16<T>(out + ch * EPV, o);
+    }
+    if (blockIdx.x == 0) {
+        for (long long i = nvec * EPV + threadIdx.x; i < n; i += 256) {
+            Philox4 r = philox4x32_10(seed, offset, (unsigned long long)i >> 2);
+            unsigned rv = (i & 3) == 0 ? r.x : (i & 3) == 1 ? r.y : (i & 3) == 2 ? r.z : r.w;
+            out[i] = from_f32<T>(rv >= thr ? to_f32<T>(x[i]) * drop_scale : 0.f);
+        }
+    }
+}
+
+// out = x * (*dev_scalar) * host_scalar
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(const T* __restrict__ x, T* __restrict__ out, long long n,
+                                                    const float* __restrict__ dev_scalar, float host_scalar) {
+    constexpr int EPV = 16 / sizeof(T);
+    const float a = (dev_scalar ? *dev_scalar : 1.f) * host_scalar;
+    const long long nvec = n / EPV;
+    for (long long ch = (long long)blockIdx.x * 256 + threadIdx.x; ch < nvec; ch += (long long)gridDim.x * 256) {
+        Vec16<T> v = load16<T>(x + ch * EPV), o;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) o.set(e, v.get(e) * a);
+        store16<T>(out + ch * EPV, o);
+    }
+    if (blockIdx.x == 0)
+        for (long long i = nvec * EPV + threadIdx.x; i < n; i += 256) out[i] = from_f32<T>(to_f32<T>(x[i]) * a);
+}
+
+inline int grid_for(long long work_items, int per_block, int cap = 2048) {
+    long long b = (work_items + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+inline bool is_aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+}  // namespace
+
+#define PK_DTYPE_SWITCH(dtype, who, ...)                                   \
+    if (dtype == PK_BF16) { using T = bf16; __VA_ARGS__ }                  \
+    else if (dtype == PK_F32) { using T = float; __VA_ARGS__ }             \
+    else { PK_CHECK_ARG(false, "%s: dtype %d not supported", who, dtype); }
+
+extern "C" int pk_embed_fwd(const long long* ids, const void* E, const void* pos, void* out, long long ntok, int Tlen,
+                            int d, long long V, float scale, int pos_start, float drop_p, unsigned long long seed,
+                            unsigned long long offset, int dtype, void* stream) {
+    PK_CHECK_ARG(ids && E && out, "pk_embed_fwd: null tensor");
+    PK_CHECK_ARG(Tlen > 0 && V > 0, "pk_embed_fwd: bad sizes");
+    PK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pk_embed_fwd: bad dropout %f", drop_p);
+    if (ntok == 0) return 0;
+    unsigned thr = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+    float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    PK_DTYPE_SWITCH(dtype, "pk_embed_fwd", {
+        constexpr int EPV = 16 / sizeof(T);
+        PK_CHECK_ARG(d % EPV == 0, "pk_embed_fwd: d=%d must be a multiple of %d", d, EPV);
+        hipLaunchKernelGGL((embed_fwd_kernel<T>), dim3(grid_for(ntok, 4)), dim3(256), 0, (hipStream_t)stream, ids,
+                           (const T*)E, (const T*)pos, (T*)out, ntok, Tlen, d, V, scale, pos_start, thr, ds, seed,
+                           offset);
+    })
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+// dE (dtype) = scatter-add of dout rows; `workspace` >= V*d*4 bytes (fp32 accumulation buffer, zeroed here)
+extern "C" int pk_embed_bwd(const long long* ids, const void* dout, void* dE, void* workspace, size_t ws_bytes,
+                            long long ntok, int d, long long V, long long pad_idx, float scale, float drop_p,
+                            unsigned long long seed, unsigned long long offset, int dtype, void* stream) {
+    PK_CHECK_ARG(ids && dout && dE, "pk_embed_bwd: null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned thr = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+    float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    float* acc;
+    if (dtype == PK_F32) {
+        acc = (float*)dE;
+    } else {
+        PK_CHECK_ARG(workspace && ws_bytes >= (size_t)V * d * 4, "pk_embed_bwd: workspace too small");
+        acc = (float*)workspace;
+    }
+    hipError_t e = hipMemsetAsync(acc, 0, (size_t)V * d * 4, s);
+    if (e != hipSuccess) { pk_set_error("pk_embed_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
+    if (ntok > 0) {
+        PK_DTYPE_SWITCH(dtype, "pk_embed_bwd", {
+            hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3(grid_for(ntok, 4)), dim3(256), 0, s, ids, (const T*)dout,
+                               acc, ntok, d, V, pad_idx, scale, thr, ds, seed, offset);
+        })
+        PK_LAUNCH_CHECK();
+    }
+    if (dtype == PK_BF16) {
+        hipLaunchKernelGGL((f32_to_T_kernel<bf16>), dim3(grid_for(V * d, 1024)), dim3(256), 0, s, acc, (bf16*)dE,
+                           V * d);
+        PK_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// Label-smoothed CE of `rows` logit rows.  row_loss/row_nll [rows] fp32 outputs (0 for pad rows); row_lse optional;
+// dlogits optional (may alias logits): d(loss_sum)/dlogits.
+extern "C" int pk_ce_rows(const void* logits, long long ld, const long long* target, void* dlogits, long long ldd,
+                          float* row_loss, float* row_nll, float* row_lse, long long rows, long long V,
+                          long long pad_idx, float eps, int dtype, void* stream) {
+    PK_CHECK_ARG(logits && target && row_loss && row_nll, "pk_ce_rows: null tensor");
+    PK_CHECK_ARG(V > 0 && eps >= 0.f && eps < 1.f, "pk_ce_rows: bad V / label smoothing");
+    PK_CHECK_ARG(rows < (1ll << 31), "pk_ce_rows: too many rows per call");
+    if (rows == 0) return 0;
+    PK_DTYPE_SWITCH(dtype, "pk_ce_rows", {
+        constexpr int EPV = 16 / sizeof(T);
+        bool vec_ok = is_aligned16(logits) && ld % EPV == 0 && (!dlogits || (is_aligned16(dlogits) && ldd % EPV == 0));
+        hipLaunchKernelGGL((ce_kernel<T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const T*)logits,
+                           ld, target, (T*)dlogits, ldd, row_loss, row_nll, row_lse, V, pad_idx, eps, vec_ok);
+    })
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_ce_finalize(const float* row_loss, const float* row_nll, const long long* target, long long rows,
+                              long long pad_idx, float* sums3, void* stream) {
+    PK_CHECK_ARG(row_loss && row_nll && target && sums3, "pk_ce_finalize: null tensor");
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, row_nll, target,
+                       rows, pad_idx, sums3);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t pk_colsum_workspace(long long M, long long N) {
+    long long parts = (M + 3) / 4;
+    if (parts > 64) parts = 64;
+    if (parts < 1) parts = 1;
+    return (size_t)parts * N * sizeof(float);
+}
+
+extern "C" int pk_colsum(const void* x, long long ld, void* out, long long M, long long N, void* workspace,
+                         size_t ws_bytes, int dtype, void* stream) {
+    PK_CHECK_ARG(x && out, "pk_colsum: null tensor");
+    if (N == 0) return 0;
+    long long parts = (M + 3) / 4;
+    if (parts > 64) parts = 64;
+    if (parts < 1) parts = 1;
+    PK_CHECK_ARG(workspace && ws_bytes >= (size_t)parts * N * 4, "pk_colsum: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    PK_DTYPE_SWITCH(dtype, "pk_colsum", {
+        constexpr int EPV = 16 / sizeof(T);
+        bool vec_ok = is_aligned16(x) && ld % EPV == 0;
+        dim3 grid((unsigned)((N + 64 * EPV - 1) / (64 * EPV)), (unsigned)parts);
+        hipLaunchKernelGGL((colsum_partial_kernel<T>), grid, dim3(256), 0, s, (const T*)x, ld, M, N,
+                           (float*)workspace, vec_ok);
+        PK_LAUNCH_CHECK();
+        hipLaunchKernelGGL((colsum_final_kernel<T>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
+                           (const float*)workspace, (T*)out, (int)parts, N);
+    })
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_dropout(const void* x, void* out, long long n, float drop_p, unsigned long long seed,
+                          unsigned long long offset, int dtype, void* stream) {
+    PK_CHECK_ARG(x && out, "pk_dropout: null tensor");
+    PK_CHECK_ARG(drop_p > 0.f && drop_p < 1.f, "pk_dropout: p must be in (0, 1), got %f", drop_p);
+    PK_CHECK_ARG(is_aligned16(x) && is_aligned16(out), "pk_dropout: tensors must be 16-byte aligned");
+    if (n == 0) return 0;
+    unsigned thr = dropout_threshold(drop_p);
+    float ds = 1.f / (1.f - drop_p);
+    PK_DTYPE_SWITCH(dtype, "pk_dropout", {
+        hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)x, (T*)out, n, thr, ds, seed, offset);
+    })
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_scale(const void* x, void* out, long long n, const float* dev_scalar, float host_scalar, int dtype,
+                        void* stream) {
+    PK_CHECK_ARG(x && out, "pk_scale: null tensor");
+    PK_CHECK_ARG(is_aligned16(x) && is_aligned16(out), "pk_scale: tensors must be 16-byte aligned");
+    if (n == 0) return 0;
+    PK_DTYPE_SWITCH(dtype, "pk_scale", {
+        hipLaunchKernelGGL((scale_kernel<T>), dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)x, (T*)out, n, dev_scalar, host_scalar);
+    })
+    PK_LAUNCH_CHECK();
+    return 0;
+}

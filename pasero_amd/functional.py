@@ -100,3 +100,136 @@ def residual_ln_bwd(dy: Optional[Tensor], dz_extra: Optional[Tensor], z: Optiona
                                ptr(dgamma), ptr(dbeta), ptr(ws), ws_bytes, rows, d, float(drop_p), int(seed),
                                int(offset), dtype_code(ref), stream_ptr()), 'pk_residual_ln_bwd')
     return dres, dx, dgamma, dbeta
+
+
+def _bs_rs(t: Tensor):
+    """(batch stride, row stride) of a (B, L, H*64) view whose last dim is contiguous"""
+    assert t.dim() == 3 and (t.stride(2) == 1 or t.size(2) == 1)
+    return t.stride(0), t.stride(1)
+
+
+def attn_fwd(q: Tensor, k: Tensor, v: Tensor, num_heads: int, key_pad: Optional[Tensor], causal: bool,
+             scale: float):
+    """q (B,T,D), k/v (B,S,D) (views with arbitrary batch/row strides), D = num_heads*64.
+    Returns (o (B,T,D) contiguous, lse (B,H,T) fp32)."""
+    require_gpu(q, k, v, key_pad)
+    B, T, D = q.shape
+    S = k.size(1)
+    hd = D // num_heads
+    o = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=q.device)
+    if key_pad is not None:
+        assert key_pad.dtype == torch.bool and key_pad.shape == (B, S) and key_pad.is_contiguous()
+    L = lib.load()
+    check(L.pk_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(key_pad), B, num_heads, T, S, hd,
+                        *_bs_rs(q), *_bs_rs(k), *_bs_rs(v), *_bs_rs(o), int(causal), float(scale), dtype_code(q),
+                        stream_ptr()), 'pk_attn_fwd')
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, d_o, lse, num_heads: int, key_pad, causal: bool, scale: float,
+             dq: Optional[Tensor] = None, dk: Optional[Tensor] = None, dv: Optional[Tensor] = None):
+    require_gpu(q, k, v, o, d_o, lse, key_pad)
+    B, T, D = q.shape
+    S = k.size(1)
+    hd = D // num_heads
+    if d_o.stride(2) != 1:
+        d_o = d_o.contiguous()
+    dq = torch.empty(B, T, D, dtype=q.dtype, device=q.device) if dq is None else dq
+    dk = torch.empty(B, S, D, dtype=q.dtype, device=q.device) if dk is None else dk
+    dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device) if dv is None else dv
+    delta = torch.empty(B, num_heads, T, dtype=torch.float32, device=q.device)
+    L = lib.load()
+    check(L.pk_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                        ptr(key_pad), B, num_heads, T, S, hd, *_bs_rs(q), *_bs_rs(k), *_bs_rs(v), *_bs_rs(o),
+                        *_bs_rs(d_o), *_bs_rs(dq), *_bs_rs(dk), *_bs_rs(dv), int(causal), float(scale),
+                        dtype_code(q), stream_ptr()), 'pk_attn_bwd')
+    return dq, dk, dv
+
+
+def embed_fwd(ids: Tensor, E: Tensor, pos: Optional[Tensor], scale: float, pos_start: int, drop_p: float = 0.0,
+              seed: int = 0, offset: int = 0) -> Tensor:
+    """ids (B,T) int64 -> (B,T,d); pos: (P,d) table in E's dtype or None; rows pos_start.. are added"""
+    require_gpu(ids, E, pos)
+    B, T = ids.shape
+    V, d = E.shape
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and E.is_contiguous()
+    if pos is not None:
+        assert pos.dtype == E.dtype and pos.is_contiguous() and pos.size(1) == d and pos_start + T <= pos.size(0), \
+            f'input sequence is too long: {T}, positional embedding size: {pos.size(0)}'
+    out = torch.empty(B, T, d, dtype=E.dtype, device=E.device)
+    L = lib.load()
+    check(L.pk_embed_fwd(ptr(ids), ptr(E), ptr(pos), ptr(out), B * T, T, d, V, float(scale), int(pos_start),
+                         float(drop_p), int(seed), int(offset), dtype_code(E), stream_ptr()), 'pk_embed_fwd')
+    return out
+
+
+def embed_bwd(ids: Tensor, dout: Tensor, V: int, pad_idx: int, scale: float, drop_p: float = 0.0, seed: int = 0,
+              offset: int = 0) -> Tensor:
+    require_gpu(ids, dout)
+    d = dout.size(-1)
+    assert dout.is_contiguous() and ids.is_contiguous()
+    dE = torch.empty(V, d, dtype=dout.dtype, device=dout.device)
+    ws, ws_bytes = None, 0
+    if dout.dtype != torch.float32:
+        ws_bytes = V * d * 4
+        ws = lib.workspace(ws_bytes, dout.device, 'embed')
+    L = lib.load()
+    check(L.pk_embed_bwd(ptr(ids), ptr(dout), ptr(dE), ptr(ws), ws_bytes, ids.numel(), d, V, int(pad_idx),
+                         float(scale), float(drop_p), int(seed), int(offset), dtype_code(dout), stream_ptr()),
+          'pk_embed_bwd')
+    return dE
+
+
+def ce_rows(logits: Tensor, target: Tensor, pad_idx: int, eps: float, row_loss: Tensor, row_nll: Tensor,
+            dlogits: Optional[Tensor] = None, row_lse: Optional[Tensor] = None):
+    """logits (rows, V) [row stride allowed]; writes row_loss/row_nll (rows,) fp32 and optionally dlogits"""
+    require_gpu(logits, target, dlogits)
+    rows, V = logits.shape
+    assert target.dtype == torch.int64 and target.is_contiguous() and target.numel() == rows
+    L = lib.load()
+    check(L.pk_ce_rows(ptr(logits), _ld(logits), ptr(target), ptr(dlogits), _ld(dlogits) if dlogits is not None else 0,
+                       ptr(row_loss), ptr(row_nll), ptr(row_lse), rows, V, int(pad_idx), float(eps or 0.0),
+                       dtype_code(logits), stream_ptr()), 'pk_ce_rows')
+
+
+def ce_finalize(row_loss: Tensor, row_nll: Tensor, target: Tensor, pad_idx: int) -> Tensor:
+    sums = torch.empty(3, dtype=torch.float32, device=row_loss.device)
+    L = lib.load()
+    check(L.pk_ce_finalize(ptr(row_loss), ptr(row_nll), ptr(target), target.numel(), int(pad_idx), ptr(sums),
+                           stream_ptr()), 'pk_ce_finalize')
+    return sums
+
+
+def colsum(x: Tensor) -> Tensor:
+    """x (M, N) -> (N,) column sums in x's dtype (fp32 accumulation)"""
+    require_gpu(x)
+    M, N = x.shape
+    out = torch.empty(N, dtype=x.dtype, device=x.device)
+    L = lib.load()
+    ws_bytes = L.pk_colsum_workspace(M, N)
+    ws = lib.workspace(ws_bytes, x.device, 'colsum')
+    check(L.pk_colsum(ptr(x), _ld(x), ptr(out), M, N, ptr(ws), ws_bytes, dtype_code(x), stream_ptr()), 'pk_colsum')
+    return out
+
+
+def dropout(x: Tensor, p: float, seed: int, offset: int) -> Tensor:
+    require_gpu(x)
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    L = lib.load()
+    check(L.pk_dropout(ptr(x), ptr(out), x.numel(), float(p), int(seed), int(offset), dtype_code(x), stream_ptr()),
+          'pk_dropout')
+    return out
+
+
+def scale(x: Tensor, dev_scalar: Optional[Tensor], host_scalar: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
+    require_gpu(x, dev_scalar)
+    assert x.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    if dev_scalar is not None:
+        assert dev_scalar.dtype == torch.float32 and dev_scalar.numel() == 1
+    L = lib.load()
+    check(L.pk_scale(ptr(x), ptr(out), x.numel(), ptr(dev_scalar), float(host_scalar), dtype_code(x), stream_ptr()),
+          'pk_scale')
+    return out

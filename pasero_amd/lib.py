@@ -25,6 +25,16 @@ SIGNATURES = {
     'pk_residual_ln_fwd': (I, [P, P, P, P, P, P, P, P, LL, I, F, F, ULL, ULL, I, P]),
     'pk_residual_ln_bwd_workspace': (SZ, [LL, I]),
     'pk_residual_ln_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, SZ, LL, I, F, ULL, ULL, I, P]),
+    'pk_attn_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I] + [LL] * 8 + [I, F, I, P]),
+    'pk_attn_bwd': (I, [P] * 11 + [I, I, I, I, I] + [LL] * 16 + [I, F, I, P]),
+    'pk_embed_fwd': (I, [P, P, P, P, LL, I, I, LL, F, I, F, ULL, ULL, I, P]),
+    'pk_embed_bwd': (I, [P, P, P, P, SZ, LL, I, LL, LL, F, F, ULL, ULL, I, P]),
+    'pk_ce_rows': (I, [P, LL, P, P, LL, P, P, P, LL, LL, LL, F, I, P]),
+    'pk_ce_finalize': (I, [P, P, P, LL, LL, P, P]),
+    'pk_colsum_workspace': (SZ, [LL, LL]),
+    'pk_colsum': (I, [P, LL, P, LL, LL, P, SZ, I, P]),
+    'pk_dropout': (I, [P, P, LL, F, ULL, ULL, I, P]),
+    'pk_scale': (I, [P, P, LL, P, F, I, P]),
 }
 
 _lib = None

@@ -170,3 +170,181 @@ def test_dropout_residual_ln_mask_consistency(F, dtype):
     assert torch.equal(dx != 0, kept)
     _, z2, _, _ = F.residual_ln_fwd(x, res, None, None, 1e-5, drop_p=p, seed=1234, offset=8)
     assert not torch.equal(z2 != 0, kept)  # a different offset gives an independent mask
+
+
+# ------------------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------------------
+def _attn_oracle(q, k, v, H, key_pad, causal, scale, dy):
+    B, T, D = q.shape
+    hd = D // H
+    q = q.clone().requires_grad_()
+    k = k.clone().requires_grad_()
+    v = v.clone().requires_grad_()
+    out, _ = O.attention_core(q.view(B, T, H, hd), k.view(B, -1, H, hd), v.view(B, -1, H, hd), key_pad, causal, scale)
+    out = out.reshape(B, T, D)
+    out.backward(dy)
+    return out.detach(), q.grad, k.grad, v.grad
+
+
+ATTN_CASES = [
+    # B, H, T, S, causal, ragged
+    (2, 2, 5, 7, False, True),
+    (3, 8, 64, 64, False, True),
+    (2, 4, 128, 128, True, False),
+    (2, 2, 100, 100, True, False),
+    (1, 2, 130, 257, False, True),     # several key tiles, ragged tails
+    (2, 2, 1, 9, True, False),          # incremental decoding step: one query, S > T
+    (2, 2, 3, 70, True, False),         # causal with offset S - T
+    (2, 1, 200, 200, True, False),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,H,T,S,causal,ragged', ATTN_CASES)
+def test_attention_fwd_bwd(F, dtype, B, H, T, S, causal, ragged):
+    D = H * 64
+    q = rnd((B, T, D), 30, dtype)
+    k = rnd((B, S, D), 31, dtype)
+    v = rnd((B, S, D), 32, dtype)
+    dy = rnd((B, T, D), 33, dtype)
+    key_pad = None
+    if ragged:
+        lens = torch.randint(1, S + 1, (B,), generator=torch.Generator().manual_seed(34))
+        lens[0] = S
+        key_pad = O.len_to_mask(lens, S)
+    scale = 1.0 / 8.0
+    o_ref, dq_ref, dk_ref, dv_ref = _attn_oracle(q.float(), k.float(), v.float(), H, key_pad, causal, scale, dy.float())
+    kp = key_pad.cuda() if key_pad is not None else None
+    o, lse = F.attn_fwd(q.cuda(), k.cuda(), v.cuda(), H, kp, causal, scale)
+    # fp32: exact arithmetic, different summation order.  bf16: P and dS are rounded to bf16 for the MFMA
+    # (relative 2^-8), outputs rounded to bf16.
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(o, o_ref) < tol
+    dq, dk, dv = F.attn_bwd(q.cuda(), k.cuda(), v.cuda(), o, dy.cuda(), lse, H, kp, causal, scale)
+    assert rel_err(dq, dq_ref) < tol
+    assert rel_err(dk, dk_ref) < tol
+    assert rel_err(dv, dv_ref) < tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_attention_fully_masked_rows_and_strided_qkv(F, dtype):
+    """a batch row whose keys are all padding outputs zeros (reference: nan_to_num, modules.py:765); q/k/v are
+    column slices of one fused (B, T, 3D) projection buffer"""
+    B, H, T = 2, 2, 12
+    D = H * 64
+    qkv = rnd((B, T, 3 * D), 35, dtype).cuda()
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    key_pad = torch.zeros(B, T, dtype=torch.bool)
+    key_pad[1, :] = True
+    o, lse = F.attn_fwd(q, k, v, H, key_pad.cuda(), False, 0.125)
+    assert o[1].abs().max().item() == 0
+    o_ref, *_ = _attn_oracle(q.float().cpu(), k.float().cpu(), v.float().cpu(), H, key_pad, False, 0.125,
+                             torch.zeros(B, T, D))
+    assert rel_err(o, o_ref) < (1e-5 if dtype == torch.float32 else 2e-2)
+    dq, dk, dv = F.attn_bwd(q, k, v, o, torch.ones_like(o), lse, H, key_pad.cuda(), False, 0.125)
+    assert torch.isfinite(dq.float()).all() and dq[1].abs().max().item() == 0
+    assert dk[1].abs().max().item() == 0 and dv[1].abs().max().item() == 0
+
+
+def test_attention_online_softmax_rescale_branch(F):
+    """force the running max to jump in a later key tile (cdna guide rule 26): spike one key against one query"""
+    B, H, T, S = 1, 1, 40, 200
+    q = rnd((B, T, 64), 36, torch.bfloat16)
+    k = rnd((B, S, 64), 37, torch.bfloat16)
+    v = rnd((B, S, 64), 38, torch.bfloat16)
+    k[0, 150] = q[0, 7] * 4  # huge score for query 7 in the third key tile
+    o_ref, *_ = _attn_oracle(q.float(), k.float(), v.float(), H, None, False, 0.125, torch.zeros(B, T, 64))
+    o, _ = F.attn_fwd(q.cuda(), k.cuda(), v.cuda(), H, None, False, 0.125)
+    assert rel_err(o, o_ref) < 2e-2
+    assert (o[0, 7].float().cpu() - v[0, 150].float()).abs().max() < 0.05
+
+
+# ------------------------------------------------------------------------------------------------------------
+# embedding, cross-entropy, helpers
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_embedding_fwd_bwd(F, dtype):
+    V, d, B, T = 101, 128, 5, 17
+    E = rnd((V, d), 40, dtype, d ** -0.5)
+    pos = O.sinusoidal_table(64, d, 2).to(dtype)
+    ids = torch.randint(0, V, (B, T), generator=torch.Generator().manual_seed(41))
+    ids[0, 3] = 1
+    ids[2, :5] = 7  # repeated ids -> several rows add into the same gradient row
+    dout = rnd((B, T, d), 42, dtype)
+    scale = math.sqrt(d)
+    E32 = E.float().requires_grad_()
+    ref = E32[ids] * scale + pos.float()[2 + 3: 2 + 3 + T][None]
+    ref.backward(dout.float())
+    gref = E32.grad.clone()
+    gref[1] = 0  # padding_idx row receives no gradient (nn.Embedding(padding_idx=1), modules.py:905)
+    out = F.embed_fwd(ids.cuda(), E.cuda(), pos.cuda(), scale, 2 + 3)
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert rel_err(out, ref.detach()) < tol
+    dE = F.embed_bwd(ids.cuda(), dout.cuda(), V, 1, scale)
+    assert rel_err(dE, gref) < (1e-5 if dtype == torch.float32 else 8e-3)
+    assert dE[1].abs().max().item() == 0
+    # dropout: same mask forward and backward
+    out_d = F.embed_fwd(ids.cuda(), E.cuda(), None, 1.0, 0, drop_p=0.3, seed=5, offset=11)
+    kept = (out_d != 0) | (E.cuda()[ids.cuda()] == 0)
+    assert abs(kept.float().mean().item() - 0.7) < 0.03
+    ones = torch.ones(B, T, d, dtype=dtype).cuda()
+    ids_u = torch.arange(B * T).view(B, T) % V  # B*T <= V: every token its own row
+    if B * T <= V:
+        out_u = F.embed_fwd(ids_u.cuda(), E.cuda(), None, 1.0, 0, drop_p=0.3, seed=5, offset=11)
+        dE_u = F.embed_bwd(ids_u.cuda(), ones, V, -1, 1.0, drop_p=0.3, seed=5, offset=11)
+        fw_kept = (out_u != 0).view(B * T, d)
+        nz = E.cuda()[ids_u.cuda().view(-1)] != 0
+        assert torch.equal((dE_u[:B * T] != 0) & nz, fw_kept & nz)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('eps', [0.0, 0.1])
+@pytest.mark.parametrize('V', [8032, 101, 70376])
+def test_cross_entropy_rows(F, dtype, eps, V):
+    rows = 37
+    logits = rnd((rows, V), 50, dtype, 2.0)
+    target = torch.randint(4, V, (rows,), generator=torch.Generator().manual_seed(51))
+    target[5] = 1
+    target[20:23] = 1
+    x = logits.float().requires_grad_()
+    loss, nll, ntok = O.label_smoothed_ce(x, target, 1, eps)
+    loss.backward()
+    row_loss = torch.empty(rows, device='cuda')
+    row_nll = torch.empty(rows, device='cuda')
+    dl = torch.empty(rows, V, dtype=dtype, device='cuda')
+    F.ce_rows(logits.cuda(), target.cuda(), 1, eps, row_loss, row_nll, dlogits=dl)
+    sums = F.ce_finalize(row_loss, row_nll, target.cuda(), 1).cpu()
+    assert abs(sums[0].item() - loss.item()) <= 2e-6 * abs(loss.item())
+    assert abs(sums[1].item() - nll.item()) <= 2e-6 * abs(nll.item())
+    assert int(sums[2].item()) == int(ntok)
+    assert rel_err(dl, x.grad) < (1e-5 if dtype == torch.float32 else 8e-3)
+    assert dl[5].abs().max().item() == 0
+    # in-place variant (dlogits aliases logits)
+    lg = logits.cuda().clone()
+    F.ce_rows(lg, target.cuda(), 1, eps, row_loss, row_nll, dlogits=lg)
+    assert torch.equal(lg, dl)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N', [(1000, 512), (7, 2048), (33000, 1536), (50, 100), (3, 9)])
+def test_colsum(F, dtype, M, N):
+    x = rnd((M, N), 60, dtype)
+    out = F.colsum(x.cuda())
+    ref = x.double().sum(0)
+    assert ((out.double().cpu() - ref).abs().max() / ref.abs().max()).item() < (1e-5 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dropout_and_scale(F, dtype):
+    n = 100003
+    x = rnd((n,), 70, dtype).cuda()
+    y = F.dropout(x, 0.25, 9, 3)
+    kept = y != 0
+    assert abs(kept.float().mean().item() - 0.75) < 0.01
+    assert rel_err(y[kept], x[kept].float() / 0.75) < 1e-2
+    y2 = F.dropout(x, 0.25, 9, 3)
+    assert torch.equal(y, y2)
+    s = torch.tensor([3.0], device='cuda')
+    z = F.scale(x, s, 0.5)
+    assert rel_err(z, x.float() * 1.5) < (1e-6 if dtype == torch.float32 else 8e-3)
