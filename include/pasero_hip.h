@@ -81,7 +81,9 @@ int pk_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
 
 /* ---- Token + positional embedding (K1): replaces Embedding.forward, `*= embed_scale`, `+= positions`, Dropout,
  * pasero/models/modules.py:916-933,435-457,467-484; pasero/models/transformer.py:727-744,866-878.
- *   out[tok] = dropout( E[clip(ids[tok])] * scale + pos[pos_start + tok % Tlen] )      (pos may be NULL) */
+ *   out[tok] = dropout( E[clip(ids[tok])] * scale + pos[pos_start + tok % Tlen] )      (pos may be NULL)
+ *   ids == NULL: E is a dense (ntok, d) input, out[tok] = dropout(E[tok] * scale + pos[...]) — the speech path,
+ *   transformer.py:739-744 */
 int pk_embed_fwd(const long long* ids, const void* E, const void* pos, void* out, long long ntok, int Tlen, int d,
                  long long V, float scale, int pos_start, float drop_p, unsigned long long seed,
                  unsigned long long offset, int dtype, void* stream);
@@ -113,6 +115,18 @@ int pk_dropout(const void* x, void* out, long long n, float drop_p, unsigned lon
 /*   out = x * (*dev_scalar) * host_scalar   (dev_scalar: device fp32 scalar or NULL) */
 int pk_scale(const void* x, void* out, long long n, const float* dev_scalar, float host_scalar, int dtype,
              void* stream);
+
+/* ---- Speech frontend (K7) helpers: the Conv1d stack of ConvolutionSubsampler (pasero/models/modules.py:774-834) is
+ * run channels-last as pk_gemm calls on a strided window view of the zero-padded input; these are the pieces around.
+ *   pk_act_fwd: out = act(x)        pk_act_bwd: out = dy * act'(x)          (modules.py:220-228)
+ *   pk_glu_*:   x [rows][2C] -> a * sigmoid(b)  (nn.GLU over channels, modules.py:802) and its backward
+ *   pk_col2im1d: dx[b][l][c] = sum_j dA[b*R + r][j*C + c] over r*stride + j - pad == l, r < Lout  (conv input grad) */
+int pk_act_fwd(const void* x, void* out, long long n, int act, int dtype, void* stream);
+int pk_act_bwd(const void* dy, const void* x, void* out, long long n, int act, int dtype, void* stream);
+int pk_glu_fwd(const void* x, void* out, long long rows, int C, int dtype, void* stream);
+int pk_glu_bwd(const void* dy, const void* x, void* dx, long long rows, int C, int dtype, void* stream);
+int pk_col2im1d(const void* dA, void* dx, int B, int L, int C, int R, int Lout, int ksize, int stride, int pad,
+                int dtype, void* stream);
 
 #ifdef __cplusplus
 }

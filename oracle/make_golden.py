@@ -141,7 +141,8 @@ def gen_encdec(name, V, B, S, T, seed, store_grads='full', **overrides):
     }
     grads = {k: p.grad for k, p in model.named_parameters()}
     out['grad_names'] = np.array(list(grads))
-    out['grad_norms'] = np.array([g.norm().item() for g in grads.values()])
+    out['grad_norms'] = np.array([g.double().norm().item() for g in grads.values()])  # fp64: the fp32 CPU norm of a
+    # 4M-element tensor is off by 4e-4
     out['grad_sums'] = np.array([g.double().sum().item() for g in grads.values()])
     if store_grads == 'full':
         for k, g in grads.items():
@@ -307,7 +308,7 @@ def gen_speech():
             if 'subsample' in k or 'in_linear' in k:
                 out['grad:' + k] = npy(p.grad)
         out['grad_names'] = np.array([k for k, _ in model.named_parameters()])
-        out['grad_norms'] = np.array([p.grad.norm().item() for _, p in model.named_parameters()])
+        out['grad_norms'] = np.array([p.grad.double().norm().item() for _, p in model.named_parameters()])
         with torch.no_grad():
             x = feats.detach()
             if model.encoder.in_linear is not None:

@@ -1,0 +1,448 @@
+"""torch.autograd.Function wrappers: each one is a forward + a hand-written backward made of C-ABI kernel calls
+(pasero_amd.functional).  PyTorch's autograd engine is only the glue that orders them; no aten compute op runs
+on the hot path.
+"""
+import math
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import functional as F
+from . import rng
+
+
+def _2d(x: Tensor) -> Tensor:
+    return x.reshape(-1, x.size(-1))
+
+
+def _contig(x: Tensor) -> Tensor:
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def weight_grad(dy2d: Tensor, x2d: Tensor) -> Tensor:
+    """dW[N,K] = dyᵀ x : both operands in "col" form (contraction over the rows), split-K when the output is small"""
+    M = dy2d.size(0)
+    N, K = dy2d.size(1), x2d.size(1)
+    return F.gemm(dy2d, x2d, a_col=True, b_col=True, splitk=F.choose_splitk(N, K, M))
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x Wᵀ + b)   (pasero/models/modules.py:92-96 + the activation that follows fc1)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act: str = 'none'):
+        x2 = _2d(_contig(x))
+        need_pre = act not in ('none', 'relu') and any(ctx.needs_input_grad)
+        pre = torch.empty(x2.size(0), weight.size(0), dtype=x.dtype, device=x.device) if need_pre else None
+        y = F.gemm(x2, weight, bias=bias, act=act, preact=pre)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x2, weight, pre if need_pre else (y if act == 'relu' else None))
+        return y.view(*x.shape[:-1], weight.size(0))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, aux = ctx.saved_tensors
+        dy2 = _2d(_contig(dy))
+        if ctx.act != 'none':
+            dy2 = F.act_bwd(dy2, aux, ctx.act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = F.gemm(dy2, weight, b_col=True).view(*dy.shape[:-1], weight.size(1))
+        if ctx.needs_input_grad[1]:
+            dw = weight_grad(dy2, x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = F.colsum(dy2)
+        return dx, dw, db, None
+
+
+class FFNFn(torch.autograd.Function):
+    """y = fc2(act(fc1(x)))   (pasero/models/transformer.py:999-1019, 1224-1244; no fc3, no activation dropout).
+    Backward fuses act'(.) into the epilogue of the dH = dY·W2 GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act: str):
+        x2 = _2d(_contig(x))
+        grad = any(ctx.needs_input_grad)  # (grad mode is always off inside Function.forward)
+        need_pre = grad and act not in ('none', 'relu')
+        pre = torch.empty(x2.size(0), w1.size(0), dtype=x.dtype, device=x.device) if need_pre else None
+        h = F.gemm(x2, w1, bias=b1, act=act, preact=pre)
+        y = F.gemm(h, w2, bias=b2)
+        ctx.act = act
+        ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+        ctx.save_for_backward(x2, w1, w2, h, pre)
+        return y.view(*x.shape[:-1], w2.size(0))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, h, pre = ctx.saved_tensors
+        dy2 = _2d(_contig(dy))
+        aux = h if pre is None else pre
+        if ctx.act == 'none':
+            dh = F.gemm(dy2, w2, b_col=True)
+        else:
+            dh = F.gemm(dy2, w2, b_col=True, act=ctx.act, aux=aux, mode=2)
+        dw2 = weight_grad(dy2, h) if ctx.needs_input_grad[3] else None
+        db2 = F.colsum(dy2) if ctx.has_b2 and ctx.needs_input_grad[4] else None
+        dx = F.gemm(dh, w1, b_col=True).view(*dy.shape[:-1], w1.size(1)) if ctx.needs_input_grad[0] else None
+        dw1 = weight_grad(dh, x2) if ctx.needs_input_grad[1] else None
+        db1 = F.colsum(dh) if ctx.has_b1 and ctx.needs_input_grad[2] else None
+        return dx, dw1, db1, dw2, db2, None
+
+
+class PackedLinearFn(torch.autograd.Function):
+    """y = x · W_flatᵀ + b_flat where W_flat [n*D, K] is the flat arena holding `n` projection weights back to back
+    (q|k|v or k|v, pasero/models/modules.py:610-615).  ONE GEMM reads x once; the gradient of each nn.Parameter is the
+    matching slice of one flat gradient GEMM.  `params` = n weights followed by n biases (or None)."""
+
+    @staticmethod
+    def forward(ctx, x, w_flat, b_flat, n: int, *params):
+        x2 = _2d(_contig(x))
+        y = F.gemm(x2, w_flat, bias=b_flat)
+        ctx.n = n
+        ctx.has_bias = [p is not None for p in params[n:]]
+        ctx.save_for_backward(x2, w_flat)
+        return y.view(*x.shape[:-1], w_flat.size(0))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w_flat = ctx.saved_tensors
+        n = ctx.n
+        dy2 = _2d(_contig(dy))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = F.gemm(dy2, w_flat, b_col=True).view(*dy.shape[:-1], w_flat.size(1))
+        D = w_flat.size(0) // n
+        grads = [None] * (2 * n)
+        if any(ctx.needs_input_grad[4:4 + n]):
+            dw = weight_grad(dy2, x2)
+            for i in range(n):
+                if ctx.needs_input_grad[4 + i]:
+                    grads[i] = dw[i * D:(i + 1) * D]
+        if any(ctx.has_bias[i] and ctx.needs_input_grad[4 + n + i] for i in range(n)):
+            db = F.colsum(dy2)
+            for i in range(n):
+                if ctx.has_bias[i] and ctx.needs_input_grad[4 + n + i]:
+                    grads[n + i] = db[i * D:(i + 1) * D]
+        return (dx, None, None, None, *grads)
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q kᵀ * scale + masks) v on projection outputs, without reshapes or transposes:
+       self-attention:  a = packed (B,T,3D) [q|k|v], b = c = None      -> backward returns one (B,T,3D) tensor
+       cross-attention: a = q (B,T,D), b = packed (B,S,2D) [k|v], c = None
+       general:         a = q, b = k, c = v
+    (pasero/models/modules.py:654-720)"""
+
+    @staticmethod
+    def _split(a, b, c):
+        if b is None:
+            D = a.size(-1) // 3
+            return D, a[..., :D], a[..., D:2 * D], a[..., 2 * D:]
+        if c is None:
+            D = a.size(-1)
+            return D, a, b[..., :D], b[..., D:]
+        return a.size(-1), a, b, c
+
+    @staticmethod
+    def forward(ctx, a, b, c, key_pad, num_heads: int, causal: bool, scale: float):
+        D, q, k, v = AttentionFn._split(a, b, c)
+        o, lse = F.attn_fwd(q, k, v, num_heads, key_pad, causal, scale)
+        ctx.num_heads, ctx.causal, ctx.scale = num_heads, causal, scale
+        ctx.save_for_backward(a, b, c, key_pad, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        a, b, c, key_pad, o, lse = ctx.saved_tensors
+        D, q, k, v = AttentionFn._split(a, b, c)
+        da = torch.empty_like(a)
+        db = torch.empty_like(b) if b is not None else None
+        dc = torch.empty_like(c) if c is not None else None
+        _, dq, dk, dv = AttentionFn._split(da, db, dc)
+        F.attn_bwd(q, k, v, o, _contig(d_o), lse, ctx.num_heads, key_pad, ctx.causal, ctx.scale, dq=dq, dk=dk, dv=dv)
+        return da, db, dc, None, None, None, None
+
+
+class ResidualLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(residual + dropout(x)) in one pass (post-norm blocks, pasero/models/transformer.py:1043-1048);
+    with residual=None and p=0 it is a plain LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps: float, p: float):
+        x = _contig(x)
+        residual = _contig(residual) if residual is not None else None
+        seed, offset = rng.next_offset() if p > 0 else (0, 0)
+        fused = residual is not None or p > 0
+        y, z, mean, rstd = F.residual_ln_fwd(x, residual, gamma, beta, eps, p, seed, offset,
+                                             want_z=fused and any(ctx.needs_input_grad))
+        ctx.p, ctx.seed, ctx.offset = p, seed, offset
+        ctx.has_res, ctx.has_beta = residual is not None, beta is not None
+        ctx.save_for_backward(z if fused else x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, gamma, mean, rstd = ctx.saved_tensors
+        dy = _contig(dy)
+        want_pg = ctx.needs_input_grad[2] or (ctx.has_beta and ctx.needs_input_grad[3])
+        need_dx = ctx.needs_input_grad[0]
+        dres, dx, dgamma, dbeta = F.residual_ln_bwd(
+            dy, None, z, gamma, mean, rstd, want_dres=True, want_dx=need_dx and ctx.p > 0,
+            want_param_grads=want_pg, has_beta=ctx.has_beta, drop_p=ctx.p, seed=ctx.seed, offset=ctx.offset)
+        if ctx.p == 0:
+            dx = dres
+        return (dx if need_dx else None, dres if ctx.has_res else None, dgamma,
+                dbeta if ctx.has_beta else None, None, None)
+
+
+class ResidualDropoutFn(torch.autograd.Function):
+    """z = residual + dropout(x)   (pre-norm blocks: pasero/models/transformer.py:1043-1044,1049-1050)"""
+
+    @staticmethod
+    def forward(ctx, x, residual, p: float):
+        x, residual = _contig(x), _contig(residual)
+        seed, offset = rng.next_offset() if p > 0 else (0, 0)
+        _, z, _, _ = F.residual_ln_fwd(x, residual, None, None, 0.0, p, seed, offset)
+        ctx.p, ctx.seed, ctx.offset = p, seed, offset
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        dz = _contig(dz)
+        dx = dz
+        if ctx.p > 0 and ctx.needs_input_grad[0]:
+            dx = F.dropout(dz, ctx.p, ctx.seed, ctx.offset)
+        return dx, dz, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout with a regenerable Philox mask"""
+
+    @staticmethod
+    def forward(ctx, x, p: float):
+        ctx.p = p
+        ctx.seed, ctx.offset = rng.next_offset()
+        return F.dropout(_contig(x), p, ctx.seed, ctx.offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return F.dropout(_contig(dy), ctx.p, ctx.seed, ctx.offset), None
+
+
+class EmbeddingFn(torch.autograd.Function):
+    """dropout(E[ids] * scale + pos[pos_start : pos_start+T])
+    (pasero/models/modules.py:916-933; pasero/models/transformer.py:727-744, 866-878)"""
+
+    @staticmethod
+    def forward(ctx, ids, weight, pos_table, scale: float, pos_start: int, p: float, padding_idx: int):
+        ids = _contig(ids)
+        seed, offset = rng.next_offset() if p > 0 else (0, 0)
+        out = F.embed_fwd(ids, weight, pos_table, scale, pos_start, p, seed, offset)
+        ctx.args = (scale, pos_start, p, seed, offset, padding_idx, weight.size(0))
+        ctx.pos_rows = pos_table.size(0) if pos_table is not None else 0
+        ctx.save_for_backward(ids)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        scale, pos_start, p, seed, offset, padding_idx, V = ctx.args
+        dout = _contig(dout)
+        dE = dpos = None
+        if ctx.needs_input_grad[1]:
+            dE = F.embed_bwd(ids, dout, V, padding_idx, scale, p, seed, offset)
+        if ctx.needs_input_grad[2]:  # learned positions: sum over the batch of the (masked) gradient
+            B, T, d = dout.shape
+            dm = F.dropout(dout, p, seed, offset) if p > 0 else dout
+            rows = F.colsum(dm.view(B, T * d)).view(T, d)
+            dpos = torch.zeros(ctx.pos_rows, d, dtype=dout.dtype, device=dout.device)
+            dpos[pos_start:pos_start + T] = rows
+        return None, dE, dpos, None, None, None, None
+
+
+def _ce_chunk_rows(rows: int, V: int, itemsize: int, budget_bytes: int = 128 << 20) -> int:
+    """rows per logits chunk so that one chunk stays resident in the 256 MiB Infinity Cache between the GEMM that
+    writes it, the CE kernel that rewrites it in place and the two gradient GEMMs that read it"""
+    per = max(1, budget_bytes // (V * itemsize))
+    per = max(128, (per // 128) * 128)
+    return min(rows, per)
+
+
+class VocabCrossEntropyFn(torch.autograd.Function):
+    """Tied vocabulary projection + label-smoothed cross-entropy, chunked over rows so the (rows, V) logits never
+    exist as a whole (pasero/models/modules.py:935-947 + pasero/models/transformer.py:354-380).
+    Returns sums = [loss, nll_loss, num_tokens] (fp32, device).  Only sums[0] is differentiable.
+    The gradient chunks dX, dW are produced in the forward pass (the logits chunk is still cache-resident) and only
+    multiplied by the incoming scalar gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, target, padding_idx: int, eps: float):
+        x2 = _2d(_contig(x))
+        tgt = _contig(target).view(-1)
+        rows, V = x2.size(0), weight.size(0)
+        grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        row_loss = torch.empty(rows, dtype=torch.float32, device=x.device)
+        row_nll = torch.empty(rows, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x2) if grad else None
+        dw = None
+        step = _ce_chunk_rows(rows, V, x.element_size())
+        logits = torch.empty(step, V, dtype=x.dtype, device=x.device)
+        for r0 in range(0, rows, step):
+            r1 = min(rows, r0 + step)
+            lg = logits[: r1 - r0]
+            F.gemm(x2[r0:r1], weight, out=lg)
+            F.ce_rows(lg, tgt[r0:r1], padding_idx, eps, row_loss[r0:r1], row_nll[r0:r1],
+                      dlogits=lg if grad else None)
+            if grad:
+                F.gemm(lg, weight, b_col=True, out=dx[r0:r1])
+                if dw is None:
+                    dw = F.gemm(lg, x2[r0:r1], a_col=True, b_col=True)
+                else:
+                    F.gemm(lg, x2[r0:r1], a_col=True, b_col=True, aux=dw, mode=1, out=dw)
+        sums = F.ce_finalize(row_loss, row_nll, tgt, padding_idx)
+        ctx.x_shape = x.shape
+        if grad:
+            ctx.save_for_backward(dx, dw)
+        return sums
+
+    @staticmethod
+    def backward(ctx, dsums):
+        dx, dw = ctx.saved_tensors
+        g = _contig(dsums)[:1].float()  # d(total)/d(loss); nll / num_tokens are logging outputs
+        gx = F.scale(dx, g).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        gw = F.scale(dw, g) if ctx.needs_input_grad[1] else None
+        return gx, gw, None, None, None
+
+
+class ActivationFn(torch.autograd.Function):
+    """stand-alone activation (non-fused fallback of pasero/models/modules.py:220-228)"""
+
+    @staticmethod
+    def forward(ctx, x, act: str):
+        x = _contig(x)
+        ctx.act = act
+        ctx.save_for_backward(x)
+        return F.act_fwd(x, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return F.act_bwd(_contig(dy), x, ctx.act), None
+
+
+class GLUFn(torch.autograd.Function):
+    """nn.GLU over the channel (last) dim of a channels-last tensor (pasero/models/modules.py:802)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(x)
+        ctx.save_for_backward(x)
+        return F.glu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return F.glu_bwd(_contig(dy), x)
+
+
+class Conv1dChannelsLastFn(torch.autograd.Function):
+    """nn.Conv1d(C_in, C_out, k, stride, padding) + optional activation on a channels-last (B, L, C_in) input
+    (pasero/models/modules.py:793-799,829-833) as an implicit GEMM: with R = ceil((L+2p)/stride) rows per batch, row r
+    of the im2col matrix is the contiguous window x_pad[b, r*stride : r*stride+k, :] — a strided VIEW (lda =
+    stride*C_in), never materialised.  `weight` keeps the nn.Conv1d layout (C_out, C_in, k)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride: int, padding: int, act: str):
+        B, L, C = x.shape
+        O, _, k = weight.shape
+        Lout = (L + 2 * padding - k) // stride + 1
+        R = -(-(L + 2 * padding) // stride)
+        Lp = R * stride
+        xp = x.new_zeros(B * Lp + k, C)  # + k rows: the windows of the last (discarded) rows stay in bounds
+        xp[:B * Lp].view(B, Lp, C)[:, padding:padding + L] = x
+        A = torch.as_strided(xp, (B * R, k * C), (stride * C, 1))
+        wr = weight.permute(0, 2, 1).reshape(O, k * C).contiguous()  # [o][(j, c)]
+        need_pre = act != 'none' and any(ctx.needs_input_grad)
+        pre = torch.empty(B * R, O, dtype=x.dtype, device=x.device) if need_pre else None
+        y = F.gemm(A, wr, bias=bias, act=act, preact=pre)
+        ctx.geom = (B, L, C, O, k, stride, padding, Lout, R)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(xp, wr, pre)
+        return y.view(B, R, O)[:, :Lout].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wr, pre = ctx.saved_tensors
+        B, L, C, O, k, stride, padding, Lout, R = ctx.geom
+        dyf = dy.new_zeros(B, R, O)
+        dyf[:, :Lout] = dy
+        dz = dyf.view(B * R, O)
+        if ctx.act != 'none':
+            dz = F.act_bwd(dz, pre, ctx.act)
+        A = torch.as_strided(xp, (B * R, k * C), (stride * C, 1))
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dA = F.gemm(dz, wr, b_col=True)
+            dx = F.col2im1d(dA, B, L, C, R, Lout, k, stride, padding)
+        if ctx.needs_input_grad[1]:
+            dwr = F.gemm(dz, A, a_col=True, b_col=True, splitk=F.choose_splitk(O, k * C, B * R))
+            dw = dwr.view(O, k, C).permute(0, 2, 1).contiguous()
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = F.colsum(dz)
+        return dx, dw, db, None, None, None
+
+
+class AddPositionsFn(torch.autograd.Function):
+    """dropout(x * scale + pos[pos_start : pos_start+T]) for dense (speech) encoder inputs
+    (pasero/models/transformer.py:739-744)"""
+
+    @staticmethod
+    def forward(ctx, x, pos_table, scale: float, pos_start: int, p: float):
+        x = _contig(x)
+        seed, offset = rng.next_offset() if p > 0 else (0, 0)
+        ctx.args = (scale, pos_start, p, seed, offset)
+        ctx.pos_rows = pos_table.size(0) if pos_table is not None else 0
+        return F.add_positions(x, pos_table, scale, pos_start, p, seed, offset)
+
+    @staticmethod
+    def backward(ctx, dout):
+        scale, pos_start, p, seed, offset = ctx.args
+        dout = _contig(dout)
+        dm = F.dropout(dout, p, seed, offset) if p > 0 else dout
+        dx = dpos = None
+        if ctx.needs_input_grad[0]:
+            dx = dm if scale == 1.0 else F.scale(dm, None, scale)
+        if ctx.needs_input_grad[1]:
+            B, T, d = dout.shape
+            rows = F.colsum(dm.view(B, T * d)).view(T, d)
+            dpos = torch.zeros(ctx.pos_rows, d, dtype=dout.dtype, device=dout.device)
+            dpos[pos_start:pos_start + T] = rows
+        return dx, dpos, None, None, None
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """Label-smoothed cross-entropy on materialised logits (the reference API `compute_loss(logits, target, ...)`,
+    pasero/models/transformer.py:324-380).  Returns sums = [loss, nll_loss, num_tokens]."""
+
+    @staticmethod
+    def forward(ctx, logits, target, padding_idx: int, eps: float):
+        lg = _2d(_contig(logits))
+        tgt = _contig(target).view(-1)
+        rows = lg.size(0)
+        row_loss = torch.empty(rows, dtype=torch.float32, device=lg.device)
+        row_nll = torch.empty(rows, dtype=torch.float32, device=lg.device)
+        grad = ctx.needs_input_grad[0]
+        dl = torch.empty_like(lg) if grad else None
+        F.ce_rows(lg, tgt, padding_idx, eps, row_loss, row_nll, dlogits=dl)
+        ctx.shape = logits.shape
+        if grad:
+            ctx.save_for_backward(dl)
+        return F.ce_finalize(row_loss, row_nll, tgt, padding_idx)
+
+    @staticmethod
+    def backward(ctx, dsums):
+        (dl,) = ctx.saved_tensors
+        return F.scale(dl, _contig(dsums)[:1].float()).view(ctx.shape), None, None, None

@@ -1,0 +1,143 @@
+// Elementwise helpers of the speech frontend (K7) and of the non-fused fallback paths:
+//   activation fwd/bwd (pasero/models/modules.py:220-228), GLU over the channel dim (modules.py:802, nn.GLU),
+//   col2im for the Conv1d input gradient (modules.py:793-799 backward).
+// HBM-bound: 16-byte accesses, grid-stride over <= 2048 workgroups.
+#include "common.h"
+
+namespace {
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                  T* __restrict__ out, long long n, int act) {
+    constexpr int EPV = 16 / sizeof(T);
+    const long long nvec = n / EPV;
+    for (long long ch = (long long)blockIdx.x * 256 + threadIdx.x; ch < nvec; ch += (long long)gridDim.x * 256) {
+        Vec16<T> xv = load16<T>(x + ch * EPV), o, g;
+        if (BWD) g = load16<T>(dy + ch * EPV);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) o.set(e, BWD ? g.get(e) * act_bwd(act, xv.get(e)) : act_fwd(act, xv.get(e)));
+        store16<T>(out + ch * EPV, o);
+    }
+    if (blockIdx.x == 0)
+        for (long long i = nvec * EPV + threadIdx.x; i < n; i += 256) {
+            float xv = to_f32<T>(x[i]);
+            out[i] = from_f32<T>(BWD ? to_f32<T>(dy[i]) * act_bwd(act, xv) : act_fwd(act, xv));
+        }
+}
+
+// x [rows][2C] -> out [rows][C] = a * sigmoid(b)
+template <typename T>
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, long long rows,
+                                                      int C) {
+    long long total = rows * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long r = i / C;
+        int c = (int)(i % C);
+        float a = to_f32<T>(x[r * 2 * C + c]), b = to_f32<T>(x[r * 2 * C + C + c]);
+        out[i] = from_f32<T>(a / (1.f + __expf(-b)));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                      T* __restrict__ dx, long long rows, int C) {
+    long long total = rows * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long r = i / C;
+        int c = (int)(i % C);
+        float a = to_f32<T>(x[r * 2 * C + c]), b = to_f32<T>(x[r * 2 * C + C + c]), g = to_f32<T>(dy[i]);
+        float s = 1.f / (1.f + __expf(-b));
+        dx[r * 2 * C + c] = from_f32<T>(g * s);
+        dx[r * 2 * C + C + c] = from_f32<T>(g * a * s * (1.f - s));
+    }
+}
+
+// dx[b][l][c] = sum_{j} dA[b*R + r][j*C + c]  over (r, j) with r*stride + j - pad == l, 0 <= r < Lout
+template <typename T>
+__global__ __launch_bounds__(256) void col2im1d_kernel(const T* __restrict__ dA, T* __restrict__ dx, int B, int L,
+                                                       int C, int R, int Lout, int ksize, int stride, int pad) {
+    long long total = (long long)B * L * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int c = (int)(i % C);
+        long long t = i / C;
+        int l = (int)(t % L), b = (int)(t / L);
+        float s = 0.f;
+        for (int j = 0; j < ksize; ++j) {
+            int num = l + pad - j;
+            if (num < 0 || num % stride) continue;
+            int r = num / stride;
+            if (r >= Lout) continue;
+            s += to_f32<T>(dA[((long long)b * R + r) * ksize * C + (long long)j * C + c]);
+        }
+        dx[i] = from_f32<T>(s);
+    }
+}
+
+inline int grid_for(long long work, int per_block) {
+    long long b = (work + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+}  // namespace
+
+#define PK_DTYPE_SWITCH(dtype, who, ...)                                   \
+    if (dtype == PK_BF16) { using T = bf16; __VA_ARGS__ }                  \
+    else if (dtype == PK_F32) { using T = float; __VA_ARGS__ }             \
+    else { PK_CHECK_ARG(false, "%s: dtype %d not supported", who, dtype); }
+
+extern "C" int pk_act_fwd(const void* x, void* out, long long n, int act, int dtype, void* stream) {
+    PK_CHECK_ARG(x && out, "pk_act_fwd: null tensor");
+    PK_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0, "pk_act_fwd: 16-byte alignment required");
+    if (n == 0) return 0;
+    PK_DTYPE_SWITCH(dtype, "pk_act_fwd", {
+        hipLaunchKernelGGL((act_kernel<T, false>), dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)nullptr, (const T*)x, (T*)out, n, act);
+    })
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_act_bwd(const void* dy, const void* x, void* out, long long n, int act, int dtype, void* stream) {
+    PK_CHECK_ARG(dy && x && out, "pk_act_bwd: null tensor");
+    PK_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)dy % 16) == 0,
+                 "pk_act_bwd: 16-byte alignment required");
+    if (n == 0) return 0;
+    PK_DTYPE_SWITCH(dtype, "pk_act_bwd", {
+        hipLaunchKernelGGL((act_kernel<T, true>), dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)dy, (const T*)x, (T*)out, n, act);
+    })
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_glu_fwd(const void* x, void* out, long long rows, int C, int dtype, void* stream) {
+    PK_CHECK_ARG(x && out && C > 0, "pk_glu_fwd: bad arguments");
+    if (rows == 0) return 0;
+    PK_DTYPE_SWITCH(dtype, "pk_glu_fwd", {
+        hipLaunchKernelGGL((glu_fwd_kernel<T>), dim3(grid_for(rows * C, 1024)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)x, (T*)out, rows, C);
+    })
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_glu_bwd(const void* dy, const void* x, void* dx, long long rows, int C, int dtype, void* stream) {
+    PK_CHECK_ARG(dy && x && dx && C > 0, "pk_glu_bwd: bad arguments");
+    if (rows == 0) return 0;
+    PK_DTYPE_SWITCH(dtype, "pk_glu_bwd", {
+        hipLaunchKernelGGL((glu_bwd_kernel<T>), dim3(grid_for(rows * C, 1024)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)dy, (const T*)x, (T*)dx, rows, C);
+    })
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_col2im1d(const void* dA, void* dx, int B, int L, int C, int R, int Lout, int ksize, int stride,
+                           int pad, int dtype, void* stream) {
+    PK_CHECK_ARG(dA && dx && stride > 0 && ksize > 0, "pk_col2im1d: bad arguments");
+    if ((long long)B * L * C == 0) return 0;
+    PK_DTYPE_SWITCH(dtype, "pk_col2im1d", {
+        hipLaunchKernelGGL((col2im1d_kernel<T>), dim3(grid_for((long long)B * L * C, 1024)), dim3(256), 0,
+                           (hipStream_t)stream, (const T*)dA, (T*)dx, B, L, C, R, Lout, ksize, stride, pad);
+    })
+    PK_LAUNCH_CHECK();
+    return 0;
+}

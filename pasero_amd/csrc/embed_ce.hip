@@ -24,8 +24,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunks = d / EPV;
     for (long long tok = (long long)blockIdx.x * 4 + wave; tok < ntok; tok += (long long)gridDim.x * 4) {
-        long long id = ids[tok];
-        id = id < 0 ? 0 : (id >= V ? V - 1 : id);  // modules.py:923 clip(min=0); upper clamp keeps the read in bounds
+        long long id = ids ? ids[tok] : tok;  // ids == NULL: E is a dense (ntok, d) input (speech features path)
+        if (ids) id = id < 0 ? 0 : (id >= V ? V - 1 : id);  // modules.py:923 clip(min=0); upper clamp: stay in bounds
         const T* erow = E + id * d;
         const T* prow = pos ? pos + (long long)(pos_start + (int)(tok % Tlen)) * d : nullptr;
         for (int ch = lane; ch < nchunks; ch += 64) {
@@ -312,7 +312,7 @@ inline bool is_aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 extern "C" int pk_embed_fwd(const long long* ids, const void* E, const void* pos, void* out, long long ntok, int Tlen,
                             int d, long long V, float scale, int pos_start, float drop_p, unsigned long long seed,
                             unsigned long long offset, int dtype, void* stream) {
-    PK_CHECK_ARG(ids && E && out, "pk_embed_fwd: null tensor");
+    PK_CHECK_ARG(E && out, "pk_embed_fwd: null tensor");
     PK_CHECK_ARG(Tlen > 0 && V > 0, "pk_embed_fwd: bad sizes");
     PK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pk_embed_fwd: bad dropout %f", drop_p);
     if (ntok == 0) return 0;

@@ -164,6 +164,22 @@ def embed_fwd(ids: Tensor, E: Tensor, pos: Optional[Tensor], scale: float, pos_s
     return out
 
 
+def add_positions(x: Tensor, pos: Optional[Tensor], scale: float, pos_start: int, drop_p: float = 0.0, seed: int = 0,
+                  offset: int = 0) -> Tensor:
+    """x (B,T,d) dense features -> dropout(x * scale + pos[pos_start : pos_start+T])"""
+    require_gpu(x, pos)
+    B, T, d = x.shape
+    assert x.is_contiguous()
+    if pos is not None:
+        assert pos.dtype == x.dtype and pos.is_contiguous() and pos_start + T <= pos.size(0), \
+            f'input sequence is too long: {T}, positional embedding size: {pos.size(0)}'
+    out = torch.empty_like(x)
+    L = lib.load()
+    check(L.pk_embed_fwd(None, ptr(x), ptr(pos), ptr(out), B * T, T, d, B * T, float(scale), int(pos_start),
+                         float(drop_p), int(seed), int(offset), dtype_code(x), stream_ptr()), 'pk_embed_fwd')
+    return out
+
+
 def embed_bwd(ids: Tensor, dout: Tensor, V: int, pad_idx: int, scale: float, drop_p: float = 0.0, seed: int = 0,
               offset: int = 0) -> Tensor:
     require_gpu(ids, dout)
@@ -233,3 +249,48 @@ def scale(x: Tensor, dev_scalar: Optional[Tensor], host_scalar: float = 1.0, out
     check(L.pk_scale(ptr(x), ptr(out), x.numel(), ptr(dev_scalar), float(host_scalar), dtype_code(x), stream_ptr()),
           'pk_scale')
     return out
+
+
+def act_fwd(x: Tensor, act: str) -> Tensor:
+    require_gpu(x)
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    check(lib.load().pk_act_fwd(ptr(x), ptr(out), x.numel(), ACT[act], dtype_code(x), stream_ptr()), 'pk_act_fwd')
+    return out
+
+
+def act_bwd(dy: Tensor, x: Tensor, act: str) -> Tensor:
+    require_gpu(dy, x)
+    assert x.is_contiguous() and dy.is_contiguous()
+    out = torch.empty_like(x)
+    check(lib.load().pk_act_bwd(ptr(dy), ptr(x), ptr(out), x.numel(), ACT[act], dtype_code(x), stream_ptr()),
+          'pk_act_bwd')
+    return out
+
+
+def glu_fwd(x: Tensor) -> Tensor:
+    require_gpu(x)
+    assert x.is_contiguous() and x.size(-1) % 2 == 0
+    C = x.size(-1) // 2
+    out = torch.empty(*x.shape[:-1], C, dtype=x.dtype, device=x.device)
+    check(lib.load().pk_glu_fwd(ptr(x), ptr(out), x.numel() // (2 * C), C, dtype_code(x), stream_ptr()), 'pk_glu_fwd')
+    return out
+
+
+def glu_bwd(dy: Tensor, x: Tensor) -> Tensor:
+    require_gpu(dy, x)
+    assert x.is_contiguous() and dy.is_contiguous()
+    C = x.size(-1) // 2
+    dx = torch.empty_like(x)
+    check(lib.load().pk_glu_bwd(ptr(dy), ptr(x), ptr(dx), x.numel() // (2 * C), C, dtype_code(x), stream_ptr()),
+          'pk_glu_bwd')
+    return dx
+
+
+def col2im1d(dA: Tensor, B: int, L: int, C: int, R: int, Lout: int, ksize: int, stride: int, pad: int) -> Tensor:
+    require_gpu(dA)
+    assert dA.is_contiguous() and dA.shape == (B * R, ksize * C)
+    dx = torch.empty(B, L, C, dtype=dA.dtype, device=dA.device)
+    check(lib.load().pk_col2im1d(ptr(dA), ptr(dx), B, L, C, R, Lout, ksize, stride, pad, dtype_code(dA),
+                                 stream_ptr()), 'pk_col2im1d')
+    return dx

@@ -35,6 +35,11 @@ SIGNATURES = {
     'pk_colsum': (I, [P, LL, P, LL, LL, P, SZ, I, P]),
     'pk_dropout': (I, [P, P, LL, F, ULL, ULL, I, P]),
     'pk_scale': (I, [P, P, LL, P, F, I, P]),
+    'pk_act_fwd': (I, [P, P, LL, I, I, P]),
+    'pk_act_bwd': (I, [P, P, P, LL, I, I, P]),
+    'pk_glu_fwd': (I, [P, P, LL, I, I, P]),
+    'pk_glu_bwd': (I, [P, P, P, LL, I, I, P]),
+    'pk_col2im1d': (I, [P, P, I, I, I, I, I, I, I, I, I, P]),
 }
 
 _lib = None

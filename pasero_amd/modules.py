@@ -1,0 +1,431 @@
+"""Host-side mirror of `pasero/models/modules.py` for the Transformer hot path: same class names, constructor
+arguments, parameter names/shapes (= checkpoint keys) and forward signatures, with every forward/backward routed to
+the HIP kernels of libpasero_hip.so.  Variants that are outside the hot-path scope (LoRA, tensor parallelism, ALiBi /
+T5 / rotary biases, grouped-query attention, attention-probability dropout) raise NotImplementedError loudly instead
+of silently falling back to eager PyTorch.
+"""
+import contextlib
+import functools
+import math
+from typing import Optional, Union
+
+import torch
+import torch.nn as nn
+from torch import Tensor, LongTensor, BoolTensor
+
+from . import functional as F
+from .autograd import (LinearFn, PackedLinearFn, AttentionFn, ResidualLayerNormFn, DropoutFn, EmbeddingFn,
+                       ActivationFn, GLUFn)
+
+
+class Identity(nn.Identity):
+    """nn.Identity whose forward accepts extra dummy arguments (modules.py:30-40)"""
+
+    def __init__(self, return_tuple: bool = False):
+        super().__init__()
+        self.return_tuple = return_tuple
+
+    def forward(self, input, *args, **kwargs):
+        return (input, *args) if self.return_tuple else input
+
+
+_fast_init = False
+
+
+@contextlib.contextmanager
+def fast_init(device=None, dtype=None):
+    """Skip random initialisation and create parameters directly with the target dtype/device (modules.py:45-64)"""
+    global _fast_init
+    old_dtype, old_flag = torch.get_default_dtype(), _fast_init
+    _fast_init = True
+    if dtype:
+        torch.set_default_dtype(dtype)
+    if device is not None:
+        torch.set_default_device(device)
+    try:
+        yield
+    finally:
+        _fast_init = old_flag
+        torch.set_default_dtype(old_dtype)
+        torch.set_default_device(None)
+
+
+def set_tp_group(tp_group=None):
+    """modules.py:174-176.  Tensor parallelism is out of the hot-path scope: only `None` is accepted."""
+    if tp_group is not None:
+        raise NotImplementedError('pasero_amd: tensor parallelism (--tp-size) is not implemented; use data parallelism')
+
+
+def set_sequence_parallel(enable: bool = True):
+    """modules.py:169-171 (no-op without tensor parallelism)"""
+    if enable:
+        raise NotImplementedError('pasero_amd: Megatron sequence parallelism is not implemented')
+
+
+class Linear(nn.Linear):
+    """nn.Linear running on the MFMA GEMM kernel (modules.py:67-100).  LoRA is out of scope."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
+                 lora_rank: int = 0, lora_alpha: int = 1):
+        if lora_rank:
+            raise NotImplementedError('pasero_amd: LoRA adapters are not implemented')
+        super().__init__(in_features, out_features, bias, device, dtype)
+        self.lora_rank, self.lora_alpha, self.lora = lora_rank, lora_alpha, None
+
+    def forward(self, input: Tensor) -> Tensor:
+        return LinearFn.apply(input, self.weight, self.bias, 'none')
+
+    def reset_parameters(self) -> None:
+        if not _fast_init:
+            super().reset_parameters()
+
+
+class WrappableLinear(Linear):
+    pass
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (transformer.py:941-947) on the wave-per-row HIP kernel"""
+
+    def forward(self, x: Tensor) -> Tensor:
+        return ResidualLayerNormFn.apply(x, None, self.weight, self.bias, self.eps, 0.0)
+
+
+class LayerNormWithoutBias(LayerNorm):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.bias = None
+
+
+class WrappableLayerNorm(LayerNorm):
+    pass
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim: int, eps: float = 1e-6):
+        super().__init__()
+        raise NotImplementedError('pasero_amd: RMSNorm (decoder-only LLM configs) is outside the hot-path scope')
+
+
+WrappableRMSNorm = RMSNorm
+
+
+class Dropout(nn.Dropout):
+    """nn.Dropout with an in-kernel Philox mask that the backward pass regenerates"""
+
+    def forward(self, x: Tensor) -> Tensor:
+        if not self.training or self.p == 0:
+            return x
+        return DropoutFn.apply(x, self.p)
+
+
+class Activation(nn.Module):
+    def __init__(self, name: str):
+        super().__init__()
+        self.name = name
+
+    def forward(self, x: Tensor) -> Tensor:
+        return ActivationFn.apply(x, self.name)
+
+
+def get_activation_fn(activation_fn: str = 'relu'):
+    """modules.py:220-228 — returns a module with `.name` (the fused FFN path reads it)"""
+    if activation_fn in ('gelu_tanh', 'geglu'):
+        return Activation('gelu_tanh')
+    if activation_fn == 'swiglu':
+        return Activation('silu')
+    if activation_fn == 'gelu':
+        return Activation('gelu')
+    return Activation('relu')
+
+
+def checkpoint_wrapper(module: nn.Module, activate: bool = True) -> nn.Module:
+    """modules.py:386-391"""
+    if activate:
+        from torch.utils.checkpoint import checkpoint
+        module._no_ckpt_forward = module.forward
+        module.forward = functools.partial(checkpoint, module._no_ckpt_forward, use_reentrant=False)
+    return module
+
+
+# ------------------------------------------------------------------------------------------------------------
+# positional embeddings
+# ------------------------------------------------------------------------------------------------------------
+def PositionalEmbedding(type: str, num_embeddings: int, embedding_dim: int, shift: int = 2):
+    """modules.py:394-404"""
+    if type in ('alibi', 'rotary', 't5'):
+        raise NotImplementedError(f"pasero_amd: '{type}' positional encoding is outside the hot-path scope")
+    if type == 'learned':
+        return LearnedPositionalEmbedding(num_embeddings, embedding_dim, shift=shift)
+    if type == 'sinusoidal':
+        return SinusoidalPositionalEmbedding(num_embeddings, embedding_dim, shift=shift)
+    raise NotImplementedError(type)
+
+
+class SinusoidalPositionalEmbedding(nn.Module):
+    """fairseq-style table [sin | cos], `shift` extra leading rows (modules.py:415-457).  The table is built once in
+    fp32 on the host; `table()` returns it on the model's device/dtype for the embedding kernel to add in place."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, shift: int = 0):
+        super().__init__()
+        self.shift = shift
+        self.embedding_dim = embedding_dim
+        n = num_embeddings + shift
+        half = embedding_dim // 2
+        step = math.log(10000) / (half - 1)
+        freq = torch.exp(torch.arange(half, dtype=torch.float) * -step)
+        ang = torch.arange(n, dtype=torch.float)[:, None] * freq[None, :]
+        weight = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+        if embedding_dim % 2 == 1:
+            weight = torch.cat([weight, torch.zeros(n, 1)], dim=1)
+        self.weight = weight
+        self.register_buffer('_float_tensor', torch.FloatTensor(1))  # follows module.to(): tells device and dtype
+        self._cache = None
+
+    def table(self) -> Tensor:
+        ref = self._float_tensor
+        if self._cache is None or self._cache.device != ref.device or self._cache.dtype != ref.dtype:
+            self._cache = self.weight.to(device=ref.device, dtype=ref.dtype).contiguous()
+        return self._cache
+
+    def check_length(self, length: int, offset: int = 0):
+        assert length + self.shift - 1 + offset < self.weight.size(0), (
+            f'input sequence is too long: {length}, positional embedding size: {self.weight.size(0)}')
+
+    def forward(self, length: int, offset: Union[LongTensor, int] = 0) -> Tensor:
+        if torch.is_tensor(offset):
+            raise NotImplementedError('pasero_amd: per-sequence position offsets are not implemented')
+        self.check_length(length, offset)
+        start = self.shift + offset
+        return self.table()[start:start + length][None]
+
+
+class LearnedPositionalEmbedding(nn.Embedding):
+    """modules.py:460-484"""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, shift: int = 0):
+        self.shift = shift
+        super().__init__(num_embeddings + shift, embedding_dim)
+        nn.init.normal_(self.weight, mean=0, std=embedding_dim ** -0.5)
+
+    def table(self) -> Tensor:
+        return self.weight
+
+    def check_length(self, length: int, offset: int = 0):
+        assert length + self.shift - 1 + offset < self.weight.size(0), (
+            f'input sequence is too long: {length}, positional embedding size: {self.weight.size(0)}')
+
+    def forward(self, length: int, offset: Union[LongTensor, int] = 0) -> Tensor:
+        if torch.is_tensor(offset):
+            raise NotImplementedError('pasero_amd: per-sequence position offsets are not implemented')
+        self.check_length(length, offset)
+        start = self.shift + offset
+        return self.weight[start:start + length][None]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# embeddings
+# ------------------------------------------------------------------------------------------------------------
+class Embedding(nn.Embedding):
+    """Token embedding + tied output projection (modules.py:890-947).  Partially frozen embeddings are out of scope."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, padding_idx: int,
+                 freeze_mask: Optional[BoolTensor] = None):
+        if freeze_mask is not None:
+            raise NotImplementedError('pasero_amd: partially frozen embeddings are not implemented')
+        super().__init__(num_embeddings, embedding_dim, padding_idx)
+        if not _fast_init:
+            nn.init.normal_(self.weight, mean=0, std=embedding_dim ** -0.5)
+            nn.init.constant_(self.weight[padding_idx], 0)
+        self.frozen_embedding = None
+
+    def forward(self, input: LongTensor) -> Tensor:
+        # the reference asserts `input.max() < V` here (a host sync per call, modules.py:924-926); the kernel clamps
+        return EmbeddingFn.apply(input, self.weight, None, 1.0, 0, 0.0, self.padding_idx)
+
+    def embed(self, input: LongTensor, pos_table: Optional[Tensor], scale: float, pos_start: int, p: float) -> Tensor:
+        """fused  dropout(E[ids] * scale + positions)  (transformer.py:727-744, 866-878)"""
+        return EmbeddingFn.apply(input, self.weight, pos_table, scale, pos_start, p, self.padding_idx)
+
+    def projection(self, input: Tensor) -> Tensor:
+        return LinearFn.apply(input, self.weight, None, 'none')
+
+
+# ------------------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------------------
+class MultiheadAttention(nn.Module):
+    """modules.py:487-771.  q/k/v projections live in one flat [3D, D] arena (the three nn.Parameters are views of
+    it, names and shapes unchanged) so self-attention runs ONE projection GEMM that reads x once, and the attention
+    kernels read q, k, v in place from the packed output."""
+
+    def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.0, shard_id: int = 0, shard_count: int = 1,
+                 positional_encoding: str = 'none', lora_rank: int = 0, max_len: Optional[int] = None,
+                 causal: bool = False, has_bias: bool = True, kv_heads: Optional[int] = None, key_bias: bool = True,
+                 sliding_window: Optional[int] = None, layer_id: int = 0, scaled: bool = True, rope_base: int = 10000,
+                 alibi_max_bias: int = 8, max_qkv: Optional[float] = None, lora_alpha: int = 1):
+        super().__init__()
+        if shard_count != 1:
+            raise NotImplementedError('pasero_amd: tensor parallelism is not implemented')
+        if (kv_heads or num_heads) != num_heads:
+            raise NotImplementedError('pasero_amd: grouped-query attention is not implemented')
+        if positional_encoding in ('alibi', 'rotary', 't5'):
+            raise NotImplementedError(f"pasero_amd: '{positional_encoding}' attention bias is not implemented")
+        if sliding_window or max_qkv:
+            raise NotImplementedError('pasero_amd: sliding-window attention / qkv clamping are not implemented')
+        self.layer_id = layer_id
+        self.embed_dim = embed_dim
+        self.num_heads = self.kv_heads = num_heads
+        self.dropout = dropout
+        self.head_dim = embed_dim // num_heads
+        if self.head_dim != 64:
+            raise NotImplementedError(f'pasero_amd: attention kernels are specialised for head_dim 64, got {self.head_dim}')
+        self.kv_dim = self.q_dim = embed_dim
+        self.scaled = scaled
+        self.has_bias = has_bias
+        self.sliding_window = None
+        self.max_qkv = None
+        self.k_proj = Linear(embed_dim, embed_dim, bias=has_bias and key_bias)
+        self.v_proj = Linear(embed_dim, embed_dim, bias=has_bias)
+        self.q_proj = Linear(embed_dim, embed_dim, bias=has_bias)
+        self.out_proj = Linear(embed_dim, embed_dim, bias=has_bias)
+        self.shard_count, self.shard_id = 1, 0
+        self.max_len = max_len
+        self.rotary_embed = self.alibi = self.t5_embed = None
+        if not _fast_init:
+            self.reset_parameters()
+        self.causal = causal
+        self._w_flat = self._b_flat = None
+
+    def reset_parameters(self) -> None:
+        # xavier-uniform with gain 1/sqrt(2) for q, k, v (modules.py:565-576)
+        for proj in (self.k_proj, self.v_proj, self.q_proj):
+            nn.init.xavier_uniform_(proj.weight, gain=1 / math.sqrt(2))
+        nn.init.xavier_uniform_(self.out_proj.weight)
+        if self.out_proj.bias is not None:
+            nn.init.constant_(self.out_proj.bias, 0.0)
+
+    # ---- flat q|k|v arena ----
+    def _packed(self) -> bool:
+        w = self._w_flat
+        q, k, v = self.q_proj.weight, self.k_proj.weight, self.v_proj.weight
+        if w is None or w.device != q.device or w.dtype != q.dtype:
+            return False
+        n = q.numel() * q.element_size()
+        base = w.data_ptr()
+        return q.data_ptr() == base and k.data_ptr() == base + n and v.data_ptr() == base + 2 * n
+
+    @torch.no_grad()
+    def _pack(self) -> None:
+        D = self.embed_dim
+        q, k, v = self.q_proj, self.k_proj, self.v_proj
+        w = torch.empty(3 * D, D, dtype=q.weight.dtype, device=q.weight.device)
+        for i, proj in enumerate((q, k, v)):
+            w[i * D:(i + 1) * D].copy_(proj.weight)
+            proj.weight.data = w[i * D:(i + 1) * D]
+        self._w_flat = w
+        self._b_flat = None
+        if self.has_bias:
+            b = torch.zeros(3 * D, dtype=q.weight.dtype, device=q.weight.device)
+            for i, proj in enumerate((q, k, v)):
+                if proj.bias is not None:
+                    b[i * D:(i + 1) * D].copy_(proj.bias)
+                    proj.bias.data = b[i * D:(i + 1) * D]
+            self._b_flat = b
+
+    def _flat(self):
+        if not self._packed():
+            self._pack()
+        return self._w_flat, self._b_flat
+
+    def forward(self, query: Tensor, key: Tensor, value: Tensor, attn_mask: Optional[BoolTensor] = None,
+                state: Optional[dict] = None, return_attn: bool = False):
+        """
+        Shape: query (B,T,D), key/value (B,S,D), attn_mask (B,S) bool with True at masked keys.
+        Returns (attn (B,T,D), attn_weights or None)
+        """
+        if return_attn:
+            raise NotImplementedError('pasero_amd: returning attention weights (return_layers) is not implemented '
+                                      'by the flash attention kernels')
+        if attn_mask is not None and attn_mask.dim() == 2 and self.causal:
+            attn_mask = None  # padding is at the end: useless for causal attention (modules.py:602-605)
+        if attn_mask is not None and attn_mask.dim() != 2:
+            raise NotImplementedError('pasero_amd: (B,T,S) attention masks are not implemented')
+        if self.training and self.dropout > 0:
+            raise NotImplementedError('pasero_amd: attention-probability dropout (--attention-dropout) is not implemented')
+        B, T, D = query.shape
+        H = self.num_heads
+        scale = 1.0 / math.sqrt(self.head_dim) if self.scaled else 1.0
+        if attn_mask is not None:
+            attn_mask = attn_mask if attn_mask.is_contiguous() else attn_mask.contiguous()
+        w, b = self._flat()
+        q_w, k_w, v_w = self.q_proj.weight, self.k_proj.weight, self.v_proj.weight
+        q_b, k_b, v_b = self.q_proj.bias, self.k_proj.bias, self.v_proj.bias
+
+        if state is not None:  # incremental decoding (inference): K/V cache of shape (B,S,H,hd) (modules.py:621-641)
+            qkv = PackedLinearFn.apply(query, w, b, 3, q_w, k_w, v_w, q_b, k_b, v_b)
+            q = qkv[..., :D]
+            k = qkv[..., D:2 * D].reshape(B, T, H, self.head_dim)
+            v = qkv[..., 2 * D:].reshape(B, T, H, self.head_dim)
+            if 'key' in state:
+                prev_k, prev_v = state['key'], state['value']
+                if self.max_len is not None:
+                    delta = max(0, prev_k.size(1) + T - self.max_len)
+                    prev_k, prev_v = prev_k[:, delta:], prev_v[:, delta:]
+                k = torch.cat([prev_k, k], dim=1)
+                v = torch.cat([prev_v, v], dim=1)
+            state['key'], state['value'] = k, v
+            S = k.size(1)
+            attn = AttentionFn.apply(q, k.view(B, S, D), v.view(B, S, D), attn_mask, H, self.causal and T > 1, scale)
+        elif key is query and value is query:
+            qkv = PackedLinearFn.apply(query, w, b, 3, q_w, k_w, v_w, q_b, k_b, v_b)
+            attn = AttentionFn.apply(qkv, None, None, attn_mask, H, self.causal and T > 1, scale)
+        elif key is value:
+            q = LinearFn.apply(query, q_w, q_b, 'none')
+            kv = PackedLinearFn.apply(key, w[D:], None if b is None else b[D:], 2, k_w, v_w, k_b, v_b)
+            attn = AttentionFn.apply(q, kv, None, attn_mask, H, self.causal and T > 1, scale)
+        else:
+            q = LinearFn.apply(query, q_w, q_b, 'none')
+            k = LinearFn.apply(key, k_w, k_b, 'none')
+            v = LinearFn.apply(value, v_w, v_b, 'none')
+            attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale)
+        attn = self.out_proj(attn)
+        return attn, None
+
+
+# ------------------------------------------------------------------------------------------------------------
+# speech frontend
+# ------------------------------------------------------------------------------------------------------------
+class ConvolutionSubsampler(nn.Module):
+    """Conv1d (+GLU | GELU) stack (modules.py:774-834) computed channels-last as implicit GEMMs on the MFMA kernel:
+    a (k*C_in)-wide window of the zero-padded (B, L, C_in) input IS a contiguous row of the im2col matrix, so the
+    activations are never unfolded, and the two transposes of the reference disappear."""
+
+    def __init__(self, in_channels: int, mid_channels: int, out_channels: int, kernel_sizes=(3, 3),
+                 strides=None, activation: str = 'glu'):
+        super().__init__()
+        strides = strides or tuple(2 for _ in kernel_sizes)
+        assert len(strides) == len(kernel_sizes)
+        r = 2 if activation == 'glu' else 1
+        self.conv_layers = nn.ModuleList()
+        for i, (k, s) in enumerate(zip(kernel_sizes, strides)):
+            first, last = i == 0, i == len(kernel_sizes) - 1
+            self.conv_layers.append(nn.Conv1d(in_channels if first else mid_channels // r,
+                                              out_channels * r if last else mid_channels, k, stride=s, padding=k // 2))
+        self.activation_name = activation
+        self.activation = nn.GLU(dim=1) if activation == 'glu' else nn.GELU()  # kept for introspection only
+
+    def get_new_length(self, length: LongTensor) -> LongTensor:
+        for conv in self.conv_layers:
+            length = 1 + torch.div(length - conv.kernel_size[0] + 2 * conv.padding[0], conv.stride[0],
+                                   rounding_mode='floor')
+        return length
+
+    def forward(self, x: Tensor, length: LongTensor):
+        from .autograd import Conv1dChannelsLastFn
+        for conv in self.conv_layers:
+            act = 'gelu' if self.activation_name != 'glu' else 'none'
+            x = Conv1dChannelsLastFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], act)
+            if self.activation_name == 'glu':
+                x = GLUFn.apply(x)
+        return x, self.get_new_length(length)

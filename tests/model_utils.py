@@ -1,0 +1,53 @@
+"""helpers shared by the model-level tests"""
+import json
+
+import numpy as np
+import torch
+
+import paramgen
+from conftest import load_golden, golden_names_shapes
+
+
+def build_cfg(g):
+    from pasero_amd.config import TransformerConfig
+    return TransformerConfig(**json.loads(str(g['cfg'])))
+
+
+def build_model(g, dtype=torch.float32, device='cpu'):
+    """pasero_amd Transformer with the fixture's config and the deterministic paramgen weights"""
+    from pasero_amd.config import DistributedConfig, SyntheticTask
+    from pasero_amd.transformer import Transformer
+    cfg = build_cfg(g)
+    V = int(g['V'])
+    model = Transformer(cfg, DistributedConfig(), SyntheticTask(V))
+    load_paramgen(model, int(g['seed']))
+    return cfg, model.to(dtype).to(device)
+
+
+def load_paramgen(model, seed):
+    sd = model.state_dict()
+    names_shapes = [(k, tuple(v.shape)) for k, v in sd.items()]
+    new = paramgen.make_state_dict(seed, names_shapes)
+    first = {}
+    for k, v in sd.items():  # tied tensors: value of the FIRST alias (same rule as oracle/make_golden.py)
+        new[k] = new[first.setdefault(v.data_ptr(), k)]
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()})
+
+
+def oracle_state(g, cfg):
+    from oracle import ref_cpu as O
+    P = O.to_torch_state(paramgen.make_state_dict(int(g['seed']), golden_names_shapes(g)))
+    if cfg.shared_embeddings and 'encoder.embed_tokens.weight' in P:
+        P['decoder.embed_tokens.weight'] = P['encoder.embed_tokens.weight']
+    return P
+
+
+def text_batch(g, device='cpu'):
+    b = paramgen.make_text_batch(int(g['seed']), int(g['B']), int(g['S']), int(g['T']), int(g['V']))
+    return {k: torch.from_numpy(v).to(device) for k, v in b.items()}
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).double().cpu()
+    b = torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b).double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()

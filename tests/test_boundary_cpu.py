@@ -1,0 +1,64 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol of include/pasero_hip.h, the
+host-side mirror exposes the reference's parameter names / shapes (= checkpoint keys) and class surface, and the
+product path fails loudly without a GPU (no fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, golden_names_shapes
+from model_utils import build_model
+
+
+def test_library_exports_every_header_symbol():
+    from pasero_amd import lib
+    L = lib.load()
+    header = open(os.path.join(ROOT, 'include', 'pasero_hip.h')).read()
+    names = set(re.findall(r'\b(pk_[a-z0-9_]+)\s*\(', header))
+    assert len(names) >= 20
+    for n in sorted(names):
+        assert hasattr(L, n), f'{n} declared in include/pasero_hip.h but not exported'
+    assert names == set(lib.SIGNATURES), 'pasero_amd/lib.py SIGNATURES out of sync with the header'
+    assert L.pk_version() >= 100
+
+
+@pytest.mark.parametrize('name', ['tiny_encdec_post', 'tiny_encdec_pre', 'speech_whisper', 'speech_iwslt', 'base_c1'])
+def test_parameter_names_and_shapes_match_reference(name):
+    g = load_golden(name)
+    _, model = build_model(g)
+    ours = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert ours == golden_names_shapes(g)
+
+
+def test_base_model_parameter_count():
+    g = load_golden('base_c1')
+    _, model = build_model(g)
+    assert model.total_param_count == 48_250_880  # SURVEY §8c / examples/TED-top20/training-en-centric.yaml:6
+    assert len(list(model.state_dict())) == len(golden_names_shapes(g))
+
+
+def test_no_cpu_fallback():
+    g = load_golden('tiny_encdec_post')
+    _, model = build_model(g)
+    from model_utils import text_batch
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        model(**text_batch(g))
+
+
+def test_class_surface():
+    from pasero_amd import transformer as T, modules as M
+    for n in ('Transformer', 'TransformerEncoder', 'TransformerDecoder', 'TransformerEncoderLayer',
+              'TransformerDecoderLayer', 'Encoder', 'Decoder', 'EncoderDecoder', 'DummyEncoder', 'BaseModel'):
+        assert hasattr(T, n)
+    for n in ('MultiheadAttention', 'Linear', 'Embedding', 'SinusoidalPositionalEmbedding',
+              'LearnedPositionalEmbedding', 'ConvolutionSubsampler', 'fast_init', 'set_tp_group',
+              'set_sequence_parallel', 'checkpoint_wrapper', 'get_activation_fn', 'Identity', 'WrappableLinear'):
+        assert hasattr(M, n)
+    for hook in ('ffn', 'self_attention', 'self_attn_residual', 'self_attn_prenorm', 'self_attn_postnorm',
+                 'ffn_residual', 'ffn_prenorm', 'ffn_postnorm'):
+        assert hasattr(T.TransformerEncoderLayer, hook) and hasattr(T.TransformerDecoderLayer, hook)
+    for hook in ('cross_attention', 'cross_attn_residual', 'cross_attn_prenorm', 'cross_attn_postnorm'):
+        assert hasattr(T.TransformerDecoderLayer, hook)
+    with pytest.raises(NotImplementedError):
+        M.set_tp_group(object())

@@ -46,7 +46,7 @@ def _run_encdec(name, full=True):
         gr = P[n].grad
         assert gr is not None, n
         # (k_proj.bias gradients are mathematically zero: softmax is shift-invariant -> pure round-off)
-        assert abs(gr.norm().item() - ref_norm) <= 1e-4 * ref_norm + 2e-6, n
+        assert abs(gr.double().norm().item() - ref_norm) <= 1e-4 * ref_norm + 2e-6, n
         if full:
             close(gr.numpy(), g['grad:' + n], rtol=1e-4)
         else:
@@ -152,7 +152,7 @@ def test_speech_frontend(name):
     close(feats.grad.numpy(), g['dfeats'], rtol=1e-4)
     for n, ref_norm in zip(g['grad_names'], g['grad_norms']):
         n = str(n)
-        assert abs(P[n].grad.norm().item() - ref_norm) <= 1e-4 * ref_norm + 2e-6, n
+        assert abs(P[n].grad.double().norm().item() - ref_norm) <= 1e-4 * ref_norm + 2e-6, n
         if 'grad:' + n in g:
             close(P[n].grad.numpy(), g['grad:' + n], rtol=1e-4)
     with torch.no_grad():
