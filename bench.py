@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Benchmark of the Pasero Transformer training hot path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch per GPU: Transformer.forward (encoder, decoder, fused
+tied-projection + label-smoothed CE, the logs' device->host copy) + loss.backward() + (N > 1) the bucketed gradient
+all-reduce over RCCL, i.e. what `Trainer.train_step` does between `zero_grad` and the optimizer (pasero/training.py:
+329-408).  Workload: BASELINE configs[1] — `transformer` base (6+6, d=512, 8 heads, ffn 2048, V=8032), bf16, batch
+(256, 128, 128) per GPU, dropout 0.1, label smoothing 0.1, inputs resident in HBM before the timed region.
+Metric: target tokens/s (non-pad positions of decoder_input[:, 1:], the reference's own `wps`), whole job.
+
+Rank 0 prints ONE JSON line (schema in the task contract) with two extra objects:
+  roofline     — the dominant kernel (bf16 MFMA GEMM instantiation with the largest total time): algorithmic FLOPs per
+                 launch (2*M*N*K) / average launch duration, measured with HIP events on the launch stream INSIDE the
+                 timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  cpu_baseline — the CPU oracle (oracle/ref_cpu.py, a port pinned to the reference by golden vectors) timed on the
+                 host cores on BASELINE configs[0] (8 x (64, 64), fp32), a bounded ~10-30 s sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+
+PEAK_BF16_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+
+WORKLOADS = {
+    # name: (config class name, V, B, S, T)
+    'c2_base_bf16': ('TransformerConfig', 8032, 256, 128, 128),
+    'c1_base': ('TransformerConfig', 8032, 8, 64, 64),
+    'c3_big': ('TransformerBigConfig', 70376, 256, 128, 128),
+    'c5_nllb_1b3': ('NLLB1B3Config', 256206, 64, 128, 128),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='c2_base_bf16', choices=list(WORKLOADS))
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' to rehearse)")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true', help='skip the per-launch HIP-event instrumentation')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
+    return ap.parse_args()
+
+
+def synthetic_batch(B, S, T, V, seed, device):
+    """SURVEY §8d recipe, full-length rows: ids ~ U[4, V), last source token / first+last decoder tokens = 2"""
+    import paramgen
+    b = paramgen.make_text_batch(seed, B, S, T, V, ragged=False)
+    return {k: torch.from_numpy(v).to(device) for k, v in b.items()}
+
+
+class GemmTimer:
+    """wraps pasero_amd.functional.gemm: a pair of HIP events around every launch (on the launching stream)"""
+
+    def __init__(self):
+        self.records = []  # (key, flops, start, end)
+        self.enabled = False
+
+    def install(self):
+        from pasero_amd import functional as F
+        from pasero_amd import autograd as A
+        orig = F.gemm
+        timer = self
+
+        def timed(a, b, **kw):
+            if not timer.enabled:
+                return orig(a, b, **kw)
+            a_col, b_col = kw.get('a_col', False), kw.get('b_col', False)
+            M, K = (a.size(1), a.size(0)) if a_col else (a.size(0), a.size(1))
+            N = b.size(1) if b_col else b.size(0)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = orig(a, b, **kw)
+            e.record()
+            name = 'gemm_kernel<%s,%s,%s>%s' % ('bf16' if a.dtype == torch.bfloat16 else 'f32',
+                                               'col' if a_col else 'row', 'col' if b_col else 'row',
+                                               '+splitk' if kw.get('splitk', 1) > 1 else '')
+            timer.records.append((name, 2.0 * M * N * K, s, e))
+            return out
+        F.gemm = timed
+        A.F.gemm = timed
+
+    def summary(self):
+        agg = {}
+        for name, flops, s, e in self.records:
+            ms = s.elapsed_time(e)
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += ms
+        return {k: {'launches': v[0], 'avg_us': 1e3 * v[2] / v[0], 'tflops': v[1] / (v[2] * 1e-3) / 1e12,
+                    'total_ms': v[2], 'flops_per_launch': v[1] / v[0]} for k, v in agg.items()}
+
+
+def cpu_baseline(budget_s: float):
+    """the CPU oracle on BASELINE configs[0] (fp32, 8 x (64, 64), ragged=False), fwd+bwd, host cores"""
+    import numpy as np
+    import paramgen
+    from oracle import ref_cpu as O
+    from pasero_amd.config import TransformerConfig, DistributedConfig, SyntheticTask
+    from pasero_amd.transformer import Transformer
+    cfg = TransformerConfig(dropout=0.0)
+    V, B, S, T = 8032, 8, 64, 64
+    model = Transformer(cfg, DistributedConfig(), SyntheticTask(V))  # only to enumerate names / shapes (CPU, no compute)
+    names_shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    del model
+    P = O.to_torch_state(paramgen.make_state_dict(1, names_shapes))
+    P['decoder.embed_tokens.weight'] = P['encoder.embed_tokens.weight']
+    for v in P.values():
+        v.requires_grad_()
+    b = paramgen.make_text_batch(1, B, S, T, V, ragged=False)
+    tb = {k: torch.from_numpy(v) for k, v in b.items()}
+
+    def step():
+        for v in P.values():
+            v.grad = None
+        loss, logs = O.transformer_forward(P, cfg, **tb)
+        loss.backward()
+        return logs['num_tokens']
+
+    step()  # warm-up (first call pages in the kernels)
+    t0 = time.perf_counter()
+    n, tokens = 0, 0
+    while True:
+        tokens += step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 50:
+            break
+    return {'value': tokens / el, 'unit': 'target tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'oracle/ref_cpu.py fwd+bwd, Transformer-base fp32, batch 8x(64,64), {n} steps in {el:.1f} s '
+                      f'({os.cpu_count()} logical CPUs)'}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run '
+                         f'--nproc-per-node {args.gpus}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % ndev)
+    device = torch.device('cuda', local_rank % ndev)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+
+    from pasero_amd import config as C, rng
+    from pasero_amd.transformer import Transformer
+    from pasero_amd.ddp import DistributedDataParallel
+
+    cfg_name, V, B, S, T = WORKLOADS[args.workload]
+    cfg = getattr(C, cfg_name)()  # dropout 0.1, label smoothing 0.1: the training configuration
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    torch.manual_seed(1234)  # identical random-init weights on every rank
+    model = Transformer(cfg, C.DistributedConfig(dp_size=world, dp_rank=rank), C.SyntheticTask(V))
+    model = model.to(dtype).to(device)
+    model.train()
+    rng.manual_seed(1 + rank)
+    ddp = DistributedDataParallel(model) if world > 1 else model
+    batch = synthetic_batch(B, S, T, V, seed=1 + rank, device=device)
+
+    timer = GemmTimer()
+    if not args.no_roofline:
+        timer.install()
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss, logs = ddp(**batch)
+        loss.backward()
+        return logs['num_tokens']
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timer.enabled = not args.no_roofline
+    t0 = time.perf_counter()
+    tokens = 0
+    for _ in range(args.steps):
+        tokens += step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+        n = torch.tensor([tokens], dtype=torch.float64, device=device)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        tokens = n.item()
+
+    if rank == 0:
+        from oracle.ref_cpu import count_flops
+        step_flops = count_flops(cfg, B, S, T, V)  # SURVEY §8d algorithmic FLOPs of one fwd+bwd batch
+        out = {
+            'metric': 'target tokens/sec (fwd+bwd), Transformer-base d=512',
+            'value': tokens / elapsed,
+            'unit': 'target tokens/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': args.dtype,
+            'data': 'synthetic',
+            'config': {'workload': f'{args.workload}: {cfg_name} V={V}, per-GPU batch (B,S,T)=({B},{S},{T}), '
+                                   f'dropout {cfg.dropout}, label smoothing {cfg.label_smoothing}, full-length rows',
+                       'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}',
+                       'step': 'forward + backward' + (' + bucketed RCCL all-reduce' if world > 1 else ''),
+                       'algorithmic_tflop_per_step_per_gpu': step_flops / 1e12,
+                       'model_tflops_per_gpu': step_flops * args.steps / elapsed / 1e12,
+                       'mfma_peak_fraction_whole_step': step_flops * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS},
+        }
+        if not args.no_roofline and timer.records:
+            summ = timer.summary()
+            dom = max(summ, key=lambda k: summ[k]['total_ms'])
+            d = summ[dom]
+            out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': d['tflops'], 'peak': PEAK_BF16_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': d['tflops'] / PEAK_BF16_TFLOPS, 'traffic': None,
+                               'avg_launch_us': d['avg_us'], 'launches': d['launches'],
+                               'flops_per_launch': d['flops_per_launch'],
+                               'gemm_share_of_step': sum(v['total_ms'] for v in summ.values()) / (1e3 * elapsed),
+                               'all_gemm_kernels': {k: {'tflops': round(v['tflops'], 1), 'avg_us': round(v['avg_us'], 1),
+                                                        'launches': v['launches']} for k, v in summ.items()}}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
