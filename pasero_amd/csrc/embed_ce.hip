@@ -244,12 +244,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     }
 }
 template <typename T>
-__global__ void colsum_final_kernel(const float* __restrict__ partials, T* __restrict__ out, int nparts, long long N) {
-    long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= N) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partials, T* __restrict__ out,
+                                                           int nparts, long long N) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long col = (long long)blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partials[(long long)p * N + col];
-    out[col] = from_f32<T>(s);
+    if (col < N)
+        for (int p = ty; p < nparts; p += 4) s += partials[(long long)p * N + col];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && col < N) out[col] = from_f32<T>(red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -389,30 +394,37 @@ extern "C" int pk_ce_finalize(const float* row_loss, const float* row_nll, const
     return 0;
 }
 
-extern "C" size_t pk_colsum_workspace(long long M, long long N) {
-    long long parts = (M + 3) / 4;
-    if (parts > 64) parts = 64;
+// row-slices per column block: enough workgroups (~1024) to stream at HBM rate even for narrow matrices
+static long long colsum_parts(long long M, long long N, int epv) {
+    long long colblocks = (N + 64 * epv - 1) / (64 * epv);
+    long long parts = (1024 + colblocks - 1) / colblocks;
+    long long maxparts = (M + 15) / 16;  // >= 4 rows per row-lane
+    if (parts > maxparts) parts = maxparts;
+    if (parts > 1024) parts = 1024;
     if (parts < 1) parts = 1;
-    return (size_t)parts * N * sizeof(float);
+    return parts;
+}
+
+extern "C" size_t pk_colsum_workspace(long long M, long long N) {
+    long long a = colsum_parts(M, N, 4), b = colsum_parts(M, N, 8);
+    return (size_t)(a > b ? a : b) * N * sizeof(float);
 }
 
 extern "C" int pk_colsum(const void* x, long long ld, void* out, long long M, long long N, void* workspace,
                          size_t ws_bytes, int dtype, void* stream) {
     PK_CHECK_ARG(x && out, "pk_colsum: null tensor");
     if (N == 0) return 0;
-    long long parts = (M + 3) / 4;
-    if (parts > 64) parts = 64;
-    if (parts < 1) parts = 1;
-    PK_CHECK_ARG(workspace && ws_bytes >= (size_t)parts * N * 4, "pk_colsum: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     PK_DTYPE_SWITCH(dtype, "pk_colsum", {
         constexpr int EPV = 16 / sizeof(T);
+        const long long parts = colsum_parts(M, N, EPV);
+        PK_CHECK_ARG(workspace && ws_bytes >= (size_t)parts * N * 4, "pk_colsum: workspace too small");
         bool vec_ok = is_aligned16(x) && ld % EPV == 0;
         dim3 grid((unsigned)((N + 64 * EPV - 1) / (64 * EPV)), (unsigned)parts);
         hipLaunchKernelGGL((colsum_partial_kernel<T>), grid, dim3(256), 0, s, (const T*)x, ld, M, N,
                            (float*)workspace, vec_ok);
         PK_LAUNCH_CHECK();
-        hipLaunchKernelGGL((colsum_final_kernel<T>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL((colsum_final_kernel<T>), dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s,
                            (const float*)workspace, (T*)out, (int)parts, N);
     })
     PK_LAUNCH_CHECK();

@@ -223,18 +223,23 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
 }
 
 // out[which][col] = sum_b partials[b][which][col]   (which = 0: dgamma, 1: dbeta)
+// workgroup = 64 columns x 4 partial-row lanes (coalesced 256-B reads), grid = (d/64, 2)
 template <typename T>
-__global__ void ln_param_grad_kernel(const float* __restrict__ partials, T* __restrict__ dgamma, T* __restrict__ dbeta,
-                                     int nblocks, int d) {
-    int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= d) return;
-    float sg = 0.f, sb = 0.f;
-    for (int b = 0; b < nblocks; ++b) {
-        sg += partials[((long long)b * 2 + 0) * d + col];
-        sb += partials[((long long)b * 2 + 1) * d + col];
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ partials, T* __restrict__ dgamma,
+                                                            T* __restrict__ dbeta, int nblocks, int d) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + tx, which = blockIdx.y;
+    float s = 0.f;
+    if (col < d)
+        for (int b = ty; b < nblocks; b += 4) s += partials[((long long)b * 2 + which) * d + col];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && col < d) {
+        float t = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        T* out = which == 0 ? dgamma : dbeta;
+        if (out) out[col] = from_f32<T>(t);
     }
-    if (dgamma) dgamma[col] = from_f32<T>(sg);
-    if (dbeta) dbeta[col] = from_f32<T>(sb);
 }
 
 inline int ln_grid(long long rows) {
@@ -276,7 +281,7 @@ int launch_bwd(const void* dy, const void* dz_extra, const void* z, const void* 
     float scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
     int nch = (d / EPV + 63) / 64;
     int nblocks = ln_grid(rows);
-    if (nblocks > 512) nblocks = 512;
+    if (nblocks > 256) nblocks = 256;
     bool want_pg = gamma && (dgamma || dbeta);
     if (want_pg) {
         size_t need = (size_t)nblocks * 2 * d * sizeof(float);
@@ -294,7 +299,7 @@ int launch_bwd(const void* dy, const void* dz_extra, const void* z, const void* 
 #undef PK_L
     PK_LAUNCH_CHECK();
     if (want_pg) {
-        hipLaunchKernelGGL((ln_param_grad_kernel<T>), dim3((d + 255) / 256), dim3(256), 0, s, ws, (T*)dgamma,
+        hipLaunchKernelGGL((ln_param_grad_kernel<T>), dim3((d + 63) / 64, 2), dim3(256), 0, s, ws, (T*)dgamma,
                            (T*)dbeta, nblocks, d);
         PK_LAUNCH_CHECK();
     }
@@ -322,7 +327,7 @@ extern "C" int pk_residual_ln_fwd(const void* x, const void* residual, const voi
 
 extern "C" size_t pk_residual_ln_bwd_workspace(long long rows, int d) {
     int nblocks = ln_grid(rows);
-    if (nblocks > 512) nblocks = 512;
+    if (nblocks > 256) nblocks = 256;
     return (size_t)nblocks * 2 * d * sizeof(float);
 }
 
