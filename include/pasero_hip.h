@@ -41,11 +41,13 @@ const char* pk_last_error(void);
  *   mode 0: C = act(v + bias)        (preact, if given, receives v + bias)
  *   mode 1: C = act(v + bias) + aux  (residual add, or gradient accumulation with aux == C)
  *   mode 2: C = v * act'(aux)        (backward through the activation; aux = pre-activation, or post- for ReLU)
- *   splitk > 1: K is cut into `splitk` slices reduced through `workspace` (>= splitk*M*N*4 bytes), deterministic. */
+ *   splitk > 1: K is cut into `splitk` slices reduced through `workspace` (>= splitk*M*(N+1)*4 bytes), deterministic.
+ *   asum_out (optional, needs a_col = 1): asum_out[m] = sum_k A(m,k) — the bias gradient db = colsum(dY) comes out of
+ *   the weight-gradient GEMM that already streams dY, instead of a separate pass over it. */
 int pk_gemm(const void* A, const void* B, void* C, const void* bias, const void* aux, void* preact, long long M,
             long long N, long long K, long long lda, long long ldb, long long ldc, long long ldaux, long long ldpre,
             int a_col, int b_col, int act, int mode, float alpha, int dtype, int splitk, void* workspace,
-            size_t ws_bytes, void* stream);
+            size_t ws_bytes, void* asum_out, void* stream);
 
 /* ---- Residual + dropout + LayerNorm (K4): replaces `residual + dropout(x)` followed by nn.LayerNorm,
  * pasero/models/transformer.py:1043-1054,1073-1086 (encoder), :1322-1339,1389-1407 (decoder), :941-947 (Norm).

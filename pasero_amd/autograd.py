@@ -20,11 +20,21 @@ def _contig(x: Tensor) -> Tensor:
     return x if x.is_contiguous() else x.contiguous()
 
 
-def weight_grad(dy2d: Tensor, x2d: Tensor) -> Tensor:
-    """dW[N,K] = dyᵀ x : both operands in "col" form (contraction over the rows), split-K when the output is small"""
+def weight_grad(dy2d: Tensor, x2d: Tensor, want_bias: bool = False):
+    """dW[N,K] = dyᵀ x : both operands in "col" form (contraction over the rows), split-K when the output is small.
+    With `want_bias` the bias gradient colsum(dy) comes out of the same GEMM (it already streams dy): -> (dW, db)"""
     M = dy2d.size(0)
     N, K = dy2d.size(1), x2d.size(1)
-    return F.gemm(dy2d, x2d, a_col=True, b_col=True, splitk=F.choose_splitk(N, K, M))
+    db = torch.empty(N, dtype=dy2d.dtype, device=dy2d.device) if want_bias else None
+    dw = F.gemm(dy2d, x2d, a_col=True, b_col=True, splitk=F.choose_splitk(N, K, M), asum_out=db)
+    return (dw, db) if want_bias else dw
+
+
+def _wgrad(dy2d: Tensor, x2d: Tensor, want_w: bool, want_b: bool):
+    if want_w:
+        r = weight_grad(dy2d, x2d, want_b)
+        return r if want_b else (r, None)
+    return None, (F.colsum(dy2d) if want_b else None)
 
 
 class LinearFn(torch.autograd.Function):
@@ -50,9 +60,12 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = F.gemm(dy2, weight, b_col=True).view(*dy.shape[:-1], weight.size(1))
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = weight_grad(dy2, x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dw = weight_grad(dy2, x2, want_b)
+            if want_b:
+                dw, db = dw
+        elif want_b:
             db = F.colsum(dy2)
         return dx, dw, db, None
 
@@ -83,11 +96,9 @@ class FFNFn(torch.autograd.Function):
             dh = F.gemm(dy2, w2, b_col=True)
         else:
             dh = F.gemm(dy2, w2, b_col=True, act=ctx.act, aux=aux, mode=2)
-        dw2 = weight_grad(dy2, h) if ctx.needs_input_grad[3] else None
-        db2 = F.colsum(dy2) if ctx.has_b2 and ctx.needs_input_grad[4] else None
+        dw2, db2 = _wgrad(dy2, h, ctx.needs_input_grad[3], ctx.has_b2 and ctx.needs_input_grad[4])
         dx = F.gemm(dh, w1, b_col=True).view(*dy.shape[:-1], w1.size(1)) if ctx.needs_input_grad[0] else None
-        dw1 = weight_grad(dh, x2) if ctx.needs_input_grad[1] else None
-        db1 = F.colsum(dh) if ctx.has_b1 and ctx.needs_input_grad[2] else None
+        dw1, db1 = _wgrad(dh, x2, ctx.needs_input_grad[1], ctx.has_b1 and ctx.needs_input_grad[2])
         return dx, dw1, db1, dw2, db2, None
 
 
@@ -115,16 +126,14 @@ class PackedLinearFn(torch.autograd.Function):
             dx = F.gemm(dy2, w_flat, b_col=True).view(*dy.shape[:-1], w_flat.size(1))
         D = w_flat.size(0) // n
         grads = [None] * (2 * n)
-        if any(ctx.needs_input_grad[4:4 + n]):
-            dw = weight_grad(dy2, x2)
-            for i in range(n):
-                if ctx.needs_input_grad[4 + i]:
-                    grads[i] = dw[i * D:(i + 1) * D]
-        if any(ctx.has_bias[i] and ctx.needs_input_grad[4 + n + i] for i in range(n)):
-            db = F.colsum(dy2)
-            for i in range(n):
-                if ctx.has_bias[i] and ctx.needs_input_grad[4 + n + i]:
-                    grads[n + i] = db[i * D:(i + 1) * D]
+        want_w = any(ctx.needs_input_grad[4:4 + n])
+        want_b = any(ctx.has_bias[i] and ctx.needs_input_grad[4 + n + i] for i in range(n))
+        dw, db = _wgrad(dy2, x2, want_w, want_b)
+        for i in range(n):
+            if want_w and ctx.needs_input_grad[4 + i]:
+                grads[i] = dw[i * D:(i + 1) * D]
+            if want_b and ctx.has_bias[i] and ctx.needs_input_grad[4 + n + i]:
+                grads[n + i] = db[i * D:(i + 1) * D]
         return (dx, None, None, None, *grads)
 
 
@@ -387,11 +396,9 @@ class Conv1dChannelsLastFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dA = F.gemm(dz, wr, b_col=True)
             dx = F.col2im1d(dA, B, L, C, R, Lout, k, stride, padding)
-        if ctx.needs_input_grad[1]:
-            dwr = F.gemm(dz, A, a_col=True, b_col=True, splitk=F.choose_splitk(O, k * C, B * R))
+        dwr, db = _wgrad(dz, A, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        if dwr is not None:
             dw = dwr.view(O, k, C).permute(0, 2, 1).contiguous()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = F.colsum(dz)
         return dx, dw, db, None, None, None
 
 

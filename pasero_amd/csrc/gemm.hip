@@ -193,8 +193,9 @@ __device__ __forceinline__ void epilogue_chunk(float (&v)[8], int n_valid, long 
 
 template <typename T, bool A_COL, bool B_COL>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
-    const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C, float* __restrict__ ws, long long M,
-    long long N, long long K, long long lda, long long ldb, int kchunk, EpiParams ep, int flags) {
+    const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C, float* __restrict__ ws,
+    float* __restrict__ asum_ws, T* __restrict__ asum_out, long long M, long long N, long long K, long long lda,
+    long long ldb, int kchunk, EpiParams ep, int flags) {
     using TR = Traits<T>;
     using GA = TileGeom<T, A_COL>;
     using GB = TileGeom<T, B_COL>;
@@ -228,6 +229,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     Vec16<T> ra[GA::NCH], rb[GB::NCH];
+    // fused bias gradient (weight-gradient GEMMs, A = dY in col form): the sum over k of A(m, k) for this tile's 128
+    // m-columns.  Every staging chunk of a thread covers the same EPV columns (NTHREADS % CPR == 0), so each thread
+    // keeps EPV running sums; only the tile_n == 0 workgroups do it.
+    const bool do_asum = A_COL && (asum_ws || asum_out) && tile_n == 0;
+    float asum[TR::EPV];
+#pragma unroll
+    for (int e = 0; e < TR::EPV; ++e) asum[e] = 0.f;
     auto g2r = [&](int kt) {
         long long k0 = kbeg + (long long)kt * TR::BK;
         if constexpr (A_COL) tile_g2r<T, true>(ra, A, lda, k0, m0, kend, M, a_vec, tid);
@@ -237,6 +245,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
     };
     auto r2s = [&](int buf) {
         char* s = smem + buf * STAGE;
+        if constexpr (A_COL) {
+            if (do_asum) {
+#pragma unroll
+                for (int i = 0; i < GA::NCH; ++i)
+#pragma unroll
+                    for (int e = 0; e < TR::EPV; ++e) asum[e] += ra[i].get(e);
+            }
+        }
         tile_r2s<T, A_COL>(ra, s, tid);
         tile_r2s<T, B_COL>(rb, s + GA::BYTES, tid);
     };
@@ -278,6 +294,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
         }
         if (kt + 1 < nk) r2s((kt + 1) & 1);
         __syncthreads();
+    }
+
+    if constexpr (A_COL) {
+        if (do_asum) {  // (block-uniform) smem is free here: the k-loop ended with a barrier
+            constexpr int CPR = GA::CPR, RL = NTHREADS / CPR;  // threads tid, tid + CPR, ... share a column chunk
+            float* red = reinterpret_cast<float*>(smem);       // [RL][128]
+#pragma unroll
+            for (int e = 0; e < TR::EPV; ++e) red[(tid / CPR) * BM + (tid % CPR) * TR::EPV + e] = asum[e];
+            __syncthreads();
+            if (tid < BM && m0 + tid < M) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < RL; ++r) t += red[r * BM + tid];
+                if (asum_ws) asum_ws[(long long)blockIdx.y * M + m0 + tid] = t;
+                else asum_out[m0 + tid] = from_f32<T>(t);
+            }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: accumulators -> LDS (f32) -> row-contiguous chunks -> global ----
@@ -330,8 +364,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
 // split-K reduction + epilogue: C = epi(sum_z ws[z])
 template <typename T>
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict__ C, long long M, long long N,
-                                     int splitk, EpiParams ep, int flags) {
+                                     int splitk, EpiParams ep, int flags, const float* __restrict__ asum_ws,
+                                     T* __restrict__ asum_out) {
     constexpr int EPV = Traits<T>::EPV;
+    if (asum_ws) {
+        for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < M;
+             m += (long long)gridDim.x * blockDim.x) {
+            float t = 0.f;
+            for (int z = 0; z < splitk; ++z) t += asum_ws[(long long)z * M + m];
+            asum_out[m] = from_f32<T>(t);
+        }
+    }
     const bool c_vec = flags & 4, aux_vec = flags & 8;
     long long nchunks_row = (N + EPV - 1) / EPV;
     long long total = M * nchunks_row;
@@ -359,7 +402,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict
 template <typename T>
 int launch_gemm(const void* A, const void* B, void* C, long long M, long long N, long long K, long long lda,
                 long long ldb, int a_col, int b_col, EpiParams ep, int splitk, void* workspace,
-                size_t ws_bytes, hipStream_t stream) {
+                size_t ws_bytes, void* asum_out, hipStream_t stream) {
     using TR = Traits<T>;
     constexpr int EPV = TR::EPV;
     auto aligned = [&](const void* p, long long ld) { return ((uintptr_t)p % 16) == 0 && (ld % EPV) == 0; };
@@ -377,10 +420,12 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         splitk = (int)((K + per - 1) / per);
         kchunk = (int)per;
     }
+    float* asum_ws = nullptr;
     if (splitk > 1) {
-        size_t need = (size_t)splitk * M * N * sizeof(float);
+        size_t need = (size_t)splitk * M * (N + (asum_out ? 1 : 0)) * sizeof(float);
         PK_CHECK_ARG(workspace && ws_bytes >= need, "pk_gemm: split-K workspace too small (%zu < %zu)", ws_bytes, need);
         ws = (float*)workspace;
+        if (asum_out) asum_ws = ws + (size_t)splitk * M * N;
     } else {
         splitk = 1;
     }
@@ -389,7 +434,8 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
     const T* b = (const T*)B;
     T* c = (T*)C;
 #define PK_LAUNCH(AC, BC) \
-    hipLaunchKernelGGL((gemm_kernel<T, AC, BC>), grid, block, 0, stream, a, b, c, ws, M, N, K, lda, ldb, kchunk, ep, flags)
+    hipLaunchKernelGGL((gemm_kernel<T, AC, BC>), grid, block, 0, stream, a, b, c, ws, asum_ws, (T*)asum_out, M, N, K, \
+                       lda, ldb, kchunk, ep, flags)
     if (!a_col && !b_col) PK_LAUNCH(false, false);
     else if (!a_col && b_col) PK_LAUNCH(false, true);
     else if (a_col && !b_col) PK_LAUNCH(true, false);
@@ -400,7 +446,7 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         long long chunks = M * ((N + EPV - 1) / EPV);
         int blocks = (int)min((long long)2048, (chunks + 255) / 256);
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, stream, ws, c, M, N, splitk, ep,
-                           flags);
+                           flags, (const float*)asum_ws, (T*)asum_out);
         PK_LAUNCH_CHECK();
     }
     return 0;
@@ -411,8 +457,9 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
 extern "C" int pk_gemm(const void* A, const void* B, void* C, const void* bias, const void* aux, void* preact,
                        long long M, long long N, long long K, long long lda, long long ldb, long long ldc,
                        long long ldaux, long long ldpre, int a_col, int b_col, int act, int mode, float alpha,
-                       int dtype, int splitk, void* workspace, size_t ws_bytes, void* stream) {
+                       int dtype, int splitk, void* workspace, size_t ws_bytes, void* asum_out, void* stream) {
     PK_CHECK_ARG(A && B && C, "pk_gemm: null operand");
+    PK_CHECK_ARG(!asum_out || a_col, "pk_gemm: asum_out (fused bias gradient) needs A in col form");
     PK_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "pk_gemm: negative size");
     PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16, "pk_gemm: dtype %d not supported", dtype);
     PK_CHECK_ARG(mode >= 0 && mode <= 2, "pk_gemm: bad epilogue mode %d", mode);
@@ -425,6 +472,6 @@ extern "C" int pk_gemm(const void* A, const void* B, void* C, const void* bias, 
     ep.act = act; ep.mode = mode; ep.alpha = alpha;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PK_BF16)
-        return launch_gemm<bf16>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, s);
-    return launch_gemm<float>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, s);
+        return launch_gemm<bf16>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
+    return launch_gemm<float>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
 }

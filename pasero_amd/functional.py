@@ -17,7 +17,8 @@ def _ld(t: Tensor) -> int:
 
 def gemm(a: Tensor, b: Tensor, *, a_col: bool = False, b_col: bool = False, bias: Optional[Tensor] = None,
          aux: Optional[Tensor] = None, act: str = 'none', mode: int = 0, alpha: float = 1.0,
-         out: Optional[Tensor] = None, preact: Optional[Tensor] = None, splitk: int = 1) -> Tensor:
+         out: Optional[Tensor] = None, preact: Optional[Tensor] = None, splitk: int = 1,
+         asum_out: Optional[Tensor] = None) -> Tensor:
     """C[m,n] = epi(alpha * sum_k A(m,k) B(n,k)).  `a` is [M,K] (or [K,M] if a_col), `b` is [N,K] (or [K,N] if b_col).
     See include/pasero_hip.h:pk_gemm for the epilogue modes."""
     require_gpu(a, b, bias, aux, out, preact)
@@ -34,15 +35,17 @@ def gemm(a: Tensor, b: Tensor, *, a_col: bool = False, b_col: bool = False, bias
         assert aux.dtype == a.dtype and aux.shape == (M, N)
     if preact is not None:
         assert preact.dtype == a.dtype and preact.shape == (M, N)
+    if asum_out is not None:
+        assert a_col and asum_out.dtype == a.dtype and asum_out.numel() == M and asum_out.is_contiguous()
     ws, ws_bytes = None, 0
     if splitk > 1:
-        ws_bytes = splitk * M * N * 4
+        ws_bytes = splitk * M * (N + 1) * 4
         ws = lib.workspace(ws_bytes, a.device, 'splitk')
     L = lib.load()
     check(L.pk_gemm(ptr(a), ptr(b), ptr(out), ptr(bias), ptr(aux), ptr(preact), M, N, K, _ld(a), _ld(b), _ld(out),
                     _ld(aux) if aux is not None else 0, _ld(preact) if preact is not None else 0,
                     int(a_col), int(b_col), ACT[act], mode, float(alpha), dtype_code(a), int(splitk),
-                    ptr(ws), ws_bytes, stream_ptr()), 'pk_gemm')
+                    ptr(ws), ws_bytes, ptr(asum_out), stream_ptr()), 'pk_gemm')
     return out
 
 

@@ -21,7 +21,7 @@ P, I, F, LL, SZ, ULL = c_void_p, c_int, c_float, c_longlong, c_size_t, c_ulonglo
 SIGNATURES = {
     'pk_version': (I, []),
     'pk_last_error': (c_char_p, []),
-    'pk_gemm': (I, [P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, SZ, P]),
+    'pk_gemm': (I, [P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, SZ, P, P]),
     'pk_residual_ln_fwd': (I, [P, P, P, P, P, P, P, P, LL, I, F, F, ULL, ULL, I, P]),
     'pk_residual_ln_bwd_workspace': (SZ, [LL, I]),
     'pk_residual_ln_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, SZ, LL, I, F, ULL, ULL, I, P]),

@@ -107,6 +107,20 @@ def test_gemm_splitk(F, dtype, splitk):
     assert rel_err(out, ref) < tol
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('splitk', [1, 7])
+@pytest.mark.parametrize('M,N,K', [(192, 160, 4100), (2048, 512, 3000), (130, 70, 100)])
+def test_gemm_fused_bias_gradient(F, dtype, splitk, M, N, K):
+    """weight-gradient GEMM dW = dYᵀ X that also emits db = colsum(dY) (asum_out)"""
+    dY = rnd((K, M), 12, dtype)
+    X = rnd((K, N), 13, dtype)
+    db = torch.empty(M, dtype=dtype, device='cuda')
+    dW = F.gemm(dY.cuda(), X.cuda(), a_col=True, b_col=True, splitk=splitk, asum_out=db)
+    tol = 2e-5 if dtype == torch.float32 else 6e-3
+    assert rel_err(dW, dY.double().t() @ X.double()) < tol
+    assert rel_err(db, dY.double().sum(0)) < tol
+
+
 def test_gemm_strided_views(F):
     """q/k/v-style column slices and a padded leading dimension"""
     M, N, K = 96, 64, 128
