@@ -7,14 +7,18 @@
 //
 // gfx950 design: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, each 64x64 = 2x2 MFMA 32x32 tiles),
 // bf16: v_mfma_f32_32x32x16_bf16, BK = 64; f32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), BK = 16.
-// Tiles are staged global -> VGPR (16 B per lane, coalesced) -> LDS with the next tile's global loads issued before
-// the MFMAs of the current one (double-buffered LDS, one barrier per K-step).  Row-form tiles are read back with
-// ds_read_b128 (row pitch padded by 16 B: conflict-free), col-form tiles with ds_read_b64_tr_b16 (hardware
-// transpose; row pitch = 256 + 64 B so the 4 k-rows of a read land on distinct bank quarters).  The f32 accumulators
-// are staged through LDS in the epilogue so that bias / activation / residual are applied on row-contiguous
-// 16-byte chunks and C is written fully coalesced.  Workgroup ids are remapped so that each XCD (blockIdx % 8)
-// owns a contiguous range of tiles, and tiles are walked in 8-row-panel groups, so the A and B panels a tile
-// shares with its neighbours are hits in that XCD's private L2.
+// bf16 staging is LDS-DMA: `global_load_lds_dwordx4` writes each wave-instruction's 64 x 16 B straight into a linear
+// 1-KiB piece of the LDS tile (no VGPR round trip, no ds_write), the next K-tile's DMA is in flight under the current
+// tile's MFMAs (double-buffered LDS, one vmcnt(0)+barrier per K-step).  Because the DMA destination is lane-linear, the
+// bank-conflict swizzle is applied to the per-lane SOURCE address and undone on the read: row-form tiles
+// ([128][128 B]) XOR the 16-B chunk index with (row>>1)&7 so ds_read_b128 is conflict-free; col-form tiles
+// ([64][256 B], read with the hardware-transposing ds_read_b64_tr_b16) XOR it with (row&3)<<2 so the 4 k-rows of a
+// transposed read land on distinct bank quarters.  K tails / unaligned operands take a register-staged path into the
+// same LDS image.  fp32 keeps register staging with padded rows.  The f32 accumulators are staged through LDS in the
+// epilogue so that bias / activation / residual are applied on row-contiguous 16-byte chunks and C is written fully
+// coalesced.  Workgroup ids are remapped so that each XCD (blockIdx % 8) owns a contiguous range of tiles, and tiles
+// are walked in 8-row-panel groups, so the A and B panels a tile shares with its neighbours are hits in that XCD's
+// private L2.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -27,24 +31,39 @@ constexpr int C_PITCH = 132;  // floats; epilogue staging [128][132]
 
 template <typename T> struct Traits;
 template <> struct Traits<bf16> {
-    static constexpr int BK = 64, EPV = 8, KSTEP = 16;
-    static constexpr int ROW_PITCH = BK * 2 + 16;   // bytes, [128][BK] tile
-    static constexpr int COL_PITCH = 128 * 2 + 64;  // bytes, [BK][128] tile
+    static constexpr int BK = 32, EPV = 8, KSTEP = 16;
+    static constexpr bool GLDS = true;
+    static constexpr int NSTAGE = 4;  // LDS-DMA ring: up to 3 K-tiles in flight under the MFMAs of the current one
 };
 template <> struct Traits<float> {
     static constexpr int BK = 16, EPV = 4, KSTEP = 2;
-    static constexpr int ROW_PITCH = BK * 4 + 4;  // 17 words: ds_read_b32 column reads are conflict-free
-    static constexpr int COL_PITCH = 128 * 4;
+    static constexpr bool GLDS = false;
+    static constexpr int NSTAGE = 2;
 };
 
-template <typename T, bool COL> struct TileGeom {
-    using TR = Traits<T>;
-    static constexpr int ROWS = COL ? TR::BK : 128;   // memory rows of the tile
-    static constexpr int COLS = COL ? 128 : TR::BK;   // contiguous elements per row
-    static constexpr int PITCH = COL ? TR::COL_PITCH : TR::ROW_PITCH;
+// LDS image of one operand tile.  ROWS x COLS elements as they lie in memory (COLS contiguous):
+//   row form: 128 x BK (k contiguous)      col form: BK x 128 (m/n contiguous)
+// offset(row, chunk) = byte offset of 16-byte chunk `chunk` of row `row`.
+template <typename T, bool COL> struct TileGeom;
+template <bool COL> struct TileGeom<bf16, COL> {
+    static constexpr int ROWS = COL ? 32 : 128, COLS = COL ? 128 : 32;
+    static constexpr int ROWB = COLS * 2;  // 64 or 256 bytes, linear (LDS-DMA pieces are 1 KiB = 16 or 4 whole rows)
+    static constexpr int BYTES = ROWS * ROWB;  // 8 KiB
+    static constexpr int PIECES = BYTES / 1024;
+    static constexpr int CPR = COLS / 8, NCH = ROWS * CPR / NTHREADS;
+    static constexpr bool VEC_WRITE = true;
+    // row form (64-B rows, ds_read_b128 of 16 rows x one chunk): 4 rows per 256-B bank row, chunk ^= (row>>2)&3
+    // col form (256-B rows, transposed reads of 4 k-rows x 64 B): 64-B group ^= row&3
+    __device__ static __forceinline__ int swz(int row) { return COL ? ((row & 3) << 2) : ((row >> 2) & 3); }
+    __device__ static __forceinline__ int offset(int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); }
+};
+template <bool COL> struct TileGeom<float, COL> {
+    static constexpr int ROWS = COL ? 16 : 128, COLS = COL ? 128 : 16;
+    static constexpr int PITCH = COL ? 512 : 68;  // row form: 17 words, ds_read_b32 column reads conflict-free
     static constexpr int BYTES = ROWS * PITCH;
-    static constexpr int CPR = COLS / TR::EPV;              // 16-B chunks per row
-    static constexpr int NCH = ROWS * CPR / NTHREADS;       // chunks per thread
+    static constexpr int CPR = COLS / 4, NCH = ROWS * CPR / NTHREADS;
+    static constexpr bool VEC_WRITE = COL;
+    __device__ static __forceinline__ int offset(int row, int chunk) { return row * PITCH + (chunk << 4); }
 };
 
 struct EpiParams {
@@ -87,12 +106,11 @@ template <typename T, bool COL, int NCH>
 __device__ __forceinline__ void tile_r2s(const Vec16<T> (&v)[NCH], char* lds, int tid) {
     using G = TileGeom<T, COL>;
     static_assert(NCH == G::NCH, "staging register count");
-    constexpr int EPV = Traits<T>::EPV;
 #pragma unroll
     for (int i = 0; i < G::NCH; ++i) {
         int c = tid + i * NTHREADS;
-        char* p = lds + (c / G::CPR) * G::PITCH + (c % G::CPR) * EPV * (int)sizeof(T);
-        if constexpr (G::PITCH % 16 == 0) {
+        char* p = lds + G::offset(c / G::CPR, c % G::CPR);
+        if constexpr (G::VEC_WRITE) {
             *reinterpret_cast<decltype(v[i].raw)*>(p) = v[i].raw;
         } else {
             const float* s = reinterpret_cast<const float*>(&v[i].raw);
@@ -102,24 +120,46 @@ __device__ __forceinline__ void tile_r2s(const Vec16<T> (&v)[NCH], char* lds, in
     }
 }
 
+// LDS-DMA staging of one bf16 operand tile: 8 pieces of 1 KiB, 2 per wave; lane l of piece b lands at byte
+// b*1024 + l*16 and fetches the (row, logical chunk) that the swizzle maps there.  Rows / column chunks past the
+// matrix edge re-read a valid address (their products only reach outputs that are never stored); the caller
+// guarantees that every k of the tile is in range.
+template <bool COL>
+__device__ __forceinline__ void tile_glds(char* lds, const bf16* __restrict__ base, long long ld, long long row0,
+                                          long long col0, long long row_lim, long long col_lim, int wave, int lane) {
+    using G = TileGeom<bf16, COL>;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void g_void;
+#pragma unroll
+    for (int i = 0; i < G::PIECES / 4; ++i) {
+        const int piece = i * 4 + wave;
+        const int o = piece * 1024 + lane * 16;
+        const int row = o / G::ROWB;
+        const int chunk = ((o % G::ROWB) >> 4) ^ G::swz(row);
+        long long gr = row0 + row, gc = col0 + chunk * 8;
+        if (gr >= row_lim) gr = row_lim - 1;
+        if (gc + 8 > col_lim) gc = col0;
+        __builtin_amdgcn_global_load_lds((g_void*)(base + gr * ld + gc), (lds_void*)(lds + piece * 1024), 16, 0, 0);
+    }
+}
+
 // MFMA operand fragment of a 32-row block starting at tile row/col `r0`, k-step `kk` (KSTEP wide), from LDS.
 // bf16, 32x32x16: lane l (r = l&31, h = l>>5) holds elements k = 16*kk + 8*h + j, j = 0..7, of row r0 + r.
 template <bool COL>
 __device__ __forceinline__ bf16x8_t frag_bf16(const char* lds, int r0, int kk, int lane) {
     using G = TileGeom<bf16, COL>;
     if constexpr (!COL) {
-        const char* p = lds + (r0 + (lane & 31)) * G::PITCH + (kk * 16 + 8 * (lane >> 5)) * 2;
-        return *reinterpret_cast<const bf16x8_t*>(p);
+        return *reinterpret_cast<const bf16x8_t*>(lds + G::offset(r0 + (lane & 31), kk * 2 + (lane >> 5)));
     } else {
         // tile is [k][m]; ds_read_b64_tr_b16: lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of a
         // 4x16 block and receives column (lane & 15), rows 0..3 -> 4 consecutive k of one m.
         int q = (lane & 15) >> 2, p4 = lane & 3;
         int col = r0 + 16 * ((lane >> 4) & 1) + 4 * p4;
         int krow = kk * 16 + 8 * (lane >> 5) + q;
-        const char* p = lds + krow * G::PITCH + col * 2;
+        const char* p = lds + G::offset(krow, col >> 3) + (col & 7) * 2;
         typedef __attribute__((address_space(3))) s16x4 lds_s4;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p + 4 * G::PITCH));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p + 4 * G::ROWB));  // (row+4)&3 == row&3
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8_t, f);
@@ -191,6 +231,67 @@ __device__ __forceinline__ void epilogue_chunk(float (&v)[8], int n_valid, long 
     }
 }
 
+// Lean epilogue for interior tiles (full 128x128, 16-byte addressable C / aux / bias) and the common epilogues
+// (no activation or ReLU; plain, +residual, or x ReLU'): thread t owns the 8-column (bf16) / 4-column (fp32) chunk
+// t % CPR of rows t / CPR + i * RPT, so its bias chunk is loaded once, all LDS reads / aux loads / stores are
+// straight-line 16-byte accesses with no per-element branching (the generic path below costs ~2500 instructions per
+// wave; this one ~300).
+template <typename T, int ACT, int MODE>
+__device__ __forceinline__ void fast_epilogue(const float* __restrict__ cs, T* __restrict__ C, const EpiParams& ep,
+                                              long long m0, long long n0, int tid) {
+    constexpr int EPV = 16 / sizeof(T), CPR = BN / EPV, RPT = NTHREADS / CPR, NIT = BM / RPT;
+    const int col = (tid % CPR) * EPV, r0 = tid / CPR;
+    float b[EPV];
+    if (MODE != 2 && ep.bias) {
+        Vec16<T> bv = load16<T>(reinterpret_cast<const T*>(ep.bias) + n0 + col);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) b[e] = bv.get(e);
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) b[e] = 0.f;
+    }
+    T* cp = C + (m0 + r0) * ep.ldc + n0 + col;
+    const T* ap = MODE != 0 ? reinterpret_cast<const T*>(ep.aux) + (m0 + r0) * ep.ldaux + n0 + col : nullptr;
+    const float alpha = ep.alpha;
+    Vec16<T> av[NIT];
+    if (MODE != 0) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) av[i] = load16<T>(ap + (long long)i * RPT * ep.ldaux);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const float* src = cs + (r0 + i * RPT) * C_PITCH + col;
+        float x[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; e += 4) {
+            float4 t4 = *reinterpret_cast<const float4*>(src + e);
+            x[e] = t4.x; x[e + 1] = t4.y; x[e + 2] = t4.z; x[e + 3] = t4.w;
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            float y = x[e] * alpha;
+            if (MODE == 2) {
+                if (ACT == PK_ACT_RELU) y = av[i].get(e) > 0.f ? y : 0.f;
+            } else {
+                y += b[e];
+                if (ACT == PK_ACT_RELU) y = fmaxf(y, 0.f);
+                if (MODE == 1) y += av[i].get(e);
+            }
+            x[e] = y;
+        }
+        if constexpr (sizeof(T) == 2) {
+            typedef __attribute__((ext_vector_type(8))) float f32x8;
+            f32x8 f = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
+            bf16x8_t h = __builtin_convertvector(f, bf16x8_t);
+            o.raw = __builtin_bit_cast(uint4, h);
+        } else {
+            o.raw = make_float4(x[0], x[1], x[2], x[3]);
+        }
+        store16<T>(cp + (long long)i * RPT * ep.ldc, o);
+    }
+}
+
 template <typename T, bool A_COL, bool B_COL>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
     const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C, float* __restrict__ ws,
@@ -200,7 +301,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
     using GA = TileGeom<T, A_COL>;
     using GB = TileGeom<T, B_COL>;
     constexpr int STAGE = GA::BYTES + GB::BYTES;
-    constexpr int SMEM = (2 * STAGE > BM * C_PITCH * 4) ? 2 * STAGE : BM * C_PITCH * 4;
+    constexpr int NS = TR::NSTAGE;
+    constexpr int SMEM = (NS * STAGE > BM * C_PITCH * 4) ? NS * STAGE : BM * C_PITCH * 4;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,7 +320,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
 
     const long long kbeg = (long long)blockIdx.y * kchunk;
     const long long kend = min(K, kbeg + (long long)kchunk);
+#if !defined(PK_ABLATE) || PK_ABLATE != 5
     const int nk = (int)((kend - kbeg + TR::BK - 1) / TR::BK);
+#endif
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -228,14 +332,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    Vec16<T> ra[GA::NCH], rb[GB::NCH];
     // fused bias gradient (weight-gradient GEMMs, A = dY in col form): the sum over k of A(m, k) for this tile's 128
-    // m-columns.  Every staging chunk of a thread covers the same EPV columns (NTHREADS % CPR == 0), so each thread
-    // keeps EPV running sums; only the tile_n == 0 workgroups do it.
+    // m-columns, accumulated from the staged LDS tile: thread t owns column chunk t % CPR, rows t / CPR + i*RL.
+    // Only the tile_n == 0 workgroups do it.
     const bool do_asum = A_COL && (asum_ws || asum_out) && tile_n == 0;
     float asum[TR::EPV];
 #pragma unroll
     for (int e = 0; e < TR::EPV; ++e) asum[e] = 0.f;
+
+    // register staging (fp32 always; bf16 only for K tails / unaligned operands)
+    Vec16<T> ra[GA::NCH], rb[GB::NCH];
     auto g2r = [&](int kt) {
         long long k0 = kbeg + (long long)kt * TR::BK;
         if constexpr (A_COL) tile_g2r<T, true>(ra, A, lda, k0, m0, kend, M, a_vec, tid);
@@ -245,41 +351,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
     };
     auto r2s = [&](int buf) {
         char* s = smem + buf * STAGE;
-        if constexpr (A_COL) {
-            if (do_asum) {
-#pragma unroll
-                for (int i = 0; i < GA::NCH; ++i)
-#pragma unroll
-                    for (int e = 0; e < TR::EPV; ++e) asum[e] += ra[i].get(e);
-            }
-        }
         tile_r2s<T, A_COL>(ra, s, tid);
         tile_r2s<T, B_COL>(rb, s + GA::BYTES, tid);
     };
-
-    if (nk > 0) {
-        g2r(0);
-        r2s(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) g2r(kt + 1);  // next tile's HBM/L2 loads fly under this tile's MFMAs
-        const char* sa = smem + (kt & 1) * STAGE;
-        const char* sb = sa + GA::BYTES;
+    // one K-tile of MFMAs from LDS stage `sa`/`sb`
+    auto compute = [&](const char* sa, const char* sb) {
+        if constexpr (A_COL) {
+            if (do_asum) {
+                constexpr int RL = NTHREADS / GA::CPR;
 #pragma unroll
-        for (int kk = 0; kk < TR::BK / TR::KSTEP; ++kk) {
-            if constexpr (sizeof(T) == 2) {
-                bf16x8_t fa[2], fb[2];
+                for (int i = 0; i < GA::ROWS / RL; ++i) {
+                    Vec16<T> v;
+                    v.raw = *reinterpret_cast<const decltype(v.raw)*>(sa + GA::offset(tid / GA::CPR + i * RL, tid % GA::CPR));
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = frag_bf16<A_COL>(sa, wm + 32 * i, kk, lane);
+                    for (int e = 0; e < TR::EPV; ++e) asum[e] += v.get(e);
+                }
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            // fragment reads of k-step kk+1 are issued before the MFMAs of k-step kk (register double buffer)
+            constexpr int NKK = TR::BK / TR::KSTEP;
+            bf16x8_t fa[2][2], fb[2][2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j] = frag_bf16<B_COL>(sb, wn + 32 * j, kk, lane);
+            for (int i = 0; i < 2; ++i) fa[0][i] = frag_bf16<A_COL>(sa, wm + 32 * i, 0, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[0][j] = frag_bf16<B_COL>(sb, wn + 32 * j, 0, lane);
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk + 1 < NKK) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fa[nxt][i] = frag_bf16<A_COL>(sa, wm + 32 * i, kk + 1, lane);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb[nxt][j] = frag_bf16<B_COL>(sb, wn + 32 * j, kk + 1, lane);
+                }
+#if defined(PK_ABLATE) && PK_ABLATE == 2
+#pragma unroll
+                for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(fa[cur][i]), "v"(fb[cur][i]));
+#else
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+#endif
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < TR::BK / TR::KSTEP; ++kk) {
                 float fa[2], fb[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) fa[i] = frag_f32<A_COL>(sa, wm + 32 * i, kk, lane);
@@ -292,8 +411,59 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (kt + 1 < nk) r2s((kt + 1) & 1);
+    };
+
+    // ---- main loop ----
+    // bf16, 16-byte addressable operands: the K-tiles that are full in k go through a 4-stage LDS-DMA ring with counted
+    // vmcnt waits and raw barriers (a __syncthreads() would drain the DMA queue): tile kt+3 is issued right after the
+    // barrier that retires tile kt-1's stage, so up to 3 tiles (24 KiB per workgroup) stay in flight under the MFMAs.
+    const bool dma_ok = TR::GLDS && a_vec && b_vec && (M % TR::EPV == 0 || !A_COL) && (N % TR::EPV == 0 || !B_COL);
+#if defined(PK_ABLATE) && PK_ABLATE == 5
+    const int nk_dma = 0;
+    const int nk = 0;
+#else
+    const int nk_dma = dma_ok ? (int)((kend - kbeg) / TR::BK) : 0;
+#endif
+    if constexpr (TR::GLDS) {
+        constexpr int D = NS - 1;                        // prefetch distance
+        constexpr int LPT = (GA::PIECES + GB::PIECES) / 4;  // LDS-DMA instructions per thread per K-tile
+        static_assert(LPT == 4 && D == 3, "vmcnt immediates below assume 4 loads per tile, 3 tiles ahead");
+        auto dma = [&](int kt) {
+            long long k0 = kbeg + (long long)kt * TR::BK;
+            char* s = smem + (kt % NS) * STAGE;
+            if constexpr (A_COL) tile_glds<true>(s, (const bf16*)A, lda, k0, m0, kend, M, wave, lane);
+            else tile_glds<false>(s, (const bf16*)A, lda, m0, k0, M, kend, wave, lane);
+            if constexpr (B_COL) tile_glds<true>(s + GA::BYTES, (const bf16*)B, ldb, k0, n0, kend, N, wave, lane);
+            else tile_glds<false>(s + GA::BYTES, (const bf16*)B, ldb, n0, k0, N, kend, wave, lane);
+        };
+        for (int kt = 0; kt < D && kt < nk_dma; ++kt) dma(kt);
+        for (int kt = 0; kt < nk_dma; ++kt) {
+            const int ahead = min(nk_dma, kt + D) - kt - 1;  // tiles issued after kt that may stay in flight
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; stage (kt-1)%NS is no longer read
+#if !defined(PK_ABLATE) || PK_ABLATE != 1
+            if (kt + D < nk_dma) dma(kt + D);
+#endif
+            const char* sa = smem + (kt % NS) * STAGE;
+            compute(sa, sa + GA::BYTES);
+        }
+        if (nk_dma > 0) __syncthreads();
+    }
+    // register-staged path: fp32, unaligned operands, and the K tail (rows/cols past kend are zero-filled)
+    if (nk_dma < nk) {
+        g2r(nk_dma);
+        r2s(0);
         __syncthreads();
+        for (int kt = nk_dma; kt < nk; ++kt) {
+            const int buf = (kt - nk_dma) & 1;
+            if (kt + 1 < nk) g2r(kt + 1);  // next tile's loads fly under this tile's MFMAs
+            const char* sa = smem + buf * STAGE;
+            compute(sa, sa + GA::BYTES);
+            if (kt + 1 < nk) r2s(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     if constexpr (A_COL) {
@@ -314,6 +484,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
         }
     }
 
+#if defined(PK_ABLATE) && PK_ABLATE == 4
+    if (acc[0][0][0] != 12345.f) return;
+#endif
     // ---- epilogue: accumulators -> LDS (f32) -> row-contiguous chunks -> global ----
     float* cs = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -345,6 +518,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
         return;
     }
     constexpr int EPV = TR::EPV;
+    {   // block-uniform: interior tile + vectorisable operands + a common epilogue -> lean path
+        const bool interior = m0 + BM <= M && n0 + BN <= N;
+        const bool bias_ok = !ep.bias || (((uintptr_t)ep.bias % 16) == 0);
+        const bool simple = !ep.preact && c_vec && bias_ok && (ep.mode == 0 || aux_vec) &&
+                            (ep.act == PK_ACT_NONE || ep.act == PK_ACT_RELU);
+        if (interior && simple) {
+            if (ep.mode == 0) {
+                if (ep.act == PK_ACT_RELU) fast_epilogue<T, PK_ACT_RELU, 0>(cs, C, ep, m0, n0, tid);
+                else fast_epilogue<T, PK_ACT_NONE, 0>(cs, C, ep, m0, n0, tid);
+            } else if (ep.mode == 1) {
+                if (ep.act == PK_ACT_RELU) fast_epilogue<T, PK_ACT_RELU, 1>(cs, C, ep, m0, n0, tid);
+                else fast_epilogue<T, PK_ACT_NONE, 1>(cs, C, ep, m0, n0, tid);
+            } else {
+                if (ep.act == PK_ACT_RELU) fast_epilogue<T, PK_ACT_RELU, 2>(cs, C, ep, m0, n0, tid);
+                else fast_epilogue<T, PK_ACT_NONE, 2>(cs, C, ep, m0, n0, tid);
+            }
+            return;
+        }
+    }
 #pragma unroll 2
     for (int c = tid; c < BM * (BN / EPV); c += NTHREADS) {
         int row = c / (BN / EPV), col = (c % (BN / EPV)) * EPV;

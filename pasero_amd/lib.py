@@ -10,7 +10,7 @@ from ctypes import c_int, c_float, c_longlong, c_size_t, c_ulonglong, c_void_p, 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpasero_hip.so')
+LIB_PATH = os.environ.get('PASERO_HIP_LIB') or os.path.join(_HERE, 'libpasero_hip.so')  # env: diagnostic builds
 
 PK_F32, PK_BF16 = 0, 1
 ACT = {'none': 0, None: 0, 'relu': 1, 'gelu': 2, 'gelu_tanh': 3, 'geglu': 3, 'swiglu': 4, 'silu': 4}

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of pk_gemm on the hot-path shapes (random bf16 data), next to torch.matmul (hipBLASLt) on the same
+data as the known-good reference.  usage: tools/gemm_bench.py [--only NAME] [--iters N] [--no-torch]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pasero_amd import functional as F  # noqa: E402
+
+SHAPES = {
+    # name: (M, N, K, a_col, b_col, splitk)
+    'qkv_fwd': (32768, 1536, 512, False, False, 1),
+    'out_fwd': (32768, 512, 512, False, False, 1),
+    'fc1_fwd': (32768, 2048, 512, False, False, 1),
+    'fc2_fwd': (32768, 512, 2048, False, False, 1),
+    'vocab_fwd': (8192, 8032, 512, False, False, 1),
+    'fc1_dx': (32768, 512, 2048, False, True, 1),
+    'fc2_dx': (32768, 2048, 512, False, True, 1),
+    'qkv_dx': (32768, 512, 1536, False, True, 1),
+    'fc1_dw': (2048, 512, 32768, True, True, 0),
+    'out_dw': (512, 512, 32768, True, True, 0),
+    'big_4k': (4096, 4096, 4096, False, False, 1),
+}
+
+
+def bench(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', nargs='*')
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--no-torch', action='store_true')
+    args = ap.parse_args()
+    for name, (M, N, K, a_col, b_col, splitk) in SHAPES.items():
+        if args.only and name not in args.only:
+            continue
+        A = torch.randn(M, K, device='cuda').bfloat16()
+        B = torch.randn(N, K, device='cuda').bfloat16()
+        a = A.t().contiguous() if a_col else A
+        b = B.t().contiguous() if b_col else B
+        sk = F.choose_splitk(M, N, K) if splitk == 0 else splitk
+        out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+        us = bench(lambda: F.gemm(a, b, a_col=a_col, b_col=b_col, splitk=sk, out=out), args.iters)
+        tf = 2.0 * M * N * K / us / 1e6
+        line = f'{name:10s} M={M:6d} N={N:5d} K={K:6d} {"col" if a_col else "row"},{"col" if b_col else "row"} sk={sk:2d}  ours {us:8.1f} us {tf:7.1f} TF'
+        if not args.no_torch:
+            if a_col and b_col:
+                ref = lambda: torch.matmul(a.t(), b)  # noqa: E731
+            elif b_col:
+                ref = lambda: torch.matmul(a, b)  # noqa: E731
+            else:
+                ref = lambda: torch.matmul(a, b.t())  # noqa: E731
+            us2 = bench(ref, args.iters)
+            line += f' | torch {us2:8.1f} us {2.0 * M * N * K / us2 / 1e6:7.1f} TF'
+        print(line, flush=True)
+
+
+if __name__ == '__main__':
+    main()
