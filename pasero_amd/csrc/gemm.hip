@@ -28,12 +28,19 @@ namespace {
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
 constexpr int C_PITCH = 132;  // floats; epilogue staging [128][132]
+constexpr int EPI_PASSES = 1;
 
 template <typename T> struct Traits;
+#ifndef PK_BK
+#define PK_BK 64
+#endif
+#ifndef PK_NS
+#define PK_NS 2
+#endif
 template <> struct Traits<bf16> {
-    static constexpr int BK = 32, EPV = 8, KSTEP = 16;
+    static constexpr int BK = PK_BK, EPV = 8, KSTEP = 16;
     static constexpr bool GLDS = true;
-    static constexpr int NSTAGE = 4;  // LDS-DMA ring: up to 3 K-tiles in flight under the MFMAs of the current one
+    static constexpr int NSTAGE = PK_NS;  // LDS-DMA ring: NSTAGE-1 K-tiles in flight under the MFMAs of the current one
 };
 template <> struct Traits<float> {
     static constexpr int BK = 16, EPV = 4, KSTEP = 2;
@@ -46,15 +53,18 @@ template <> struct Traits<float> {
 // offset(row, chunk) = byte offset of 16-byte chunk `chunk` of row `row`.
 template <typename T, bool COL> struct TileGeom;
 template <bool COL> struct TileGeom<bf16, COL> {
-    static constexpr int ROWS = COL ? 32 : 128, COLS = COL ? 128 : 32;
-    static constexpr int ROWB = COLS * 2;  // 64 or 256 bytes, linear (LDS-DMA pieces are 1 KiB = 16 or 4 whole rows)
-    static constexpr int BYTES = ROWS * ROWB;  // 8 KiB
+    static constexpr int BKB = Traits<bf16>::BK;
+    static constexpr int ROWS = COL ? BKB : 128, COLS = COL ? 128 : BKB;
+    static constexpr int ROWB = COLS * 2;  // 64/128 or 256 bytes, linear (LDS-DMA pieces are 1 KiB of whole rows)
+    static constexpr int BYTES = ROWS * ROWB;
     static constexpr int PIECES = BYTES / 1024;
     static constexpr int CPR = COLS / 8, NCH = ROWS * CPR / NTHREADS;
     static constexpr bool VEC_WRITE = true;
     // row form (64-B rows, ds_read_b128 of 16 rows x one chunk): 4 rows per 256-B bank row, chunk ^= (row>>2)&3
     // col form (256-B rows, transposed reads of 4 k-rows x 64 B): 64-B group ^= row&3
-    __device__ static __forceinline__ int swz(int row) { return COL ? ((row & 3) << 2) : ((row >> 2) & 3); }
+    __device__ static __forceinline__ int swz(int row) {
+        return COL ? ((row & 3) << 2) : (BKB == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7));
+    }
     __device__ static __forceinline__ int offset(int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); }
 };
 template <bool COL> struct TileGeom<float, COL> {
@@ -239,7 +249,7 @@ __device__ __forceinline__ void epilogue_chunk(float (&v)[8], int n_valid, long 
 template <typename T, int ACT, int MODE>
 __device__ __forceinline__ void fast_epilogue(const float* __restrict__ cs, T* __restrict__ C, const EpiParams& ep,
                                               long long m0, long long n0, int tid) {
-    constexpr int EPV = 16 / sizeof(T), CPR = BN / EPV, RPT = NTHREADS / CPR, NIT = BM / RPT;
+    constexpr int EPV = 16 / sizeof(T), CPR = BN / EPV, RPT = NTHREADS / CPR, NIT = (BM / EPI_PASSES) / RPT;
     const int col = (tid % CPR) * EPV, r0 = tid / CPR;
     float b[EPV];
     if (MODE != 2 && ep.bias) {
@@ -292,8 +302,11 @@ __device__ __forceinline__ void fast_epilogue(const float* __restrict__ cs, T* _
     }
 }
 
+#ifndef PK_OCC
+#define PK_OCC 2
+#endif
 template <typename T, bool A_COL, bool B_COL>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
+__global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
     const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C, float* __restrict__ ws,
     float* __restrict__ asum_ws, T* __restrict__ asum_out, long long M, long long N, long long K, long long lda,
     long long ldb, int kchunk, EpiParams ep, int flags) {
@@ -302,7 +315,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
     using GB = TileGeom<T, B_COL>;
     constexpr int STAGE = GA::BYTES + GB::BYTES;
     constexpr int NS = TR::NSTAGE;
-    constexpr int SMEM = (NS * STAGE > BM * C_PITCH * 4) ? NS * STAGE : BM * C_PITCH * 4;
+    constexpr int CST = (BM / EPI_PASSES) * C_PITCH * 4;
+    constexpr int SMEM = (NS * STAGE > CST) ? NS * STAGE : CST;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -427,7 +441,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
     if constexpr (TR::GLDS) {
         constexpr int D = NS - 1;                        // prefetch distance
         constexpr int LPT = (GA::PIECES + GB::PIECES) / 4;  // LDS-DMA instructions per thread per K-tile
-        static_assert(LPT == 4 && D == 3, "vmcnt immediates below assume 4 loads per tile, 3 tiles ahead");
+        static_assert(D >= 1 && D <= 3 && (LPT == 4 || LPT == 8), "vmcnt immediates below");
         auto dma = [&](int kt) {
             long long k0 = kbeg + (long long)kt * TR::BK;
             char* s = smem + (kt % NS) * STAGE;
@@ -439,9 +453,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
         for (int kt = 0; kt < D && kt < nk_dma; ++kt) dma(kt);
         for (int kt = 0; kt < nk_dma; ++kt) {
             const int ahead = min(nk_dma, kt + D) - kt - 1;  // tiles issued after kt that may stay in flight
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (LPT == 4) {
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; stage (kt-1)%NS is no longer read
 #if !defined(PK_ABLATE) || PK_ABLATE != 1
             if (kt + D < nk_dma) dma(kt + D);
@@ -487,69 +507,73 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(
 #if defined(PK_ABLATE) && PK_ABLATE == 4
     if (acc[0][0][0] != 12345.f) return;
 #endif
-    // ---- epilogue: accumulators -> LDS (f32) -> row-contiguous chunks -> global ----
+    // ---- epilogue: accumulators -> LDS (f32) -> row-contiguous chunks -> global, in EPI_PASSES row slabs (1: the
+    // whole 128x128 tile through a 66 KiB staging buffer — measured faster than 2 x 33 KiB at 2 workgroups/CU) ----
     float* cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                int col = wn + 32 * j + (lane & 31);
-                cs[row * C_PITCH + col] = acc[i][j][r];
-            }
-    __syncthreads();
-
-    if (ws) {  // split-K partial: raw f32 slab [gridDim.y][M][N]
-        float* slab = ws + (long long)blockIdx.y * M * N;
-        const bool ws_vec = (N % 4) == 0;
-#pragma unroll 4
-        for (int c = tid; c < BM * (BN / 4); c += NTHREADS) {
-            int row = c / (BN / 4), col = (c % (BN / 4)) * 4;
-            long long gm = m0 + row, gn = n0 + col;
-            if (gm >= M || gn >= N) continue;
-            float4 v = *reinterpret_cast<const float4*>(cs + row * C_PITCH + col);
-            float* p = slab + gm * N + gn;
-            if (ws_vec && gn + 4 <= N) *reinterpret_cast<float4*>(p) = v;
-            else
-                for (int e = 0; e < 4 && gn + e < N; ++e) p[e] = (&v.x)[e];
-        }
-        return;
-    }
     constexpr int EPV = TR::EPV;
-    {   // block-uniform: interior tile + vectorisable operands + a common epilogue -> lean path
-        const bool interior = m0 + BM <= M && n0 + BN <= N;
-        const bool bias_ok = !ep.bias || (((uintptr_t)ep.bias % 16) == 0);
-        const bool simple = !ep.preact && c_vec && bias_ok && (ep.mode == 0 || aux_vec) &&
-                            (ep.act == PK_ACT_NONE || ep.act == PK_ACT_RELU);
-        if (interior && simple) {
-            if (ep.mode == 0) {
-                if (ep.act == PK_ACT_RELU) fast_epilogue<T, PK_ACT_RELU, 0>(cs, C, ep, m0, n0, tid);
-                else fast_epilogue<T, PK_ACT_NONE, 0>(cs, C, ep, m0, n0, tid);
-            } else if (ep.mode == 1) {
-                if (ep.act == PK_ACT_RELU) fast_epilogue<T, PK_ACT_RELU, 1>(cs, C, ep, m0, n0, tid);
-                else fast_epilogue<T, PK_ACT_NONE, 1>(cs, C, ep, m0, n0, tid);
-            } else {
-                if (ep.act == PK_ACT_RELU) fast_epilogue<T, PK_ACT_RELU, 2>(cs, C, ep, m0, n0, tid);
-                else fast_epilogue<T, PK_ACT_NONE, 2>(cs, C, ep, m0, n0, tid);
-            }
-            return;
-        }
-    }
-#pragma unroll 2
-    for (int c = tid; c < BM * (BN / EPV); c += NTHREADS) {
-        int row = c / (BN / EPV), col = (c % (BN / EPV)) * EPV;
-        long long gm = m0 + row, gn = n0 + col;
-        if (gm >= M || gn >= N) continue;
-        float v[8];
+    constexpr int HM = BM / EPI_PASSES;
+    const bool interior = m0 + BM <= M && n0 + BN <= N;
+    const bool bias_ok = !ep.bias || (((uintptr_t)ep.bias % 16) == 0);
+    const bool simple = !ep.preact && c_vec && bias_ok && (ep.mode == 0 || aux_vec) &&
+                        (ep.act == PK_ACT_NONE || ep.act == PK_ACT_RELU);
+#pragma unroll 1
+    for (int half = 0; half < EPI_PASSES; ++half) {
+        if (EPI_PASSES == 1 || (wave >> 1) == half) {
 #pragma unroll
-        for (int e = 0; e < EPV; e += 4) {
-            float4 t4 = *reinterpret_cast<const float4*>(cs + row * C_PITCH + col + e);
-            v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int row = (EPI_PASSES == 1 ? wm : 0) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        int col = wn + 32 * j + (lane & 31);
+                        cs[row * C_PITCH + col] = acc[i][j][r];
+                    }
         }
-        int n_valid = (int)min((long long)EPV, N - gn);
-        epilogue_chunk<T>(v, n_valid, gm, gn, ep, sizeof(T) == 2, C, c_vec, aux_vec);
+        __syncthreads();
+        const long long mh = m0 + half * HM;
+        if (ws) {  // split-K partial: raw f32 slab [gridDim.y][M][N]
+            float* slab = ws + (long long)blockIdx.y * M * N;
+            const bool ws_vec = (N % 4) == 0;
+#pragma unroll 4
+            for (int c = tid; c < HM * (BN / 4); c += NTHREADS) {
+                int row = c / (BN / 4), col = (c % (BN / 4)) * 4;
+                long long gm = mh + row, gn = n0 + col;
+                if (gm >= M || gn >= N) continue;
+                float4 v = *reinterpret_cast<const float4*>(cs + row * C_PITCH + col);
+                float* p = slab + gm * N + gn;
+                if (ws_vec && gn + 4 <= N) *reinterpret_cast<float4*>(p) = v;
+                else
+                    for (int e = 0; e < 4 && gn + e < N; ++e) p[e] = (&v.x)[e];
+            }
+        } else if (interior && simple) {  // block-uniform: lean path
+            if (ep.mode == 0) {
+                if (ep.act == PK_ACT_RELU) fast_epilogue<T, PK_ACT_RELU, 0>(cs, C, ep, mh, n0, tid);
+                else fast_epilogue<T, PK_ACT_NONE, 0>(cs, C, ep, mh, n0, tid);
+            } else if (ep.mode == 1) {
+                if (ep.act == PK_ACT_RELU) fast_epilogue<T, PK_ACT_RELU, 1>(cs, C, ep, mh, n0, tid);
+                else fast_epilogue<T, PK_ACT_NONE, 1>(cs, C, ep, mh, n0, tid);
+            } else {
+                if (ep.act == PK_ACT_RELU) fast_epilogue<T, PK_ACT_RELU, 2>(cs, C, ep, mh, n0, tid);
+                else fast_epilogue<T, PK_ACT_NONE, 2>(cs, C, ep, mh, n0, tid);
+            }
+        } else {
+#pragma unroll 2
+            for (int c = tid; c < HM * (BN / EPV); c += NTHREADS) {
+                int row = c / (BN / EPV), col = (c % (BN / EPV)) * EPV;
+                long long gm = mh + row, gn = n0 + col;
+                if (gm >= M || gn >= N) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < EPV; e += 4) {
+                    float4 t4 = *reinterpret_cast<const float4*>(cs + row * C_PITCH + col + e);
+                    v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
+                }
+                int n_valid = (int)min((long long)EPV, N - gn);
+                epilogue_chunk<T>(v, n_valid, gm, gn, ep, sizeof(T) == 2, C, c_vec, aux_vec);
+            }
+        }
+        if (half + 1 < EPI_PASSES) __syncthreads();
     }
 }
 
