@@ -130,6 +130,14 @@ int pk_glu_bwd(const void* dy, const void* x, void* dx, long long rows, int C, i
 int pk_col2im1d(const void* dA, void* dx, int B, int L, int C, int R, int Lout, int ksize, int stride, int pad,
                 int dtype, void* stream);
 
+/* ---- Whisper log-mel features (K8).  The reference computes them offline with the third-party
+ * transformers.WhisperFeatureExtractor (examples/Whisper/extract-features.py:107-117, no mel code in the repo); this
+ * restates that algorithm: wav (B clips, fp32, 16 kHz, `wav_stride` floats apart, wav_len[b] valid samples or NULL = all
+ * 480000) -> out (B, 3000, 80) fp32 = ((max(log10 mel, max - 8)) + 4) / 4, frames x mel as extract-features.py:116. */
+size_t pk_logmel_workspace(int B);
+int pk_logmel(const float* wav, const long long* wav_len, long long wav_stride, float* out, void* workspace,
+              size_t ws_bytes, int B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -297,3 +297,21 @@ def col2im1d(dA: Tensor, B: int, L: int, C: int, R: int, Lout: int, ksize: int, 
     check(lib.load().pk_col2im1d(ptr(dA), ptr(dx), B, L, C, R, Lout, ksize, stride, pad, dtype_code(dA),
                                  stream_ptr()), 'pk_col2im1d')
     return dx
+
+
+def log_mel(wav: Tensor, wav_len: Optional[Tensor] = None) -> Tensor:
+    """wav (B, n<=480000) fp32 on the GPU (16 kHz) -> Whisper log-mel features (B, 3000, 80) fp32.
+    `wav_len` (B,) int64: valid samples per clip (default: all n)."""
+    require_gpu(wav, wav_len)
+    assert wav.dim() == 2 and wav.dtype == torch.float32 and wav.stride(1) == 1
+    B, n = wav.shape
+    if wav_len is None:
+        wav_len = torch.full((B,), min(n, 480000), dtype=torch.int64, device=wav.device)
+    assert wav_len.dtype == torch.int64 and wav_len.is_contiguous() and wav_len.numel() == B
+    out = torch.empty(B, 3000, 80, dtype=torch.float32, device=wav.device)
+    L = lib.load()
+    ws_bytes = L.pk_logmel_workspace(B)
+    ws = lib.workspace(ws_bytes, wav.device, 'logmel')
+    check(L.pk_logmel(ptr(wav), ptr(wav_len), wav.stride(0), ptr(out), ptr(ws), ws_bytes, B, stream_ptr()),
+          'pk_logmel')
+    return out

@@ -362,3 +362,39 @@ def test_dropout_and_scale(F, dtype):
     s = torch.tensor([3.0], device='cuda')
     z = F.scale(x, s, 0.5)
     assert rel_err(z, x.float() * 1.5) < (1e-6 if dtype == torch.float32 else 8e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# K8: Whisper log-mel
+# ------------------------------------------------------------------------------------------------------------
+def test_log_mel_vs_golden_and_oracle(F):
+    """golden = transformers.WhisperFeatureExtractor (the third-party code the reference calls); oracle = numpy fp64.
+    fp32 DFT on the matrix cores vs fp64: features are O(1) on a log10 scale -> 5e-4 absolute"""
+    from conftest import load_golden
+    g = load_golden('logmel')
+    w0, w1 = g['wav0'], g['wav1']
+    n = max(len(w0), len(w1))
+    wav = torch.zeros(2, n)
+    wav[0, :len(w0)] = torch.from_numpy(w0)
+    wav[1, :len(w1)] = torch.from_numpy(w1)
+    lens = torch.tensor([len(w0), len(w1)])
+    out = F.log_mel(wav.cuda(), lens.cuda()).cpu().numpy()
+    assert out.shape == (2, 3000, 80)
+    for i, w in enumerate((w0, w1)):
+        ref = O.log_mel(w)
+        assert np.abs(out[i] - ref).max() < 5e-4
+        assert np.abs(out[i, :240] - g['feats'][i]).max() < 5e-4
+        assert np.abs(out[i, -4:] - g['feats_tail'][i]).max() < 5e-4
+
+
+def test_log_mel_full_30s_clip_and_truncation(F):
+    """maximum size: a clip longer than 30 s is truncated to 480000 samples; reflect padding at both ends"""
+    gen = torch.Generator().manual_seed(80)
+    wav = 0.1 * torch.randn(2, 500000, generator=gen)
+    out = F.log_mel(wav.cuda()).cpu().numpy()
+    ref = O.log_mel(wav[1].numpy())
+    assert np.abs(out[1] - ref).max() < 5e-4
+    assert np.isfinite(out).all()
+    silent = torch.zeros(1, 16000)
+    o2 = F.log_mel(silent.cuda()).cpu().numpy()
+    assert np.allclose(o2, (np.log10(1e-10) + 4) / 4)  # all-zero input: every bin clamps at 1e-10
