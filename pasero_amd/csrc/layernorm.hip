@@ -4,7 +4,8 @@
 // HBM-bound: one wave (64 lanes) owns one row, each lane keeps its 16-byte chunks of the row in registers, so a row
 // is read exactly once; mean / variance are wave-shuffle reductions in fp32 (two-pass variance, like aten).
 // The dropout mask is regenerated from (seed, offset, element index) in the backward pass, never stored.
-// dgamma / dbeta: per-workgroup partial column sums in fp32 -> second kernel (deterministic, no atomics).
+// dgamma / dbeta: per-lane running sums over a wave's rows, one LDS reduction per workgroup, then fp32 atomic adds
+// (256-byte wave-instructions, ~4 KiB per workgroup) into a [2][d] accumulator and a tiny conversion kernel.
 #include "common.h"
 
 namespace {
@@ -111,7 +112,7 @@ template <typename T, int NCH>
 __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ dz_extra, const T* __restrict__ z, const T* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dres_out, T* __restrict__ dx_out,
-    float* __restrict__ partials /* [gridDim.x][2][d] */, long long rows, int d, unsigned thr, float drop_scale,
+    float* __restrict__ partials /* accum[2][d], zeroed by the caller */, long long rows, int d, unsigned thr, float drop_scale,
     unsigned long long seed, unsigned long long offset) {
     constexpr int EPV = 16 / sizeof(T);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
         }
     }
     if (!partials) return;
-    // 4 waves -> one partial row per block
+    // 4 waves -> one partial per workgroup -> fp32 atomics into accum[2][d]
     __shared__ float red[ROWS_PER_BLOCK][2][64 * EPV];  // per wave, one chunk-column set at a time
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -215,31 +216,21 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
             int gcol = i * 64 * EPV + col;
             if (gcol < d) {
                 float s = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
-                partials[((long long)blockIdx.x * 2 + which) * d + gcol] = s;
+                atomicAdd(partials + (long long)which * d + gcol, s);
             }
         }
         __syncthreads();
     }
 }
 
-// out[which][col] = sum_b partials[b][which][col]   (which = 0: dgamma, 1: dbeta)
-// workgroup = 64 columns x 4 partial-row lanes (coalesced 256-B reads), grid = (d/64, 2)
+// accum[2][d] fp32 -> dgamma / dbeta in T
 template <typename T>
-__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ partials, T* __restrict__ dgamma,
-                                                            T* __restrict__ dbeta, int nblocks, int d) {
-    __shared__ float red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + tx, which = blockIdx.y;
-    float s = 0.f;
-    if (col < d)
-        for (int b = ty; b < nblocks; b += 4) s += partials[((long long)b * 2 + which) * d + col];
-    red[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && col < d) {
-        float t = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
-        T* out = which == 0 ? dgamma : dbeta;
-        if (out) out[col] = from_f32<T>(t);
-    }
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ accum, T* __restrict__ dgamma,
+                                                            T* __restrict__ dbeta, int d) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= d) return;
+    if (dgamma) dgamma[col] = from_f32<T>(accum[col]);
+    if (dbeta) dbeta[col] = from_f32<T>(accum[d + col]);
 }
 
 inline int ln_grid(long long rows) {
@@ -281,11 +272,13 @@ int launch_bwd(const void* dy, const void* dz_extra, const void* z, const void* 
     float scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
     int nch = (d / EPV + 63) / 64;
     int nblocks = ln_grid(rows);
-    if (nblocks > 256) nblocks = 256;
+    if (nblocks > 1024) nblocks = 1024;  // 16 waves/CU stream at HBM rate; fewer workgroups = fewer dgamma/dbeta atomics
     bool want_pg = gamma && (dgamma || dbeta);
     if (want_pg) {
-        size_t need = (size_t)nblocks * 2 * d * sizeof(float);
+        size_t need = (size_t)2 * d * sizeof(float);
         PK_CHECK_ARG(ws && ws_bytes >= need, "pk_residual_ln_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
+        hipError_t e = hipMemsetAsync(ws, 0, need, s);
+        if (e != hipSuccess) { pk_set_error("pk_residual_ln_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
     }
     dim3 grid(nblocks), block(256);
 #define PK_L(N)                                                                                                  \
@@ -299,8 +292,8 @@ int launch_bwd(const void* dy, const void* dz_extra, const void* z, const void* 
 #undef PK_L
     PK_LAUNCH_CHECK();
     if (want_pg) {
-        hipLaunchKernelGGL((ln_param_grad_kernel<T>), dim3((d + 63) / 64, 2), dim3(256), 0, s, ws, (T*)dgamma,
-                           (T*)dbeta, nblocks, d);
+        hipLaunchKernelGGL((ln_param_grad_kernel<T>), dim3((d + 255) / 256), dim3(256), 0, s, ws, (T*)dgamma,
+                           (T*)dbeta, d);
         PK_LAUNCH_CHECK();
     }
     return 0;
@@ -326,9 +319,8 @@ extern "C" int pk_residual_ln_fwd(const void* x, const void* residual, const voi
 }
 
 extern "C" size_t pk_residual_ln_bwd_workspace(long long rows, int d) {
-    int nblocks = ln_grid(rows);
-    if (nblocks > 256) nblocks = 256;
-    return (size_t)nblocks * 2 * d * sizeof(float);
+    (void)rows;
+    return (size_t)2 * d * sizeof(float);
 }
 
 extern "C" int pk_residual_ln_bwd(const void* dy, const void* dz_extra, const void* z, const void* gamma,
