@@ -439,37 +439,76 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
     const int nk_dma = dma_ok ? (int)((kend - kbeg) / TR::BK) : 0;
 #endif
     if constexpr (TR::GLDS) {
-        constexpr int D = NS - 1;                        // prefetch distance
-        constexpr int LPT = (GA::PIECES + GB::PIECES) / 4;  // LDS-DMA instructions per thread per K-tile
-        static_assert(D >= 1 && D <= 3 && (LPT == 4 || LPT == 8), "vmcnt immediates below");
+        static_assert(NS == 2, "the software-pipelined DMA loop below is written for a double buffer");
+        constexpr int NKK = TR::BK / TR::KSTEP;
+        static_assert(NKK % 2 == 0, "fragment register parity must be the same at every tile start");
         auto dma = [&](int kt) {
             long long k0 = kbeg + (long long)kt * TR::BK;
-            char* s = smem + (kt % NS) * STAGE;
+            char* s = smem + (kt & 1) * STAGE;
             if constexpr (A_COL) tile_glds<true>(s, (const bf16*)A, lda, k0, m0, kend, M, wave, lane);
             else tile_glds<false>(s, (const bf16*)A, lda, m0, k0, M, kend, wave, lane);
             if constexpr (B_COL) tile_glds<true>(s + GA::BYTES, (const bf16*)B, ldb, k0, n0, kend, N, wave, lane);
             else tile_glds<false>(s + GA::BYTES, (const bf16*)B, ldb, n0, k0, N, kend, wave, lane);
         };
-        for (int kt = 0; kt < D && kt < nk_dma; ++kt) dma(kt);
-        for (int kt = 0; kt < nk_dma; ++kt) {
-            const int ahead = min(nk_dma, kt + D) - kt - 1;  // tiles issued after kt that may stay in flight
-            if constexpr (LPT == 4) {
-                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; stage (kt-1)%NS is no longer read
+        if (nk_dma > 0) {
+            // Software pipeline across K-tiles: the fragments of (tile t+1, k-step 0) are read from LDS — and the DMA of
+            // tile t+2 is issued — BEFORE the last 4 MFMAs of tile t, right behind the one barrier per tile, so neither the
+            // LDS read latency nor the DMA issue sits in front of a tile's first MFMA.
+            bf16x8_t fa[2][2], fb[2][2];
+            dma(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[0][i] = frag_bf16<A_COL>(smem, wm + 32 * i, 0, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[0][j] = frag_bf16<B_COL>(smem + GA::BYTES, wn + 32 * j, 0, lane);
+            if (nk_dma > 1) dma(1);
+            for (int kt = 0; kt < nk_dma; ++kt) {
+                const char* sa = smem + (kt & 1) * STAGE;
+                const char* sb = sa + GA::BYTES;
+                if constexpr (A_COL) {
+                    if (do_asum) {
+                        constexpr int RL = NTHREADS / GA::CPR;
+#pragma unroll
+                        for (int i = 0; i < GA::ROWS / RL; ++i) {
+                            Vec16<T> v;
+                            v.raw = *reinterpret_cast<const decltype(v.raw)*>(
+                                sa + GA::offset(tid / GA::CPR + i * RL, tid % GA::CPR));
+#pragma unroll
+                            for (int e = 0; e < TR::EPV; ++e) asum[e] += v.get(e);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const int cur = kk & 1, nxt = cur ^ 1;
+                    if (kk + 1 < NKK) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) fa[nxt][i] = frag_bf16<A_COL>(sa, wm + 32 * i, kk + 1, lane);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) fb[nxt][j] = frag_bf16<B_COL>(sb, wn + 32 * j, kk + 1, lane);
+                    } else if (kt + 1 < nk_dma) {
+                        // every LDS read of tile kt has returned, my pieces of tile kt+1 have landed
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        const char* na = smem + ((kt + 1) & 1) * STAGE;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) fa[nxt][i] = frag_bf16<A_COL>(na, wm + 32 * i, 0, lane);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) fb[nxt][j] = frag_bf16<B_COL>(na + GA::BYTES, wn + 32 * j, 0, lane);
 #if !defined(PK_ABLATE) || PK_ABLATE != 1
-            if (kt + D < nk_dma) dma(kt + D);
+                        if (kt + 2 < nk_dma) dma(kt + 2);  // into the stage tile kt just vacated
 #endif
-            const char* sa = smem + (kt % NS) * STAGE;
-            compute(sa, sa + GA::BYTES);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                }
+            }
+            __syncthreads();
         }
-        if (nk_dma > 0) __syncthreads();
     }
     // register-staged path: fp32, unaligned operands, and the K tail (rows/cols past kend are zero-filled)
     if (nk_dma < nk) {
