@@ -326,7 +326,9 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
     // tile walk: XCD-contiguous, 8-row-panel groups, n fastest inside a group
     const int nt_m = (int)((M + BM - 1) / BM), nt_n = (int)((N + BN - 1) / BN);
     int t = xcd_remap(blockIdx.x, nt_m * nt_n);
-    const int GROUP_M = 8;
+    // panel-group height: the GROUP_M A panels + the B panels touched by the ~64 workgroups resident on an XCD should stay
+    // inside its 4 MiB L2; narrow outputs (nt_n <= 4) afford 16 A panels, which quarters the re-reads of B
+    const int GROUP_M = nt_n <= 4 ? 16 : 8;
     int group_size = GROUP_M * nt_n, gid = t / group_size, first_m = gid * GROUP_M;
     int gsz = min(nt_m - first_m, GROUP_M);
     int tile_m = first_m + (t % group_size) % gsz, tile_n = (t % group_size) / gsz;
@@ -633,6 +635,40 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict
     const bool c_vec = flags & 4, aux_vec = flags & 8;
     long long nchunks_row = (N + EPV - 1) / EPV;
     long long total = M * nchunks_row;
+    // lean path (weight gradients: no bias / activation, optional accumulate): straight-line 16-byte accesses, the
+    // splitk slab reads of a chunk are independent loads in flight together
+    const bool lean = c_vec && (N % EPV) == 0 && !ep.bias && !ep.preact && ep.act == PK_ACT_NONE &&
+                      (ep.mode == 0 || (ep.mode == 1 && aux_vec));
+    if (lean) {
+        const long long slab = M * N;
+        for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+             c += (long long)gridDim.x * blockDim.x) {
+            const long long gm = c / nchunks_row, gn = (c % nchunks_row) * EPV;
+            const float* p = ws + gm * N + gn;
+            float v[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) v[e] = 0.f;
+#pragma unroll 4
+            for (int z = 0; z < splitk; ++z) {
+#pragma unroll
+                for (int e = 0; e < EPV; e += 4) {
+                    float4 t4 = *reinterpret_cast<const float4*>(p + (long long)z * slab + e);
+                    v[e] += t4.x; v[e + 1] += t4.y; v[e + 2] += t4.z; v[e + 3] += t4.w;
+                }
+            }
+            Vec16<T> o;
+            if (ep.mode == 1) {
+                Vec16<T> a = load16<T>(reinterpret_cast<const T*>(ep.aux) + gm * ep.ldaux + gn);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o.set(e, v[e] * ep.alpha + a.get(e));
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o.set(e, v[e] * ep.alpha);
+            }
+            store16<T>(C + gm * ep.ldc + gn, o);
+        }
+        return;
+    }
     for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
          c += (long long)gridDim.x * blockDim.x) {
         long long gm = c / nchunks_row, gn = (c % nchunks_row) * EPV;
