@@ -223,6 +223,25 @@ __device__ __forceinline__ void stage_tile(char* lds, int pitch, const bf16* __r
     }
 }
 
+// the same in two halves, so the next tile's global loads fly under the current tile's MFMAs
+__device__ __forceinline__ void tile_g2r(uint4 (&regs)[2], const bf16* __restrict__ base, long long rs, int r0, int lim,
+                                         int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int c = tid + i * 256;
+        int r = c >> 3, cc = (c & 7) * 8;
+        regs[i] = make_uint4(0, 0, 0, 0);
+        if (r0 + r < lim) regs[i] = *reinterpret_cast<const uint4*>(base + (long long)(r0 + r) * rs + cc);
+    }
+}
+__device__ __forceinline__ void tile_r2s(const uint4 (&regs)[2], char* lds, int pitch, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int c = tid + i * 256;
+        *reinterpret_cast<uint4*>(lds + (c >> 3) * pitch + (c & 7) * 16) = regs[i];
+    }
+}
+
 // row fragment: lane (r = l&31, h = l>>5) gets row row0 + r, elements d = 16*kk + 8*h .. +7
 __device__ __forceinline__ bf16x8_t row_frag(const char* lds, int pitch, int row0, int kk, int lane) {
     return *reinterpret_cast<const bf16x8_t*>(lds + (row0 + (lane & 31)) * pitch + (kk * 16 + 8 * (lane >> 5)) * 2);
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
     constexpr int VP = MODE == 0 ? VPITCH : PITCH;
     __shared__ __attribute__((aligned(16))) char k_lds[KT * PITCH];
     __shared__ __attribute__((aligned(16))) char v_lds[KT * VP];
-    __shared__ unsigned char pad_lds[KT];
+    __shared__ __attribute__((aligned(16))) float kbias_lds[KT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
     const int t = blockIdx.x * 128 + wave * 32 + (lane & 31);
@@ -320,15 +339,37 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
         }
     }
 
+    if (MODE == 1 && !valid) L2 = INFINITY;  // exp2(x - inf) = 0: rows past T contribute nothing
     // causal: keys beyond the last query of this workgroup are never visible
+    const int off = p.S - p.T;
     int s_end = p.S;
-    if (p.causal) s_end = min(p.S, blockIdx.x * 128 + 128 + (p.S - p.T));
+    if (p.causal) s_end = min(p.S, blockIdx.x * 128 + 128 + off);
+    const int wt0 = blockIdx.x * 128 + wave * 32;  // first query of this wave
+    const bf16* kbase = k + b * p.k_bs + h * HD;
+    const bf16* vbase = v + b * p.v_bs + h * HD;
+    uint4 kreg[2], vreg[2];
+    if (s_end > 0) {
+        tile_g2r(kreg, kbase, p.k_rs, 0, p.S, tid);
+        tile_g2r(vreg, vbase, p.v_rs, 0, p.S, tid);
+    }
     for (int s0 = 0; s0 < s_end; s0 += KT) {
+        __syncthreads();  // previous tile fully consumed
+        tile_r2s(kreg, k_lds, PITCH, tid);
+        tile_r2s(vreg, v_lds, VP, tid);
+        if (tid < KT) {  // additive key bias: 0, or -inf for keys past S / padding keys (modules.py:654-677)
+            const int sk = s0 + tid;
+            const bool dead = sk >= p.S || (p.key_pad && p.key_pad[(long long)b * p.S + sk]);
+            kbias_lds[tid] = dead ? -INFINITY : 0.f;
+        }
+        if (s0 + KT < s_end) {  // prefetch the next tile into registers
+            tile_g2r(kreg, kbase, p.k_rs, s0 + KT, p.S, tid);
+            tile_g2r(vreg, vbase, p.v_rs, s0 + KT, p.S, tid);
+        }
         __syncthreads();
-        stage_tile(k_lds, PITCH, k + b * p.k_bs + h * HD, p.k_rs, s0, p.S, tid);
-        stage_tile(v_lds, VP, v + b * p.v_bs + h * HD, p.v_rs, s0, p.S, tid);
-        if (tid < KT) pad_lds[tid] = (p.key_pad && s0 + tid < p.S) ? p.key_pad[(long long)b * p.S + s0 + tid] : 0;
-        __syncthreads();
+        // causal classification of (this wave's 32 queries) x (this tile's 64 keys): wave-uniform
+        const bool skip = p.causal && s0 > wt0 + 31 + off;        // every key is in the future of every query
+        if (skip) continue;
+        const bool check = p.causal && s0 + KT - 1 > wt0 + off;   // some (query, key) pairs are masked
 
         f32x16 sc[2];  // Sᵀ[key][query] for the two 32-key blocks of the tile
 #pragma unroll
@@ -340,28 +381,35 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
                 sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(k_lds, PITCH, kb * 32, kk, lane), qf[kk],
                                                                  sc[kb], 0, 0, 0);
         }
-        // scale + mask (exp2 domain)
+        // scale + key bias (exp2 domain): registers 4g..4g+3 of a block are 4 consecutive keys -> one 16-B bias read
         float tmax = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int kl = kb * 32 + acc_row(r, lane), s = s0 + kl;
-                bool masked = s >= p.S || pad_lds[kl] || (p.causal && s > t + (p.S - p.T));
-                float x = masked ? -INFINITY : sc[kb][r] * c;
-                sc[kb][r] = x;
-                tmax = fmaxf(tmax, x);
+            for (int g = 0; g < 4; ++g) {
+                const float4 kb4 = *reinterpret_cast<const float4*>(kbias_lds + kb * 32 + 8 * g + 4 * (lane >> 5));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = fmaf(sc[kb][4 * g + j], c, (&kb4.x)[j]);
+                    if (check) {
+                        const int sk = s0 + kb * 32 + 8 * g + 4 * (lane >> 5) + j;
+                        x = sk > t + off ? -INFINITY : x;
+                    }
+                    sc[kb][4 * g + j] = x;
+                    tmax = fmaxf(tmax, x);
+                }
             }
         if constexpr (MODE == 0) {
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            float mn = fmaxf(m, tmax);
-            float alpha = mn == -INFINITY ? 1.f : exp2f(m - mn);
+            const float mn = fmaxf(m, tmax);
+            const float ms = mn == -INFINITY ? 0.f : mn;  // all keys masked so far: exp2(-inf - 0) = 0 everywhere
+            const float alpha = __builtin_amdgcn_exp2f(m - ms);
             float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float pw = mn == -INFINITY ? 0.f : exp2f(sc[kb][r] - mn);
+                    float pw = __builtin_amdgcn_exp2f(sc[kb][r] - ms);
                     sc[kb][r] = pw;
                     psum += pw;
                 }
@@ -395,8 +443,8 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
                                                                      dp[kb], 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float pw = (sc[kb][r] == -INFINITY || !valid) ? 0.f : exp2f(sc[kb][r] - L2);
-                    sc[kb][r] = pw * (dp[kb][r] - dl);  // dSᵀ
+                    float pw = __builtin_amdgcn_exp2f(sc[kb][r] - L2);  // masked: exp2(-inf) = 0
+                    sc[kb][r] = pw * (dp[kb][r] - dl);                   // dSᵀ
                 }
             }
             // dQᵀ[d][query] += Kᵀ[d][key] · dSᵀ[key][query]
@@ -430,7 +478,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
                                                            bf16* __restrict__ dv, AttnParams p) {
     __shared__ __attribute__((aligned(16))) char q_lds[KT * PITCH];
     __shared__ __attribute__((aligned(16))) char do_lds[KT * PITCH];
-    __shared__ float l2_lds[KT], dl_lds[KT];
+    __shared__ __attribute__((aligned(16))) float l2_lds[KT], dl_lds[KT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
     const int s = blockIdx.x * 128 + wave * 32 + (lane & 31);
@@ -447,19 +495,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
         for (int r = 0; r < 16; ++r) dka[dt][r] = dva[dt][r] = 0.f;
 
     // causal: queries before the first key of this workgroup (minus the offset) never see it
+    const int off = p.S - p.T;
     int t_begin = 0;
-    if (p.causal) t_begin = max(0, (int)(blockIdx.x * 128) - (p.S - p.T)) / KT * KT;
+    if (p.causal) t_begin = max(0, (int)(blockIdx.x * 128) - off) / KT * KT;
+    const int ws0 = blockIdx.x * 128 + wave * 32;          // first key of this wave
+    const float lane_bias = kvalid ? 0.f : -INFINITY;      // padding keys / keys past S: p = exp2(-inf) = 0
+    const bf16* qbase = q + b * p.q_bs + h * HD;
+    const bf16* dobase = d_o + b * p.do_bs + h * HD;
+    uint4 qreg[2], doreg[2];
+    if (t_begin < p.T) {
+        tile_g2r(qreg, qbase, p.q_rs, t_begin, p.T, tid);
+        tile_g2r(doreg, dobase, p.do_rs, t_begin, p.T, tid);
+    }
     for (int t0 = t_begin; t0 < p.T; t0 += KT) {
         __syncthreads();
-        stage_tile(q_lds, PITCH, q + b * p.q_bs + h * HD, p.q_rs, t0, p.T, tid);
-        stage_tile(do_lds, PITCH, d_o + b * p.do_bs + h * HD, p.do_rs, t0, p.T, tid);
+        tile_r2s(qreg, q_lds, PITCH, tid);
+        tile_r2s(doreg, do_lds, PITCH, tid);
         if (tid < KT) {
             int t = t0 + tid;
             long long row = ((long long)b * p.H + h) * p.T + t;
             l2_lds[tid] = t < p.T ? lse[row] * LOG2E : INFINITY;  // +inf -> p = 0 for rows past T
             dl_lds[tid] = t < p.T ? delta[row] : 0.f;
         }
+        if (t0 + KT < p.T) {  // prefetch the next query tile into registers
+            tile_g2r(qreg, qbase, p.q_rs, t0 + KT, p.T, tid);
+            tile_g2r(doreg, dobase, p.do_rs, t0 + KT, p.T, tid);
+        }
         __syncthreads();
+        // causal classification of (this tile's 64 queries) x (this wave's 32 keys): wave-uniform
+        if (p.causal && ws0 > t0 + KT - 1 + off) continue;        // every key is in the future of every query
+        const bool check = p.causal && ws0 + 31 > t0 + off;      // some pairs are masked
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 sc, dp;  // S[query][key], dP[query][key]
@@ -474,12 +539,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
             }
             f32x16 ds;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int tl = qb * 32 + acc_row(r, lane), t = t0 + tl;
-                bool masked = !kvalid || (p.causal && s > t + (p.S - p.T));
-                float pw = masked ? 0.f : exp2f(sc[r] * c - l2_lds[tl]);
-                sc[r] = pw;
-                ds[r] = pw * (dp[r] - dl_lds[tl]);
+            for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are 4 consecutive queries: one 16-B read each of lse, delta
+                const int tl = qb * 32 + 8 * g + 4 * (lane >> 5);
+                const float4 l4 = *reinterpret_cast<const float4*>(l2_lds + tl);
+                const float4 d4 = *reinterpret_cast<const float4*>(dl_lds + tl);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = fmaf(sc[4 * g + j], c, lane_bias) - (&l4.x)[j];
+                    if (check) x = s > t0 + tl + j + off ? -INFINITY : x;
+                    const float pw = __builtin_amdgcn_exp2f(x);
+                    sc[4 * g + j] = pw;
+                    ds[4 * g + j] = pw * (dp[4 * g + j] - (&d4.x)[j]);
+                }
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
