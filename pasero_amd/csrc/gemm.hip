@@ -19,10 +19,18 @@
 // coalesced.  Workgroup ids are remapped so that each XCD (blockIdx % 8) owns a contiguous range of tiles, and tiles
 // are walked in 8-row-panel groups, so the A and B panels a tile shares with its neighbours are hits in that XCD's
 // private L2.
+#include <stdlib.h>
+#include <algorithm>
+
 #include "common.h"
+#include "gemm_epi.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+extern "C" int pk_gemm256_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
+                                 long long M, long long N, long long K, long long lda, long long ldb, int a_col,
+                                 int b_col, int kchunk, int splitk, EpiParams ep, void* stream);
 
 namespace {
 
@@ -74,16 +82,6 @@ template <bool COL> struct TileGeom<float, COL> {
     static constexpr int CPR = COLS / 4, NCH = ROWS * CPR / NTHREADS;
     static constexpr bool VEC_WRITE = COL;
     __device__ static __forceinline__ int offset(int row, int chunk) { return row * PITCH + (chunk << 4); }
-};
-
-struct EpiParams {
-    const void* bias;   // [N] or null
-    const void* aux;    // [M, ldaux] or null
-    void* preact;       // optional second output: value before the activation
-    long long ldaux, ldc, ldpre;
-    int act;            // PK_ACT_*
-    int mode;           // 0: act(v+bias)   1: act(v+bias) + aux   2: v * act'(aux)
-    float alpha;
 };
 
 // global -> registers.  (row0, col0) origin inside the matrix; rows >= row_lim / cols >= col_lim read as zero.
@@ -705,6 +703,42 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
     int nt = (int)(((M + BM - 1) / BM) * ((N + BN - 1) / BN));
     int kchunk = (int)K;
     float* ws = nullptr;
+    if constexpr (sizeof(T) == 2) {
+        // 256x256-tile kernel (gemm256.hip): LDS-DMA only, so it needs 16-byte addressable operands, K in whole 64-tiles
+        // and one of the lean epilogues; it pays when its (4x fewer) tiles still fill the chip.
+        static const int tile_pref = [] { const char* e = getenv("PK_GEMM_TILE"); return e ? atoi(e) : 0; }();
+        const bool simple = !ep.preact && (ep.act == PK_ACT_NONE || ep.act == PK_ACT_RELU) && (flags & 4) &&
+                            (!ep.bias || ((uintptr_t)ep.bias % 16) == 0) && (ep.mode == 0 || (flags & 8));
+        const bool addr_ok = (flags & 1) && (flags & 2) && (!a_col || M % 8 == 0) && (!b_col || N % 8 == 0) &&
+                             N % 8 == 0 && K % 64 == 0 && K > 0;
+        const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
+        if (simple && addr_ok && tile_pref != 128 && M >= 256 && N >= 256) {
+            int sk = 1;
+            long long per = K;
+            if (splitk > 1) {  // the caller allows split-K: re-derive the factor for 256-tiles (~1 workgroup per CU)
+                sk = (int)std::max(1LL, std::min((long long)(256 / std::max(1LL, t256)), K / 512));
+                per = ((K + sk - 1) / sk + 63) / 64 * 64;
+                sk = (int)((K + per - 1) / per);
+                if ((size_t)sk * M * (N + (asum_out ? 1 : 0)) * sizeof(float) > ws_bytes) sk = 0;  // does not fit
+            }
+            const bool fills = t256 * std::max(sk, 1) >= 160;
+            if (sk > 0 && (tile_pref == 256 || fills)) {
+                float* w2 = sk > 1 ? (float*)workspace : nullptr;
+                float* asw = (sk > 1 && asum_out) ? w2 + (size_t)sk * M * N : nullptr;
+                int rc = pk_gemm256_launch(A, B, C, w2, asw, asum_out, M, N, K, lda, ldb, a_col, b_col, (int)per,
+                                           std::max(sk, 1), ep, stream);
+                if (rc != 1) return rc;
+                if (w2) {
+                    long long chunks = M * ((N + EPV - 1) / EPV);
+                    int blocks = (int)min((long long)2048, (chunks + 255) / 256);
+                    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, stream, w2, (T*)C, M, N,
+                                       sk, ep, flags, (const float*)asw, (T*)asum_out);
+                    PK_LAUNCH_CHECK();
+                }
+                return 0;
+            }
+        }
+    }
     if (splitk > 1) {
         long long per = (K + splitk - 1) / splitk;
         per = (per + TR::BK - 1) / TR::BK * TR::BK;

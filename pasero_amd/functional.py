@@ -39,7 +39,7 @@ def gemm(a: Tensor, b: Tensor, *, a_col: bool = False, b_col: bool = False, bias
         assert a_col and asum_out.dtype == a.dtype and asum_out.numel() == M and asum_out.is_contiguous()
     ws, ws_bytes = None, 0
     if splitk > 1:
-        ws_bytes = splitk * M * (N + 1) * 4
+        ws_bytes = 2 * splitk * M * (N + 1) * 4  # room for the 256-tile kernel's (up to 2x) larger split factor
         ws = lib.workspace(ws_bytes, a.device, 'splitk')
     L = lib.load()
     check(L.pk_gemm(ptr(a), ptr(b), ptr(out), ptr(bias), ptr(aux), ptr(preact), M, N, K, _ld(a), _ld(b), _ld(out),
