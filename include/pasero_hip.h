@@ -138,6 +138,14 @@ size_t pk_logmel_workspace(int B);
 int pk_logmel(const float* wav, const long long* wav_len, long long wav_stride, float* out, void* workspace,
               size_t ws_bytes, int B, void* stream);
 
+/* ---- Rotary position embedding (RoPE) on a packed projection output: replaces RotaryEmbedding.forward,
+ * pasero/models/modules.py:982-1025 (GPT-J style halves: rotate(x) = cat(-x2, x1), head_dim 64).
+ *   x, y: (rows, ld) with `total_cols` used columns; the first `ncols` columns (q|k heads of 64) are rotated by the
+ *   angle of position pos_offset + row % Tlen, the rest (v) is copied.  cos_t / sin_t: fp32 [max_pos][32] tables.
+ *   inverse = 1 applies the transposed rotation (backward pass).  y must not alias x. */
+int pk_rope(const void* x, void* y, long long rows, int Tlen, long long ld, int ncols, int total_cols,
+            const float* cos_t, const float* sin_t, int max_pos, int pos_offset, int inverse, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

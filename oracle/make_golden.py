@@ -113,7 +113,7 @@ CFG_KEYS = [
     'label_smoothing', 'activation_fn', 'encoder_prenorm', 'decoder_prenorm', 'encoder_embed_norm',
     'decoder_embed_norm', 'encoder_positional_encoding', 'decoder_positional_encoding',
     'positional_encoding_shift', 'scale_embed', 'encoder_max_len', 'decoder_max_len', 'shared_embeddings',
-    'tied_output_projection', 'input_dim', 'conv_input_dim', 'conv_channels', 'conv_kernel_sizes',
+    'tied_output_projection', 'rope_base', 'input_dim', 'conv_input_dim', 'conv_channels', 'conv_kernel_sizes',
     'conv_strides', 'conv_activation', 'norm_eps', 'padding_idx', 'eos_idx', 'bos_idx',
 ]
 
@@ -229,6 +229,38 @@ def gen_mha():
         out[variant + ':param_names'] = np.array([n for n, _ in ns])
         out[variant + ':param_shapes'] = np.array([','.join(map(str, s)) for _, s in ns])
     save('mha', d=d, H=H, B=B, T=T, S=S, **out)
+
+
+def gen_mha_rotary():
+    """MultiheadAttention with positional_encoding='rotary' (modules.py:554-555,621-623,950-1025): causal self-attention,
+    full sequence and the same sequence decoded incrementally (position offset = cached length)"""
+    d, H, B, T = 128, 2, 2, 9
+    mha = modules.MultiheadAttention(d, H, dropout=0.0, causal=True, positional_encoding='rotary')
+    sd = mha.state_dict()
+    ns = [(k, tuple(v.shape)) for k, v in sd.items()]
+    mha.load_state_dict({k: t(v) for k, v in paramgen.make_state_dict(33, ns).items()})
+    x = t(paramgen.make_array(33, 'rot.x', (B, T, d))).requires_grad_()
+    y, _ = mha(query=x, key=x, value=x)
+    dy = t(paramgen.make_array(33, 'rot.dy', (B, T, d)))
+    y.backward(dy)
+    out = {'y': npy(y), 'dx': npy(x.grad), 'param_names': np.array([n for n, _ in ns]),
+           'param_shapes': np.array([','.join(map(str, s)) for _, s in ns])}
+    for k, p in mha.named_parameters():
+        out['grad:' + k] = npy(p.grad)
+    with torch.no_grad():
+        state, steps = {}, []
+        for i in range(T):
+            yi, _ = mha(query=x[:, i:i + 1], key=x[:, i:i + 1], value=x[:, i:i + 1], state=state)
+            steps.append(yi)
+        out['y_incremental'] = npy(torch.cat(steps, dim=1))
+    save('mha_rotary', d=d, H=H, B=B, T=T, **out)
+
+
+def gen_tiny_rotary():
+    gen_encdec('tiny_encdec_rotary', V=59, B=3, S=8, T=6, seed=13,
+               embed_dim=128, encoder_ffn_dim=128, decoder_ffn_dim=128, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=1, decoder_layers=1, dropout=0.0,
+               encoder_positional_encoding='rotary', decoder_positional_encoding='rotary', activation_fn='gelu_tanh')
 
 
 def gen_ce():
@@ -392,6 +424,8 @@ GENERATORS = {
     'tiny_encdec_pre': gen_tiny_pre,
     'base_c1': gen_base_c1,
     'mha': gen_mha,
+    'mha_rotary': gen_mha_rotary,
+    'tiny_encdec_rotary': gen_tiny_rotary,
     'ce_ls': gen_ce,
     'sinpos': gen_sinpos,
     'speech': gen_speech,

@@ -107,10 +107,24 @@ def attention_core(q: Tensor, k: Tensor, v: Tensor, key_pad: Optional[Tensor], c
     return out, w.permute(0, 2, 1, 3)
 
 
+def rotary(q: Tensor, k: Tensor, offset: int, base: float = 10000.0):
+    """models/modules.py:950-1025: q (B,T,H,hd), k (B,S,H,hd) with S == T; halves convention rotate(x) = cat(-x2, x1)"""
+    hd = q.size(-1)
+    T = q.size(1)
+    inv_freq = 1.0 / (base ** (torch.arange(0, hd, 2).float() / hd))
+    ang = (torch.arange(offset, offset + T, dtype=torch.float)[:, None] * inv_freq[None, :])  # T x hd/2
+    cos = torch.cat([ang.cos(), ang.cos()], dim=-1)[None, :, None, :]
+    sin = torch.cat([ang.sin(), ang.sin()], dim=-1)[None, :, None, :]
+
+    def rot(x):
+        return torch.cat([-x[..., hd // 2:], x[..., :hd // 2]], dim=-1)
+    return q * cos + rot(q) * sin, k * cos + rot(k) * sin
+
+
 def multihead_attention(P: dict, prefix: str, query: Tensor, key: Tensor, value: Tensor, num_heads: int,
                         attn_mask: Optional[Tensor] = None, causal: bool = False,
-                        state: Optional[dict] = None, scaled: bool = True):
-    """models/modules.py:579-739 (MHA, kv_heads == num_heads, no rotary/alibi/t5, no LoRA)"""
+                        state: Optional[dict] = None, scaled: bool = True, rope_base: Optional[float] = None):
+    """models/modules.py:579-739 (MHA, kv_heads == num_heads, optional rotary, no alibi/t5, no LoRA)"""
     if attn_mask is not None and attn_mask.dim() == 2 and causal:
         attn_mask = None  # modules.py:602-605: padding mask is dropped for causal attention
     B, T, D = query.shape
@@ -122,6 +136,8 @@ def multihead_attention(P: dict, prefix: str, query: Tensor, key: Tensor, value:
     q = proj('q_proj', query).view(B, T, num_heads, hd)
     k = proj('k_proj', key).view(B, -1, num_heads, hd)
     v = proj('v_proj', value).view(B, -1, num_heads, hd)
+    if rope_base is not None:  # modules.py:621-623
+        q, k = rotary(q, k, state['key'].size(1) if state and 'key' in state else 0, rope_base)
     if state is not None and 'key' in state:  # modules.py:625-637
         k = torch.cat([state['key'], k], dim=1)
         v = torch.cat([state['value'], v], dim=1)
@@ -192,6 +208,10 @@ def conv_subsampler(P: dict, prefix: str, x: Tensor, length: Tensor, kernel_size
 # ------------------------------------------------------------------------------------------------------------
 # layers
 # ------------------------------------------------------------------------------------------------------------
+def _rope(cfg, kind):
+    return float(getattr(cfg, 'rope_base', 10000)) if kind == 'rotary' else None
+
+
 def _ln(P, prefix, x, cfg):
     return layer_norm(x, P[prefix + '.weight'], P.get(prefix + '.bias'), cfg.norm_eps)
 
@@ -210,7 +230,8 @@ def encoder_layer(P: dict, prefix: str, x: Tensor, pad_mask: Tensor, cfg) -> Ten
     res = x
     if pre:
         x = _ln(P, prefix + '.self_attn_layer_norm', x, cfg)
-    x, _ = multihead_attention(P, prefix + '.self_attn', x, x, x, cfg.encoder_attention_heads, pad_mask)
+    x, _ = multihead_attention(P, prefix + '.self_attn', x, x, x, cfg.encoder_attention_heads, pad_mask,
+                               rope_base=_rope(cfg, cfg.encoder_positional_encoding))
     x = res + x
     if not pre:
         x = _ln(P, prefix + '.self_attn_layer_norm', x, cfg)
@@ -236,7 +257,8 @@ def decoder_layer(P: dict, prefix: str, x: Tensor, enc_out: Tensor, enc_mask: Te
     if state is not None:  # transformer.py:1263-1289
         key = f'dec_{layer_id}_self_attn_'
         sa_state = {k[len(key):]: v for k, v in state.items() if k.startswith(key)}
-    x, _ = multihead_attention(P, prefix + '.self_attn', x, x, x, H, None, causal=True, state=sa_state)
+    x, _ = multihead_attention(P, prefix + '.self_attn', x, x, x, H, None, causal=True, state=sa_state,
+                               rope_base=_rope(cfg, cfg.decoder_positional_encoding))
     if sa_state:
         state.update({f'dec_{layer_id}_self_attn_{k}': v for k, v in sa_state.items()})
     x = res + x

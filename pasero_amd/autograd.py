@@ -453,3 +453,18 @@ class CrossEntropyFn(torch.autograd.Function):
     def backward(ctx, dsums):
         (dl,) = ctx.saved_tensors
         return F.scale(dl, _contig(dsums)[:1].float()).view(ctx.shape), None, None, None
+
+
+class RotaryFn(torch.autograd.Function):
+    """RoPE on the q|k part of a packed projection (pasero/models/modules.py:982-1025); backward = inverse rotation"""
+
+    @staticmethod
+    def forward(ctx, x, cos_t, sin_t, ncols: int, pos_offset: int):
+        ctx.ncols, ctx.pos_offset = ncols, pos_offset
+        ctx.save_for_backward(cos_t, sin_t)
+        return F.rope(_contig(x), cos_t, sin_t, ncols, pos_offset, inverse=False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        cos_t, sin_t = ctx.saved_tensors
+        return F.rope(_contig(dy), cos_t, sin_t, ctx.ncols, ctx.pos_offset, inverse=True), None, None, None, None

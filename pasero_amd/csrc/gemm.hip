@@ -715,8 +715,14 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         if (simple && addr_ok && tile_pref != 128 && M >= 256 && N >= 256) {
             int sk = 1;
             long long per = K;
-            if (splitk > 1) {  // the caller allows split-K: re-derive the factor for 256-tiles (~1 workgroup per CU)
+            // split-K (weight-gradient) GEMMs stay on the 128 kernel by default: with 4x fewer tiles the 256 kernel needs
+            // twice the split factor, and the extra fp32 slab traffic costs more than the tile saves (measured in the
+            // training step: 22.3 ms vs 22.6 ms).  PK_GEMM_SK256=0 / 1 select the other policies for experiments.
+            static const int sk_mode = [] { const char* e = getenv("PK_GEMM_SK256"); return e ? atoi(e) : 2; }();
+            if (splitk > 1 && sk_mode == 2) sk = 0;
+            else if (splitk > 1) {  // the caller allows split-K: re-derive the factor for 256-tiles (~1 workgroup per CU)
                 sk = (int)std::max(1LL, std::min((long long)(256 / std::max(1LL, t256)), K / 512));
+                if (sk_mode == 1) sk = std::min(sk, splitk);
                 per = ((K + sk - 1) / sk + 63) / 64 * 64;
                 sk = (int)((K + per - 1) / per);
                 if ((size_t)sk * M * (N + (asum_out ? 1 : 0)) * sizeof(float) > ws_bytes) sk = 0;  // does not fit

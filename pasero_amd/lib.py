@@ -40,6 +40,7 @@ SIGNATURES = {
     'pk_glu_fwd': (I, [P, P, LL, I, I, P]),
     'pk_glu_bwd': (I, [P, P, P, LL, I, I, P]),
     'pk_col2im1d': (I, [P, P, I, I, I, I, I, I, I, I, I, P]),
+    'pk_rope': (I, [P, P, LL, I, LL, I, I, P, P, I, I, I, I, P]),
     'pk_logmel_workspace': (SZ, [I]),
     'pk_logmel': (I, [P, P, LL, P, P, SZ, I, P]),
 }

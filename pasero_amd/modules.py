@@ -15,7 +15,7 @@ from torch import Tensor, LongTensor, BoolTensor
 
 from . import functional as F
 from .autograd import (LinearFn, PackedLinearFn, AttentionFn, ResidualLayerNormFn, DropoutFn, EmbeddingFn,
-                       ActivationFn, GLUFn)
+                       ActivationFn, GLUFn, RotaryFn)
 
 
 class Identity(nn.Identity):
@@ -151,9 +151,28 @@ def checkpoint_wrapper(module: nn.Module, activate: bool = True) -> nn.Module:
 # ------------------------------------------------------------------------------------------------------------
 # positional embeddings
 # ------------------------------------------------------------------------------------------------------------
+class DummyPositionalEmbedding(nn.Module):
+    """modules.py:407-412 — rotary models add no absolute positions to the embeddings"""
+    shift = 0
+
+    def __init__(self, num_embeddings: int = 0, embedding_dim: int = 0):
+        super().__init__()
+
+    def table(self):
+        return None
+
+    def check_length(self, length: int, offset: int = 0):
+        pass
+
+    def forward(self, input, offset=0):
+        return 0.0
+
+
 def PositionalEmbedding(type: str, num_embeddings: int, embedding_dim: int, shift: int = 2):
     """modules.py:394-404"""
-    if type in ('alibi', 'rotary', 't5'):
+    if type == 'rotary':
+        return DummyPositionalEmbedding(num_embeddings, embedding_dim)
+    if type in ('alibi', 't5'):
         raise NotImplementedError(f"pasero_amd: '{type}' positional encoding is outside the hot-path scope")
     if type == 'learned':
         return LearnedPositionalEmbedding(num_embeddings, embedding_dim, shift=shift)
@@ -223,6 +242,32 @@ class LearnedPositionalEmbedding(nn.Embedding):
         return self.weight[start:start + length][None]
 
 
+class RotaryEmbedding(nn.Module):
+    """cos / sin tables of modules.py:950-975 (inv_freq = base^(-2i/dim), fp32), kept as [max_len][dim/2] because the
+    two halves of the reference's `cat(freqs, freqs)` are identical; extended to the next power of two on demand."""
+
+    def __init__(self, dim: int, base: int = 10000):
+        super().__init__()
+        self.dim = dim
+        self.inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+        self.build(256)
+        self._dev = None
+
+    def build(self, max_len: int):
+        t = torch.arange(max_len, dtype=torch.float32)
+        freqs = torch.einsum('i,j->ij', t, self.inv_freq)
+        self.cos, self.sin = freqs.cos().contiguous(), freqs.sin().contiguous()
+        self.max_len = max_len
+        self._dev = None
+
+    def tables(self, total_len: int, device):
+        if total_len > self.max_len:
+            self.build(2 ** math.ceil(math.log2(total_len)))
+        if self._dev is None or self._dev[0].device != device:
+            self._dev = (self.cos.to(device), self.sin.to(device))
+        return self._dev
+
+
 # ------------------------------------------------------------------------------------------------------------
 # embeddings
 # ------------------------------------------------------------------------------------------------------------
@@ -269,7 +314,7 @@ class MultiheadAttention(nn.Module):
             raise NotImplementedError('pasero_amd: tensor parallelism is not implemented')
         if (kv_heads or num_heads) != num_heads:
             raise NotImplementedError('pasero_amd: grouped-query attention is not implemented')
-        if positional_encoding in ('alibi', 'rotary', 't5'):
+        if positional_encoding in ('alibi', 't5'):
             raise NotImplementedError(f"pasero_amd: '{positional_encoding}' attention bias is not implemented")
         if sliding_window or max_qkv:
             raise NotImplementedError('pasero_amd: sliding-window attention / qkv clamping are not implemented')
@@ -292,6 +337,8 @@ class MultiheadAttention(nn.Module):
         self.shard_count, self.shard_id = 1, 0
         self.max_len = max_len
         self.rotary_embed = self.alibi = self.t5_embed = None
+        if positional_encoding == 'rotary':
+            self.rotary_embed = RotaryEmbedding(self.head_dim, base=rope_base)
         if not _fast_init:
             self.reset_parameters()
         self.causal = causal
@@ -362,8 +409,17 @@ class MultiheadAttention(nn.Module):
         q_w, k_w, v_w = self.q_proj.weight, self.k_proj.weight, self.v_proj.weight
         q_b, k_b, v_b = self.q_proj.bias, self.k_proj.bias, self.v_proj.bias
 
+        def rope(packed, offset):  # modules.py:621-623: q and k are rotated, v is not
+            if self.rotary_embed is None:
+                return packed
+            cos_t, sin_t = self.rotary_embed.tables(offset + T, packed.device)
+            return RotaryFn.apply(packed, cos_t, sin_t, 2 * D, offset)
+
+        if self.rotary_embed is not None and not (key is query and value is query):
+            raise NotImplementedError('pasero_amd: rotary embeddings are implemented for self-attention only')
         if state is not None:  # incremental decoding (inference): K/V cache of shape (B,S,H,hd) (modules.py:621-641)
             qkv = PackedLinearFn.apply(query, w, b, 3, q_w, k_w, v_w, q_b, k_b, v_b)
+            qkv = rope(qkv, state['key'].size(1) if 'key' in state else 0)
             q = qkv[..., :D]
             k = qkv[..., D:2 * D].reshape(B, T, H, self.head_dim)
             v = qkv[..., 2 * D:].reshape(B, T, H, self.head_dim)
@@ -378,7 +434,7 @@ class MultiheadAttention(nn.Module):
             S = k.size(1)
             attn = AttentionFn.apply(q, k.view(B, S, D), v.view(B, S, D), attn_mask, H, self.causal and T > 1, scale)
         elif key is query and value is query:
-            qkv = PackedLinearFn.apply(query, w, b, 3, q_w, k_w, v_w, q_b, k_b, v_b)
+            qkv = rope(PackedLinearFn.apply(query, w, b, 3, q_w, k_w, v_w, q_b, k_b, v_b), 0)
             attn = AttentionFn.apply(qkv, None, None, attn_mask, H, self.causal and T > 1, scale)
         elif key is value:
             q = LinearFn.apply(query, q_w, q_b, 'none')

@@ -74,6 +74,38 @@ def test_tiny_prenorm_gelu_learned_fp32_vs_reference():
     _check_encdec('tiny_encdec_pre')
 
 
+def test_tiny_rotary_gelu_tanh_fp32_vs_reference():
+    """RoPE on the packed q|k projection + tanh-GELU FFN (north_star: "QKV-projection+RoPE", "bias+GELU FFN")"""
+    _check_encdec('tiny_encdec_rotary')
+
+
+def test_mha_rotary_incremental_offsets():
+    """rotary self-attention decoded one token at a time (offset = cached length) equals the full causal pass"""
+    from pasero_amd.modules import MultiheadAttention
+    g = load_golden('mha_rotary')
+    d, H, B, T = (int(g[k]) for k in 'dHBT')
+    mha = MultiheadAttention(d, H, causal=True, positional_encoding='rotary')
+    names = [str(n) for n in g['param_names']]
+    shapes = [tuple(int(x) for x in str(s).split(',')) for s in g['param_shapes']]
+    assert [(k, tuple(v.shape)) for k, v in mha.state_dict().items()] == list(zip(names, shapes))
+    mha.load_state_dict({k: torch.from_numpy(v) for k, v in paramgen.make_state_dict(33, list(zip(names, shapes))).items()})
+    mha = mha.cuda()
+    x = torch.from_numpy(paramgen.make_array(33, 'rot.x', (B, T, d))).cuda().requires_grad_()
+    y, _ = mha(query=x, key=x, value=x)
+    y.backward(torch.from_numpy(paramgen.make_array(33, 'rot.dy', (B, T, d))).cuda())
+    assert rel(y, g['y']) < 2e-5
+    assert rel(x.grad, g['dx']) < 2e-4
+    for n, p in mha.named_parameters():
+        assert rel(p.grad, g['grad:' + n]) < 2e-4 or np.abs(g['grad:' + n]).max() < 1e-5, n
+    with torch.no_grad():
+        state, steps = {}, []
+        for i in range(T):
+            xi = x[:, i:i + 1].contiguous()
+            yi, _ = mha(query=xi, key=xi, value=xi, state=state)
+            steps.append(yi)
+    assert rel(torch.cat(steps, 1), g['y_incremental']) < 2e-5
+
+
 def test_base_c1_fp32_vs_reference():
     """BASELINE configs[0]: Transformer-base 6+6 d=512 V=8032, batch 8x(64,64)"""
     _check_encdec('base_c1', full=False)

@@ -72,6 +72,33 @@ def test_tiny_encdec_prenorm_gelu_learned():
     _run_encdec('tiny_encdec_pre')
 
 
+def test_tiny_encdec_rotary_gelu_tanh():
+    _run_encdec('tiny_encdec_rotary')
+
+
+def test_mha_rotary_full_and_incremental():
+    g = load_golden('mha_rotary')
+    d, H, B, T = (int(g[k]) for k in 'dHBT')
+    names = [str(n) for n in g['param_names']]
+    shapes = [tuple(int(x) for x in str(s).split(',')) for s in g['param_shapes']]
+    P = {'a.' + k: v.requires_grad_() for k, v in
+         O.to_torch_state(paramgen.make_state_dict(33, list(zip(names, shapes)))).items()}
+    x = torch.from_numpy(paramgen.make_array(33, 'rot.x', (B, T, d))).requires_grad_()
+    y, _ = O.multihead_attention(P, 'a', x, x, x, H, None, causal=True, rope_base=10000.0)
+    y.backward(torch.from_numpy(paramgen.make_array(33, 'rot.dy', (B, T, d))))
+    close(y.detach().numpy(), g['y'])
+    close(x.grad.numpy(), g['dx'], rtol=1e-4)
+    for n in names:
+        close(P['a.' + n].grad.numpy(), g['grad:' + n], rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        state, steps = {}, []
+        for i in range(T):
+            yi, _ = O.multihead_attention(P, 'a', x[:, i:i + 1], x[:, i:i + 1], x[:, i:i + 1], H, None, causal=True,
+                                          state=state, rope_base=10000.0)
+            steps.append(yi)
+    close(torch.cat(steps, 1).numpy(), g['y_incremental'])
+
+
 def test_base_c1():
     _run_encdec('base_c1', full=False)
 
