@@ -146,6 +146,20 @@ int pk_logmel(const float* wav, const long long* wav_len, long long wav_stride, 
 int pk_rope(const void* x, void* y, long long rows, int Tlen, long long ld, int ncols, int total_cols,
             const float* cos_t, const float* sin_t, int max_pos, int pos_offset, int inverse, int dtype, void* stream);
 
+/* ---- "Next" row: fused gradient normalisation + global-norm clipping + Adam over all parameters.
+ * Replaces the per-parameter Python loops of Trainer.train_step (pasero/training.py:455-482), clip_grad_norm_
+ * (pasero/optimization.py:390-427) and Adam.step (pasero/optimization.py:56-149; fp32 moments, bf16 params updated
+ * through fp32).  `table` (device int64): [param ptrs | grad ptrs | exp_avg ptrs | exp_avg_sq ptrs | numel], each
+ * `ntensors` long; the chunk list maps workgroup -> (tensor, start), pk_mt_chunk_size() elements per chunk.
+ *   pk_mt_sqnorm: gnorm_out[0] = scale * sqrt(sum ||g||^2)       (`partial`: nchunks floats of scratch)
+ *   pk_mt_adam  : g' = g * scale * min(1, max_norm / (gnorm + 1e-6)) (max_norm <= 0: no clipping); Adam update of m, v, p */
+int pk_mt_chunk_size(void);
+int pk_mt_sqnorm(const long long* table, int ntensors, const int* chunk_tensor, const long long* chunk_start, int nchunks,
+                 float scale, float* partial, float* gnorm_out, int dtype, void* stream);
+int pk_mt_adam(const long long* table, int ntensors, const int* chunk_tensor, const long long* chunk_start, int nchunks,
+               const float* gnorm, float scale, float max_norm, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int step, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -398,3 +398,43 @@ def test_log_mel_full_30s_clip_and_truncation(F):
     silent = torch.zeros(1, 16000)
     o2 = F.log_mel(silent.cuda()).cpu().numpy()
     assert np.allclose(o2, (np.log10(1e-10) + 4) / 4)  # all-zero input: every bin clamps at 1e-10
+
+
+# ------------------------------------------------------------------------------------------------------------
+# "next" row: fused clip + Adam
+# ------------------------------------------------------------------------------------------------------------
+def test_fused_adam_and_clip_vs_reference():
+    """optimization.clip_grad_norm_ + optimization.Adam.step of the reference (golden: adam_step), 3 steps"""
+    from conftest import load_golden
+    from pasero_amd.optim import Adam
+    g = load_golden('adam_step')
+    n, steps = int(g['n']), int(g['steps'])
+    params = [torch.nn.Parameter(torch.from_numpy(g[f'p0:{i}']).cuda()) for i in range(n)]
+    opt = Adam(params, lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    for s in range(steps):
+        for i, p in enumerate(params):
+            p.grad = torch.from_numpy(g[f'g{s}:{i}']).cuda()
+        gnorm = opt.fused_step(scale=1.0, max_norm=1.0)
+        assert abs(gnorm.item() - float(g[f'gnorm{s}'])) <= 1e-5 * float(g[f'gnorm{s}'])
+        for i, p in enumerate(params):
+            assert rel_err(p.detach(), torch.from_numpy(g[f'p{s + 1}:{i}'])) < 1e-5
+
+
+def test_fused_adam_bf16_scale_and_state_layout():
+    """bf16 parameters: fp32 moments, update through fp32, one rounding (optimization.py:88-149); `scale` = the
+    Trainer's dp_size / num_tokens factor (training.py:455-470)"""
+    from pasero_amd.optim import Adam
+    p0 = rnd((300, 70), 90, torch.float32)
+    g0 = rnd((300, 70), 91, torch.float32)
+    pb = torch.nn.Parameter(p0.bfloat16().cuda())
+    pb.grad = g0.bfloat16().cuda()
+    opt = Adam([pb], lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0)
+    gnorm = opt.fused_step(scale=0.25, max_norm=0.0)
+    gq = g0.bfloat16().float() * 0.25
+    ref, m, v = O.adam_step(p0.bfloat16().float(), gq, torch.zeros_like(p0), torch.zeros_like(p0), 1, 1e-2, 0.9, 0.98,
+                            1e-8, 0.0)
+    assert abs(gnorm.item() - gq.double().norm().item()) <= 1e-4 * gq.norm().item()
+    assert torch.equal(pb.detach().cpu(), ref.bfloat16())
+    st = opt.state[pb]
+    assert set(st) == {'step', 'exp_avg', 'exp_avg_sq'} and st['step'] == 1
+    assert st['exp_avg'].dtype == torch.float32 and rel_err(st['exp_avg'], m) < 1e-6 and rel_err(st['exp_avg_sq'], v) < 1e-6
