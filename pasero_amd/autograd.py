@@ -30,6 +30,30 @@ def weight_grad(dy2d: Tensor, x2d: Tensor, want_bias: bool = False):
     return (dw, db) if want_bias else dw
 
 
+class ResidualLink:
+    """Couples the two ends of a residual sub-block  y = Norm(x + f(x))  in backward: the block-end function parks the
+    gradient of the residual branch here instead of returning it to autograd, and the FIRST op of f (the GEMM that
+    consumed x) adds it in the epilogue of its dX GEMM (mode 1).  That removes the engine's separate `dx_f + dres`
+    accumulation kernel (a 3-tensor elementwise pass per sub-block).  Valid because the block-end backward always runs
+    before f's first op (data dependency) and x has no other consumer inside the block."""
+    __slots__ = ('dres',)
+
+    def __init__(self):
+        self.dres = None
+
+    def take(self):
+        d, self.dres = self.dres, None
+        return d
+
+
+def _dx_gemm(dy2d: Tensor, weight: Tensor, link, **kw) -> Tensor:
+    """dX = dY · W (+ parked residual gradient)"""
+    dres = link.take() if link is not None else None
+    if dres is not None:
+        return F.gemm(dy2d, weight, b_col=True, aux=_2d(dres), mode=1, **kw)
+    return F.gemm(dy2d, weight, b_col=True, **kw)
+
+
 def _wgrad(dy2d: Tensor, x2d: Tensor, want_w: bool, want_b: bool):
     if want_w:
         r = weight_grad(dy2d, x2d, want_b)
@@ -41,7 +65,8 @@ class LinearFn(torch.autograd.Function):
     """y = act(x Wᵀ + b)   (pasero/models/modules.py:92-96 + the activation that follows fc1)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act: str = 'none'):
+    def forward(ctx, x, weight, bias, act: str = 'none', link=None):
+        ctx.link = link
         x2 = _2d(_contig(x))
         need_pre = act not in ('none', 'relu') and any(ctx.needs_input_grad)
         pre = torch.empty(x2.size(0), weight.size(0), dtype=x.dtype, device=x.device) if need_pre else None
@@ -59,7 +84,7 @@ class LinearFn(torch.autograd.Function):
             dy2 = F.act_bwd(dy2, aux, ctx.act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = F.gemm(dy2, weight, b_col=True).view(*dy.shape[:-1], weight.size(1))
+            dx = _dx_gemm(dy2, weight, ctx.link).view(*dy.shape[:-1], weight.size(1))
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = weight_grad(dy2, x2, want_b)
@@ -67,7 +92,7 @@ class LinearFn(torch.autograd.Function):
                 dw, db = dw
         elif want_b:
             db = F.colsum(dy2)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class FFNFn(torch.autograd.Function):
@@ -75,7 +100,8 @@ class FFNFn(torch.autograd.Function):
     Backward fuses act'(.) into the epilogue of the dH = dY·W2 GEMM."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act: str):
+    def forward(ctx, x, w1, b1, w2, b2, act: str, link=None):
+        ctx.link = link
         x2 = _2d(_contig(x))
         grad = any(ctx.needs_input_grad)  # (grad mode is always off inside Function.forward)
         need_pre = grad and act not in ('none', 'relu')
@@ -97,9 +123,9 @@ class FFNFn(torch.autograd.Function):
         else:
             dh = F.gemm(dy2, w2, b_col=True, act=ctx.act, aux=aux, mode=2)
         dw2, db2 = _wgrad(dy2, h, ctx.needs_input_grad[3], ctx.has_b2 and ctx.needs_input_grad[4])
-        dx = F.gemm(dh, w1, b_col=True).view(*dy.shape[:-1], w1.size(1)) if ctx.needs_input_grad[0] else None
+        dx = _dx_gemm(dh, w1, ctx.link).view(*dy.shape[:-1], w1.size(1)) if ctx.needs_input_grad[0] else None
         dw1, db1 = _wgrad(dh, x2, ctx.needs_input_grad[1], ctx.has_b1 and ctx.needs_input_grad[2])
-        return dx, dw1, db1, dw2, db2, None
+        return dx, dw1, db1, dw2, db2, None, None
 
 
 class PackedLinearFn(torch.autograd.Function):
@@ -108,7 +134,8 @@ class PackedLinearFn(torch.autograd.Function):
     matching slice of one flat gradient GEMM.  `params` = n weights followed by n biases (or None)."""
 
     @staticmethod
-    def forward(ctx, x, w_flat, b_flat, n: int, *params):
+    def forward(ctx, x, w_flat, b_flat, n: int, link, *params):
+        ctx.link = link
         x2 = _2d(_contig(x))
         y = F.gemm(x2, w_flat, bias=b_flat)
         ctx.n = n
@@ -123,18 +150,18 @@ class PackedLinearFn(torch.autograd.Function):
         dy2 = _2d(_contig(dy))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = F.gemm(dy2, w_flat, b_col=True).view(*dy.shape[:-1], w_flat.size(1))
+            dx = _dx_gemm(dy2, w_flat, ctx.link).view(*dy.shape[:-1], w_flat.size(1))
         D = w_flat.size(0) // n
         grads = [None] * (2 * n)
-        want_w = any(ctx.needs_input_grad[4:4 + n])
-        want_b = any(ctx.has_bias[i] and ctx.needs_input_grad[4 + n + i] for i in range(n))
+        want_w = any(ctx.needs_input_grad[5:5 + n])
+        want_b = any(ctx.has_bias[i] and ctx.needs_input_grad[5 + n + i] for i in range(n))
         dw, db = _wgrad(dy2, x2, want_w, want_b)
         for i in range(n):
-            if want_w and ctx.needs_input_grad[4 + i]:
+            if want_w and ctx.needs_input_grad[5 + i]:
                 grads[i] = dw[i * D:(i + 1) * D]
-            if want_b and ctx.has_bias[i] and ctx.needs_input_grad[4 + n + i]:
+            if want_b and ctx.has_bias[i] and ctx.needs_input_grad[5 + n + i]:
                 grads[n + i] = db[i * D:(i + 1) * D]
-        return (dx, None, None, None, *grads)
+        return (dx, None, None, None, None, *grads)
 
 
 class AttentionFn(torch.autograd.Function):
@@ -179,7 +206,8 @@ class ResidualLayerNormFn(torch.autograd.Function):
     with residual=None and p=0 it is a plain LayerNorm."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps: float, p: float):
+    def forward(ctx, x, residual, gamma, beta, eps: float, p: float, link=None):
+        ctx.link = link if (link is not None and residual is not None and residual.requires_grad) else None
         x = _contig(x)
         residual = _contig(residual) if residual is not None else None
         seed, offset = rng.next_offset() if p > 0 else (0, 0)
@@ -202,8 +230,11 @@ class ResidualLayerNormFn(torch.autograd.Function):
             want_param_grads=want_pg, has_beta=ctx.has_beta, drop_p=ctx.p, seed=ctx.seed, offset=ctx.offset)
         if ctx.p == 0:
             dx = dres
+        if ctx.link is not None:  # the residual-branch gradient rides on the sub-block's first dX GEMM instead
+            ctx.link.dres = dres
+            dres = None
         return (dx if need_dx else None, dres if ctx.has_res else None, dgamma,
-                dbeta if ctx.has_beta else None, None, None)
+                dbeta if ctx.has_beta else None, None, None, None)
 
 
 class ResidualDropoutFn(torch.autograd.Function):

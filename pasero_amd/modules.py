@@ -15,7 +15,7 @@ from torch import Tensor, LongTensor, BoolTensor
 
 from . import functional as F
 from .autograd import (LinearFn, PackedLinearFn, AttentionFn, ResidualLayerNormFn, DropoutFn, EmbeddingFn,
-                       ActivationFn, GLUFn, RotaryFn)
+                       ActivationFn, GLUFn, RotaryFn, ResidualLink)
 
 
 class Identity(nn.Identity):
@@ -343,6 +343,7 @@ class MultiheadAttention(nn.Module):
             self.reset_parameters()
         self.causal = causal
         self._w_flat = self._b_flat = None
+        self._residual_link = None  # set by the owning layer for one call (see transformer._LayerBase._linked)
 
     def reset_parameters(self) -> None:
         # xavier-uniform with gain 1/sqrt(2) for q, k, v (modules.py:565-576)
@@ -406,6 +407,7 @@ class MultiheadAttention(nn.Module):
         if attn_mask is not None:
             attn_mask = attn_mask if attn_mask.is_contiguous() else attn_mask.contiguous()
         w, b = self._flat()
+        link, self._residual_link = self._residual_link, None  # gradient of the residual branch rides on the dX GEMM
         q_w, k_w, v_w = self.q_proj.weight, self.k_proj.weight, self.v_proj.weight
         q_b, k_b, v_b = self.q_proj.bias, self.k_proj.bias, self.v_proj.bias
 
@@ -418,7 +420,7 @@ class MultiheadAttention(nn.Module):
         if self.rotary_embed is not None and not (key is query and value is query):
             raise NotImplementedError('pasero_amd: rotary embeddings are implemented for self-attention only')
         if state is not None:  # incremental decoding (inference): K/V cache of shape (B,S,H,hd) (modules.py:621-641)
-            qkv = PackedLinearFn.apply(query, w, b, 3, q_w, k_w, v_w, q_b, k_b, v_b)
+            qkv = PackedLinearFn.apply(query, w, b, 3, None, q_w, k_w, v_w, q_b, k_b, v_b)
             qkv = rope(qkv, state['key'].size(1) if 'key' in state else 0)
             q = qkv[..., :D]
             k = qkv[..., D:2 * D].reshape(B, T, H, self.head_dim)
@@ -434,14 +436,14 @@ class MultiheadAttention(nn.Module):
             S = k.size(1)
             attn = AttentionFn.apply(q, k.view(B, S, D), v.view(B, S, D), attn_mask, H, self.causal and T > 1, scale)
         elif key is query and value is query:
-            qkv = rope(PackedLinearFn.apply(query, w, b, 3, q_w, k_w, v_w, q_b, k_b, v_b), 0)
+            qkv = rope(PackedLinearFn.apply(query, w, b, 3, link, q_w, k_w, v_w, q_b, k_b, v_b), 0)
             attn = AttentionFn.apply(qkv, None, None, attn_mask, H, self.causal and T > 1, scale)
         elif key is value:
-            q = LinearFn.apply(query, q_w, q_b, 'none')
-            kv = PackedLinearFn.apply(key, w[D:], None if b is None else b[D:], 2, k_w, v_w, k_b, v_b)
+            q = LinearFn.apply(query, q_w, q_b, 'none', link)
+            kv = PackedLinearFn.apply(key, w[D:], None if b is None else b[D:], 2, None, k_w, v_w, k_b, v_b)
             attn = AttentionFn.apply(q, kv, None, attn_mask, H, self.causal and T > 1, scale)
         else:
-            q = LinearFn.apply(query, q_w, q_b, 'none')
+            q = LinearFn.apply(query, q_w, q_b, 'none', link)
             k = LinearFn.apply(key, k_w, k_b, 'none')
             v = LinearFn.apply(value, v_w, v_b, 'none')
             attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale)

@@ -22,7 +22,7 @@ from torch import Tensor, LongTensor, BoolTensor
 from . import modules
 from .modules import Embedding, Identity
 from .autograd import (FFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn,
-                       AddPositionsFn, LinearFn)
+                       AddPositionsFn, LinearFn, ResidualLink)
 
 try:  # inside the reference tree: register under the reference's own registry (config.py:91-122)
     from pasero.config import register_model  # type: ignore
@@ -409,9 +409,10 @@ class _LayerBase(nn.Module):
         self.activation_dropout = modules.Dropout(cfg.activation_dropout)
 
     def _ffn(self, x: Tensor) -> Tensor:
+        link, self._ffn_link = getattr(self, '_ffn_link', None), None
         if not (self.training and self.activation_dropout.p > 0):
             return FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
-                               self.activation_fn.name)
+                               self.activation_fn.name, link)
         y = self.activation_dropout(self.activation_fn(self.fc1(x)))
         return self.fc2(y)
 
@@ -422,16 +423,29 @@ class _LayerBase(nn.Module):
         """`final_layer_norm` is a lambda when --shared-norm (:977-980)"""
         return norm if isinstance(norm, nn.Module) else self.self_attn_layer_norm
 
-    def _block_end(self, x: Tensor, residual: Tensor, norm, residual_hook: str, postnorm_hook: str) -> Tensor:
+    def _hooks_are_base(self, *names) -> bool:
+        cls = TransformerDecoderLayer if isinstance(self, TransformerDecoderLayer) else TransformerEncoderLayer
+        return all(getattr(type(self), n) is getattr(cls, n) for n in names)
+
+    def _linked(self, branch_hooks, residual_hook: str, postnorm_hook: str, norm, target, attr: str):
+        """For a post-norm sub-block whose hooks are all the stock ones: hand a ResidualLink to the module that runs the
+        sub-block's first GEMM (`target.attr`), to be passed on to the fused block end.  None otherwise."""
+        norm = self._norm_module(norm)
+        if (self.prenorm or not torch.is_grad_enabled() or not isinstance(norm, modules.LayerNorm)
+                or not self._hooks_are_base(residual_hook, postnorm_hook, *branch_hooks)):
+            return None
+        link = ResidualLink()
+        setattr(target, attr, link)
+        return link
+
+    def _block_end(self, x: Tensor, residual: Tensor, norm, residual_hook: str, postnorm_hook: str,
+                   link=None) -> Tensor:
         """`x = *_residual(x, residual); x = *_postnorm(x)` — one fused kernel for post-norm layers whose hooks are not
         overridden by a subclass, the reference's two hook calls otherwise"""
-        cls = TransformerDecoderLayer if isinstance(self, TransformerDecoderLayer) else TransformerEncoderLayer
-        hooks_are_base = (getattr(type(self), residual_hook) is getattr(cls, residual_hook)
-                          and getattr(type(self), postnorm_hook) is getattr(cls, postnorm_hook))
         norm = self._norm_module(norm)
-        if hooks_are_base and not self.prenorm and isinstance(norm, modules.LayerNorm):
+        if self._hooks_are_base(residual_hook, postnorm_hook) and not self.prenorm and isinstance(norm, modules.LayerNorm):
             return ResidualLayerNormFn.apply(x, residual, norm.weight, norm.bias, norm.eps,
-                                             self.dropout.p if self.training else 0.0)
+                                             self.dropout.p if self.training else 0.0, link)
         x = getattr(self, residual_hook)(x, residual)
         return getattr(self, postnorm_hook)(x)
 
@@ -489,13 +503,17 @@ class TransformerEncoderLayer(_LayerBase):
             raise NotImplementedError('pasero_amd: --check-inf clamping (fp16 T5) is not implemented')
         self.return_layers = return_layers
         residual = x
+        link = self._linked(('self_attention', 'self_attn_prenorm'), 'self_attn_residual', 'self_attn_postnorm',
+                            self.self_attn_layer_norm, self.self_attn, '_residual_link')
         x = self.self_attn_prenorm(x)
         x = self.self_attention(x, residual, padding_mask)
-        x = self._block_end(x, residual, self.self_attn_layer_norm, 'self_attn_residual', 'self_attn_postnorm')
+        x = self._block_end(x, residual, self.self_attn_layer_norm, 'self_attn_residual', 'self_attn_postnorm', link)
         residual = x
+        link = self._linked(('ffn', 'ffn_prenorm'), 'ffn_residual', 'ffn_postnorm', self.final_layer_norm, self,
+                            '_ffn_link')
         x = self.ffn_prenorm(x)
         x = self.ffn(x, residual, padding_mask)
-        x = self._block_end(x, residual, self.final_layer_norm, 'ffn_residual', 'ffn_postnorm')
+        x = self._block_end(x, residual, self.final_layer_norm, 'ffn_residual', 'ffn_postnorm', link)
         layer_outputs = self.layer_outputs
         self.layer_outputs = {}
         self.return_layers = []
@@ -588,17 +606,26 @@ class TransformerDecoderLayer(_LayerBase):
             raise NotImplementedError('pasero_amd: --check-inf clamping (fp16 T5) is not implemented')
         self.return_layers = return_layers
         residual = x
+        link = None
+        if state is None:
+            link = self._linked(('self_attention', 'self_attn_prenorm'), 'self_attn_residual', 'self_attn_postnorm',
+                                self.self_attn_layer_norm, self.self_attn, '_residual_link')
         x = self.self_attn_prenorm(x)
         x = self.self_attention(x, residual, padding_mask, self_attn_mask=self_attn_mask, state=state)
-        x = self._block_end(x, residual, self.self_attn_layer_norm, 'self_attn_residual', 'self_attn_postnorm')
+        x = self._block_end(x, residual, self.self_attn_layer_norm, 'self_attn_residual', 'self_attn_postnorm', link)
         residual = x
+        link = self._linked(('cross_attention', 'cross_attn_prenorm'), 'cross_attn_residual', 'cross_attn_postnorm',
+                            self.encoder_attn_layer_norm, self.encoder_attn, '_residual_link')
         x = self.cross_attn_prenorm(x)
         x = self.cross_attention(x, residual, encoder_out, encoder_mask)
-        x = self._block_end(x, residual, self.encoder_attn_layer_norm, 'cross_attn_residual', 'cross_attn_postnorm')
+        x = self._block_end(x, residual, self.encoder_attn_layer_norm, 'cross_attn_residual', 'cross_attn_postnorm',
+                            link)
         residual = x
+        link = self._linked(('ffn', 'ffn_prenorm'), 'ffn_residual', 'ffn_postnorm', self.final_layer_norm, self,
+                            '_ffn_link')
         x = self.ffn_prenorm(x)
         x = self.ffn(x, residual, padding_mask)
-        x = self._block_end(x, residual, self.final_layer_norm, 'ffn_residual', 'ffn_postnorm')
+        x = self._block_end(x, residual, self.final_layer_norm, 'ffn_residual', 'ffn_postnorm', link)
         layer_outputs = self.layer_outputs
         self.layer_outputs = {}
         if self.name in return_layers:
