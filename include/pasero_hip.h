@@ -41,6 +41,7 @@ const char* pk_last_error(void);
  *   mode 0: C = act(v + bias)        (preact, if given, receives v + bias)
  *   mode 1: C = act(v + bias) + aux  (residual add, or gradient accumulation with aux == C)
  *   mode 2: C = v * act'(aux)        (backward through the activation; aux = pre-activation, or post- for ReLU)
+ *   mode 3: C = act(v + bias) * aux  (gated FFN: SwiGLU / GEGLU, pasero/models/transformer.py:1013-1016)
  *   splitk > 1: K is cut into `splitk` slices reduced through `workspace` (>= splitk*M*(N+1)*4 bytes), deterministic.
  *   asum_out (optional, needs a_col = 1): asum_out[m] = sum_k A(m,k) — the bias gradient db = colsum(dY) comes out of
  *   the weight-gradient GEMM that already streams dY, instead of a separate pass over it. */
@@ -159,6 +160,11 @@ int pk_mt_sqnorm(const long long* table, int ntensors, const int* chunk_tensor, 
 int pk_mt_adam(const long long* table, int ntensors, const int* chunk_tensor, const long long* chunk_start, int nchunks,
                const float* gnorm, float scale, float max_norm, float lr, float beta1, float beta2, float eps,
                float weight_decay, int step, int dtype, void* stream);
+
+/* gated activation backward (SwiGLU / GEGLU FFN, transformer.py:1013-1016): h = act(z) * u
+ *   dz = dh * u * act'(z)      du = dh * act(z) */
+int pk_gated_act_bwd(const void* dh, const void* z, const void* u, void* dz, void* du, long long n, int act, int dtype,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -263,6 +263,13 @@ def gen_tiny_rotary():
                encoder_positional_encoding='rotary', decoder_positional_encoding='rotary', activation_fn='gelu_tanh')
 
 
+def gen_tiny_swiglu():
+    gen_encdec('tiny_encdec_swiglu', V=61, B=3, S=7, T=6, seed=14,
+               embed_dim=128, encoder_ffn_dim=160, decoder_ffn_dim=160, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=1, decoder_layers=1, dropout=0.0, activation_fn='swiglu',
+               encoder_prenorm=True, decoder_prenorm=True)
+
+
 def gen_ce():
     """Transformer.compute_loss (transformer.py:324-380): label-smoothed CE, sum reduction, pad ignored,
     logs in bits"""
@@ -426,6 +433,7 @@ GENERATORS = {
     'mha': gen_mha,
     'mha_rotary': gen_mha_rotary,
     'tiny_encdec_rotary': gen_tiny_rotary,
+    'tiny_encdec_swiglu': gen_tiny_swiglu,
     'ce_ls': gen_ce,
     'sinpos': gen_sinpos,
     'speech': gen_speech,

@@ -128,6 +128,40 @@ class FFNFn(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2, None, None
 
 
+class GatedFFNFn(torch.autograd.Function):
+    """y = fc2( act(fc1 x) * fc3 x )   (SwiGLU / GEGLU, pasero/models/transformer.py:1011-1018): the gate product is the
+    epilogue of the fc1 GEMM (mode 3), its backward one elementwise kernel"""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w3, b3, w2, b2, act: str, link=None):
+        ctx.link = link
+        x2 = _2d(_contig(x))
+        u = F.gemm(x2, w3, bias=b3)
+        z = torch.empty(x2.size(0), w1.size(0), dtype=x.dtype, device=x.device)
+        h = F.gemm(x2, w1, bias=b1, act=act, aux=u, mode=3, preact=z)
+        y = F.gemm(h, w2, bias=b2)
+        ctx.act = act
+        ctx.has_b = (b1 is not None, b3 is not None, b2 is not None)
+        ctx.save_for_backward(x2, w1, w3, w2, z, u, h)
+        return y.view(*x.shape[:-1], w2.size(0))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w3, w2, z, u, h = ctx.saved_tensors
+        dy2 = _2d(_contig(dy))
+        dh = F.gemm(dy2, w2, b_col=True)
+        dz, du = F.gated_act_bwd(dh, z, u, ctx.act)
+        dw2, db2 = _wgrad(dy2, h, ctx.needs_input_grad[5], ctx.has_b[2] and ctx.needs_input_grad[6])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _dx_gemm(dz, w1, ctx.link)
+            F.gemm(du, w3, b_col=True, aux=dx, mode=1, out=dx)
+            dx = dx.view(*dy.shape[:-1], w1.size(1))
+        dw1, db1 = _wgrad(dz, x2, ctx.needs_input_grad[1], ctx.has_b[0] and ctx.needs_input_grad[2])
+        dw3, db3 = _wgrad(du, x2, ctx.needs_input_grad[3], ctx.has_b[1] and ctx.needs_input_grad[4])
+        return dx, dw1, db1, dw3, db3, dw2, db2, None, None
+
+
 class PackedLinearFn(torch.autograd.Function):
     """y = x · W_flatᵀ + b_flat where W_flat [n*D, K] is the flat arena holding `n` projection weights back to back
     (q|k|v or k|v, pasero/models/modules.py:610-615).  ONE GEMM reads x once; the gradient of each nn.Parameter is the

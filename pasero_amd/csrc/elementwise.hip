@@ -25,6 +25,30 @@ __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ dy, cons
         }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void gated_act_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ z,
+                                                            const T* __restrict__ u, T* __restrict__ dz,
+                                                            T* __restrict__ du, long long n, int act) {
+    constexpr int EPV = 16 / sizeof(T);
+    const long long nvec = n / EPV;
+    for (long long ch = (long long)blockIdx.x * 256 + threadIdx.x; ch < nvec; ch += (long long)gridDim.x * 256) {
+        Vec16<T> g = load16<T>(dh + ch * EPV), zv = load16<T>(z + ch * EPV), uv = load16<T>(u + ch * EPV), o1, o2;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            o1.set(e, g.get(e) * uv.get(e) * act_bwd(act, zv.get(e)));
+            o2.set(e, g.get(e) * act_fwd(act, zv.get(e)));
+        }
+        store16<T>(dz + ch * EPV, o1);
+        store16<T>(du + ch * EPV, o2);
+    }
+    if (blockIdx.x == 0)
+        for (long long i = nvec * EPV + threadIdx.x; i < n; i += 256) {
+            float gi = to_f32<T>(dh[i]), zi = to_f32<T>(z[i]), ui = to_f32<T>(u[i]);
+            dz[i] = from_f32<T>(gi * ui * act_bwd(act, zi));
+            du[i] = from_f32<T>(gi * act_fwd(act, zi));
+        }
+}
+
 // x [rows][2C] -> out [rows][C] = a * sigmoid(b)
 template <typename T>
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, long long rows,
@@ -189,6 +213,18 @@ extern "C" int pk_rope(const void* x, void* y, long long rows, int Tlen, long lo
         hipLaunchKernelGGL((rope_kernel<T>), dim3(grid_for(rows * (total_cols / (16 / (int)sizeof(T))), 512)), dim3(256),
                            0, (hipStream_t)stream, (const T*)x, (T*)y, rows, Tlen, ld, ncols, total_cols, cos_t, sin_t,
                            pos_offset, inverse);
+    })
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_gated_act_bwd(const void* dh, const void* z, const void* u, void* dz, void* du, long long n, int act,
+                                int dtype, void* stream) {
+    PK_CHECK_ARG(dh && z && u && dz && du, "pk_gated_act_bwd: null tensor");
+    if (n == 0) return 0;
+    PK_DTYPE_SWITCH(dtype, "pk_gated_act_bwd", {
+        hipLaunchKernelGGL((gated_act_bwd_kernel<T>), dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)dh, (const T*)z, (const T*)u, (T*)dz, (T*)du, n, act);
     })
     PK_LAUNCH_CHECK();
     return 0;

@@ -218,6 +218,7 @@ __device__ __forceinline__ void epilogue_chunk(float (&v)[8], int n_valid, long 
             pre.set(e, x);
             x = act_fwd(ep.act, x);
             if (ep.mode == 1) x += a[e];
+            else if (ep.mode == 3) x *= a[e];
         }
         v[e] = x;
     }
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
     constexpr int HM = BM / EPI_PASSES;
     const bool interior = m0 + BM <= M && n0 + BN <= N;
     const bool bias_ok = !ep.bias || (((uintptr_t)ep.bias % 16) == 0);
-    const bool simple = !ep.preact && c_vec && bias_ok && (ep.mode == 0 || aux_vec) &&
+    const bool simple = !ep.preact && c_vec && bias_ok && (ep.mode == 0 || aux_vec) && ep.mode < 3 &&
                         (ep.act == PK_ACT_NONE || ep.act == PK_ACT_RELU);
 #pragma unroll 1
     for (int half = 0; half < EPI_PASSES; ++half) {
@@ -636,7 +637,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict
     // lean path (weight gradients: no bias / activation, optional accumulate): straight-line 16-byte accesses, the
     // splitk slab reads of a chunk are independent loads in flight together
     const bool lean = c_vec && (N % EPV) == 0 && !ep.bias && !ep.preact && ep.act == PK_ACT_NONE &&
-                      (ep.mode == 0 || (ep.mode == 1 && aux_vec));
+                      (ep.mode == 0 || (ep.mode == 1 && aux_vec));  // (mode 3 takes the generic path)
     if (lean) {
         const long long slab = M * N;
         for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
@@ -708,7 +709,7 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         // and one of the lean epilogues; it pays when its (4x fewer) tiles still fill the chip.
         static const int tile_pref = [] { const char* e = getenv("PK_GEMM_TILE"); return e ? atoi(e) : 0; }();
         const bool simple = !ep.preact && (ep.act == PK_ACT_NONE || ep.act == PK_ACT_RELU) && (flags & 4) &&
-                            (!ep.bias || ((uintptr_t)ep.bias % 16) == 0) && (ep.mode == 0 || (flags & 8));
+                            (!ep.bias || ((uintptr_t)ep.bias % 16) == 0) && (ep.mode == 0 || (flags & 8)) && ep.mode < 3;
         const bool addr_ok = (flags & 1) && (flags & 2) && (!a_col || M % 8 == 0) && (!b_col || N % 8 == 0) &&
                              N % 8 == 0 && K % 64 == 0 && K > 0;
         const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
@@ -793,7 +794,7 @@ extern "C" int pk_gemm(const void* A, const void* B, void* C, const void* bias, 
     PK_CHECK_ARG(!asum_out || a_col, "pk_gemm: asum_out (fused bias gradient) needs A in col form");
     PK_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "pk_gemm: negative size");
     PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16, "pk_gemm: dtype %d not supported", dtype);
-    PK_CHECK_ARG(mode >= 0 && mode <= 2, "pk_gemm: bad epilogue mode %d", mode);
+    PK_CHECK_ARG(mode >= 0 && mode <= 3, "pk_gemm: bad epilogue mode %d", mode);
     PK_CHECK_ARG(mode == 0 || aux, "pk_gemm: epilogue mode %d needs aux", mode);
     PK_CHECK_ARG(((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31), "pk_gemm: too many tiles");
     if (M == 0 || N == 0) return 0;

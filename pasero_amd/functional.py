@@ -327,3 +327,13 @@ def rope(x: Tensor, cos_t: Tensor, sin_t: Tensor, ncols: int, pos_offset: int, i
     check(lib.load().pk_rope(ptr(x), ptr(y), B * T, T, C, int(ncols), C, ptr(cos_t), ptr(sin_t), cos_t.size(0),
                              int(pos_offset), int(inverse), dtype_code(x), stream_ptr()), 'pk_rope')
     return y
+
+
+def gated_act_bwd(dh: Tensor, z: Tensor, u: Tensor, act: str):
+    """h = act(z) * u  ->  (dz, du)"""
+    require_gpu(dh, z, u)
+    assert dh.is_contiguous() and z.is_contiguous() and u.is_contiguous()
+    dz, du = torch.empty_like(z), torch.empty_like(u)
+    check(lib.load().pk_gated_act_bwd(ptr(dh), ptr(z), ptr(u), ptr(dz), ptr(du), z.numel(), ACT[act], dtype_code(z),
+                                      stream_ptr()), 'pk_gated_act_bwd')
+    return dz, du

@@ -21,7 +21,7 @@ from torch import Tensor, LongTensor, BoolTensor
 
 from . import modules
 from .modules import Embedding, Identity
-from .autograd import (FFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn,
+from .autograd import (FFNFn, GatedFFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn,
                        AddPositionsFn, LinearFn, ResidualLink)
 
 try:  # inside the reference tree: register under the reference's own registry (config.py:91-122)
@@ -400,16 +400,20 @@ class _LayerBase(nn.Module):
     """pieces shared by the encoder and decoder layers"""
 
     def _build_ffn(self, cfg, ffn_dim: int):
-        if cfg.activation_fn in ('swiglu', 'geglu'):
-            raise NotImplementedError('pasero_amd: gated FFNs (swiglu / geglu, fc3) are outside the hot-path scope')
         self.fc1 = modules.Linear(cfg.embed_dim, ffn_dim, bias=cfg.has_bias)
         self.fc2 = modules.Linear(ffn_dim, cfg.embed_dim, bias=cfg.has_bias)
-        self.fc3 = None
+        self.fc3 = (modules.Linear(cfg.embed_dim, ffn_dim, bias=cfg.has_bias)
+                    if cfg.activation_fn in ('swiglu', 'geglu') else None)  # Llama / T5 gate (:966-972)
         self.activation_fn = modules.get_activation_fn(cfg.activation_fn)
         self.activation_dropout = modules.Dropout(cfg.activation_dropout)
 
     def _ffn(self, x: Tensor) -> Tensor:
         link, self._ffn_link = getattr(self, '_ffn_link', None), None
+        if self.training and self.activation_dropout.p > 0 and self.fc3 is not None:
+            raise NotImplementedError('pasero_amd: activation dropout inside a gated FFN is not implemented')
+        if self.fc3 is not None:
+            return GatedFFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc3.weight, self.fc3.bias,
+                                    self.fc2.weight, self.fc2.bias, self.activation_fn.name, link)
         if not (self.training and self.activation_dropout.p > 0):
             return FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
                                self.activation_fn.name, link)

@@ -23,7 +23,7 @@ def test_library_exports_every_header_symbol():
     assert L.pk_version() >= 100
 
 
-@pytest.mark.parametrize('name', ['tiny_encdec_post', 'tiny_encdec_pre', 'tiny_encdec_rotary', 'speech_whisper',
+@pytest.mark.parametrize('name', ['tiny_encdec_post', 'tiny_encdec_pre', 'tiny_encdec_rotary', 'tiny_encdec_swiglu', 'speech_whisper',
                                   'speech_iwslt', 'base_c1'])
 def test_parameter_names_and_shapes_match_reference(name):
     g = load_golden(name)

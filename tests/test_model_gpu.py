@@ -79,6 +79,11 @@ def test_tiny_rotary_gelu_tanh_fp32_vs_reference():
     _check_encdec('tiny_encdec_rotary')
 
 
+def test_tiny_swiglu_prenorm_fp32_vs_reference():
+    """gated FFN (fc3): the gate product is the fc1 GEMM's epilogue"""
+    _check_encdec('tiny_encdec_swiglu')
+
+
 def test_mha_rotary_incremental_offsets():
     """rotary self-attention decoded one token at a time (offset = cached length) equals the full causal pass"""
     from pasero_amd.modules import MultiheadAttention

@@ -76,6 +76,10 @@ def test_tiny_encdec_rotary_gelu_tanh():
     _run_encdec('tiny_encdec_rotary')
 
 
+def test_tiny_encdec_swiglu_prenorm():
+    _run_encdec('tiny_encdec_swiglu')
+
+
 def test_mha_rotary_full_and_incremental():
     g = load_golden('mha_rotary')
     d, H, B, T = (int(g[k]) for k in 'dHBT')
