@@ -362,7 +362,8 @@ class VocabCrossEntropyFn(torch.autograd.Function):
         dx = torch.empty_like(x2) if grad else None
         dw = None
         step = _ce_chunk_rows(rows, V, x.element_size())
-        logits = torch.empty(step, V, dtype=x.dtype, device=x.device)
+        ldp = (V + 15) // 16 * 16  # padded leading dimension: rows stay 16-byte addressable for any vocabulary size
+        logits = torch.empty(step, ldp, dtype=x.dtype, device=x.device)[:, :V]
         for r0 in range(0, rows, step):
             r1 = min(rows, r0 + step)
             lg = logits[: r1 - r0]
@@ -370,7 +371,8 @@ class VocabCrossEntropyFn(torch.autograd.Function):
             F.ce_rows(lg, tgt[r0:r1], padding_idx, eps, row_loss[r0:r1], row_nll[r0:r1],
                       dlogits=lg if grad else None)
             if grad:
-                F.gemm(lg, weight, b_col=True, out=dx[r0:r1])
+                # dX chunk: few output tiles (chunk rows x d) but a vocabulary-long contraction -> split-K
+                F.gemm(lg, weight, b_col=True, out=dx[r0:r1], splitk=F.choose_splitk(r1 - r0, x2.size(1), V))
                 if dw is None:
                     dw = F.gemm(lg, x2[r0:r1], a_col=True, b_col=True)
                 else:
