@@ -206,8 +206,18 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_f32_kernel(const float* __re
 // =====================================================================================================
 // bf16 MFMA path
 // =====================================================================================================
-constexpr int PITCH = 144;   // bytes per 64-element bf16 row in LDS (+16 B: ds_read_b128 row reads conflict-free)
+// LDS images of a [64 rows][64 x bf16] tile.  `P` > 0: plain rows of P bytes.
+constexpr int PITCH = 144;   // +16 B pad: ds_read_b128 row reads conflict-free (tiles that are only read by rows)
 constexpr int VPITCH = 192;  // V tile of the forward pass: only transposed reads (4 key rows on distinct bank quarters)
+constexpr int DUAL = 0;      // tiles read BOTH by rows (ds_read_b128) and transposed (ds_read_b64_tr_b16): 8-row x 32-col
+                             // subtiles of 512 B with the 16-B chunk XOR-swizzled by (row>>2)&3 — both kinds of read are
+                             // conflict-free (cdna guide T10 image (a), cut down to 128-B rows)
+template <int P> __device__ __forceinline__ int lds_off(int row, int ch) {
+    if constexpr (P == DUAL)
+        return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+    else
+        return row * P + ch * 16;
+}
 constexpr int KT = 64;       // rows (keys or queries) staged per LDS tile
 
 // stage a [64 rows][64 cols] bf16 tile (rows r0.., row limit `lim`, zero fill) into LDS with the given pitch
@@ -234,27 +244,31 @@ __device__ __forceinline__ void tile_g2r(uint4 (&regs)[2], const bf16* __restric
         if (r0 + r < lim) regs[i] = *reinterpret_cast<const uint4*>(base + (long long)(r0 + r) * rs + cc);
     }
 }
-__device__ __forceinline__ void tile_r2s(const uint4 (&regs)[2], char* lds, int pitch, int tid) {
+template <int P>
+__device__ __forceinline__ void tile_r2s(const uint4 (&regs)[2], char* lds, int tid) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int c = tid + i * 256;
-        *reinterpret_cast<uint4*>(lds + (c >> 3) * pitch + (c & 7) * 16) = regs[i];
+        *reinterpret_cast<uint4*>(lds + lds_off<P>(c >> 3, c & 7)) = regs[i];
     }
 }
 
 // row fragment: lane (r = l&31, h = l>>5) gets row row0 + r, elements d = 16*kk + 8*h .. +7
-__device__ __forceinline__ bf16x8_t row_frag(const char* lds, int pitch, int row0, int kk, int lane) {
-    return *reinterpret_cast<const bf16x8_t*>(lds + (row0 + (lane & 31)) * pitch + (kk * 16 + 8 * (lane >> 5)) * 2);
+template <int P>
+__device__ __forceinline__ bf16x8_t row_frag(const char* lds, int row0, int kk, int lane) {
+    return *reinterpret_cast<const bf16x8_t*>(lds + lds_off<P>(row0 + (lane & 31), kk * 2 + (lane >> 5)));
 }
 // transposed fragment for "accumulator tile as next operand" products (cdna guide §3): lane (r, h) gets column
 // c0 + r of rows  row0 + 16*s + 8*(j>>2) + 4*h + (j&3),  j = 0..7
-__device__ __forceinline__ bf16x8_t tr_frag(const char* lds, int pitch, int row0, int s, int c0, int lane) {
+template <int P>
+__device__ __forceinline__ bf16x8_t tr_frag(const char* lds, int row0, int s, int c0, int lane) {
     int q = (lane & 15) >> 2, p4 = lane & 3;
     int col = c0 + 16 * ((lane >> 4) & 1) + 4 * p4;
     int row = row0 + 16 * s + 4 * (lane >> 5) + q;
-    const char* ptr = lds + row * pitch + col * 2;
+    const char* ptr = lds + lds_off<P>(row, col >> 3) + (col & 7) * 2;
+    const char* ptr8 = lds + lds_off<P>(row + 8, col >> 3) + (col & 7) * 2;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)ptr);
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(ptr + 8 * pitch));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)ptr8);
     s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, f);
 }
@@ -307,8 +321,9 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
                                                      const bf16* __restrict__ v, bf16* __restrict__ o,
                                                      const bf16* __restrict__ d_o, float* __restrict__ lse,
                                                      float* __restrict__ delta, bf16* __restrict__ dq, AttnParams p) {
-    constexpr int VP = MODE == 0 ? VPITCH : PITCH;
-    __shared__ __attribute__((aligned(16))) char k_lds[KT * PITCH];
+    // forward: K by rows only, V transposed only.  dQ backward: K by rows AND transposed (dual image), V by rows only
+    constexpr int KP = MODE == 0 ? PITCH : DUAL, VP = MODE == 0 ? VPITCH : PITCH;
+    __shared__ __attribute__((aligned(16))) char k_lds[KT * (KP == DUAL ? 128 : KP)];
     __shared__ __attribute__((aligned(16))) char v_lds[KT * VP];
     __shared__ __attribute__((aligned(16))) float kbias_lds[KT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -354,8 +369,8 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
     }
     for (int s0 = 0; s0 < s_end; s0 += KT) {
         __syncthreads();  // previous tile fully consumed
-        tile_r2s(kreg, k_lds, PITCH, tid);
-        tile_r2s(vreg, v_lds, VP, tid);
+        tile_r2s<KP>(kreg, k_lds, tid);
+        tile_r2s<VP>(vreg, v_lds, tid);
         if (tid < KT) {  // additive key bias: 0, or -inf for keys past S / padding keys (modules.py:654-677)
             const int sk = s0 + tid;
             const bool dead = sk >= p.S || (p.key_pad && p.key_pad[(long long)b * p.S + sk]);
@@ -378,7 +393,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
             for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(k_lds, PITCH, kb * 32, kk, lane), qf[kk],
+                sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<KP>(k_lds, kb * 32, kk, lane), qf[kk],
                                                                  sc[kb], 0, 0, 0);
         }
         // scale + key bias (exp2 domain): registers 4g..4g+3 of a block are 4 consecutive keys -> one 16-B bias read
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
                     bf16x8_t pf = acc_frag(sc[kb], s);
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
-                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(v_lds, VP, kb * 32, s, dt * 32, lane),
+                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<VP>(v_lds, kb * 32, s, dt * 32, lane),
                                                                           pf, acc[dt], 0, 0, 0);
                 }
         } else {
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
                 for (int r = 0; r < 16; ++r) dp[kb][r] = 0.f;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
-                    dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(v_lds, VP, kb * 32, kk, lane), dof[kk],
+                    dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<VP>(v_lds, kb * 32, kk, lane), dof[kk],
                                                                      dp[kb], 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -456,7 +471,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
                         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            tr_frag(k_lds, PITCH, kb * 32, s, dt * 32, lane), pf, acc[dt], 0, 0, 0);
+                            tr_frag<KP>(k_lds, kb * 32, s, dt * 32, lane), pf, acc[dt], 0, 0, 0);
                 }
         }
     }
@@ -476,8 +491,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16* __restrict__ dk,
                                                            bf16* __restrict__ dv, AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char q_lds[KT * PITCH];
-    __shared__ __attribute__((aligned(16))) char do_lds[KT * PITCH];
+    __shared__ __attribute__((aligned(16))) char q_lds[KT * 128];   // dual-use images: read by rows and transposed
+    __shared__ __attribute__((aligned(16))) char do_lds[KT * 128];
     __shared__ __attribute__((aligned(16))) float l2_lds[KT], dl_lds[KT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -509,8 +524,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
     }
     for (int t0 = t_begin; t0 < p.T; t0 += KT) {
         __syncthreads();
-        tile_r2s(qreg, q_lds, PITCH, tid);
-        tile_r2s(doreg, do_lds, PITCH, tid);
+        tile_r2s<DUAL>(qreg, q_lds, tid);
+        tile_r2s<DUAL>(doreg, do_lds, tid);
         if (tid < KT) {
             int t = t0 + tid;
             long long row = ((long long)b * p.H + h) * p.T + t;
@@ -532,9 +547,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
             for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(q_lds, PITCH, qb * 32, kk, lane), kf[kk], sc, 0,
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DUAL>(q_lds, qb * 32, kk, lane), kf[kk], sc, 0,
                                                              0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(do_lds, PITCH, qb * 32, kk, lane), vf[kk], dp,
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DUAL>(do_lds, qb * 32, kk, lane), vf[kk], dp,
                                                              0, 0, 0);
             }
             f32x16 ds;
@@ -559,9 +574,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
                 for (int dt = 0; dt < 2; ++dt) {
                     // dVᵀ[d][key] += dOᵀ[d][query] · P[query][key] ;  dKᵀ[d][key] += Qᵀ[d][query] · dS[query][key]
                     dva[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        tr_frag(do_lds, PITCH, qb * 32, st, dt * 32, lane), pf, dva[dt], 0, 0, 0);
+                        tr_frag<DUAL>(do_lds, qb * 32, st, dt * 32, lane), pf, dva[dt], 0, 0, 0);
                     dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        tr_frag(q_lds, PITCH, qb * 32, st, dt * 32, lane), dsf, dka[dt], 0, 0, 0);
+                        tr_frag<DUAL>(q_lds, qb * 32, st, dt * 32, lane), dsf, dka[dt], 0, 0, 0);
                 }
             }
         }

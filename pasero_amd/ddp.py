@@ -5,7 +5,7 @@ Trainer touches (`.module`, `__call__`, `.no_sync()`, `.parameters()`, `.train()
 
 Design for 8 x MI355X over xGMI (RCCL):
   * parameters are grouped, in REVERSE registration order (≈ the order autograd produces their gradients: decoder top
-    -> encoder bottom -> shared embedding last), into flat buckets of `bucket_cap_mb`;
+    -> encoder bottom -> shared embedding last), into flat buckets of `bucket_cap_mb` (16 MiB: the last, non-overlapped all-reduce of a step stays short);
   * a post-accumulate hook per parameter marks it ready; when a bucket is complete its gradients are packed into the
     flat buffer with one multi-tensor copy and ONE all-reduce (average) is launched on a dedicated communication stream
     that waits on the compute stream's event — the collective overlaps the rest of backward;
@@ -49,7 +49,7 @@ class _Bucket:
 class DistributedDataParallel(nn.Module):
     def __init__(self, module: nn.Module, device_ids=None, output_device=None, broadcast_buffers: bool = False,
                  gradient_as_bucket_view: bool = True, find_unused_parameters: bool = False,
-                 bucket_cap_mb: float = 32.0, process_group=None):
+                 bucket_cap_mb: float = 16.0, process_group=None):
         super().__init__()
         self.module = module
         self.process_group = process_group

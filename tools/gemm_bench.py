@@ -22,8 +22,31 @@ SHAPES = {
     'qkv_dx': (32768, 512, 1536, False, True, 1),
     'fc1_dw': (2048, 512, 32768, True, True, 0),
     'out_dw': (512, 512, 32768, True, True, 0),
+    'qkv_dw': (1536, 512, 32768, True, True, 0),
+    'fc2_dw': (512, 2048, 32768, True, True, 0),
     'big_4k': (4096, 4096, 4096, False, False, 1),
 }
+
+
+_flush = None
+
+
+def bench_cold(fn, iters):
+    """like bench(), but a 1 GiB write between launches evicts L2 / Infinity Cache (the in-model situation)"""
+    global _flush
+    if _flush is None:
+        _flush = torch.empty(1 << 30, dtype=torch.uint8, device='cuda')
+    tot = 0.0
+    for i in range(iters + 2):
+        _flush.fill_(i & 1)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        if i >= 2:
+            tot += s.elapsed_time(e)
+    return tot / iters * 1e3
 
 
 def bench(fn, iters):
@@ -44,6 +67,7 @@ def main():
     ap.add_argument('--only', nargs='*')
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--no-torch', action='store_true')
+    ap.add_argument('--cold', action='store_true', help='evict caches between launches')
     args = ap.parse_args()
     for name, (M, N, K, a_col, b_col, splitk) in SHAPES.items():
         if args.only and name not in args.only:
@@ -54,7 +78,8 @@ def main():
         b = B.t().contiguous() if b_col else B
         sk = F.choose_splitk(M, N, K) if splitk == 0 else splitk
         out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
-        us = bench(lambda: F.gemm(a, b, a_col=a_col, b_col=b_col, splitk=sk, out=out), args.iters)
+        timer = bench_cold if args.cold else bench
+        us = timer(lambda: F.gemm(a, b, a_col=a_col, b_col=b_col, splitk=sk, out=out), args.iters)
         tf = 2.0 * M * N * K / us / 1e6
         line = f'{name:10s} M={M:6d} N={N:5d} K={K:6d} {"col" if a_col else "row"},{"col" if b_col else "row"} sk={sk:2d}  ours {us:8.1f} us {tf:7.1f} TF'
         if not args.no_torch:
