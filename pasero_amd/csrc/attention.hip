@@ -585,6 +585,161 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
     store_rowT(dv + b * p.dv_bs + h * HD, p.dv_rs, s, s < p.S, dva, 1.f, lane);
 }
 
+// ---- whole backward of one (batch, head) in one workgroup, for T <= 128 queries and S <= 128 keys ----
+// (the training shapes of the path: sentences of <= 128 tokens).  Q, dO, O, K are read from HBM exactly once; S and dP
+// are computed once (the split dQ / dKdV kernels each recompute them).  Phase 1 (key on the lane, wave w owns keys
+// 32w..32w+31) produces dK, dV and leaves dSᵀ[key][query] in LDS; phase 2 (query on the lane, wave w owns queries
+// 32w..) contracts it with the K tile: dQᵀ[d][q] = Σ_key Kᵀ[d][key] · dSᵀ[key][q].
+constexpr int FUSED_LDS = 2 * (2 * KT * 128) + 128 * 256 + 2 * 128 * 4;  // Q | dO (K later) | dSᵀ | lse, delta
+__device__ __forceinline__ int ds_off(int key, int qcol) {  // dSᵀ image: 256-B rows, 16-B chunk swizzled so that both
+    // the 8-B row-segment writes of phase 1 and the transposed reads of phase 2 spread over the banks
+    return key * 256 + ((((qcol >> 3) ^ ((key & 3) << 2) ^ ((key >> 2) & 3)) & 15) << 4) + (qcol & 7) * 2;
+}
+__device__ __forceinline__ bf16x8_t ds_tr_frag(const char* lds, int row0, int s, int c0, int lane) {
+    int q = (lane & 15) >> 2, p4 = lane & 3;
+    int col = c0 + 16 * ((lane >> 4) & 1) + 4 * p4;
+    int row = row0 + 16 * s + 4 * (lane >> 5) + q;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds + ds_off(row, col)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds + ds_off(row + 8, col)));
+    s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, f);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
+    const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v, const bf16* __restrict__ o,
+    const bf16* __restrict__ d_o, const float* __restrict__ lse, float* __restrict__ delta, bf16* __restrict__ dq,
+    bf16* __restrict__ dk, bf16* __restrict__ dv, AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char fused_lds[];
+    char* q_lds = fused_lds;                    // [128 queries] dual image
+    char* do_lds = fused_lds + 2 * KT * 128;    // [128 queries] dual image; reused for the K tile in phase 2
+    char* ds_lds = do_lds + 2 * KT * 128;       // dSᵀ [128 keys][128 queries]
+    float* l2_lds = reinterpret_cast<float*>(ds_lds + 128 * 256);
+    float* dl_lds = l2_lds + 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, h = blockIdx.x;
+    const float c = p.scale * LOG2E;
+    const int off = p.S - p.T;
+
+    // ---- loads: Q, dO (+O for delta) tiles, the K tile (kept in registers until phase 2), own-key K/V fragments ----
+    const bf16* qbase = q + b * p.q_bs + h * HD;
+    const bf16* dobase = d_o + b * p.do_bs + h * HD;
+    const bf16* obase = o + b * p.o_bs + h * HD;
+    const bf16* kbase = k + b * p.k_bs + h * HD;
+    uint4 kreg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cidx = tid + i * 256, r = cidx >> 3, ch = cidx & 7;
+        uint4 qv = {0, 0, 0, 0}, dov = {0, 0, 0, 0}, ov = {0, 0, 0, 0};
+        kreg[i] = make_uint4(0, 0, 0, 0);
+        if (r < p.T) {
+            qv = *reinterpret_cast<const uint4*>(qbase + (long long)r * p.q_rs + ch * 8);
+            dov = *reinterpret_cast<const uint4*>(dobase + (long long)r * p.do_rs + ch * 8);
+            ov = *reinterpret_cast<const uint4*>(obase + (long long)r * p.o_rs + ch * 8);
+        }
+        if (r < p.S) kreg[i] = *reinterpret_cast<const uint4*>(kbase + (long long)r * p.k_rs + ch * 8);
+        *reinterpret_cast<uint4*>(q_lds + lds_off<DUAL>(r, ch)) = qv;
+        *reinterpret_cast<uint4*>(do_lds + lds_off<DUAL>(r, ch)) = dov;
+        float part = frag_dot(__builtin_bit_cast(bf16x8_t, dov), __builtin_bit_cast(bf16x8_t, ov));
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 4);  // the 8 lanes of a row
+        if (ch == 0) {
+            dl_lds[r] = part;
+            if (r < p.T) delta[((long long)b * p.H + h) * p.T + r] = part;
+        }
+    }
+    if (tid < 128) l2_lds[tid] = tid < p.T ? lse[((long long)b * p.H + h) * p.T + tid] * LOG2E : INFINITY;
+    const int s = wave * 32 + (lane & 31);
+    const bool kvalid = s < p.S && !(p.key_pad && p.key_pad[(long long)b * p.S + min(s, p.S - 1)]);
+    const float lane_bias = kvalid ? 0.f : -INFINITY;
+    bf16x8_t kf[4], vf[4];
+    load_row_frags(kf, kbase, p.k_rs, s, s < p.S, lane);
+    load_row_frags(vf, v + b * p.v_bs + h * HD, p.v_rs, s, s < p.S, lane);
+    f32x16 dka[2], dva[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dka[dt][r] = dva[dt][r] = 0.f;
+    __syncthreads();
+
+    // ---- phase 1: key on the lane ----
+    const int ws0 = wave * 32;
+    for (int qb = 0; qb < 4; ++qb) {
+        const int t0 = qb * 32;
+        if (t0 >= p.T) break;
+        if (p.causal && ws0 > t0 + 31 + off) continue;       // every key of this wave is in the future of these queries
+        const bool check = p.causal && ws0 + 31 > t0 + off;
+        f32x16 sc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DUAL>(q_lds, t0, kk, lane), kf[kk], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DUAL>(do_lds, t0, kk, lane), vf[kk], dp, 0, 0, 0);
+        }
+        f32x16 ds;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int tl = t0 + 8 * g + 4 * (lane >> 5);
+            const float4 l4 = *reinterpret_cast<const float4*>(l2_lds + tl);
+            const float4 d4 = *reinterpret_cast<const float4*>(dl_lds + tl);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = fmaf(sc[4 * g + j], c, lane_bias) - (&l4.x)[j];
+                if (check) x = s > tl + j + off ? -INFINITY : x;
+                const float pw = __builtin_amdgcn_exp2f(x);
+                sc[4 * g + j] = pw;
+                ds[4 * g + j] = pw * (dp[4 * g + j] - (&d4.x)[j]);
+            }
+            unsigned lo = (unsigned)f2bf(ds[4 * g]) | ((unsigned)f2bf(ds[4 * g + 1]) << 16);
+            unsigned hi = (unsigned)f2bf(ds[4 * g + 2]) | ((unsigned)f2bf(ds[4 * g + 3]) << 16);
+            *reinterpret_cast<uint2*>(ds_lds + ds_off(s, tl)) = make_uint2(lo, hi);
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8_t pf = acc_frag(sc, st), dsf = acc_frag(ds, st);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dva[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DUAL>(do_lds, t0, st, dt * 32, lane), pf,
+                                                                  dva[dt], 0, 0, 0);
+                dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DUAL>(q_lds, t0, st, dt * 32, lane), dsf,
+                                                                  dka[dt], 0, 0, 0);
+            }
+        }
+    }
+    store_rowT(dk + b * p.dk_bs + h * HD, p.dk_rs, s, s < p.S, dka, p.scale, lane);
+    store_rowT(dv + b * p.dv_bs + h * HD, p.dv_rs, s, s < p.S, dva, 1.f, lane);
+    __syncthreads();  // dSᵀ complete; the dO tile is dead
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cidx = tid + i * 256;
+        *reinterpret_cast<uint4*>(do_lds + lds_off<DUAL>(cidx >> 3, cidx & 7)) = kreg[i];
+    }
+    __syncthreads();
+
+    // ---- phase 2: query on the lane ----
+    const int t = wave * 32 + (lane & 31);
+    if (wave * 32 >= p.T) return;
+    f32x16 acc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    for (int kb = 0; kb < 4; ++kb) {
+        if (kb * 32 >= p.S) break;
+        if (p.causal && kb * 32 > wave * 32 + 31 + off) break;  // the (queries, keys) blocks phase 1 skipped
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8_t dsf = ds_tr_frag(ds_lds, kb * 32, st, wave * 32, lane);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DUAL>(do_lds, kb * 32, st, dt * 32, lane), dsf,
+                                                                  acc[dt], 0, 0, 0);
+        }
+    }
+    store_rowT(dq + b * p.dq_bs + h * HD, p.dq_rs, t, t < p.T, acc, p.scale, lane);
+}
+
 int check_common(const AttnParams& p, int hd, int dtype, const char* who) {
     PK_CHECK_ARG(hd == HD, "%s: head_dim %d not supported (64 only)", who, hd);
     PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16, "%s: dtype %d not supported", who, dtype);
@@ -645,7 +800,15 @@ extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const vo
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     dim3 gq((T + 127) / 128, H, B), gk((S + 127) / 128, H, B);
-    if (dtype == PK_BF16) {
+    static const bool no_fused = getenv("PK_ATTN_NO_FUSED_BWD") != nullptr;
+    if (dtype == PK_BF16 && T > 0 && S > 0 && T <= 128 && S <= 128 && !no_fused) {
+        static const int attr_rc = hipFuncSetAttribute((const void*)attn_bwd_fused128_kernel,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
+        PK_CHECK_ARG(attr_rc == 0, "pk_attn_bwd: cannot reserve %d B of LDS", FUSED_LDS);
+        hipLaunchKernelGGL(attn_bwd_fused128_kernel, dim3(H, B), dim3(256), FUSED_LDS, s, (const bf16*)q,
+                           (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dq,
+                           (bf16*)dk, (bf16*)dv, p);
+    } else if (dtype == PK_BF16) {
         if (T > 0)
             hipLaunchKernelGGL((attn_q_kernel<1>), gq, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v,
                                (bf16*)const_cast<void*>(o), (const bf16*)d_o, const_cast<float*>(lse), delta, (bf16*)dq, p);
