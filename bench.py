@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='c2_base_bf16', choices=list(WORKLOADS))
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--force-ddp', action='store_true',
+                    help='rehearsal: run the bucketed all-reduce path even on one rank (exercises RCCL on a 1-GPU box)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' to rehearse)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true', help='skip the per-launch HIP-event instrumentation')
@@ -186,6 +188,15 @@ def cpu_baseline(budget_s: float):
                       f'({os.cpu_count()} logical CPUs)'}
 
 
+def count_flops(cfg, B: int, S: int, T: int, V: int) -> float:
+    """SURVEY §8d algorithmic FLOPs of one fwd+bwd step (2·MACs, bwd = 2x fwd, causal self-attention at half)"""
+    d, fe, fd = cfg.embed_dim, cfg.encoder_ffn_dim, cfg.decoder_ffn_dim
+    Le, Ld = cfg.encoder_layers, cfg.decoder_layers
+    enc = B * S * Le * (8 * d * d + 4 * d * fe + 4 * S * d)
+    dec = B * T * Ld * (12 * d * d + 4 * d * fd + 2 * T * d + 4 * S * d) + B * S * Ld * 4 * d * d
+    return 3.0 * (enc + dec + B * T * 2 * d * V)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get('RANK', 0))
@@ -200,10 +211,13 @@ def main():
     torch.cuda.set_device(local_rank % ndev)
     device = torch.device('cuda', local_rank % ndev)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_ddp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if args.force_ddp:
+            os.environ['PASERO_DDP_FORCE_REDUCE'] = '1'
+        kw = {'device_id': device} if args.backend == 'nccl' else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
 
     from pasero_amd import config as C, rng
     from pasero_amd.transformer import Transformer
@@ -217,7 +231,7 @@ def main():
     model = model.to(dtype).to(device)
     model.train()
     rng.manual_seed(1 + rank)
-    ddp = DistributedDataParallel(model) if world > 1 else model
+    ddp = DistributedDataParallel(model) if world > 1 or args.force_ddp else model
     batch = synthetic_batch(B, S, T, V, seed=1 + rank, device=device)
 
     timer = GemmTimer()
@@ -232,7 +246,7 @@ def main():
         return logs['num_tokens']
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -258,7 +272,6 @@ def main():
         tokens = n.item()
 
     if rank == 0:
-        from oracle.ref_cpu import count_flops
         step_flops = count_flops(cfg, B, S, T, V)  # SURVEY §8d algorithmic FLOPs of one fwd+bwd batch
         out = {
             'metric': 'target tokens/sec (fwd+bwd), Transformer-base d=512',
@@ -296,7 +309,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -21,7 +21,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64, NT = 512, NKK = BK / 16;
+constexpr int BM = 256, BN = 256, BK = 64, NKK = BK / 16;
 constexpr int OP_BYTES = 32768, STAGE = 2 * OP_BYTES, SMEM = 2 * STAGE;
 constexpr int CP = BN + 4;  // floats, epilogue staging pitch
 
@@ -31,15 +31,15 @@ template <bool COL> struct G2 {
     __device__ static __forceinline__ int offset(int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); }
 };
 
-template <bool COL>
+template <bool COL, int NW>
 __device__ __forceinline__ void tile_glds(char* lds, const bf16* __restrict__ base, long long ld, long long row0,
                                           long long col0, long long row_lim, long long col_lim, int wave, int lane) {
     using G = G2<COL>;
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(1))) const void g_void;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = i * 8 + wave;  // 32 pieces of 1 KiB per operand tile, 4 per wave
+    for (int i = 0; i < 32 / NW; ++i) {
+        const int piece = i * NW + wave;  // 32 pieces of 1 KiB per operand tile
         const int o = piece * 1024 + lane * 16;
         const int row = o / G::ROWB;
         const int chunk = ((o % G::ROWB) >> 4) ^ G::swz(row);
@@ -74,7 +74,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 }
 
 // one 64-row pass of the epilogue: thread t owns 16-byte chunk t % 32 of rows t / 32 + 16*it
-template <int ACT, int MODE>
+template <int ACT, int MODE, int NW>
 __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, bf16* __restrict__ C, const EpiParams& ep,
                                               long long mh, long long n0, long long M, long long N, int tid) {
     const int col = (tid & 31) * 8, r0 = tid >> 5;
@@ -90,19 +90,20 @@ __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, bf16
         for (int e = 0; e < 8; ++e) b[e] = 0.f;
     }
     const float alpha = ep.alpha;
-    Vec16<bf16> av[4];
+    constexpr int RS = NW * 2, NIT = 64 / RS;  // rows per sweep of the workgroup, sweeps per 64-row pass
+    Vec16<bf16> av[NIT];
     if (MODE != 0) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const long long gm = mh + r0 + 16 * it;
+        for (int it = 0; it < NIT; ++it) {
+            const long long gm = mh + r0 + RS * it;
             if (gm < M) av[it] = load16<bf16>(reinterpret_cast<const bf16*>(ep.aux) + gm * ep.ldaux + gn);
         }
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const long long gm = mh + r0 + 16 * it;
+    for (int it = 0; it < NIT; ++it) {
+        const long long gm = mh + r0 + RS * it;
         if (gm >= M) continue;
-        const float* src = cs + (r0 + 16 * it) * CP + col;
+        const float* src = cs + (r0 + RS * it) * CP + col;
         const float4 a4 = *reinterpret_cast<const float4*>(src), b4 = *reinterpret_cast<const float4*>(src + 4);
         float x[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
@@ -125,8 +126,8 @@ __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, bf16
     }
 }
 
-template <bool A_COL, bool B_COL>
-__global__ __launch_bounds__(NT, 2) void gemm256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
+template <bool A_COL, bool B_COL, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                         bf16* __restrict__ C, float* __restrict__ ws,
                                                         float* __restrict__ asum_ws, bf16* __restrict__ asum_out,
                                                         long long M, long long N, long long K, long long lda,
@@ -135,7 +136,10 @@ __global__ __launch_bounds__(NT, 2) void gemm256_kernel(const bf16* __restrict__
     using GB = G2<B_COL>;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    constexpr int NT = NW * 64, WAVES_N = NW / 2, TJ = 16 / NW;  // wave slab: 128 x (32*TJ)
+    static_assert(NW == 8 || NW == 4, "8 waves of 128x64 or 4 waves of 128x128");
+    constexpr int RS = NW * 2, NIT = 64 / RS;
+    const int wm = (wave / WAVES_N) * 128, wn = (wave % WAVES_N) * (32 * TJ);
 
     const int nt_m = (int)((M + BM - 1) / BM), nt_n = (int)((N + BN - 1) / BN);
     int t = xcd_remap(blockIdx.x, nt_m * nt_n);
@@ -148,11 +152,11 @@ __global__ __launch_bounds__(NT, 2) void gemm256_kernel(const bf16* __restrict__
     const long long kend = min(K, kbeg + (long long)kchunk);
     const int nk = (int)((kend - kbeg) / BK);  // the launcher guarantees full K-tiles
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][TJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -164,30 +168,30 @@ __global__ __launch_bounds__(NT, 2) void gemm256_kernel(const bf16* __restrict__
     auto dma = [&](int kt) {
         long long k0 = kbeg + (long long)kt * BK;
         char* s = smem + (kt & 1) * STAGE;
-        if constexpr (A_COL) tile_glds<true>(s, A, lda, k0, m0, kend, M, wave, lane);
-        else tile_glds<false>(s, A, lda, m0, k0, M, kend, wave, lane);
-        if constexpr (B_COL) tile_glds<true>(s + OP_BYTES, B, ldb, k0, n0, kend, N, wave, lane);
-        else tile_glds<false>(s + OP_BYTES, B, ldb, n0, k0, N, kend, wave, lane);
+        if constexpr (A_COL) tile_glds<true, NW>(s, A, lda, k0, m0, kend, M, wave, lane);
+        else tile_glds<false, NW>(s, A, lda, m0, k0, M, kend, wave, lane);
+        if constexpr (B_COL) tile_glds<true, NW>(s + OP_BYTES, B, ldb, k0, n0, kend, N, wave, lane);
+        else tile_glds<false, NW>(s + OP_BYTES, B, ldb, n0, k0, N, kend, wave, lane);
     };
     if (nk > 0) {
-        bf16x8_t fa[2][4], fb[2][2];
+        bf16x8_t fa[2][4], fb[2][TJ];
         dma(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[0][i] = frag<A_COL>(smem, wm + 32 * i, 0, lane);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[0][j] = frag<B_COL>(smem + OP_BYTES, wn + 32 * j, 0, lane);
+        for (int j = 0; j < TJ; ++j) fb[0][j] = frag<B_COL>(smem + OP_BYTES, wn + 32 * j, 0, lane);
         if (nk > 1) dma(1);
         for (int kt = 0; kt < nk; ++kt) {
             const char* sa = smem + (kt & 1) * STAGE;
             const char* sb = sa + OP_BYTES;
             if constexpr (A_COL) {
-                if (do_asum) {  // thread owns column chunk tid % 32 of the [64][256] A tile, rows tid / 32 + 16 i
+                if (do_asum) {  // thread owns column chunk tid % 32 of the [64][256] A tile, rows tid / 32 + RS i
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < NIT; ++i) {
                         Vec16<bf16> v;
-                        v.raw = *reinterpret_cast<const uint4*>(sa + GA::offset((tid >> 5) + 16 * i, tid & 31));
+                        v.raw = *reinterpret_cast<const uint4*>(sa + GA::offset((tid >> 5) + RS * i, tid & 31));
 #pragma unroll
                         for (int e = 0; e < 8; ++e) asum[e] += v.get(e);
                     }
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(NT, 2) void gemm256_kernel(const bf16* __restrict__
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[nxt][i] = frag<A_COL>(sa, wm + 32 * i, kk + 1, lane);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) fb[nxt][j] = frag<B_COL>(sb, wn + 32 * j, kk + 1, lane);
+                    for (int j = 0; j < TJ; ++j) fb[nxt][j] = frag<B_COL>(sb, wn + 32 * j, kk + 1, lane);
                 } else if (kt + 1 < nk) {
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
@@ -208,13 +212,13 @@ __global__ __launch_bounds__(NT, 2) void gemm256_kernel(const bf16* __restrict__
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[nxt][i] = frag<A_COL>(na, wm + 32 * i, 0, lane);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) fb[nxt][j] = frag<B_COL>(na + OP_BYTES, wn + 32 * j, 0, lane);
+                    for (int j = 0; j < TJ; ++j) fb[nxt][j] = frag<B_COL>(na + OP_BYTES, wn + 32 * j, 0, lane);
                     if (kt + 2 < nk) dma(kt + 2);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < TJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
             }
         }
@@ -223,14 +227,14 @@ __global__ __launch_bounds__(NT, 2) void gemm256_kernel(const bf16* __restrict__
 
     if constexpr (A_COL) {
         if (do_asum) {
-            float* red = reinterpret_cast<float*>(smem);  // [16][256]
+            float* red = reinterpret_cast<float*>(smem);  // [RS][256]
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[(tid >> 5) * BM + (tid & 31) * 8 + e] = asum[e];
             __syncthreads();
             if (tid < BM && m0 + tid < M) {
                 float s = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += red[r * BM + tid];
+                for (int r = 0; r < RS; ++r) s += red[r * BM + tid];
                 if (asum_ws) asum_ws[(long long)blockIdx.y * M + m0 + tid] = s;
                 else asum_out[m0 + tid] = __float2bfloat16(s);
             }
@@ -242,11 +246,11 @@ __global__ __launch_bounds__(NT, 2) void gemm256_kernel(const bf16* __restrict__
     float* cs = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        if ((wave >> 2) == (p >> 1)) {
+        if ((wave / WAVES_N) == (p >> 1)) {
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = 32 * ii + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -261,24 +265,24 @@ __global__ __launch_bounds__(NT, 2) void gemm256_kernel(const bf16* __restrict__
             const long long gn = n0 + col;
             if (gn + 8 <= N) {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const long long gm = mh + r0 + 16 * it;
+                for (int it = 0; it < NIT; ++it) {
+                    const long long gm = mh + r0 + RS * it;
                     if (gm >= M) continue;
-                    const float* src = cs + (r0 + 16 * it) * CP + col;
+                    const float* src = cs + (r0 + RS * it) * CP + col;
                     float* dst = slab + gm * N + gn;
                     *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
                     *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(src + 4);
                 }
             }
         } else if (ep.mode == 0) {
-            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 0>(cs, C, ep, mh, n0, M, N, tid);
-            else epilogue_pass<PK_ACT_NONE, 0>(cs, C, ep, mh, n0, M, N, tid);
+            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 0, NW>(cs, C, ep, mh, n0, M, N, tid);
+            else epilogue_pass<PK_ACT_NONE, 0, NW>(cs, C, ep, mh, n0, M, N, tid);
         } else if (ep.mode == 1) {
-            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 1>(cs, C, ep, mh, n0, M, N, tid);
-            else epilogue_pass<PK_ACT_NONE, 1>(cs, C, ep, mh, n0, M, N, tid);
+            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 1, NW>(cs, C, ep, mh, n0, M, N, tid);
+            else epilogue_pass<PK_ACT_NONE, 1, NW>(cs, C, ep, mh, n0, M, N, tid);
         } else {
-            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 2>(cs, C, ep, mh, n0, M, N, tid);
-            else epilogue_pass<PK_ACT_NONE, 2>(cs, C, ep, mh, n0, M, N, tid);
+            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 2, NW>(cs, C, ep, mh, n0, M, N, tid);
+            else epilogue_pass<PK_ACT_NONE, 2, NW>(cs, C, ep, mh, n0, M, N, tid);
         }
         if (p < 3) __syncthreads();
     }
@@ -291,13 +295,20 @@ __global__ __launch_bounds__(NT, 2) void gemm256_kernel(const bf16* __restrict__
 extern "C" int pk_gemm256_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
                                  long long M, long long N, long long K, long long lda, long long ldb, int a_col,
                                  int b_col, int kchunk, int splitk, EpiParams ep, void* stream) {
-    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN)), (unsigned)splitk), block(NT);
+    static const int nw = getenv("PK_GEMM256_NW") ? atoi(getenv("PK_GEMM256_NW")) : 8;
+    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN)), (unsigned)splitk), block(nw * 64);
     hipStream_t s = (hipStream_t)stream;
     const bf16* a = (const bf16*)A;
     const bf16* b = (const bf16*)B;
-#define PK_L(AC, BC)                                                                                                 \
-    hipLaunchKernelGGL((gemm256_kernel<AC, BC>), grid, block, 0, s, a, b, (bf16*)C, ws, asum_ws, (bf16*)asum_out, M, \
-                       N, K, lda, ldb, kchunk, ep)
+#define PK_L(AC, BC)                                                                                                  \
+    do {                                                                                                              \
+        if (nw == 4)                                                                                                  \
+            hipLaunchKernelGGL((gemm256_kernel<AC, BC, 4>), grid, block, 0, s, a, b, (bf16*)C, ws, asum_ws,           \
+                               (bf16*)asum_out, M, N, K, lda, ldb, kchunk, ep);                                       \
+        else                                                                                                          \
+            hipLaunchKernelGGL((gemm256_kernel<AC, BC, 8>), grid, block, 0, s, a, b, (bf16*)C, ws, asum_ws,           \
+                               (bf16*)asum_out, M, N, K, lda, ldb, kchunk, ep);                                       \
+    } while (0)
     if (!a_col && !b_col) PK_L(false, false);
     else if (!a_col && b_col) PK_L(false, true);
     else if (a_col && !b_col) PK_L(true, false);

@@ -17,6 +17,7 @@ normalisation (training.py:455-477) stays unchanged.
 Works with any torch.distributed backend ('nccl' = RCCL on ROCm; 'gloo' on CPU for the tests).
 """
 import contextlib
+import os
 from typing import List, Optional
 
 import torch
@@ -55,6 +56,10 @@ class DistributedDataParallel(nn.Module):
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.find_unused_parameters = find_unused_parameters
+        # a single rank has nothing to reduce; PASERO_DDP_FORCE_REDUCE=1 keeps the bucket / collective / stream path
+        # live anyway (how the RCCL path is exercised on a one-GPU box)
+        self._reduce_enabled = self.world_size > 1 or (dist.is_initialized()
+                                                        and os.environ.get('PASERO_DDP_FORCE_REDUCE') == '1')
         self.require_backward_grad_sync = True
         ignore = set(getattr(module, '_ddp_params_and_buffers_to_ignore', []))
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and n not in ignore]
@@ -99,7 +104,7 @@ class DistributedDataParallel(nn.Module):
     # ---- backward-time machinery ----
     def _make_hook(self, p: nn.Parameter):
         def hook(param):
-            if self.world_size == 1 or not self.require_backward_grad_sync:
+            if not self._reduce_enabled or not self.require_backward_grad_sync:
                 return
             if not self._callback_queued:
                 self._callback_queued = True

@@ -1,0 +1,74 @@
+"""The gradient reducer on the GPU through RCCL ('nccl' backend).  A GPU box has one card, so the process group has one
+rank and PASERO_DDP_FORCE_REDUCE keeps the bucket -> all-reduce(AVG) -> communication-stream -> re-pointed `.grad`
+path live; with one rank the reduced gradients must equal the plain ones (up to the order of the fp32 atomics in the
+embedding / LayerNorm-parameter gradients).  (The world_size-2 semantics are
+covered on CPU with gloo in test_ddp_cpu.py.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from conftest import load_golden
+from model_utils import build_model, text_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_rccl_bucketed_all_reduce_single_rank(monkeypatch, dtype):
+    from pasero_amd import rng
+    from pasero_amd.ddp import DistributedDataParallel
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', str(_free_port()))
+    monkeypatch.setenv('PASERO_DDP_FORCE_REDUCE', '1')
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        g = load_golden('tiny_encdec_post')
+        cfg, model = build_model(g, dtype, 'cuda')
+        model.train()
+        batch = text_batch(g, 'cuda')
+        rng.manual_seed(5)
+        loss, _ = model(**batch)
+        loss.backward()
+        plain = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        for p in model.parameters():
+            p.grad = None
+        ddp = DistributedDataParallel(model, bucket_cap_mb=0.05)
+        assert len(ddp._buckets) > 1
+        rng.manual_seed(5)
+        loss2, _ = ddp(**batch)
+        loss2.backward()
+        torch.cuda.synchronize()
+        assert loss2.item() == loss.item()
+        rtol = 1e-5 if dtype == torch.float32 else 2e-2
+        for n, p in model.named_parameters():
+            if n in plain:
+                bucket, i = ddp._where[p]
+                assert p.grad.data_ptr() == bucket.view(i).data_ptr(), f'{n}: .grad is not the bucket view'
+                err = (p.grad.float() - plain[n].float()).abs().max()
+                assert err <= rtol * plain[n].float().abs().max(), n
+        # gradient accumulation: no_sync micro-batch + reducing micro-batch == 2 x the single gradient
+        for p in model.parameters():
+            p.grad = None
+        with ddp.no_sync():
+            rng.manual_seed(5)
+            ddp(**batch)[0].backward()
+        rng.manual_seed(5)
+        ddp(**batch)[0].backward()
+        torch.cuda.synchronize()
+        for n, p in model.named_parameters():
+            if n in plain:
+                want = 2 * plain[n].float()
+                assert (p.grad.float() - want).abs().max() <= rtol * want.abs().max(), n
+    finally:
+        dist.destroy_process_group()
