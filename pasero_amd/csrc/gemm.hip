@@ -324,7 +324,11 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
 
     // tile walk: XCD-contiguous, 8-row-panel groups, n fastest inside a group
     const int nt_m = (int)((M + BM - 1) / BM), nt_n = (int)((N + BN - 1) / BN);
-    int t = xcd_remap(blockIdx.x, nt_m * nt_n);
+    // split-K: the (K-slab, tile) list is walked slab-major, so an XCD owns whole slabs — the tiles that re-read the
+    // same rows of A and B run on the XCD whose L2 already holds them, and no other XCD fetches those rows
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int kslab = lin / (nt_m * nt_n);
+    int t = lin % (nt_m * nt_n);
     // panel-group height: the GROUP_M A panels + the B panels touched by the ~64 workgroups resident on an XCD should stay
     // inside its 4 MiB L2; narrow outputs (nt_n <= 4) afford 16 A panels, which quarters the re-reads of B
     const int GROUP_M = nt_n <= 4 ? 16 : 8;
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
     int tile_m = first_m + (t % group_size) % gsz, tile_n = (t % group_size) / gsz;
     const long long m0 = (long long)tile_m * BM, n0 = (long long)tile_n * BN;
 
-    const long long kbeg = (long long)blockIdx.y * kchunk;
+    const long long kbeg = (long long)kslab * kchunk;
     const long long kend = min(K, kbeg + (long long)kchunk);
 #if !defined(PK_ABLATE) || PK_ABLATE != 5
     const int nk = (int)((kend - kbeg + TR::BK - 1) / TR::BK);
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
                 float t = 0.f;
 #pragma unroll
                 for (int r = 0; r < RL; ++r) t += red[r * BM + tid];
-                if (asum_ws) asum_ws[(long long)blockIdx.y * M + m0 + tid] = t;
+                if (asum_ws) asum_ws[(long long)kslab * M + m0 + tid] = t;
                 else asum_out[m0 + tid] = from_f32<T>(t);
             }
             __syncthreads();
@@ -572,8 +576,8 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
         }
         __syncthreads();
         const long long mh = m0 + half * HM;
-        if (ws) {  // split-K partial: raw f32 slab [gridDim.y][M][N]
-            float* slab = ws + (long long)blockIdx.y * M * N;
+        if (ws) {  // split-K partial: raw f32 slab [splitk][M][N]
+            float* slab = ws + (long long)kslab * M * N;
             const bool ws_vec = (N % 4) == 0;
 #pragma unroll 4
             for (int c = tid; c < HM * (BN / 4); c += NTHREADS) {
@@ -761,7 +765,7 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
     } else {
         splitk = 1;
     }
-    dim3 grid(nt, splitk), block(NTHREADS);
+    dim3 grid(nt * splitk), block(NTHREADS);
     const T* a = (const T*)A;
     const T* b = (const T*)B;
     T* c = (T*)C;

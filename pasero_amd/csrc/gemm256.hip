@@ -142,13 +142,15 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
     const int wm = (wave / WAVES_N) * 128, wn = (wave % WAVES_N) * (32 * TJ);
 
     const int nt_m = (int)((M + BM - 1) / BM), nt_n = (int)((N + BN - 1) / BN);
-    int t = xcd_remap(blockIdx.x, nt_m * nt_n);
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);  // slab-major (K-slab, tile) walk: an XCD owns whole K-slabs
+    const int kslab = lin / (nt_m * nt_n);
+    int t = lin % (nt_m * nt_n);
     const int GROUP_M = nt_n <= 2 ? 8 : 4;
     int group_size = GROUP_M * nt_n, gid = t / group_size, first_m = gid * GROUP_M;
     int gsz = min(nt_m - first_m, GROUP_M);
     int tile_m = first_m + (t % group_size) % gsz, tile_n = (t % group_size) / gsz;
     const long long m0 = (long long)tile_m * BM, n0 = (long long)tile_n * BN;
-    const long long kbeg = (long long)blockIdx.y * kchunk;
+    const long long kbeg = (long long)kslab * kchunk;
     const long long kend = min(K, kbeg + (long long)kchunk);
     const int nk = (int)((kend - kbeg) / BK);  // the launcher guarantees full K-tiles
 
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
                 float s = 0.f;
 #pragma unroll
                 for (int r = 0; r < RS; ++r) s += red[r * BM + tid];
-                if (asum_ws) asum_ws[(long long)blockIdx.y * M + m0 + tid] = s;
+                if (asum_ws) asum_ws[(long long)kslab * M + m0 + tid] = s;
                 else asum_out[m0 + tid] = __float2bfloat16(s);
             }
             __syncthreads();
@@ -259,8 +261,8 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
         }
         __syncthreads();
         const long long mh = m0 + p * 64;
-        if (ws) {  // split-K partial: raw fp32 slab [gridDim.y][M][N]
-            float* slab = ws + (long long)blockIdx.y * M * N;
+        if (ws) {  // split-K partial: raw fp32 slab [splitk][M][N]
+            float* slab = ws + (long long)kslab * M * N;
             const int col = (tid & 31) * 8, r0 = tid >> 5;
             const long long gn = n0 + col;
             if (gn + 8 <= N) {
@@ -296,7 +298,7 @@ extern "C" int pk_gemm256_launch(const void* A, const void* B, void* C, float* w
                                  long long M, long long N, long long K, long long lda, long long ldb, int a_col,
                                  int b_col, int kchunk, int splitk, EpiParams ep, void* stream) {
     static const int nw = getenv("PK_GEMM256_NW") ? atoi(getenv("PK_GEMM256_NW")) : 8;
-    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN)), (unsigned)splitk), block(nw * 64);
+    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN) * splitk)), block(nw * 64);
     hipStream_t s = (hipStream_t)stream;
     const bf16* a = (const bf16*)A;
     const bf16* b = (const bf16*)B;
