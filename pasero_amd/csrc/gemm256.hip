@@ -12,6 +12,7 @@
 // fragments of the next tile's first k-step are read and the DMA of the tile after it is issued before the current tile's
 // last MFMAs.  Epilogue: four 64-row passes through a 66 KiB fp32 staging buffer, 16-byte coalesced stores with fused
 // bias / ReLU / residual / ReLU' (or raw fp32 split-K slabs); fused bias gradient (column sums of A) as in gemm.hip.
+#include <algorithm>
 #include "common.h"
 #include "gemm_epi.h"
 
@@ -25,21 +26,25 @@ constexpr int BM = 256, BN = 256, BK = 64, NKK = BK / 16;
 constexpr int OP_BYTES = 32768, STAGE = 2 * OP_BYTES, SMEM = 2 * STAGE;
 constexpr int CP = BN + 4;  // floats, epilogue staging pitch
 
-template <bool COL> struct G2 {
-    static constexpr int ROWS = COL ? BK : 256, ROWB = COL ? 512 : 128, CPR = ROWB / 16;
-    __device__ static __forceinline__ int swz(int row) { return COL ? ((row & 3) << 2) : ((row >> 1) & 7); }
+template <bool COL, int KB = BK> struct G2 {
+    static constexpr int ROWS = COL ? KB : 256, ROWB = COL ? 512 : KB * 2, CPR = ROWB / 16;
+    static constexpr int BYTES = 256 * KB * 2, PIECES = BYTES / 1024;
+    // row form: 16 consecutive rows x one 16-B chunk (a ds_read_b128 lane group) must cover all 64 banks
+    __device__ static __forceinline__ int swz(int row) {
+        return COL ? ((row & 3) << 2) : (KB == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
+    }
     __device__ static __forceinline__ int offset(int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); }
 };
 
-template <bool COL, int NW>
+template <bool COL, int NW, int KB = BK>
 __device__ __forceinline__ void tile_glds(char* lds, const bf16* __restrict__ base, long long ld, long long row0,
                                           long long col0, long long row_lim, long long col_lim, int wave, int lane) {
-    using G = G2<COL>;
+    using G = G2<COL, KB>;
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(1))) const void g_void;
 #pragma unroll
-    for (int i = 0; i < 32 / NW; ++i) {
-        const int piece = i * NW + wave;  // 32 pieces of 1 KiB per operand tile
+    for (int i = 0; i < G::PIECES / NW; ++i) {
+        const int piece = i * NW + wave;  // pieces of 1 KiB (one wave-instruction) per operand tile
         const int o = piece * 1024 + lane * 16;
         const int row = o / G::ROWB;
         const int chunk = ((o % G::ROWB) >> 4) ^ G::swz(row);
@@ -50,9 +55,9 @@ __device__ __forceinline__ void tile_glds(char* lds, const bf16* __restrict__ ba
     }
 }
 
-template <bool COL>
+template <bool COL, int KB = BK>
 __device__ __forceinline__ bf16x8_t frag(const char* lds, int r0, int kk, int lane) {
-    using G = G2<COL>;
+    using G = G2<COL, KB>;
     if constexpr (!COL) {
         return *reinterpret_cast<const bf16x8_t*>(lds + G::offset(r0 + (lane & 31), kk * 2 + (lane >> 5)));
     } else {
@@ -123,6 +128,79 @@ __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, bf16
         Vec16<bf16> o;
         o.raw = __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8_t));
         store16<bf16>(C + gm * ep.ldc + gn, o);
+    }
+}
+
+// everything after the K loop (all LDS stages are free): fused bias-gradient column sums, then four 64-row passes of the
+// accumulators through the fp32 staging buffer with the fused epilogue (or raw split-K slabs)
+template <bool A_COL, int NW>
+__device__ __forceinline__ void finish_tile(char* smem, f32x16 (&acc)[4][16 / NW], float (&asum)[8], bool do_asum,
+                                            bf16* __restrict__ C, float* __restrict__ ws, float* __restrict__ asum_ws,
+                                            bf16* __restrict__ asum_out, long long M, long long N, long long m0,
+                                            long long n0, int kslab, const EpiParams& ep) {
+    constexpr int WAVES_N = NW / 2, TJ = 16 / NW, RS = NW * 2, NIT = 64 / RS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = (wave % WAVES_N) * (32 * TJ);
+    if constexpr (A_COL) {
+        if (do_asum) {
+            float* red = reinterpret_cast<float*>(smem);  // [RS][256]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(tid >> 5) * BM + (tid & 31) * 8 + e] = asum[e];
+            __syncthreads();
+            if (tid < BM && m0 + tid < M) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < RS; ++r) s += red[r * BM + tid];
+                if (asum_ws) asum_ws[(long long)kslab * M + m0 + tid] = s;
+                else asum_out[m0 + tid] = __float2bfloat16(s);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: four 64-row passes through the fp32 staging buffer ----
+    float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if ((wave / WAVES_N) == (p >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 32 * ii + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        cs[row * CP + wn + 32 * j + (lane & 31)] = acc[(p & 1) * 2 + ii][j][r];
+                    }
+        }
+        __syncthreads();
+        const long long mh = m0 + p * 64;
+        if (ws) {  // split-K partial: raw fp32 slab [splitk][M][N]
+            float* slab = ws + (long long)kslab * M * N;
+            const int col = (tid & 31) * 8, r0 = tid >> 5;
+            const long long gn = n0 + col;
+            if (gn + 8 <= N) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const long long gm = mh + r0 + RS * it;
+                    if (gm >= M) continue;
+                    const float* src = cs + (r0 + RS * it) * CP + col;
+                    float* dst = slab + gm * N + gn;
+                    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+                    *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(src + 4);
+                }
+            }
+        } else if (ep.mode == 0) {
+            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 0, NW>(cs, C, ep, mh, n0, M, N, tid);
+            else epilogue_pass<PK_ACT_NONE, 0, NW>(cs, C, ep, mh, n0, M, N, tid);
+        } else if (ep.mode == 1) {
+            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 1, NW>(cs, C, ep, mh, n0, M, N, tid);
+            else epilogue_pass<PK_ACT_NONE, 1, NW>(cs, C, ep, mh, n0, M, N, tid);
+        } else {
+            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 2, NW>(cs, C, ep, mh, n0, M, N, tid);
+            else epilogue_pass<PK_ACT_NONE, 2, NW>(cs, C, ep, mh, n0, M, N, tid);
+        }
+        if (p < 3) __syncthreads();
     }
 }
 
@@ -227,67 +305,7 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
     }
     __syncthreads();
 
-    if constexpr (A_COL) {
-        if (do_asum) {
-            float* red = reinterpret_cast<float*>(smem);  // [RS][256]
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[(tid >> 5) * BM + (tid & 31) * 8 + e] = asum[e];
-            __syncthreads();
-            if (tid < BM && m0 + tid < M) {
-                float s = 0.f;
-#pragma unroll
-                for (int r = 0; r < RS; ++r) s += red[r * BM + tid];
-                if (asum_ws) asum_ws[(long long)kslab * M + m0 + tid] = s;
-                else asum_out[m0 + tid] = __float2bfloat16(s);
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue: four 64-row passes through the fp32 staging buffer ----
-    float* cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if ((wave / WAVES_N) == (p >> 1)) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = 32 * ii + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        cs[row * CP + wn + 32 * j + (lane & 31)] = acc[(p & 1) * 2 + ii][j][r];
-                    }
-        }
-        __syncthreads();
-        const long long mh = m0 + p * 64;
-        if (ws) {  // split-K partial: raw fp32 slab [splitk][M][N]
-            float* slab = ws + (long long)kslab * M * N;
-            const int col = (tid & 31) * 8, r0 = tid >> 5;
-            const long long gn = n0 + col;
-            if (gn + 8 <= N) {
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const long long gm = mh + r0 + RS * it;
-                    if (gm >= M) continue;
-                    const float* src = cs + (r0 + RS * it) * CP + col;
-                    float* dst = slab + gm * N + gn;
-                    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
-                    *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(src + 4);
-                }
-            }
-        } else if (ep.mode == 0) {
-            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 0, NW>(cs, C, ep, mh, n0, M, N, tid);
-            else epilogue_pass<PK_ACT_NONE, 0, NW>(cs, C, ep, mh, n0, M, N, tid);
-        } else if (ep.mode == 1) {
-            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 1, NW>(cs, C, ep, mh, n0, M, N, tid);
-            else epilogue_pass<PK_ACT_NONE, 1, NW>(cs, C, ep, mh, n0, M, N, tid);
-        } else {
-            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 2, NW>(cs, C, ep, mh, n0, M, N, tid);
-            else epilogue_pass<PK_ACT_NONE, 2, NW>(cs, C, ep, mh, n0, M, N, tid);
-        }
-        if (p < 3) __syncthreads();
-    }
+    finish_tile<A_COL, NW>(smem, acc, asum, do_asum, C, ws, asum_ws, asum_out, M, N, m0, n0, kslab, ep);
 }
 
 }  // namespace
@@ -297,6 +315,9 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
 extern "C" int pk_gemm256_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
                                  long long M, long long N, long long K, long long lda, long long ldb, int a_col,
                                  int b_col, int kchunk, int splitk, EpiParams ep, void* stream) {
+    // 8 waves of 128x64 (default), or 4 waves of 128x128 with the accumulators in AGPRs (PK_GEMM256_NW=4): half the LDS
+    // fragment traffic per MFMA but half the waves to hide prologue / epilogue.  Measured: K = 2048 row,row 887 vs 811
+    // TFLOP/s in isolation, K = 512 shapes and col-form operands 5-10 % slower, no difference in the training step.
     static const int nw = getenv("PK_GEMM256_NW") ? atoi(getenv("PK_GEMM256_NW")) : 8;
     dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN) * splitk)), block(nw * 64);
     hipStream_t s = (hipStream_t)stream;
