@@ -66,57 +66,49 @@ def synthetic_batch(B, S, T, V, seed, device):
 
 
 class GemmTimer:
-    """wraps pasero_amd.functional.gemm: a pair of HIP events around every launch (on the launching stream)"""
+    """per-launch durations of the GEMM kernels, measured by the library itself: HIP events recorded around exactly the
+    main GEMM kernel of every STRIDE-th pk_gemm call, on the stream it is launched on (include/pasero_hip.h:
+    pk_gemm_timing_*).  Kernel names are the rocprofv3 names, so the averages can be checked against profiles/."""
 
-    STRIDE = 3  # every 3rd launch is bracketed (coprime with the launches per step, so every shape is sampled)
+    STRIDE = 11  # coprime with the 210 GEMM launches of a step (2*3*5*7), so over the steps every launch is sampled
 
     def __init__(self):
-        self.records = []  # (key, flops, start, end)
-        self.enabled = False
-        self.count = 0
-        self.pool = []
+        self.samples = 0
 
-    def prepare(self, n_events: int):
-        """events are created before the timed region: inside it only two `record()` calls per sampled launch remain"""
-        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(n_events)]
+    def start(self, max_samples: int):
+        from pasero_amd import lib
+        lib.check(lib.load().pk_gemm_timing_start(int(max_samples), self.STRIDE), 'pk_gemm_timing_start')
 
-    def install(self):
-        from pasero_amd import functional as F
-        from pasero_amd import autograd as A
-        orig = F.gemm
-        timer = self
+    def stop(self):
+        from pasero_amd import lib
+        self.samples = lib.load().pk_gemm_timing_stop()
 
-        def timed(a, b, **kw):
-            if not timer.enabled:
-                return orig(a, b, **kw)
-            timer.count += 1
-            if timer.count % timer.STRIDE or len(timer.pool) < 2:
-                return orig(a, b, **kw)
-            a_col, b_col = kw.get('a_col', False), kw.get('b_col', False)
-            M, K = (a.size(1), a.size(0)) if a_col else (a.size(0), a.size(1))
-            N = b.size(1) if b_col else b.size(0)
-            s, e = timer.pool.pop(), timer.pool.pop()
-            s.record()
-            out = orig(a, b, **kw)
-            e.record()
-            name = 'gemm_kernel<%s,%s,%s>%s' % ('bf16' if a.dtype == torch.bfloat16 else 'f32',
-                                               'col' if a_col else 'row', 'col' if b_col else 'row',
-                                               '+splitk' if kw.get('splitk', 1) > 1 else '')
-            timer.records.append((name, 2.0 * M * N * K, s, e))
-            return out
-        F.gemm = timed
-        A.F.gemm = timed
+    @staticmethod
+    def kernel_name(kernel, a_col, b_col, dtype):
+        tf = {0: 'false', 1: 'true'}
+        if kernel == 256:
+            return 'gemm256_kernel<%s, %s, 8>' % (tf[a_col], tf[b_col])
+        return 'gemm_kernel<%s, %s, %s>' % ('__hip_bfloat16' if dtype == 1 else 'float', tf[a_col], tf[b_col])
 
     def summary(self):
+        import ctypes
+        from pasero_amd import lib
+        L = lib.load()
+        ints = [ctypes.c_int() for _ in range(5)]
+        flops, ms = ctypes.c_double(), ctypes.c_float()
         agg = {}
-        for name, flops, s, e in self.records:
-            ms = s.elapsed_time(e)
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+        for i in range(self.samples):
+            lib.check(L.pk_gemm_timing_read(i, *[ctypes.byref(x) for x in ints], ctypes.byref(flops),
+                                            ctypes.byref(ms)), 'pk_gemm_timing_read')
+            kernel, a_col, b_col, splitk, dtype = (x.value for x in ints)
+            a = agg.setdefault(self.kernel_name(kernel, a_col, b_col, dtype), [0, 0.0, 0.0, 0])
             a[0] += 1
-            a[1] += flops
-            a[2] += ms
+            a[1] += flops.value
+            a[2] += ms.value
+            a[3] += splitk > 1
         return {k: {'launches': v[0], 'avg_us': 1e3 * v[2] / v[0], 'tflops': v[1] / (v[2] * 1e-3) / 1e12,
-                    'total_ms': v[2], 'flops_per_launch': v[1] / v[0]} for k, v in agg.items()}
+                    'total_ms': v[2], 'flops_per_launch': v[1] / v[0], 'splitk_launches': v[3]}
+                for k, v in agg.items()}
 
 
 def pmc_traffic(kernel_key: str):
@@ -128,11 +120,7 @@ def pmc_traffic(kernel_key: str):
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic_pmc.json')))
     if not files:
         return None
-    layout = {'row': 'false', 'col': 'true'}
-    parts = kernel_key.split('<')[1].split('>')[0].split(',')  # bf16,row,col
-    name = 'gemm_kernel<%s, %s, %s>' % ('__hip_bfloat16' if parts[0] == 'bf16' else 'float', layout[parts[1]],
-                                        layout[parts[2]])
-    k = json.load(open(files[-1]))['kernels'].get(name)
+    k = json.load(open(files[-1]))['kernels'].get(kernel_key)
     return k['hbm_bytes_per_launch_corrected'] if k else None
 
 
@@ -235,8 +223,6 @@ def main():
     batch = synthetic_batch(B, S, T, V, seed=1 + rank, device=device)
 
     timer = GemmTimer()
-    if not args.no_roofline:
-        timer.install()
 
     def step():
         for p in model.parameters():
@@ -252,17 +238,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if not args.no_roofline:
-        timer.prepare(2 * 400 * args.steps // GemmTimer.STRIDE + 64)
     fence()
-    timer.enabled = not args.no_roofline
+    if not args.no_roofline:
+        timer.start(400 * args.steps // GemmTimer.STRIDE + 64)
     t0 = time.perf_counter()
     tokens = 0
     for _ in range(args.steps):
         tokens += step()
     fence()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    if not args.no_roofline:
+        timer.stop()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -294,14 +280,14 @@ def main():
                        'model_tflops_per_gpu': step_flops * args.steps / elapsed / 1e12,
                        'mfma_peak_fraction_whole_step': step_flops * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS},
         }
-        if not args.no_roofline and timer.records:
+        if not args.no_roofline and timer.samples:
             summ = timer.summary()
             dom = max(summ, key=lambda k: summ[k]['total_ms'])
             d = summ[dom]
             out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': d['tflops'], 'peak': PEAK_BF16_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': d['tflops'] / PEAK_BF16_TFLOPS, 'traffic': pmc_traffic(dom),
                                'avg_launch_us': d['avg_us'], 'sampled_launches': d['launches'],
-                               'sampling': f'every {GemmTimer.STRIDE}rd launch bracketed by HIP events',
+                               'sampling': f'HIP events around the kernel of every {GemmTimer.STRIDE}th pk_gemm call, on its stream',
                                'flops_per_launch': d['flops_per_launch'],
                                'gemm_share_of_step': GemmTimer.STRIDE * sum(v['total_ms'] for v in summ.values()) / (1e3 * elapsed),
                                'all_gemm_kernels': {k: {'tflops': round(v['tflops'], 1), 'avg_us': round(v['avg_us'], 1),

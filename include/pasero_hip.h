@@ -49,6 +49,15 @@ int pk_gemm(const void* A, const void* B, void* C, const void* bias, const void*
             long long N, long long K, long long lda, long long ldb, long long ldc, long long ldaux, long long ldpre,
             int a_col, int b_col, int act, int mode, float alpha, int dtype, int splitk, void* workspace,
             size_t ws_bytes, void* asum_out, void* stream);
+/* Launch timing for the roofline measurement (no reference counterpart; the analogue of wrapping the reference's
+ * nn.Linear calls in torch.cuda.Event pairs).  After pk_gemm_timing_start(max_samples, stride) every `stride`-th pk_gemm
+ * call records a HIP event pair around exactly its main GEMM kernel (not the split-K reduce), on the launching stream.
+ * pk_gemm_timing_stop() ends sampling and returns the number of samples; pk_gemm_timing_read(i, ...) synchronises on
+ * sample i and returns the kernel that ran (128 = gemm_kernel 128x128 tiles, 256 = gemm256_kernel), its operand
+ * layouts, split-K factor, dtype, 2*M*N*K and the elapsed milliseconds. */
+int pk_gemm_timing_start(int max_samples, int stride);
+int pk_gemm_timing_stop(void);
+int pk_gemm_timing_read(int i, int* kernel, int* a_col, int* b_col, int* splitk, int* dtype, double* flops, float* ms);
 
 /* ---- Residual + dropout + LayerNorm (K4): replaces `residual + dropout(x)` followed by nn.LayerNorm,
  * pasero/models/transformer.py:1043-1054,1073-1086 (encoder), :1322-1339,1389-1407 (decoder), :941-947 (Norm).

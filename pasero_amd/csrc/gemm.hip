@@ -21,6 +21,7 @@
 // private L2.
 #include <stdlib.h>
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 #include "gemm_epi.h"
@@ -693,6 +694,33 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict
     }
 }
 
+// ---- optional launch timing (bench.py's roofline leg): HIP events around exactly the main GEMM kernel, on its stream ----
+struct GemmSample {
+    hipEvent_t start, stop;
+    int kernel, a_col, b_col, splitk, dtype;
+    double flops;
+};
+struct GemmTiming {
+    bool on = false;
+    int stride = 1, count = 0, used = 0;
+    std::vector<GemmSample> pool;
+} g_timing;
+
+// returns the sample slot to fill (events already recorded `start`) or nullptr
+inline GemmSample* timing_begin(int kernel, int a_col, int b_col, int splitk, int dtype, long long M, long long N,
+                                long long K, hipStream_t stream) {
+    if (!g_timing.on) return nullptr;
+    if (++g_timing.count % g_timing.stride != 0 || g_timing.used >= (int)g_timing.pool.size()) return nullptr;
+    GemmSample* sm = &g_timing.pool[g_timing.used++];
+    sm->kernel = kernel; sm->a_col = a_col; sm->b_col = b_col; sm->splitk = splitk; sm->dtype = dtype;
+    sm->flops = 2.0 * (double)M * (double)N * (double)K;
+    (void)hipEventRecord(sm->start, stream);
+    return sm;
+}
+inline void timing_end(GemmSample* sm, hipStream_t stream) {
+    if (sm) (void)hipEventRecord(sm->stop, stream);
+}
+
 template <typename T>
 int launch_gemm(const void* A, const void* B, void* C, long long M, long long N, long long K, long long lda,
                 long long ldb, int a_col, int b_col, EpiParams ep, int splitk, void* workspace,
@@ -736,8 +764,10 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
             if (sk > 0 && (tile_pref == 256 || fills)) {
                 float* w2 = sk > 1 ? (float*)workspace : nullptr;
                 float* asw = (sk > 1 && asum_out) ? w2 + (size_t)sk * M * N : nullptr;
+                GemmSample* sm = timing_begin(256, a_col, b_col, std::max(sk, 1), PK_BF16, M, N, K, stream);
                 int rc = pk_gemm256_launch(A, B, C, w2, asw, asum_out, M, N, K, lda, ldb, a_col, b_col, (int)per,
                                            std::max(sk, 1), ep, stream);
+                timing_end(sm, stream);
                 if (rc != 1) return rc;
                 if (w2) {
                     long long chunks = M * ((N + EPV - 1) / EPV);
@@ -772,11 +802,13 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
 #define PK_LAUNCH(AC, BC) \
     hipLaunchKernelGGL((gemm_kernel<T, AC, BC>), grid, block, 0, stream, a, b, c, ws, asum_ws, (T*)asum_out, M, N, K, \
                        lda, ldb, kchunk, ep, flags)
+    GemmSample* sm = timing_begin(128, a_col, b_col, splitk, sizeof(T) == 2 ? PK_BF16 : PK_F32, M, N, K, stream);
     if (!a_col && !b_col) PK_LAUNCH(false, false);
     else if (!a_col && b_col) PK_LAUNCH(false, true);
     else if (a_col && !b_col) PK_LAUNCH(true, false);
     else PK_LAUNCH(true, true);
 #undef PK_LAUNCH
+    timing_end(sm, stream);
     PK_LAUNCH_CHECK();
     if (ws) {
         long long chunks = M * ((N + EPV - 1) / EPV);
@@ -810,4 +842,32 @@ extern "C" int pk_gemm(const void* A, const void* B, void* C, const void* bias, 
     if (dtype == PK_BF16)
         return launch_gemm<bf16>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
     return launch_gemm<float>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
+}
+
+// ---- launch timing API (see include/pasero_hip.h) ----
+extern "C" int pk_gemm_timing_start(int max_samples, int stride) {
+    PK_CHECK_ARG(max_samples > 0 && stride > 0, "pk_gemm_timing_start: bad arguments");
+    for (auto& sm : g_timing.pool) { (void)hipEventDestroy(sm.start); (void)hipEventDestroy(sm.stop); }
+    g_timing.pool.assign((size_t)max_samples, GemmSample{});
+    for (auto& sm : g_timing.pool) {
+        hipError_t e = hipEventCreate(&sm.start);
+        if (e == hipSuccess) e = hipEventCreate(&sm.stop);
+        if (e != hipSuccess) { pk_set_error("pk_gemm_timing_start: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    g_timing.stride = stride; g_timing.count = 0; g_timing.used = 0; g_timing.on = true;
+    return 0;
+}
+extern "C" int pk_gemm_timing_stop(void) {
+    g_timing.on = false;
+    return g_timing.used;
+}
+extern "C" int pk_gemm_timing_read(int i, int* kernel, int* a_col, int* b_col, int* splitk, int* dtype, double* flops,
+                                   float* ms) {
+    PK_CHECK_ARG(i >= 0 && i < g_timing.used, "pk_gemm_timing_read: sample %d of %d", i, g_timing.used);
+    const GemmSample& sm = g_timing.pool[i];
+    hipError_t e = hipEventSynchronize(sm.stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, sm.start, sm.stop);
+    if (e != hipSuccess) { pk_set_error("pk_gemm_timing_read: %s", hipGetErrorString(e)); return (int)e; }
+    *kernel = sm.kernel; *a_col = sm.a_col; *b_col = sm.b_col; *splitk = sm.splitk; *dtype = sm.dtype; *flops = sm.flops;
+    return 0;
 }

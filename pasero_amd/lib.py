@@ -22,6 +22,9 @@ SIGNATURES = {
     'pk_version': (I, []),
     'pk_last_error': (c_char_p, []),
     'pk_gemm': (I, [P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, SZ, P, P]),
+    'pk_gemm_timing_start': (I, [I, I]),
+    'pk_gemm_timing_stop': (I, []),
+    'pk_gemm_timing_read': (I, [I, P, P, P, P, P, P, P]),
     'pk_residual_ln_fwd': (I, [P, P, P, P, P, P, P, P, LL, I, F, F, ULL, ULL, I, P]),
     'pk_residual_ln_bwd_workspace': (SZ, [LL, I]),
     'pk_residual_ln_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, SZ, LL, I, F, ULL, ULL, I, P]),
