@@ -1,0 +1,203 @@
+"""Parity at BASELINE.json's FULL sizes (configs[1] = C2: Transformer-base, V = 8032, B = 256, S = T = 128) through
+size-independent properties — the CPU oracle needs minutes at this size, so instead of comparing against it the tests
+check what must hold for ANY correct implementation of the path:
+  * the loss is a sum over target tokens: a batch equals the sum of its halves, rows may be permuted, trailing padding
+    changes nothing (reference semantics: pasero/models/transformer.py:355-377 sums the label-smoothed NLL over
+    non-pad targets; attention masks keys by length, modules.py:662-683);
+  * GEMM: scaling an operand by a power of two scales the output bit-exactly; row checksums match an fp32 reference;
+  * attention: every row of softmax weights sums to one (V = 1 gives O = 1); lse matches an fp32 logsumexp;
+  * LayerNorm (gamma = 1, beta = 0): rows have zero mean and unit variance;
+  * cross-entropy: the gradient of a row sums to zero, pad rows have zero gradient.
+Tolerances are written at each check; bf16 results are held to bf16 storage precision (2^-8 relative per element)."""
+import numpy as np
+import pytest
+import torch
+
+from model_utils import load_paramgen
+
+pytestmark = pytest.mark.gpu
+
+V, B, S, T = 8032, 256, 128, 128
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+
+
+def _model(dtype, dropout=0.0):
+    from pasero_amd.config import TransformerConfig, DistributedConfig, SyntheticTask
+    from pasero_amd.transformer import Transformer
+    cfg = TransformerConfig(dropout=dropout)
+    model = Transformer(cfg, DistributedConfig(), SyntheticTask(V))
+    load_paramgen(model, 11)
+    return model.to(dtype).cuda().train()
+
+
+def _batch(b=B, s=S, t=T, ragged=True, seed=5):
+    import paramgen
+    return {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(seed, b, s, t, V, ragged=ragged).items()}
+
+
+def _rows(batch, idx):
+    return {k: v[idx].contiguous() for k, v in batch.items()}
+
+
+WATCH = ['encoder.layers.0.fc1.weight', 'encoder.layers.5.self_attn.q_proj.weight', 'decoder.layers.3.fc2.weight',
+         'decoder.layers.5.encoder_attn.k_proj.weight', 'decoder.layers.0.self_attn_layer_norm.weight',
+         'encoder.embed_tokens.weight']
+
+
+def _step(model, batch):
+    model.zero_grad(set_to_none=True)
+    loss, logs = model(**batch)
+    loss.backward()
+    params = dict(model.named_parameters())
+    return loss.item(), logs, {n: params[n].grad.float().clone() for n in WATCH}
+
+
+def test_c2_loss_and_grads_are_additive_over_the_batch():
+    model = _model(torch.bfloat16)
+    batch = _batch()
+    full, logs, g = _step(model, batch)
+    h1, logs1, g1 = _step(model, _rows(batch, slice(0, B // 2)))
+    h2, logs2, g2 = _step(model, _rows(batch, slice(B // 2, B)))
+    assert logs['num_tokens'] == logs1['num_tokens'] + logs2['num_tokens'] == int((batch['decoder_input'][:, 1:] != 1).sum())
+    # every row is computed independently of its batch neighbours; only the final fp64 -> fp32 sum differs
+    assert abs(full - (h1 + h2)) <= 1e-5 * abs(full)
+    for n in WATCH:  # bf16 gradients: each half is rounded once more before the sum
+        err = (g[n] - (g1[n] + g2[n])).abs().max().item()
+        assert err <= 2e-2 * g[n].abs().max().item(), (n, err)
+
+
+def test_c2_row_permutation_and_trailing_padding_change_nothing():
+    model = _model(torch.bfloat16)
+    batch = _batch(s=96, t=96, ragged=True)
+    base, logs, g = _step(model, batch)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+    p_loss, p_logs, pg = _step(model, _rows(batch, perm))
+    assert abs(p_loss - base) <= 1e-5 * abs(base) and p_logs['num_tokens'] == logs['num_tokens']
+    # pad source to S = 128 and targets to T = 128: masked keys carry weight exp(-inf) = 0, pad targets no loss
+    padded = {
+        'encoder_input': torch.nn.functional.pad(batch['encoder_input'], (0, S - 96), value=1),
+        'encoder_input_length': batch['encoder_input_length'],
+        'decoder_input': torch.nn.functional.pad(batch['decoder_input'], (0, T - 96), value=1),
+        'prompt_mask': torch.nn.functional.pad(batch['prompt_mask'], (0, T - 96), value=False),
+    }
+    q_loss, q_logs, qg = _step(model, padded)
+    assert q_logs['num_tokens'] == logs['num_tokens']
+    assert abs(q_loss - base) <= 1e-4 * abs(base)  # other key-tile grouping of the online softmax (bf16 P)
+    for n in WATCH:
+        scale = g[n].abs().max().item()
+        assert (pg[n] - g[n]).abs().max().item() <= 2e-2 * scale, n
+        assert (qg[n] - g[n]).abs().max().item() <= 2e-2 * scale, n
+
+
+def test_c2_dropout_step_is_reproducible_and_bf16_tracks_fp32():
+    from pasero_amd import rng
+    model = _model(torch.bfloat16, dropout=0.1)
+    batch = _batch(ragged=False)  # the bench.py workload
+    rng.manual_seed(9)
+    a, _, ga = _step(model, batch)
+    rng.manual_seed(9)
+    b, _, gb = _step(model, batch)
+    assert a == b
+    for n in WATCH:
+        if 'embed_tokens' in n or 'layer_norm' in n:
+            continue  # scattered with fp32 atomics: order-dependent in the last bit
+        assert torch.equal(ga[n], gb[n]), n
+    # no dropout: the bf16 step against the fp32 kernels on the same weights and batch
+    m16, m32 = _model(torch.bfloat16), _model(torch.float32)
+    l16, _, g16 = _step(m16, batch)
+    l32, _, g32 = _step(m32, batch)
+    assert abs(l16 - l32) <= 2e-2 * abs(l32)  # bf16 storage precision through 12 layers
+    for n in WATCH:
+        # relative L2 error of a bf16 gradient.  Measured: 1.3-3.2 %, of which ~2.2 % is the rounding of the weights
+        # themselves (fp32 kernels on bf16-rounded weights differ from fp32 by that much).  The cross-attention key
+        # projection is the exception (11.6 %, identical with the fused and the two-kernel backward): at random init
+        # the attention is near uniform and dK = dS^T Q cancels almost completely, so the bf16 rounding of dS — which
+        # every bf16-MFMA flash backward shares — is large relative to what is left.
+        tol = 0.2 if 'encoder_attn.k_proj' in n else 0.05
+        num = (g16[n] - g32[n]).norm().item()
+        assert num <= tol * g32[n].norm().item(), (n, num)
+
+
+@pytest.mark.parametrize('a_col,b_col', [(False, False), (False, True), (True, True)])
+def test_fullsize_gemm_pow2_scaling_is_exact_and_checksums_match(a_col, b_col):
+    from pasero_amd import functional as F
+    # the C2 shapes of the three forms: y = x W^T (32768 x 2048 x 512), dX = dY W, dW = dY^T X (K = 32768)
+    M, N, K = (2048, 512, 32768) if a_col else (32768, 2048, 512)
+    g = torch.Generator(device='cuda').manual_seed(1)
+    A = torch.randn(M, K, device='cuda', generator=g).bfloat16()
+    Bm = torch.randn(N, K, device='cuda', generator=g).bfloat16()
+    a = A.t().contiguous() if a_col else A
+    b = Bm.t().contiguous() if b_col else Bm
+    sk = F.choose_splitk(M, N, K) if a_col else 1
+    c1 = F.gemm(a, b, a_col=a_col, b_col=b_col, splitk=sk)
+    c2 = F.gemm(a * 2, b * 0.5, a_col=a_col, b_col=b_col, splitk=sk)
+    assert torch.equal(c1, c2)  # powers of two commute with every rounding on the way
+    # checksum of checksums: C 1 = A (B^T 1), in fp32
+    want = A.float() @ Bm.float().sum(0)
+    got = c1.float().sum(1)
+    tol = 2.0 ** -8 * (A.float().abs() @ Bm.float().abs().sum(0)) / N ** 0.5 * 4 + 1e-3  # N independent bf16 roundings
+    assert ((got - want).abs() <= tol).all()
+
+
+@pytest.mark.parametrize('causal', [False, True])
+def test_fullsize_attention_rows_sum_to_one_and_lse_matches(causal):
+    from pasero_amd import functional as F
+    H, D = 8, 512
+    g = torch.Generator(device='cuda').manual_seed(2)
+    q = torch.randn(B, T, D, device='cuda', generator=g).bfloat16()
+    k = torch.randn(B, S, D, device='cuda', generator=g).bfloat16()
+    v = torch.ones(B, S, D, device='cuda', dtype=torch.bfloat16)
+    lens = torch.randint(S // 2, S + 1, (B,), device='cuda', generator=g)
+    pad = None if causal else torch.arange(S, device='cuda')[None, :] >= lens[:, None]
+    o, lse = F.attn_fwd(q, k, v, H, pad, causal, 0.125)
+    # weights are rounded to bf16 before they multiply V: |sum_j bf16(p_j) - 1| <= 2^-9 sum_j p_j
+    assert (o.float() - 1).abs().max().item() <= 2.0 ** -7
+    for bi, h in [(0, 0), (B - 1, H - 1), (101, 3)]:
+        s = (q[bi, :, 64 * h: 64 * h + 64].float() @ k[bi, :, 64 * h: 64 * h + 64].float().t()) * 0.125
+        if causal:
+            s = s.masked_fill(torch.ones(T, S, device='cuda', dtype=torch.bool).triu(1), float('-inf'))
+        else:
+            s = s.masked_fill(pad[bi][None, :], float('-inf'))
+        assert (lse[bi, h] - torch.logsumexp(s, 1)).abs().max().item() <= 1e-3  # fp32 accumulation of bf16 products
+
+
+def test_fullsize_layernorm_rows_are_standardised():
+    from pasero_amd import functional as F
+    rows, d = B * T, 512
+    g = torch.Generator(device='cuda').manual_seed(4)
+    x = (3 * torch.randn(rows, d, device='cuda', generator=g) + 1.5).bfloat16()
+    res = torch.randn(rows, d, device='cuda', generator=g).bfloat16()
+    gamma, beta = torch.ones(d, device='cuda', dtype=torch.bfloat16), torch.zeros(d, device='cuda', dtype=torch.bfloat16)
+    y = F.residual_ln_fwd(x, res, gamma, beta, 1e-5)[0].float()
+    assert y.shape == (rows, d)
+    assert y.mean(1).abs().max().item() <= 2e-3        # mean of 512 values each rounded to bf16 (|y| <~ 4)
+    assert (y.var(1, unbiased=False) - 1).abs().max().item() <= 2e-2
+
+
+def test_fullsize_cross_entropy_gradient_rows_sum_to_zero():
+    from pasero_amd import functional as F
+    rows = B * T
+    g = torch.Generator(device='cuda').manual_seed(6)
+    logits = (2 * torch.randn(rows, V, device='cuda', generator=g)).bfloat16()
+    target = torch.randint(4, V, (rows,), device='cuda', generator=g)
+    target[::7] = 1  # pad rows
+    row_loss = torch.empty(rows, device='cuda')
+    row_nll = torch.empty(rows, device='cuda')
+    dlogits = torch.empty_like(logits)
+    F.ce_rows(logits, target, 1, 0.1, row_loss, row_nll, dlogits)
+    sums = dlogits.float().sum(1)
+    assert sums[target == 1].abs().max().item() == 0.0 and row_loss[target == 1].abs().max().item() == 0.0
+    # softmax - smoothed one-hot sums to zero; V bf16 roundings of ~1/V plus one of ~0.9
+    assert sums.abs().max().item() <= 1e-2
+    lse = torch.logsumexp(logits[:4096].float(), 1)
+    nll = lse - logits[:4096].float().gather(1, target[:4096, None])[:, 0]
+    keep = target[:4096] != 1
+    assert (row_nll[:4096] - nll)[keep].abs().max().item() <= 1e-3 * nll[keep].abs().max().item()
+    sums3 = F.ce_finalize(row_loss, row_nll, target, 1)
+    assert int(sums3[2].item()) == int((target != 1).sum())
+    assert abs(sums3[1].item() - row_nll.double().sum().item()) <= 1e-5 * row_nll.double().sum().item()
