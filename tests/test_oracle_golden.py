@@ -157,9 +157,11 @@ def test_label_smoothed_ce(eps):
 def test_sinusoidal_positions(d):
     g = load_golden('sinpos')
     table = O.sinusoidal_table(300, d, shift=2)
-    close(table[2:42].numpy(), g[f'd{d}'], rtol=1e-6)
-    close(table[19:22].numpy(), g[f'd{d}_off'], rtol=1e-6)
-    close(table[[0, 1, 2, 150, 301]].numpy(), g[f'd{d}_rows'], rtol=1e-6)
+    # fp32 sin/cos/exp of the host libm: the last ulp of a 301-rad angle is 2e-5 absolute (another CPU's libm differs
+    # by that much; on the container that made the fixture the tables agree to 1e-6)
+    close(table[2:42].numpy(), g[f'd{d}'], rtol=0, atol=1e-5)
+    close(table[19:22].numpy(), g[f'd{d}_off'], rtol=0, atol=1e-5)
+    close(table[[0, 1, 2, 150, 301]].numpy(), g[f'd{d}_rows'], rtol=0, atol=5e-5)
 
 
 @pytest.mark.parametrize('name', ['speech_whisper', 'speech_iwslt'])
