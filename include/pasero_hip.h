@@ -175,6 +175,44 @@ int pk_mt_adam(const long long* table, int ntensors, const int* chunk_tensor, co
 int pk_gated_act_bwd(const void* dh, const void* z, const void* u, void* dz, void* du, long long n, int act, int dtype,
                      void* stream);
 
+/* ---- "Next" row: one incremental decoding step (T = 1) of the whole decoder stack in one call.
+ * Replaces TransformerDecoder.forward with a non-empty `state` (pasero/models/transformer.py:831-898), the decoder
+ * layer's self_attention / cross_attention / ffn (:1246-1320, :1224-1244, :1341-1417) and the KV-cache branch of
+ * MultiheadAttention.forward (pasero/models/modules.py:621-641) for the stock layer (ReLU / GELU / SiLU feed-forward,
+ * LayerNorm, sinusoidal / learned / no positions, post- or pre-norm).  All pointers are device memory except `plan`,
+ * `plan->layers` and the three pointer tables, which are host memory.
+ *   ids[B]            the tokens decoded at the previous step (one per sentence)
+ *   t                 rows already in the self-attention caches; this step's K/V rows are written at index t
+ *   pos_start         row of the positional table for this step (= positional shift + offset)
+ *   self_k/self_v[l]  per-layer caches [B][cap][d]  (the reference concatenates a new tensor every step, :636-637)
+ *   cross_kv[l]       per-layer [B*S][2d] = [k_proj(encoder_out) | v_proj(encoder_out)], computed once per sentence
+ *                     (the reference recomputes both projections every step, :612-615)
+ *   enc_mask          (B,S) bool key-padding mask of the encoder output, or NULL
+ *   logits            [B][ld_logits] output of the (tied) projection
+ * pk_argmax_rows: out[row * out_stride] = index of the first maximum of x[row][0..n) — the greedy choice
+ * (pasero/decoding.py:1196-1205) without leaving the device. */
+typedef struct {
+    const void *qkv_w, *qkv_b, *out_w, *out_b, *ln1_g, *ln1_b;   /* self-attention [3d][d], [d][d]; self_attn_layer_norm */
+    const void *cq_w, *cq_b, *cout_w, *cout_b, *ln2_g, *ln2_b;   /* cross-attention q and output projections; its norm */
+    const void *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ln3_g, *ln3_b;   /* feed-forward [f][d], [d][f]; final_layer_norm */
+} PkDecoderLayerWeights;
+typedef struct {
+    int n_layers, d, heads, ffn, act, prenorm, dtype, scaled_attn;
+    long long vocab;
+    float eps, embed_scale;
+    const void *embed, *pos;                 /* token embedding [V][d]; positional table rows or NULL */
+    const void *embed_ln_g, *embed_ln_b;     /* layernorm_embedding or NULL */
+    const void *final_ln_g, *final_ln_b;     /* decoder.layer_norm (pre-norm) or NULL */
+    const void* out_w;                       /* output projection [V][d] (= embed when tied) */
+    const PkDecoderLayerWeights* layers;
+} PkDecoderPlan;
+size_t pk_decoder_step_scratch(const PkDecoderPlan* plan, int B);
+int pk_decoder_step(const PkDecoderPlan* plan, const long long* ids, int B, int t, int pos_start, void* const* self_k,
+                    void* const* self_v, long long cap, const void* const* cross_kv, const unsigned char* enc_mask,
+                    int S, void* scratch, size_t scratch_bytes, void* logits, long long ld_logits, void* stream);
+int pk_argmax_rows(const void* x, long long rows, long long n, long long ld, long long* out, long long out_stride,
+                   int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

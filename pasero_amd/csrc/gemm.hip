@@ -32,6 +32,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 extern "C" int pk_gemm256_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
                                  long long M, long long N, long long K, long long lda, long long ldb, int a_col,
                                  int b_col, int kchunk, int splitk, EpiParams ep, void* stream);
+extern "C" int pk_gemm_skinny_launch(const void* A, const void* B, void* C, long long M, long long N, long long K,
+                                     long long lda, long long ldb, EpiParams ep, void* stream);
 
 namespace {
 
@@ -737,6 +739,12 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
     int kchunk = (int)K;
     float* ws = nullptr;
     if constexpr (sizeof(T) == 2) {
+        // a handful of rows (one decoding step): latency-shaped kernel without LDS staging (gemm_skinny.hip)
+        static const bool no_skinny = getenv("PK_GEMM_NO_SKINNY") != nullptr;
+        if (!a_col && !b_col && M <= 256 && splitk <= 1 && !asum_out && !no_skinny) {
+            int rc = pk_gemm_skinny_launch(A, B, C, M, N, K, lda, ldb, ep, stream);
+            if (rc != 0) return rc == 1 ? 0 : rc;  // 1 = launched, 0 = not eligible, anything else = error
+        }
         // 256x256-tile kernel (gemm256.hip): LDS-DMA only, so it needs 16-byte addressable operands, K in whole 64-tiles
         // and one of the lean epilogues; it pays when its (4x fewer) tiles still fill the chip.
         static const int tile_pref = [] { const char* e = getenv("PK_GEMM_TILE"); return e ? atoi(e) : 0; }();

@@ -87,8 +87,13 @@ class Decoder(BaseModel):
         """:68-75 — beam search reorders the incremental state along the batch dimension"""
         if not state:
             return
+        cache = state.get('_pk_decode')  # native decoding step (pasero_amd/decode.py): reorders its own buffers
+        own = set()
+        if cache is not None:
+            cache.reorder(indices, state)
+            own = {n for pair in cache.names for n in pair}
         for k, v in state.items():
-            if torch.is_tensor(v) and v.dim() > 0:
+            if k not in own and torch.is_tensor(v) and v.dim() > 0:
                 state[k] = v.index_select(0, indices.to(v.device))
 
 
@@ -369,6 +374,11 @@ class TransformerDecoder(Decoder):
         """:831-898 -> (logits (B,T,V), layer_outputs).  `project=False` (used by the fused training loss) returns the
         features before the output projection instead of the logits."""
         return_layers = return_layers or ()
+        if state:  # one new token per sentence on top of a non-empty state: the native decoding step
+            from .decode import try_step
+            logits = try_step(self, encoder_out, encoder_mask, decoder_input, state, return_layers, project)
+            if logits is not None:
+                return logits, {}
         padding_mask = decoder_input.eq(self.padding_idx)
         T = decoder_input.size(1)
         pos_offset = state.get('offset', 0) if state else 0

@@ -53,6 +53,27 @@ def test_gemm_layouts(F, dtype, a_col, b_col, M, N, K):
     assert rel_err(out, ref) < tol
 
 
+@pytest.mark.parametrize('act', ['none', 'relu', 'gelu'])
+@pytest.mark.parametrize('M,N,K', [(1, 512, 512), (7, 1536, 512), (64, 512, 2048), (64, 8032, 512), (100, 520, 64),
+                                   (256, 2048, 512), (129, 36, 192)])
+def test_gemm_few_rows_decoding_shapes(F, act, M, N, K):
+    """M <= 256, row-form bf16 operands, K % 64 == 0: the latency-shaped kernel of a decoding step (gemm_skinny.hip);
+    bias + activation (+ residual) epilogues, ragged M and N tails, a strided input (q columns of a packed projection)"""
+    x3 = rnd((M, 3 * K), 11, torch.bfloat16).cuda()
+    x = x3[:, K:2 * K]  # row stride 3K, like q = qkv[:, :D]
+    w = rnd((N, K), 12, torch.bfloat16, K ** -0.5).cuda()
+    bias = rnd((N,), 13, torch.bfloat16).cuda()
+    res = rnd((M, N), 14, torch.bfloat16).cuda()
+    pre = x.float() @ w.float().t() + bias.float()
+    ref = O.activation(act, pre.cpu()).cuda() if act != 'none' else pre
+    out = F.gemm(x, w, bias=bias, act=act)
+    assert rel_err(out, ref) < 1e-2
+    out = F.gemm(x, w, bias=bias, act=act, aux=res, mode=1)
+    assert rel_err(out, ref + res.float()) < 1e-2
+    out = F.gemm(x, w)
+    assert rel_err(out, x.float() @ w.float().t()) < 1e-2
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_gemm_asymmetric_identity(F, dtype):
     """A = I with an asymmetric B catches a transposed C write (cdna guide §3)"""

@@ -289,3 +289,71 @@ def test_subclass_hooks_are_honoured():
     yb, _ = b(x, mask)
     assert calls == ['ffn', 'ffn_residual']
     assert rel(yb, ya) < 1e-5
+
+
+def _decode_logits(model, enc_out, enc_mask, tokens, reorder_at=None, indices=None):
+    """teacher-forced incremental decoding: logits of every step (first call: 2 tokens, then one token per call)"""
+    state, out = {}, []
+    with torch.no_grad():
+        lg, _ = model.decoder(enc_out, enc_mask, tokens[:, :2], state=state)
+        out.append(lg[:, -1].float())
+        for t in range(2, tokens.size(1)):
+            if reorder_at == t:
+                model.decoder.reorder_state(state, indices)
+                enc_out, enc_mask, tokens = enc_out[indices], enc_mask[indices], tokens[indices]
+            lg, _ = model.decoder(enc_out, enc_mask, tokens[:, t:t + 1], state=state)
+            out.append(lg[:, -1].float())
+    return out, state
+
+
+@pytest.mark.parametrize('name,dtype', [('tiny_encdec_post', torch.float32), ('tiny_encdec_pre', torch.float32),
+                                        ('base_c1', torch.bfloat16)])
+def test_native_decoding_step_matches_per_op_path(name, dtype, monkeypatch):
+    """pk_decoder_step (preallocated KV caches, cross K/V computed once) against the per-op incremental path that is
+    pinned bit-exactly to the reference's greedy tokens: same kernels underneath -> same logits up to the different
+    summation order of two GEMM shapes (fp32 2e-5, bf16 2e-2 of the logit range); the state stays reference-shaped"""
+    g = load_golden(name)
+    cfg, model = build_model(g, dtype, 'cuda')
+    model.eval()
+    B, S, V = int(g['B']), int(g['S']), int(g['V'])
+    b = paramgen.make_text_batch(int(g['seed']), B, S, 12, V)
+    with torch.no_grad():
+        enc_out, enc_mask, _ = model.encoder(torch.from_numpy(b['encoder_input']).cuda(),
+                                             torch.from_numpy(b['encoder_input_length']).cuda())
+    tokens = torch.from_numpy(b['decoder_input']).cuda().clamp(min=2)  # no pad tokens inside the prefix
+    native, st = _decode_logits(model, enc_out, enc_mask, tokens)
+    assert '_pk_decode' in st, 'the native step did not engage'
+    H = cfg.decoder_attention_heads
+    assert st['dec_0_self_attn_key'].shape == (B, tokens.size(1), H, 64) and st['offset'] == tokens.size(1)
+    monkeypatch.setenv('PASERO_NO_NATIVE_DECODE', '1')
+    per_op, st2 = _decode_logits(model, enc_out, enc_mask, tokens)
+    assert '_pk_decode' not in st2
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for a, r in zip(native, per_op):
+        assert (a - r).abs().max().item() <= tol * r.abs().max().item()
+        if dtype == torch.float32:
+            assert torch.equal(a.argmax(-1), r.argmax(-1))
+    last = f'dec_{cfg.decoder_layers - 1}_self_attn_value'
+    assert rel(st[last].float(), st2[last].float()) <= tol
+    # beam-search style reordering of the state in the middle of a sentence
+    monkeypatch.delenv('PASERO_NO_NATIVE_DECODE')
+    idx = torch.tensor([B - 1] + list(range(B - 1)) + [0], device='cuda')
+    a, _ = _decode_logits(model, enc_out, enc_mask, tokens, reorder_at=6, indices=idx)
+    monkeypatch.setenv('PASERO_NO_NATIVE_DECODE', '1')
+    r, _ = _decode_logits(model, enc_out, enc_mask, tokens, reorder_at=6, indices=idx)
+    for x, y in zip(a, r):
+        assert x.shape == y.shape and (x - y).abs().max().item() <= tol * y.abs().max().item()
+
+
+def test_argmax_rows_first_maximum():
+    import ctypes
+    from pasero_amd import lib
+    x = torch.randn(37, 8032, device='cuda').bfloat16()
+    x[3, 100] = x[3, 7000] = 50.0   # tie: lowest index wins
+    x[5] = -float('inf')
+    out = torch.full((37, 2), -1, dtype=torch.long, device='cuda')
+    lib.check(lib.load().pk_argmax_rows(x.data_ptr(), 37, 8032, 8032, out.data_ptr(), 2, lib.PK_BF16,
+                                        torch.cuda.current_stream().cuda_stream), 'pk_argmax_rows')
+    want = x.float().argmax(-1)
+    want[5] = 0
+    assert torch.equal(out[:, 0], want) and out[3, 0] == 100 and (out[:, 1] == -1).all()
