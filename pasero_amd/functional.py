@@ -337,3 +337,18 @@ def gated_act_bwd(dh: Tensor, z: Tensor, u: Tensor, act: str):
     check(lib.load().pk_gated_act_bwd(ptr(dh), ptr(z), ptr(u), ptr(dz), ptr(du), z.numel(), ACT[act], dtype_code(z),
                                       stream_ptr()), 'pk_gated_act_bwd')
     return dz, du
+
+
+def argmax_rows(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """index of the first maximum of every row of x (rows, n) [row stride allowed] -> int64 (rows,), or written into
+    `out`, a 1-D int64 view with any stride (e.g. a column of the (B, T) token buffer): the greedy choice of
+    pasero/decoding.py:1196-1205 without an intermediate tensor"""
+    require_gpu(x, out)
+    rows, n = x.shape
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int64, device=x.device)
+    assert out.dtype == torch.int64 and out.dim() == 1 and out.numel() == rows
+    L = lib.load()
+    check(L.pk_argmax_rows(ptr(x), rows, n, _ld(x), ptr(out), out.stride(0) if rows > 1 else 1, dtype_code(x),
+                           stream_ptr()), 'pk_argmax_rows')
+    return out

@@ -24,7 +24,7 @@ def main():
     ap.add_argument('--no-cross-cache', action='store_true')
     args = ap.parse_args()
     import paramgen
-    from pasero_amd import config as C
+    from pasero_amd import config as C, functional as F
     from pasero_amd.transformer import Transformer
     V = 8032
     cfg = getattr(C, args.config)()
@@ -45,7 +45,7 @@ def main():
             state = {}
             for step in range(1, args.steps + 1):
                 logits, _ = model.decoder(enc_out, enc_mask, tokens[:, step - 1:step], state=state)
-                tokens[:, step] = logits[:, -1].argmax(-1)
+                F.argmax_rows(logits[:, -1], out=tokens[:, step])
         return tokens
 
     decode()
