@@ -228,6 +228,8 @@ def try_step(decoder, encoder_out: Tensor, encoder_mask: Optional[Tensor], decod
     if plan is None:
         return None
     cache = state.get(DecodeCache.KEY)
+    if cache is not None and cache.plan is not plan:
+        return None  # a state dict shared by several decoders (decoding.py EnsembleDecoder): per-op path for the others
     if cache is not None and not cache.matches(state, encoder_out):
         cache = None
     first = decoder.layers[0].self_attn_key + '_key'
