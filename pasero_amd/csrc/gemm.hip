@@ -741,7 +741,8 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
     if constexpr (sizeof(T) == 2) {
         // a handful of rows (one decoding step): latency-shaped kernel without LDS staging (gemm_skinny.hip)
         static const bool no_skinny = getenv("PK_GEMM_NO_SKINNY") != nullptr;
-        if (!a_col && !b_col && M <= 256 && splitk <= 1 && !asum_out && !no_skinny) {
+        // (every 64-row block re-reads its weight columns: only while that is cheaper than a tiled kernel's latency)
+        if (!a_col && !b_col && (M <= 64 || (M <= 256 && N <= 8192)) && splitk <= 1 && !asum_out && !no_skinny) {
             int rc = pk_gemm_skinny_launch(A, B, C, M, N, K, lda, ldb, ep, stream);
             if (rc != 0) return rc == 1 ? 0 : rc;  // 1 = launched, 0 = not eligible, anything else = error
         }
