@@ -25,6 +25,14 @@ SHAPES = {
     'qkv_dw': (1536, 512, 32768, True, True, 0),
     'fc2_dw': (512, 2048, 32768, True, True, 0),
     'big_4k': (4096, 4096, 4096, False, False, 1),
+    # transformer_big (d = 1024, f = 4096) weight gradients
+    'big_fc1_dw_sk1': (4096, 1024, 32768, True, True, 1),
+    'big_fc1_dw_sk2': (4096, 1024, 32768, True, True, 2),
+    'big_fc1_dw_sk4': (4096, 1024, 32768, True, True, 4),
+    'big_qkv_dw_sk2': (3072, 1024, 32768, True, True, 2),
+    'big_qkv_dw_sk4': (3072, 1024, 32768, True, True, 4),
+    'big_out_dw_sk8': (1024, 1024, 32768, True, True, 8),
+    'big_out_dw_sk16': (1024, 1024, 32768, True, True, 16),
 }
 
 
