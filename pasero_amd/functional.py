@@ -52,12 +52,12 @@ def gemm(a: Tensor, b: Tensor, *, a_col: bool = False, b_col: bool = False, bias
 def choose_splitk(M: int, N: int, K: int, target_blocks: int = 512) -> int:
     """Split the contraction when the output has too few 128x128 tiles to fill 256 CUs (weight-gradient GEMMs)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 512 or K < 1024:
+    if tiles > 256 or K < 1024:
         return 1
-    # 256 tiles = one workgroup per CU and nothing to overlap its prologue / epilogue / DMA waits with: still split in
-    # two (transformer_big's 4096 x 1024 weight gradients: 642 -> 363 us)
-    s = max(1, min(-(-target_blocks // tiles), K // 512))
-    return s
+    # tiles * s must stay within one round of 2 workgroups per CU (512): 560 workgroups run as two rounds and take
+    # 1.6x as long as 504.  256 tiles are still split in two — one workgroup per CU has nothing to overlap its
+    # prologue / epilogue / DMA waits with (transformer_big's 4096 x 1024 weight gradients: 642 -> 363 us)
+    return max(1, min(target_blocks // tiles, K // 512))
 
 
 def residual_ln_fwd(x: Tensor, residual: Optional[Tensor], gamma: Optional[Tensor], beta: Optional[Tensor],
