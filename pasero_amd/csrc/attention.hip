@@ -764,6 +764,7 @@ extern "C" int pk_attn_fwd(const void* q, const void* k, const void* v, void* o,
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.key_pad = key_pad; p.causal = causal; p.scale = scale;
     if (int rc = check_common(p, hd, dtype, "pk_attn_fwd")) return rc;
+    if (B == 0 || T == 0) return 0;
     PK_CHECK_ARG(q && k && v && o && lse, "pk_attn_fwd: null tensor");
     if (B == 0 || T == 0) return 0;
     dim3 grid((T + 127) / 128, H, B);
@@ -792,6 +793,7 @@ extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const vo
     p.dv_bs = dv_bs; p.dv_rs = dv_rs;
     p.key_pad = key_pad; p.causal = causal; p.scale = scale;
     if (int rc = check_common(p, hd, dtype, "pk_attn_bwd")) return rc;
+    if (B == 0) return 0;
     PK_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv, "pk_attn_bwd: null tensor");
     if (dtype == PK_BF16)
         PK_CHECK_ARG(do_rs % 8 == 0 && dq_rs % 8 == 0 && dk_rs % 8 == 0 && dv_rs % 8 == 0 && do_bs % 8 == 0 &&

@@ -371,6 +371,7 @@ extern "C" int pk_embed_bwd(const long long* ids, const void* dout, void* dE, vo
 extern "C" int pk_ce_rows(const void* logits, long long ld, const long long* target, void* dlogits, long long ldd,
                           float* row_loss, float* row_nll, float* row_lse, long long rows, long long V,
                           long long pad_idx, float eps, int dtype, void* stream) {
+    if (rows == 0) return 0;
     PK_CHECK_ARG(logits && target && row_loss && row_nll, "pk_ce_rows: null tensor");
     PK_CHECK_ARG(V > 0 && eps >= 0.f && eps < 1.f, "pk_ce_rows: bad V / label smoothing");
     PK_CHECK_ARG(rows < (1ll << 31), "pk_ce_rows: too many rows per call");
@@ -387,7 +388,7 @@ extern "C" int pk_ce_rows(const void* logits, long long ld, const long long* tar
 
 extern "C" int pk_ce_finalize(const float* row_loss, const float* row_nll, const long long* target, long long rows,
                               long long pad_idx, float* sums3, void* stream) {
-    PK_CHECK_ARG(row_loss && row_nll && target && sums3, "pk_ce_finalize: null tensor");
+    PK_CHECK_ARG(sums3 && (rows == 0 || (row_loss && row_nll && target)), "pk_ce_finalize: null tensor");
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, row_nll, target,
                        rows, pad_idx, sums3);
     PK_LAUNCH_CHECK();

@@ -835,6 +835,7 @@ extern "C" int pk_gemm(const void* A, const void* B, void* C, const void* bias, 
                        long long M, long long N, long long K, long long lda, long long ldb, long long ldc,
                        long long ldaux, long long ldpre, int a_col, int b_col, int act, int mode, float alpha,
                        int dtype, int splitk, void* workspace, size_t ws_bytes, void* asum_out, void* stream) {
+    if (M == 0 || N == 0) return 0;  // an empty output: nothing to read, nothing to write (operands may be NULL)
     PK_CHECK_ARG(A && B && C, "pk_gemm: null operand");
     PK_CHECK_ARG(!asum_out || a_col, "pk_gemm: asum_out (fused bias gradient) needs A in col form");
     PK_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "pk_gemm: negative size");

@@ -346,6 +346,7 @@ extern "C" int pk_residual_ln_fwd(const void* x, const void* residual, const voi
                                   void* z_out, void* y_out, float* mean, float* rstd, long long rows, int d,
                                   float eps, float drop_p, unsigned long long seed, unsigned long long offset,
                                   int dtype, void* stream) {
+    if (rows == 0) return 0;
     PK_CHECK_ARG(x, "pk_residual_ln_fwd: x is null");
     PK_CHECK_ARG(!gamma || (y_out && mean && rstd), "pk_residual_ln_fwd: gamma given but y/mean/rstd missing");
     PK_CHECK_ARG(gamma || z_out, "pk_residual_ln_fwd: nothing to compute");

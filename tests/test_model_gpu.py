@@ -357,3 +357,55 @@ def test_argmax_rows_first_maximum():
     want = x.float().argmax(-1)
     want[5] = 0
     assert torch.equal(out[:, 0], want) and out[3, 0] == 100 and (out[:, 1] == -1).all()
+
+
+def test_edge_cases_empty_single_token_and_all_pad_targets():
+    """degenerate batches the reference handles: one-token sentences, a batch whose targets are all padding (loss 0,
+    num_tokens 0, finite zero gradients), an empty batch at the kernel boundary"""
+    from pasero_amd import functional as F
+    g = load_golden('tiny_encdec_post')
+    cfg, model = build_model(g, torch.float32, 'cuda')
+    model.train()
+    V = int(g['V'])
+    # one source token (EOS) and one target token per sentence: S = 1, T = 1
+    batch = {'encoder_input': torch.full((3, 1), 2, device='cuda'), 'encoder_input_length': torch.ones(3, dtype=torch.long, device='cuda'),
+             'decoder_input': torch.tensor([[2, 7], [2, 9], [2, 2]], device='cuda'),
+             'prompt_mask': torch.tensor([[True, False]] * 3, device='cuda')}
+    loss, logs = model(**batch)
+    loss.backward()
+    assert logs['num_tokens'] == 3 and torch.isfinite(loss) and loss.item() > 0
+    # the same through the oracle
+    P = oracle_state(g, cfg)
+    ref, ref_logs = O.transformer_forward(P, cfg, **{k: v.cpu() for k, v in batch.items()})
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    # all targets are padding: nothing to predict
+    model.zero_grad(set_to_none=True)
+    batch['decoder_input'] = torch.tensor([[2, 1], [2, 1], [2, 1]], device='cuda')
+    loss, logs = model(**batch)
+    loss.backward()
+    assert loss.item() == 0.0 and logs['num_tokens'] == 0
+    for n, p in model.named_parameters():
+        assert p.grad is None or (torch.isfinite(p.grad).all() and p.grad.abs().max().item() == 0.0), n
+    # empty batches at the C ABI: every entry point accepts zero rows
+    e = torch.empty(0, 128, device='cuda')
+    w = torch.randn(64, 128, device='cuda')
+    assert F.gemm(e, w).shape == (0, 64)
+    y, z, mean, rstd = F.residual_ln_fwd(e, None, torch.ones(128, device='cuda'), torch.zeros(128, device='cuda'), 1e-5)
+    assert y.shape == (0, 128) and mean.numel() == 0
+    o, lse = F.attn_fwd(torch.empty(0, 4, 128, device='cuda'), torch.empty(0, 5, 128, device='cuda'),
+                        torch.empty(0, 5, 128, device='cuda'), 2, None, False, 0.125)
+    assert o.shape == (0, 4, 128)
+    rl, rn = torch.empty(0, device='cuda'), torch.empty(0, device='cuda')
+    F.ce_rows(torch.empty(0, V, device='cuda'), torch.empty(0, dtype=torch.long, device='cuda'), 1, 0.1, rl, rn)
+    assert F.ce_finalize(rl, rn, torch.empty(0, dtype=torch.long, device='cuda'), 1).tolist() == [0.0, 0.0, 0.0]
+
+
+def test_sequence_longer_than_the_positional_table_is_rejected_like_the_reference():
+    """modules.py:441-446 / :467-472: positions beyond the table raise instead of reading out of bounds"""
+    g = load_golden('tiny_encdec_pre')  # learned positions
+    cfg, model = build_model(g, torch.float32, 'cuda')
+    n = cfg.decoder_max_len + 5
+    batch = {'encoder_input': torch.full((1, 4), 5, device='cuda'), 'encoder_input_length': torch.tensor([4], device='cuda'),
+             'decoder_input': torch.full((1, n + 1), 5, device='cuda'), 'prompt_mask': torch.zeros(1, n + 1, dtype=torch.bool, device='cuda')}
+    with pytest.raises(AssertionError, match='too long'):
+        model(**batch)
