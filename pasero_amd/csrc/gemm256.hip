@@ -13,6 +13,7 @@
 // last MFMAs.  Epilogue: four 64-row passes through a 66 KiB fp32 staging buffer, 16-byte coalesced stores with fused
 // bias / ReLU / residual / ReLU' (or raw fp32 split-K slabs); fused bias gradient (column sums of A) as in gemm.hip.
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 #include "gemm_epi.h"
 
@@ -263,7 +264,11 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
 #pragma unroll
         for (int j = 0; j < TJ; ++j) fb[0][j] = frag<B_COL>(smem + OP_BYTES, wn + 32 * j, 0, lane);
         if (nk > 1) dma(1);
-        for (int kt = 0; kt < nk; ++kt) {
+        // One K-tile.  NEXT: another tile follows (barrier + its first fragments behind this tile's k-step NKK-2);
+        // DMA: the tile after that is still to be issued.  Compile-time flags keep every k-step in one basic block,
+        // so the pinned instruction order below also covers the step with the barrier.
+        auto tile = [&](int kt, auto next_c, auto dma_c) {
+            constexpr bool NEXT = decltype(next_c)::value, DMA = decltype(dma_c)::value;
             const char* sa = smem + (kt & 1) * STAGE;
             const char* sb = sa + OP_BYTES;
             if constexpr (A_COL) {
@@ -285,23 +290,51 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
                     for (int i = 0; i < 4; ++i) fa[nxt][i] = frag<A_COL>(sa, wm + 32 * i, kk + 1, lane);
 #pragma unroll
                     for (int j = 0; j < TJ; ++j) fb[nxt][j] = frag<B_COL>(sb, wn + 32 * j, kk + 1, lane);
-                } else if (kt + 1 < nk) {
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                } else if constexpr (NEXT) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile kt+1 landed, LDS reads returned
                     __builtin_amdgcn_s_barrier();
                     const char* na = smem + ((kt + 1) & 1) * STAGE;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[nxt][i] = frag<A_COL>(na, wm + 32 * i, 0, lane);
 #pragma unroll
                     for (int j = 0; j < TJ; ++j) fb[nxt][j] = frag<B_COL>(na + OP_BYTES, wn + 32 * j, 0, lane);
-                    if (kt + 2 < nk) dma(kt + 2);
+#if !defined(PK_ABLATE256) || PK_ABLATE256 != 1
+                    if constexpr (DMA) dma(kt + 2);
+#endif
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+#ifndef PK_NO_SCHED
+                // Instruction order of this k-step, pinned: hipcc otherwise sinks the next step's fragment reads to
+                // just in front of their first use (lgkmcnt(0) then stalls every wave for an LDS round trip, several
+                // times per K-tile).  One LDS read (two for transposed operands) and one DMA issue per MFMA gap.
+                if constexpr (NW == 8) {
+                    constexpr int RA = A_COL ? 2 : 1, RB = B_COL ? 2 : 1;  // DS reads per fragment
+#define PK_GAP(R) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
+#define PK_GAPV(R) PK_GAP(R) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (kk + 1 < NKK || (NEXT && !DMA)) {
+                        PK_GAP(RA) PK_GAP(RA) PK_GAP(RA) PK_GAP(RA) PK_GAP(RB) PK_GAP(RB)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    } else if constexpr (NEXT && DMA) {
+                        PK_GAPV(RA) PK_GAPV(RA) PK_GAPV(RA) PK_GAPV(RA) PK_GAPV(RB) PK_GAPV(RB)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+#undef PK_GAPV
+#undef PK_GAP
+                }
+#endif
             }
-        }
+        };
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) tile(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) tile(kt++, std::true_type{}, std::false_type{});
+        tile(kt, std::false_type{}, std::false_type{});
     }
     __syncthreads();
 

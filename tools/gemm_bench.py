@@ -25,6 +25,12 @@ SHAPES = {
     'qkv_dw': (1536, 512, 32768, True, True, 0),
     'fc2_dw': (512, 2048, 32768, True, True, 0),
     'big_4k': (4096, 4096, 4096, False, False, 1),
+    'big_qkv_fwd': (32768, 3072, 1024, False, False, 1),
+    'big_out_fwd': (32768, 1024, 1024, False, False, 1),
+    'big_fc1_fwd': (32768, 4096, 1024, False, False, 1),
+    'big_fc2_fwd': (32768, 1024, 4096, False, False, 1),
+    'big_fc1_dx': (32768, 1024, 4096, False, True, 1),
+    'big_fc2_dx': (32768, 4096, 1024, False, True, 1),
     # transformer_big (d = 1024, f = 4096) weight gradients
     'big_fc1_dw_sk1': (4096, 1024, 32768, True, True, 1),
     'big_fc1_dw_sk2': (4096, 1024, 32768, True, True, 2),
