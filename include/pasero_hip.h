@@ -213,6 +213,15 @@ int pk_decoder_step(const PkDecoderPlan* plan, const long long* ids, int B, int 
 int pk_argmax_rows(const void* x, long long rows, long long n, long long ld, long long* out, long long out_stride,
                    int dtype, void* stream);
 
+/* ---- "Next" row: feature collate.  Replaces the CPU pad_sequence + dtype cast of
+ * utils.tokens_as_tensor for floating-point feature sequences (pasero/utils.py:709-736) as used on speech batches read
+ * from NumpyFile rows (pasero/files.py:103-175): the ragged rows are uploaded once, concatenated, in the file's dtype
+ * (src_dtype: 0 = f32, 1 = bf16, 2 = f16 — the offline Whisper / wav2vec features are fp16), and scattered on the device
+ * into the zero-padded (B, Tmax, D) batch in the model dtype (out_dtype: PK_F32 / PK_BF16).
+ *   src [total_rows][D]; offsets[B+1] (device int64): rows offsets[b] .. offsets[b+1] belong to sequence b. */
+int pk_pad_rows(const void* src, int src_dtype, const long long* offsets, void* out, int out_dtype, int B,
+                long long Tmax, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

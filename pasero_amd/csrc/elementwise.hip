@@ -229,3 +229,50 @@ extern "C" int pk_gated_act_bwd(const void* dh, const void* z, const void* u, vo
     PK_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- feature collate: ragged rows -> zero-padded (B, Tmax, D) batch with dtype conversion ----
+#include <hip/hip_fp16.h>
+namespace {
+template <typename S> __device__ __forceinline__ float src_to_f32(S v);
+template <> __device__ __forceinline__ float src_to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float src_to_f32<__half>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ float src_to_f32<bf16>(bf16 v) { return __bfloat162float(v); }
+
+// one workgroup per output row (b, t); offsets[b]..offsets[b+1] are the rows of sequence b in `src`
+template <typename S, typename T>
+__global__ __launch_bounds__(256) void pad_rows_kernel(const S* __restrict__ src, const long long* __restrict__ offsets,
+                                                       T* __restrict__ out, long long Tmax, int D) {
+    const long long row = blockIdx.x, b = row / Tmax, t = row % Tmax;
+    const long long beg = offsets[b], len = offsets[b + 1] - beg;
+    T* o = out + row * D;
+    if (t < len) {
+        const S* s = src + (beg + t) * D;
+        for (int c = threadIdx.x; c < D; c += blockDim.x) o[c] = from_f32<T>(src_to_f32<S>(s[c]));
+    } else {
+        for (int c = threadIdx.x; c < D; c += blockDim.x) o[c] = from_f32<T>(0.f);
+    }
+}
+}  // namespace
+
+extern "C" int pk_pad_rows(const void* src, int src_dtype, const long long* offsets, void* out, int out_dtype, int B,
+                           long long Tmax, int D, void* stream) {
+    if (B == 0 || Tmax == 0 || D == 0) return 0;
+    PK_CHECK_ARG(src && offsets && out && B > 0 && Tmax > 0 && D > 0, "pk_pad_rows: bad arguments");
+    PK_CHECK_ARG((long long)B * Tmax < (1ll << 31), "pk_pad_rows: too many rows");
+    dim3 grid((unsigned)((long long)B * Tmax)), block(D >= 256 ? 256 : 64);
+    hipStream_t s = (hipStream_t)stream;
+#define PK_PAD(S, T) hipLaunchKernelGGL((pad_rows_kernel<S, T>), grid, block, 0, s, (const S*)src, offsets, (T*)out, Tmax, D)
+    const int key = src_dtype * 10 + out_dtype;  // src: 0 f32, 1 bf16, 2 f16; out: 0 f32, 1 bf16
+    switch (key) {
+        case 0: PK_PAD(float, float); break;
+        case 1: PK_PAD(float, bf16); break;
+        case 10: PK_PAD(bf16, float); break;
+        case 11: PK_PAD(bf16, bf16); break;
+        case 20: PK_PAD(__half, float); break;
+        case 21: PK_PAD(__half, bf16); break;
+        default: PK_CHECK_ARG(false, "pk_pad_rows: dtypes (%d -> %d) not supported", src_dtype, out_dtype);
+    }
+#undef PK_PAD
+    PK_LAUNCH_CHECK();
+    return 0;
+}

@@ -28,6 +28,7 @@ SIGNATURES = {
     'pk_decoder_step_scratch': (SZ, [P, I]),
     'pk_decoder_step': (I, [P, P, I, I, I, P, P, LL, P, P, I, P, SZ, P, LL, P]),
     'pk_argmax_rows': (I, [P, LL, LL, LL, P, LL, I, P]),
+    'pk_pad_rows': (I, [P, I, P, P, I, I, LL, I, P]),
     'pk_residual_ln_fwd': (I, [P, P, P, P, P, P, P, P, LL, I, F, F, ULL, ULL, I, P]),
     'pk_residual_ln_bwd_workspace': (SZ, [LL, I]),
     'pk_residual_ln_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, SZ, LL, I, F, ULL, ULL, I, P]),
