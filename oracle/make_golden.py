@@ -62,14 +62,19 @@ class FakeTask:
         self.decoder_num_embeddings = V
 
 
-def build_model(V, **overrides):
-    cfg = config.TransformerConfig(**overrides)
+def build_model(V, arch='transformer', **overrides):
+    if arch == 'adapter_transformer':
+        from pasero.models import adapters
+        cfg_cls, model_cls = config.AdapterTransformerConfig, adapters.AdapterTransformer
+    else:
+        cfg_cls, model_cls = config.TransformerConfig, transformer.Transformer
+    cfg = cfg_cls(**overrides)
     # task-dependent defaults (config.py:1146-1153,1241-1248,1265-1272) set by hand as in SURVEY §8c
     if cfg.label_smoothing is None:
         cfg.label_smoothing = 0.1
     cfg.model_type = cfg.model_type or 'encoder_decoder'
     cfg.decoder_max_len = cfg.decoder_max_len or 256
-    model = transformer.Transformer(cfg, config.DistributedConfig(), FakeTask(V))
+    model = model_cls(cfg, config.DistributedConfig(), FakeTask(V))
     return cfg, model
 
 
@@ -118,15 +123,21 @@ CFG_KEYS = [
 ]
 
 
+EXTRA_KEYS = ['lora_rank', 'lora_alpha', 'encoder_adapter_dim', 'decoder_adapter_dim', 'adapter_zero_init',
+              'train_all_params']
+
+
 def cfg_json(cfg):
     import json
-    return np.array(json.dumps({k: getattr(cfg, k) for k in CFG_KEYS}))
+    d = {k: getattr(cfg, k) for k in CFG_KEYS}
+    d.update({k: getattr(cfg, k) for k in EXTRA_KEYS if hasattr(cfg, k) and getattr(cfg, k) not in (0, None, False)})
+    return np.array(json.dumps(d))
 
 
 # ----------------------------------------------------------------------------------------------------------
-def gen_encdec(name, V, B, S, T, seed, store_grads='full', **overrides):
+def gen_encdec(name, V, B, S, T, seed, store_grads='full', arch='transformer', **overrides):
     """Whole Transformer.forward + backward (transformer.py:227-380), encoder (698-752), decoder (831-898)"""
-    cfg, model = build_model(V, **overrides)
+    cfg, model = build_model(V, arch=arch, **overrides)
     names_shapes = load_params(model, seed)
     model.train()  # dropout probabilities are 0 in every fixture config, so train() == eval() numerically
     batch = paramgen.make_text_batch(seed, B, S, T, V)
@@ -134,12 +145,13 @@ def gen_encdec(name, V, B, S, T, seed, store_grads='full', **overrides):
     loss, logs = model(**tb)
     loss.backward()
     out = {
-        'cfg': cfg_json(cfg), 'V': V, 'B': B, 'S': S, 'T': T, 'seed': seed,
+        'cfg': cfg_json(cfg), 'arch': arch, 'V': V, 'B': B, 'S': S, 'T': T, 'seed': seed,
         'loss': npy(loss), 'logs_loss': logs['loss'], 'logs_nll_loss': logs['nll_loss'],
         'logs_num_tokens': logs['num_tokens'], 'logs_num_lines': logs['num_lines'],
         **names_shapes_arrays(names_shapes),
     }
-    grads = {k: p.grad for k, p in model.named_parameters()}
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    out['frozen_names'] = np.array([k for k, p in model.named_parameters() if not p.requires_grad] or [''])
     out['grad_names'] = np.array(list(grads))
     out['grad_norms'] = np.array([g.double().norm().item() for g in grads.values()])  # fp64: the fp32 CPU norm of a
     # 4M-element tensor is off by 4e-4
@@ -181,6 +193,23 @@ def gen_tiny_pre():
                encoder_positional_encoding='learned', decoder_positional_encoding='learned',
                positional_encoding_shift=0, scale_embed=False, encoder_embed_norm=True,
                decoder_embed_norm=True, label_smoothing=0.2, encoder_max_len=32, decoder_max_len=32)
+
+
+def gen_tiny_adapter():
+    """adapter_transformer (adapters.py:37-301): bottleneck adapters (LayerNorm -> down -> ReLU -> up -> + residual,
+    modules.py:248-370) after every layer, frozen backbone — the IWSLT2023 fine-tuning setup"""
+    gen_encdec('tiny_adapter', V=73, B=3, S=8, T=6, seed=15, arch='adapter_transformer',
+               embed_dim=128, encoder_ffn_dim=192, decoder_ffn_dim=192, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=2, decoder_layers=2, dropout=0.0,
+               encoder_adapter_dim=16, decoder_adapter_dim=24)
+
+
+def gen_tiny_lora():
+    """LoRA branches on every Linear (modules.py:67-100, rank 4, alpha 8), pre-norm GELU stack, everything trained"""
+    gen_encdec('tiny_lora', V=71, B=3, S=7, T=6, seed=16,
+               embed_dim=128, encoder_ffn_dim=160, decoder_ffn_dim=160, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=1, decoder_layers=2, dropout=0.0, lora_rank=4, lora_alpha=8,
+               encoder_prenorm=True, decoder_prenorm=True, activation_fn='gelu')
 
 
 def gen_base_c1():
@@ -430,6 +459,8 @@ GENERATORS = {
     'tiny_encdec_post': gen_tiny_post,
     'tiny_encdec_pre': gen_tiny_pre,
     'base_c1': gen_base_c1,
+    'tiny_adapter': gen_tiny_adapter,
+    'tiny_lora': gen_tiny_lora,
     'mha': gen_mha,
     'mha_rotary': gen_mha_rotary,
     'tiny_encdec_rotary': gen_tiny_rotary,

@@ -271,6 +271,80 @@ class ResidualLayerNormFn(torch.autograd.Function):
                 dbeta if ctx.has_beta else None, None, None, None)
 
 
+class AdapterFn(torch.autograd.Function):
+    """y = res + s · up(act(down(LN(x))))   — the bottleneck adapter of Bapna et al. and, without LayerNorm / biases /
+    activation and with `res` = the frozen layer's output, LoRA (pasero/models/modules.py:248-370 AdapterLayer.forward,
+    :67-100 Linear.forward).  Three launches forward (LayerNorm, down-projection with the activation in its epilogue,
+    up-projection with the scale and the residual in its epilogue); backward fuses act′ into the dA GEMM, the bias
+    gradients into the weight-gradient GEMMs and the residual-branch gradient into the LayerNorm backward."""
+
+    @staticmethod
+    def forward(ctx, x, res, ln_w, ln_b, eps: float, down_w, down_b, up_w, up_b, act: str, scaling: float):
+        x2 = _2d(_contig(x))
+        grad = any(ctx.needs_input_grad)
+        if ln_w is not None:
+            h, _, mean, rstd = F.residual_ln_fwd(x2, None, ln_w, ln_b, eps, want_z=False)
+        else:
+            h, mean, rstd = x2, None, None
+        need_pre = grad and act not in ('none', 'relu')
+        pre = torch.empty(x2.size(0), down_w.size(0), dtype=x.dtype, device=x.device) if need_pre else None
+        a = F.gemm(h, down_w, bias=down_b, act=act, preact=pre)
+        ub = up_b if (up_b is None or scaling == 1.0) else F.scale(up_b, None, scaling)  # (v + b)·s = s·v + s·b
+        res2 = _2d(_contig(res)) if res is not None else None
+        y = F.gemm(a, up_w, bias=ub, aux=res2, mode=1 if res2 is not None else 0, alpha=scaling)
+        ctx.act, ctx.scaling, ctx.has_ln, ctx.has_ln_b = act, scaling, ln_w is not None, ln_b is not None
+        ctx.res_is_x = res is x
+        ctx.has_res = res is not None
+        ctx.has_db, ctx.has_ub = down_b is not None, up_b is not None
+        ctx.save_for_backward(x2, h if ln_w is not None else None, mean, rstd, ln_w, down_w, up_w, a, pre)
+        return y.view(*x.shape[:-1], up_w.size(0))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h, mean, rstd, ln_w, down_w, up_w, a, pre = ctx.saved_tensors
+        if h is None:
+            h = x2
+        ng = ctx.needs_input_grad  # x, res, ln_w, ln_b, eps, down_w, down_b, up_w, up_b
+        dy2 = _2d(_contig(dy))
+        s = ctx.scaling
+        dup_w = dup_b = ddown_w = ddown_b = dln_w = dln_b = dx = None
+        want_ub = ctx.has_ub and ng[8]
+        if ng[7] or want_ub:
+            dup_w, dup_b = _wgrad(dy2, a, ng[7], want_ub)
+            if s != 1.0:
+                dup_w = F.scale(dup_w, None, s) if dup_w is not None else None
+                dup_b = F.scale(dup_b, None, s) if dup_b is not None else None
+        need_da = ng[0] or ng[2] or ng[3] or ng[5] or ng[6]
+        if need_da:
+            if ctx.act == 'none':
+                da = F.gemm(dy2, up_w, b_col=True, alpha=s)
+            else:  # d(pre-activation) = s · (dY · W_up) ⊙ act′
+                da = F.gemm(dy2, up_w, b_col=True, alpha=s, act=ctx.act, aux=a if pre is None else pre, mode=2)
+            want_db = ctx.has_db and ng[6]
+            if ng[5] or want_db:
+                ddown_w, ddown_b = _wgrad(da, h, ng[5], want_db)
+            if ng[0] or ng[2] or ng[3]:
+                if ctx.has_ln:
+                    dh = F.gemm(da, down_w, b_col=True)
+                    want_pg = ng[2] or (ctx.has_ln_b and ng[3])
+                    dx, _, dln_w, dln_b = F.residual_ln_bwd(dh, dy2 if ctx.res_is_x else None, x2, ln_w, mean, rstd,
+                                                            want_dres=True, want_dx=False, want_param_grads=want_pg,
+                                                            has_beta=ctx.has_ln_b)
+                elif ctx.res_is_x:
+                    dx = F.gemm(da, down_w, b_col=True, aux=dy2, mode=1)  # residual branch folded into the epilogue
+                else:
+                    dx = F.gemm(da, down_w, b_col=True)
+        elif ctx.res_is_x and ng[0]:
+            dx = dy2
+        dres = None
+        if ctx.has_res and not ctx.res_is_x and ng[1]:
+            dres = dy
+        if dx is not None:
+            dx = dx.view(*dy.shape[:-1], x2.size(1)) if dx.dim() == 2 else dx
+        return (dx if ng[0] else None, dres, dln_w if ng[2] else None, dln_b if (ctx.has_ln_b and ng[3]) else None, None,
+                ddown_w, ddown_b, dup_w, dup_b, None, None)
+
+
 class ResidualDropoutFn(torch.autograd.Function):
     """z = residual + dropout(x)   (pre-norm blocks: pasero/models/transformer.py:1043-1044,1049-1050)"""
 

@@ -166,6 +166,21 @@ class WhisperConfig(TransformerConfig):          # config.py:2540-2560
     decoder_max_len: int = 448
 
 
+@register_model_config('adapter_transformer')
+@dataclass
+class AdapterTransformerConfig(TransformerConfig):   # config.py:1322-1383
+    encoder_adapter_dim: int = 64
+    decoder_adapter_dim: int = 64
+    encoder_adapter_layer_ids: Optional[list] = None
+    decoder_adapter_layer_ids: Optional[list] = None
+    encoder_adapters: Optional[list] = None
+    decoder_adapters: Optional[list] = None
+    encoder_adapters_by: list = field(default_factory=list)
+    decoder_adapters_by: list = field(default_factory=list)
+    adapter_zero_init: bool = False
+    train_all_params: bool = False
+
+
 class SyntheticTask:
     """What the model constructor reads from a `pasero.tasks.Task` (transformer.py:628-636,786)"""
     freeze_encoder_embed_mask = None

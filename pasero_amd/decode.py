@@ -72,7 +72,8 @@ def build_plan(decoder) -> Optional[Plan]:
     for layer in decoder.layers:
         if not isinstance(layer, TransformerDecoderLayer) or not layer._hooks_are_base(*hooks):
             return None
-        if getattr(layer, '_no_ckpt_forward', None) is not None or layer.fc3 is not None:
+        if (getattr(layer, '_no_ckpt_forward', None) is not None or layer.fc3 is not None or layer.fc1.lora is not None
+                or layer.self_attn.q_proj.lora is not None):
             return None
         norms = [ln(layer.self_attn_layer_norm), ln(layer.encoder_attn_layer_norm), ln(layer._norm_module(layer.final_layer_norm))]
         sa, ca = layer.self_attn, layer.encoder_attn

@@ -63,17 +63,20 @@ def set_sequence_parallel(enable: bool = True):
 
 
 class Linear(nn.Linear):
-    """nn.Linear running on the MFMA GEMM kernel (modules.py:67-100).  LoRA is out of scope."""
+    """nn.Linear running on the MFMA GEMM kernel, with the reference's optional LoRA branch (modules.py:67-100):
+    output = x Wᵀ + b + (alpha / rank) · up(down(x))"""
 
     def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
                  lora_rank: int = 0, lora_alpha: int = 1):
-        if lora_rank:
-            raise NotImplementedError('pasero_amd: LoRA adapters are not implemented')
         super().__init__(in_features, out_features, bias, device, dtype)
-        self.lora_rank, self.lora_alpha, self.lora = lora_rank, lora_alpha, None
+        self.lora_rank, self.lora_alpha = lora_rank, lora_alpha
+        self.lora = AdapterLayer.LoRA(in_features, lora_rank, out_features, lora_alpha) if lora_rank else None
 
-    def forward(self, input: Tensor) -> Tensor:
-        return LinearFn.apply(input, self.weight, self.bias, 'none')
+    def forward(self, input: Tensor, link=None) -> Tensor:
+        output = LinearFn.apply(input, self.weight, self.bias, 'none', link)
+        if self.lora is not None:
+            output = self.lora(input, residual=output)
+        return output
 
     def reset_parameters(self) -> None:
         if not _fast_init:
@@ -137,6 +140,110 @@ def get_activation_fn(activation_fn: str = 'relu'):
     if activation_fn == 'gelu':
         return Activation('gelu')
     return Activation('relu')
+
+
+class AdapterLayer(nn.Module):
+    """Bottleneck adapter (Bapna et al., 2019) / LoRA branch (modules.py:248-370), same constructor, parameter names
+    (`down`, `up`, `layer_norm`), initialisation, enable/disable and checkpoint-loading behaviour; the forward pass is
+    one fused autograd function (AdapterFn): LayerNorm -> down + activation -> up · scaling + residual."""
+
+    def __init__(self, input_dim: int, projection_dim: int, output_dim: Optional[int] = None, zero_init: bool = False,
+                 layer_norm: bool = True, bias: bool = True, residual: bool = True, activation_fn: str = 'relu',
+                 scaling: float = 1.0):
+        super().__init__()
+        self.input_dim = input_dim
+        self.output_dim = output_dim or input_dim
+        self.projection_dim = projection_dim
+        self.zero_init = zero_init
+        self.has_layer_norm = layer_norm
+        self.bias = bias
+        self.residual = residual
+        assert not self.residual or self.output_dim == self.input_dim
+        if activation_fn is None or activation_fn == 'none':
+            self.act_name = 'none'
+        elif activation_fn == 'relu':
+            self.act_name = 'relu'
+        elif activation_fn == 'gelu':
+            self.act_name = 'gelu_tanh'  # the reference uses nn.GELU(approximate='tanh') here
+        else:
+            raise NotImplementedError
+        self.down = None
+        self.scaling = scaling
+        self._init()
+
+    @classmethod
+    def LoRA(cls, input_dim: int, projection_dim: int, output_dim: int, lora_alpha: int) -> 'AdapterLayer':
+        return cls(input_dim, projection_dim, output_dim, layer_norm=False, bias=False, residual=False,
+                   activation_fn=None, zero_init=True, scaling=lora_alpha / projection_dim)
+
+    def _init(self) -> None:
+        self.disabled = False
+        device = None if self.down is None else self.down.weight.device
+        dtype = None if self.down is None else self.down.weight.dtype
+        self.down = nn.Linear(self.input_dim, self.projection_dim, bias=self.bias, device=device, dtype=dtype)
+        self.up = nn.Linear(self.projection_dim, self.output_dim, bias=self.bias, device=device, dtype=dtype)
+        self.layer_norm = (nn.LayerNorm(self.input_dim, device=device, dtype=dtype) if self.has_layer_norm
+                           else Identity())
+        if self.zero_init:
+            nn.init.kaiming_uniform_(self.down.weight, a=math.sqrt(5))
+            nn.init.zeros_(self.up.weight)
+        else:
+            delta = 1e-6
+            nn.init.uniform_(self.down.weight, -delta, delta)
+            nn.init.uniform_(self.up.weight, -delta, delta)
+        if self.bias:
+            nn.init.zeros_(self.down.bias)
+            nn.init.zeros_(self.up.bias)
+
+    def enable(self) -> None:
+        if self.down is not None:  # not permanently disabled
+            self.disabled = False
+
+    def disable(self) -> None:
+        self.disabled = True
+
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+        """x (B, S, D) -> (B, S, D_out).  `residual` (LoRA inside Linear): the tensor the branch is added to."""
+        if self.disabled:
+            return x if residual is None else residual
+        from .autograd import AdapterFn
+        ln = self.layer_norm if self.has_layer_norm else None
+        res = residual if residual is not None else (x if self.residual else None)
+        return AdapterFn.apply(x, res, None if ln is None else ln.weight, None if ln is None else ln.bias,
+                               1e-5 if ln is None else ln.eps, self.down.weight, self.down.bias, self.up.weight,
+                               self.up.bias, self.act_name, float(self.scaling))
+
+    def _load_from_state_dict(self, state_dict, prefix: str, *args, **kwargs) -> None:
+        # inference: adapters missing from the checkpoint are disabled, bottleneck sizes follow the checkpoint
+        if not self.training and prefix + 'down.weight' not in state_dict:
+            self.disable()
+            self.up = self.down = self.layer_norm = None
+        elif not self.training:
+            projection_dim = state_dict[prefix + 'down.weight'].size(0)
+            if projection_dim != self.projection_dim:
+                self.projection_dim = projection_dim
+                self._init()
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+def remove_unused_parameters(model: nn.Module, state_dict: dict, param_regex: Optional[str] = None) -> dict:
+    """modules.py:837-864: pops (and returns, on the CPU) the entries of `state_dict` the model has no use for — all
+    of them, or those whose name matches `param_regex` (groups: model part, parameter-set name)"""
+    import re
+    known = set(model.state_dict())
+    unused = {}
+    for name in list(state_dict):
+        if name not in known and (param_regex is None or re.match(param_regex, name)):
+            unused[name] = state_dict.pop(name).cpu()
+    return unused
+
+
+def add_missing_parameters(model: nn.Module, state_dict: dict, param_regex: Optional[str] = None) -> None:
+    """modules.py:867-887: parameters of the model that the checkpoint lacks keep their current (random) value"""
+    import re
+    for name, param in model.state_dict().items():
+        if name not in state_dict and (param_regex is None or re.match(param_regex, name)):
+            state_dict[name] = param
 
 
 def checkpoint_wrapper(module: nn.Module, activate: bool = True) -> nn.Module:
@@ -330,10 +437,11 @@ class MultiheadAttention(nn.Module):
         self.has_bias = has_bias
         self.sliding_window = None
         self.max_qkv = None
-        self.k_proj = Linear(embed_dim, embed_dim, bias=has_bias and key_bias)
-        self.v_proj = Linear(embed_dim, embed_dim, bias=has_bias)
-        self.q_proj = Linear(embed_dim, embed_dim, bias=has_bias)
-        self.out_proj = Linear(embed_dim, embed_dim, bias=has_bias)
+        lora = dict(lora_rank=lora_rank, lora_alpha=lora_alpha)
+        self.k_proj = Linear(embed_dim, embed_dim, bias=has_bias and key_bias, **lora)
+        self.v_proj = Linear(embed_dim, embed_dim, bias=has_bias, **lora)
+        self.q_proj = Linear(embed_dim, embed_dim, bias=has_bias, **lora)
+        self.out_proj = Linear(embed_dim, embed_dim, bias=has_bias, **lora)
         self.shard_count, self.shard_id = 1, 0
         self.max_len = max_len
         self.rotary_embed = self.alibi = self.t5_embed = None
@@ -419,7 +527,26 @@ class MultiheadAttention(nn.Module):
 
         if self.rotary_embed is not None and not (key is query and value is query):
             raise NotImplementedError('pasero_amd: rotary embeddings are implemented for self-attention only')
-        if state is not None:  # incremental decoding (inference): K/V cache of shape (B,S,H,hd) (modules.py:621-641)
+        if self.q_proj.lora is not None:
+            # LoRA branches on the projections (modules.py:67-100): three separate projections, each adding its own
+            # low-rank update; the fused packed projection is for the plain layer
+            if self.rotary_embed is not None:
+                raise NotImplementedError('pasero_amd: LoRA together with rotary embeddings is not implemented')
+            q = self.q_proj(query, link=link)
+            k = self.k_proj(key)
+            v = self.v_proj(value)
+            if state is not None:
+                k4, v4 = k.reshape(B, -1, H, self.head_dim), v.reshape(B, -1, H, self.head_dim)
+                if 'key' in state:
+                    prev_k, prev_v = state['key'], state['value']
+                    if self.max_len is not None:
+                        delta = max(0, prev_k.size(1) + k4.size(1) - self.max_len)
+                        prev_k, prev_v = prev_k[:, delta:], prev_v[:, delta:]
+                    k4, v4 = torch.cat([prev_k, k4], dim=1), torch.cat([prev_v, v4], dim=1)
+                state['key'], state['value'] = k4, v4
+                k, v = k4.reshape(B, -1, D), v4.reshape(B, -1, D)
+            attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale)
+        elif state is not None:  # incremental decoding (inference): K/V cache of shape (B,S,H,hd) (modules.py:621-641)
             qkv = PackedLinearFn.apply(query, w, b, 3, None, q_w, k_w, v_w, q_b, k_b, v_b)
             qkv = rope(qkv, state['key'].size(1) if 'key' in state else 0)
             q = qkv[..., :D]

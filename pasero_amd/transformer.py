@@ -227,6 +227,16 @@ class Transformer(EncoderDecoder):
                 dim = param.size(0) // 3
                 for i, s in enumerate(['.q_proj.', '.k_proj.', '.v_proj.']):
                     state_dict[name.replace('.in_proj_', s)] = param[dim * i:dim * (i + 1)]
+        if self.cfg.lora_rank and self.training:  # :479-482: new LoRA branches start from their random init
+            modules.add_missing_parameters(self, state_dict, r'.*\.lora\..*')
+        if not self.training:  # :484-497: at inference the low-rank updates are merged into the linear weights
+            for name in list(state_dict):
+                if name.endswith('.lora.down.weight'):
+                    prefix = name[:-len('lora.down.weight')]
+                    down = state_dict.pop(prefix + 'lora.down.weight')
+                    up = state_dict.pop(prefix + 'lora.up.weight')
+                    patch = torch.matmul(up.float(), down.float() * self.cfg.lora_alpha / down.size(0)).to(down.dtype)
+                    state_dict[prefix + 'weight'] = state_dict[prefix + 'weight'] + patch.to(state_dict[prefix + 'weight'].device)
 
     @classmethod
     def shard_state_dict(cls, state_dict, shard_id=0, shard_count=1, **kwargs):
@@ -410,9 +420,10 @@ class _LayerBase(nn.Module):
     """pieces shared by the encoder and decoder layers"""
 
     def _build_ffn(self, cfg, ffn_dim: int):
-        self.fc1 = modules.Linear(cfg.embed_dim, ffn_dim, bias=cfg.has_bias)
-        self.fc2 = modules.Linear(ffn_dim, cfg.embed_dim, bias=cfg.has_bias)
-        self.fc3 = (modules.Linear(cfg.embed_dim, ffn_dim, bias=cfg.has_bias)
+        lora = dict(lora_rank=cfg.lora_rank, lora_alpha=cfg.lora_alpha)
+        self.fc1 = modules.Linear(cfg.embed_dim, ffn_dim, bias=cfg.has_bias, **lora)
+        self.fc2 = modules.Linear(ffn_dim, cfg.embed_dim, bias=cfg.has_bias, **lora)
+        self.fc3 = (modules.Linear(cfg.embed_dim, ffn_dim, bias=cfg.has_bias, **lora)
                     if cfg.activation_fn in ('swiglu', 'geglu') else None)  # Llama / T5 gate (:966-972)
         self.activation_fn = modules.get_activation_fn(cfg.activation_fn)
         self.activation_dropout = modules.Dropout(cfg.activation_dropout)
@@ -421,6 +432,12 @@ class _LayerBase(nn.Module):
         link, self._ffn_link = getattr(self, '_ffn_link', None), None
         if self.training and self.activation_dropout.p > 0 and self.fc3 is not None:
             raise NotImplementedError('pasero_amd: activation dropout inside a gated FFN is not implemented')
+        if self.fc1.lora is not None:  # LoRA branches on fc1 / fc2 / fc3: the module-by-module formulation (:999-1019)
+            if self.fc3 is not None:
+                raise NotImplementedError('pasero_amd: LoRA on a gated feed-forward is not implemented')
+            h = self.fc1(x, link=link)
+            h = self.activation_fn(h)
+            return self.fc2(self.activation_dropout(h))
         if self.fc3 is not None:
             return GatedFFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc3.weight, self.fc3.bias,
                                     self.fc2.weight, self.fc2.bias, self.activation_fn.name, link)

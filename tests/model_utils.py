@@ -9,17 +9,19 @@ from conftest import load_golden, golden_names_shapes
 
 
 def build_cfg(g):
-    from pasero_amd.config import TransformerConfig
-    return TransformerConfig(**json.loads(str(g['cfg'])))
+    from pasero_amd.config import TransformerConfig, AdapterTransformerConfig
+    arch = str(g['arch']) if 'arch' in getattr(g, 'files', g) else 'transformer'
+    cls = AdapterTransformerConfig if arch == 'adapter_transformer' else TransformerConfig
+    return cls(**json.loads(str(g['cfg'])))
 
 
 def build_model(g, dtype=torch.float32, device='cpu'):
     """pasero_amd Transformer with the fixture's config and the deterministic paramgen weights"""
-    from pasero_amd.config import DistributedConfig, SyntheticTask
-    from pasero_amd.transformer import Transformer
+    from pasero_amd.config import DistributedConfig, SyntheticTask, get_architecture
+    from pasero_amd import transformer, adapters  # noqa: F401  (registers the architectures)
     cfg = build_cfg(g)
     V = int(g['V'])
-    model = Transformer(cfg, DistributedConfig(), SyntheticTask(V))
+    model = get_architecture(cfg)(cfg, DistributedConfig(), SyntheticTask(V))
     load_paramgen(model, int(g['seed']))
     return cfg, model.to(dtype).to(device)
 

@@ -39,7 +39,10 @@ def _check_encdec(name, full=True):
         n = str(n)
         gr = grads[n].grad
         assert gr is not None, n
-        assert abs(gr.double().norm().item() - ref_norm) <= 2e-4 * ref_norm + 2e-6, n
+        # (a key bias shifts all scores of a row equally: its gradient is mathematically zero, what is left is the
+        # round-off of one particular summation order)
+        atol = 2e-5 if n.endswith('k_proj.bias') else 2e-6
+        assert abs(gr.double().norm().item() - ref_norm) <= 2e-4 * ref_norm + atol, n
         if full:
             assert rel(gr, g['grad:' + n]) < 2e-4 or np.abs(g['grad:' + n]).max() < 1e-5, n
         else:
@@ -82,6 +85,23 @@ def test_tiny_rotary_gelu_tanh_fp32_vs_reference():
 def test_tiny_swiglu_prenorm_fp32_vs_reference():
     """gated FFN (fc3): the gate product is the fc1 GEMM's epilogue"""
     _check_encdec('tiny_encdec_swiglu')
+
+
+def test_adapter_transformer_frozen_backbone_fp32_vs_reference():
+    """adapter_transformer (pasero/models/adapters.py): bottleneck adapters after every layer, only they are trained;
+    loss, every adapter gradient, logits and argmax against the real reference; frozen parameters get no gradient"""
+    g, cfg, model, batch = _check_encdec('tiny_adapter')
+    frozen = {str(n) for n in g['frozen_names']}
+    assert frozen and all(not p.requires_grad and p.grad is None for n, p in model.named_parameters() if n in frozen)
+    assert all(p.requires_grad == (n not in frozen) for n, p in model.named_parameters())
+    assert any('adapters.default.down.weight' in str(n) for n in g['grad_names'])
+
+
+def test_lora_branches_fp32_vs_reference():
+    """LoRA on every Linear (q/k/v/out projections, fc1, fc2), rank 4, alpha 8: modules.py:67-100"""
+    g, cfg, model, batch = _check_encdec('tiny_lora')
+    assert any(str(n).endswith('q_proj.lora.up.weight') for n in g['grad_names'])
+    assert any(str(n).endswith('fc2.lora.down.weight') for n in g['grad_names'])
 
 
 def test_mha_rotary_incremental_offsets():
