@@ -34,9 +34,9 @@ def get_architecture(cfg):
     """walk the config class MRO for a registered model name (config.py:103-122)"""
     by_cls = {v: k for k, v in CONFIGS.items()}
     for cls in type(cfg).__mro__:
-        name = by_cls.get(cls)
-        if name in MODELS:
-            return MODELS[name]
+        for name in (by_cls.get(cls), cls.__dict__.get('_arch')):
+            if name in MODELS:
+                return MODELS[name]
     return MODELS['transformer']
 
 
@@ -109,7 +109,7 @@ class TransformerConfig:
     unk_idx: int = 3
 
 
-@register_model_config('transformer_big')
+@register_model_config('transformer_big', 'transformer_wmt_en_de_big', 'transformer_vaswani_wmt_en_de_big')
 @dataclass
 class TransformerBigConfig(TransformerConfig):   # config.py:2182-2188
     embed_dim: int = 1024
@@ -119,7 +119,7 @@ class TransformerBigConfig(TransformerConfig):   # config.py:2182-2188
     decoder_attention_heads: int = 16
 
 
-@register_model_config('transformer_small')
+@register_model_config('transformer_small', 'transformer_iwslt_de_en')
 @dataclass
 class TransformerSmallConfig(TransformerConfig):  # config.py:2195-2201
     encoder_ffn_dim: int = 1024
@@ -166,9 +166,8 @@ class WhisperConfig(TransformerConfig):          # config.py:2540-2560
     decoder_max_len: int = 448
 
 
-@register_model_config('adapter_transformer')
 @dataclass
-class AdapterTransformerConfig(TransformerConfig):   # config.py:1322-1383
+class _AdapterOptions:   # config.py:1322-1383 (the options `adapter_transformer` adds to a backbone configuration)
     encoder_adapter_dim: int = 64
     decoder_adapter_dim: int = 64
     encoder_adapter_layer_ids: Optional[list] = None
@@ -179,6 +178,97 @@ class AdapterTransformerConfig(TransformerConfig):   # config.py:1322-1383
     decoder_adapters_by: list = field(default_factory=list)
     adapter_zero_init: bool = False
     train_all_params: bool = False
+    _arch = 'adapter_transformer'  # the model every configuration with these options resolves to
+
+
+@register_model_config('adapter_transformer')
+@dataclass
+class AdapterTransformerConfig(_AdapterOptions, TransformerConfig):
+    pass
+
+
+@register_model_config('transformer_wide')
+@dataclass
+class TransformerWideConfig(TransformerBigConfig):   # config.py:2190-2193
+    encoder_ffn_dim: int = 8192
+    decoder_ffn_dim: int = 8192
+
+
+@register_model_config('mbart_large')
+@dataclass
+class MBARTConfig(TransformerBigConfig):             # config.py:2215-2226
+    encoder_layers: int = 12
+    decoder_layers: int = 12
+    encoder_embed_norm: bool = True
+    decoder_embed_norm: bool = True
+    encoder_positional_encoding: str = 'learned'
+    decoder_positional_encoding: str = 'learned'
+    encoder_prenorm: bool = True
+    decoder_prenorm: bool = True
+    encoder_max_len: int = 1024
+    decoder_max_len: int = 1024
+
+
+@register_model_config('nllb_3b3')
+@dataclass
+class NLLB3B3Config(NLLB1B3Config):                  # config.py:2242-2244
+    embed_dim: int = 2048
+
+
+@register_model_config('whisper_large')
+@dataclass
+class WhisperLargeConfig(WhisperConfig):             # config.py:2568-2577
+    encoder_layers: int = 32
+    decoder_layers: int = 32
+    embed_dim: int = 1280
+    conv_channels: int = 1280
+    encoder_ffn_dim: int = 5120
+    decoder_ffn_dim: int = 5120
+    encoder_attention_heads: int = 20
+    decoder_attention_heads: int = 20
+
+
+# adapter_* presets (config.py:2462-2509): the adapter options on top of each backbone preset
+@register_model_config('adapter_transformer_big')
+@dataclass
+class AdapterTransformerBigConfig(_AdapterOptions, TransformerBigConfig):
+    pass
+
+
+@register_model_config('adapter_transformer_small')
+@dataclass
+class AdapterTransformerSmallConfig(_AdapterOptions, TransformerSmallConfig):
+    pass
+
+
+@register_model_config('adapter_transformer_wide')
+@dataclass
+class AdapterTransformerWideConfig(_AdapterOptions, TransformerWideConfig):
+    pass
+
+
+@register_model_config('adapter_nllb_600m')
+@dataclass
+class AdapterNLLB600MConfig(_AdapterOptions, NLLB600MConfig):
+    pass
+
+
+@register_model_config('adapter_nllb_1b3')
+@dataclass
+class AdapterNLLB1B3Config(_AdapterOptions, NLLB1B3Config):
+    pass
+
+
+@register_model_config('adapter_nllb_3b3')
+@dataclass
+class AdapterNLLB3B3Config(_AdapterOptions, NLLB3B3Config):
+    pass
+
+
+@register_model_config('adapter_mbart_large')
+@dataclass
+class AdapterMBARTConfig(_AdapterOptions, MBARTConfig):
+    pass
 
 
 class SyntheticTask:
