@@ -72,3 +72,70 @@ def test_rccl_bucketed_all_reduce_single_rank(monkeypatch, dtype):
                 assert (p.grad.float() - want).abs().max() <= rtol * want.abs().max(), n
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# two ranks, the real HIP model: both processes share the box's one card (gloo carries the CUDA buckets)
+# ------------------------------------------------------------------------------------------------------------
+def _two_rank_worker(rank, world, port, ret):
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pasero_amd.ddp import DistributedDataParallel
+        g = load_golden('tiny_encdec_post')
+        cfg, model = build_model(g, torch.float32, 'cuda')
+        model.train()
+        full = text_batch(g, 'cuda')
+        B = full['encoder_input'].size(0)
+        rows = [b for b in range(B) if b % world == rank]  # rank r takes every world-th sentence
+        mine = {k: v[rows].contiguous() for k, v in full.items()}
+        ddp = DistributedDataParallel(model, bucket_cap_mb=0.05)
+        loss, logs = ddp(**mine)
+        loss.backward()
+        torch.cuda.synchronize()
+        # single-process truth on the full batch: the loss is a SUM over tokens, DDP AVERAGES over ranks
+        _, ref = build_model(g, torch.float32, 'cuda')
+        ref.train()
+        ref_loss, _ = ref(**full)
+        ref_loss.backward()
+        worst, name = 0.0, None
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            want = q.grad / world
+            err = ((p.grad - want).abs().max() / want.abs().max().clamp_min(1e-12)).item()
+            if want.abs().max().item() > 1e-6 and err > worst:
+                worst, name = err, n
+        tot = torch.tensor([loss.item()], dtype=torch.float64)
+        dist.all_reduce(tot)
+        ret[rank] = {'worst': worst, 'name': name, 'loss_sum': tot.item(), 'ref_loss': ref_loss.item(),
+                     'buckets': len(ddp._buckets)}
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_average_the_gradients_of_the_hip_model():
+    """world_size 2 with the real model: rank r trains on its share of the batch, the bucketed reducer leaves on every
+    rank (sum of the per-rank gradients) / 2 = (full-batch gradient) / 2, and the per-rank losses add up to the
+    full-batch loss (fp32: 2e-4 relative, summation order only)"""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, f'worker exited with {p.exitcode}'
+    for r in range(world):
+        out = ret[r]
+        assert out['buckets'] > 1
+        assert out['worst'] <= 2e-4, (r, out['name'], out['worst'])
+        assert abs(out['loss_sum'] - out['ref_loss']) <= 1e-5 * abs(out['ref_loss'])
