@@ -764,6 +764,7 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
             if (splitk > 1 && sk_mode == 2) sk = 0;
             else if (splitk > 1) {  // the caller allows split-K: re-derive the factor for 256-tiles (~1 workgroup per CU)
                 sk = (int)std::max(1LL, std::min((long long)(256 / std::max(1LL, t256)), K / 512));
+                sk = std::min(sk, 2 * splitk);  // the caller sized the workspace for twice its own factor
                 if (sk_mode == 1) sk = std::min(sk, splitk);
                 per = ((K + sk - 1) / sk + 63) / 64 * 64;
                 sk = (int)((K + per - 1) / per);
