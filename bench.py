@@ -39,6 +39,9 @@ WORKLOADS = {
     'c1_base': ('TransformerConfig', 8032, 8, 64, 64),
     'c3_big': ('TransformerBigConfig', 70376, 256, 128, 128),
     'c5_nllb_1b3': ('NLLB1B3Config', 256206, 64, 128, 128),
+    # C4 (speech): 30 s clips -> log-mel on the device (K8) -> conv subsampler (K7) -> whisper_base-shaped 6+6 enc-dec;
+    # S = 3000 mel frames in, 1500 encoder positions; the log-mel kernel is inside the timed step
+    'c4_whisper': ('WhisperConfig', 51865, 16, 3000, 64),
 }
 
 
@@ -220,13 +223,21 @@ def main():
     model.train()
     rng.manual_seed(1 + rank)
     ddp = DistributedDataParallel(model) if world > 1 or args.force_ddp else model
-    batch = synthetic_batch(B, S, T, V, seed=1 + rank, device=device)
+    batch = synthetic_batch(B, S if args.workload != 'c4_whisper' else 4, T, V, seed=1 + rank, device=device)
+    wav = None
+    if args.workload == 'c4_whisper':  # wav ~ N(0, 0.1^2) fp32, 30 s at 16 kHz
+        gen = torch.Generator().manual_seed(rank)
+        wav = (0.1 * torch.randn(B, 480000, generator=gen)).to(device)
+        batch['encoder_input_length'] = torch.full((B,), S, dtype=torch.int64, device=device)
 
     timer = GemmTimer()
 
     def step():
         for p in model.parameters():
             p.grad = None
+        if wav is not None:
+            from pasero_amd import functional as PF
+            batch['encoder_input'] = PF.log_mel(wav).to(dtype)
         loss, logs = ddp(**batch)
         loss.backward()
         return logs['num_tokens']
@@ -258,7 +269,9 @@ def main():
         tokens = n.item()
 
     if rank == 0:
-        step_flops = count_flops(cfg, B, S, T, V)  # SURVEY §8d algorithmic FLOPs of one fwd+bwd batch
+        # SURVEY §8d algorithmic FLOPs of one fwd+bwd batch (speech: the encoder runs on the S/2 subsampled positions;
+        # the conv frontend's own FLOPs are not counted)
+        step_flops = count_flops(cfg, B, S if args.workload != 'c4_whisper' else S // 2, T, V)
         out = {
             'metric': 'target tokens/sec (fwd+bwd), Transformer-base d=512',
             'value': tokens / elapsed,
