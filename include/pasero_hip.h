@@ -74,9 +74,9 @@ int pk_residual_ln_bwd(const void* dy, const void* dz_extra, const void* z, cons
                        size_t ws_bytes, long long rows, int d, float drop_p, unsigned long long seed,
                        unsigned long long offset, int dtype, void* stream);
 
-/* ---- Scaled-dot-product attention, head_dim 64 (K3): replaces F.scaled_dot_product_attention and the mask
+/* ---- Scaled-dot-product attention, head_dim 64 or 128 (K3): replaces F.scaled_dot_product_attention and the mask
  * assembly around it, pasero/models/modules.py:654-677,707-720 (fallback :742-771).
- *   q (B,T,H,64), k/v (B,S,H,64), o (B,T,H,64): element strides *_bs (batch) and *_rs (row), head stride 64.
+ *   q (B,T,H,hd), k/v (B,S,H,hd), o (B,T,H,hd): element strides *_bs (batch) and *_rs (row), head stride hd.
  *   key_pad: the reference's bool (B,S) key-padding mask, 1 byte per key, or NULL.  causal: query t attends keys
  *   s <= t + (S - T).  A query with every key masked outputs 0.  lse [B,H,T] fp32 (natural log, scaled scores). */
 int pk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const unsigned char* key_pad,

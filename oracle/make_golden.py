@@ -212,6 +212,13 @@ def gen_tiny_lora():
                encoder_prenorm=True, decoder_prenorm=True, activation_fn='gelu')
 
 
+def gen_tiny_hd128():
+    """heads of 128 (transformer_small = transformer_iwslt_de_en: 4 x 128; nllb_3b3: 16 x 128)"""
+    gen_encdec('tiny_hd128', V=79, B=3, S=9, T=7, seed=17,
+               embed_dim=256, encoder_ffn_dim=128, decoder_ffn_dim=128, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=1, decoder_layers=1, dropout=0.0)
+
+
 def gen_base_c1():
     """BASELINE config C1: `transformer` base 6+6 d=512 H=8 f=2048 V=8032, batch 8x(64,64), ragged.
     Weights are regenerated from the seed (193 MB), so only scalars / samples are stored."""
@@ -461,6 +468,7 @@ GENERATORS = {
     'base_c1': gen_base_c1,
     'tiny_adapter': gen_tiny_adapter,
     'tiny_lora': gen_tiny_lora,
+    'tiny_hd128': gen_tiny_hd128,
     'mha': gen_mha,
     'mha_rotary': gen_mha_rotary,
     'tiny_encdec_rotary': gen_tiny_rotary,

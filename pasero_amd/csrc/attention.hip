@@ -1,4 +1,4 @@
-// Scaled-dot-product attention, forward + backward, head_dim = 64 (K3 of SURVEY §2c).
+// Scaled-dot-product attention, forward + backward, head_dim 64 or 128 (K3 of SURVEY §2c).
 //   reference: F.scaled_dot_product_attention(q, k, v, attn_mask, is_causal, scale)  pasero/models/modules.py:707-720
 //              mask assembly (bool (B,S) key-padding -> -inf, causal triu)            pasero/models/modules.py:654-677
 //              custom fallback with fp32 softmax + nan_to_num                         pasero/models/modules.py:742-771
@@ -24,7 +24,7 @@ typedef __attribute__((address_space(3))) s16x4 lds_s4;
 
 namespace {
 
-constexpr int HD = 64;
+constexpr int HD64 = 64;  // the single-workgroup fused backward is built for this head dimension only
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -49,6 +49,7 @@ __device__ __forceinline__ bool key_masked(const AttnParams& p, int b, int t, in
 // =====================================================================================================
 constexpr int F32_TILE = 32;
 
+template <int HD>
 __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v, float* __restrict__ o,
                                                            float* __restrict__ lse, AttnParams p) {
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restri
 }
 
 // dQ (thread per query) + delta = rowsum(dO * O)
+template <int HD>
 __global__ __launch_bounds__(128) void attn_bwd_dq_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                               const float* __restrict__ v, const float* __restrict__ o,
                                                               const float* __restrict__ d_o,
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_f32_kernel(const float* __res
 }
 
 // dK, dV (thread per key)
+template <int HD>
 __global__ __launch_bounds__(128) void attn_bwd_dkv_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v,
                                                                const float* __restrict__ d_o,
@@ -219,6 +222,8 @@ template <int P> __device__ __forceinline__ int lds_off(int row, int ch) {
         return row * P + ch * 16;
 }
 constexpr int KT = 64;       // rows (keys or queries) staged per LDS tile
+// A [64 rows][head_dim] tile is head_dim / 64 images side by side (each 64 columns wide, laid out as above)
+template <int P> constexpr int img_bytes() { return KT * (P == DUAL ? 128 : P); }
 
 // stage a [64 rows][64 cols] bf16 tile (rows r0.., row limit `lim`, zero fill) into LDS with the given pitch
 __device__ __forceinline__ void stage_tile(char* lds, int pitch, const bf16* __restrict__ base, long long rs, int r0,
@@ -234,37 +239,42 @@ __device__ __forceinline__ void stage_tile(char* lds, int pitch, const bf16* __r
 }
 
 // the same in two halves, so the next tile's global loads fly under the current tile's MFMAs
-__device__ __forceinline__ void tile_g2r(uint4 (&regs)[2], const bf16* __restrict__ base, long long rs, int r0, int lim,
+template <int NR>  // NR = 2 * head_dim / 64 chunks of 16 B per thread
+__device__ __forceinline__ void tile_g2r(uint4 (&regs)[NR], const bf16* __restrict__ base, long long rs, int r0, int lim,
                                          int tid) {
+    constexpr int CPR = 4 * NR;  // 16-B chunks per row
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NR; ++i) {
         int c = tid + i * 256;
-        int r = c >> 3, cc = (c & 7) * 8;
+        int r = c / CPR, cc = (c % CPR) * 8;
         regs[i] = make_uint4(0, 0, 0, 0);
         if (r0 + r < lim) regs[i] = *reinterpret_cast<const uint4*>(base + (long long)(r0 + r) * rs + cc);
     }
 }
-template <int P>
-__device__ __forceinline__ void tile_r2s(const uint4 (&regs)[2], char* lds, int tid) {
+template <int P, int NR>
+__device__ __forceinline__ void tile_r2s(const uint4 (&regs)[NR], char* lds, int tid) {
+    constexpr int CPR = 4 * NR;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int c = tid + i * 256;
-        *reinterpret_cast<uint4*>(lds + lds_off<P>(c >> 3, c & 7)) = regs[i];
+    for (int i = 0; i < NR; ++i) {
+        int c = tid + i * 256, ch = c % CPR;
+        *reinterpret_cast<uint4*>(lds + (ch >> 3) * img_bytes<P>() + lds_off<P>(c / CPR, ch & 7)) = regs[i];
     }
 }
 
 // row fragment: lane (r = l&31, h = l>>5) gets row row0 + r, elements d = 16*kk + 8*h .. +7
 template <int P>
 __device__ __forceinline__ bf16x8_t row_frag(const char* lds, int row0, int kk, int lane) {
-    return *reinterpret_cast<const bf16x8_t*>(lds + lds_off<P>(row0 + (lane & 31), kk * 2 + (lane >> 5)));
+    return *reinterpret_cast<const bf16x8_t*>(lds + (kk >> 2) * img_bytes<P>() +
+                                              lds_off<P>(row0 + (lane & 31), (kk & 3) * 2 + (lane >> 5)));
 }
 // transposed fragment for "accumulator tile as next operand" products (cdna guide §3): lane (r, h) gets column
 // c0 + r of rows  row0 + 16*s + 8*(j>>2) + 4*h + (j&3),  j = 0..7
 template <int P>
 __device__ __forceinline__ bf16x8_t tr_frag(const char* lds, int row0, int s, int c0, int lane) {
     int q = (lane & 15) >> 2, p4 = lane & 3;
-    int col = c0 + 16 * ((lane >> 4) & 1) + 4 * p4;
+    int col = (c0 & 63) + 16 * ((lane >> 4) & 1) + 4 * p4;
     int row = row0 + 16 * s + 4 * (lane >> 5) + q;
+    lds += (c0 >> 6) * img_bytes<P>();  // the 64-column image this d-tile lives in
     const char* ptr = lds + lds_off<P>(row, col >> 3) + (col & 7) * 2;
     const char* ptr8 = lds + lds_off<P>(row + 8, col >> 3) + (col & 7) * 2;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)ptr);
@@ -282,10 +292,11 @@ __device__ __forceinline__ bf16x8_t acc_frag(const f32x16& a, int s) {
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // global row fragment (rows beyond `lim` read as zero): lane (r, h) row row0 + r, d = 16kk + 8h .. +7
-__device__ __forceinline__ void load_row_frags(bf16x8_t (&f)[4], const bf16* __restrict__ base, long long rs, int row,
+template <int NF>
+__device__ __forceinline__ void load_row_frags(bf16x8_t (&f)[NF], const bf16* __restrict__ base, long long rs, int row,
                                                bool valid, int lane) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < NF; ++kk) {
         uint4 val = {0, 0, 0, 0};
         if (valid) val = *reinterpret_cast<const uint4*>(base + (long long)row * rs + kk * 16 + 8 * (lane >> 5));
         f[kk] = __builtin_bit_cast(bf16x8_t, val);
@@ -301,11 +312,12 @@ __device__ __forceinline__ float frag_dot(const bf16x8_t& a, const bf16x8_t& b) 
 }
 
 // write a transposed accumulator pair Xᵀ[d][row-on-lane] (2 d-tiles) as bf16 rows: lane (r, h) owns row `row`
+template <int ND>
 __device__ __forceinline__ void store_rowT(bf16* __restrict__ base, long long rs, int row, bool valid,
-                                           const f32x16 (&acc)[2], float mul, int lane) {
+                                           const f32x16 (&acc)[ND], float mul, int lane) {
     if (!valid) return;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             int d = dt * 32 + 8 * g + 4 * (lane >> 5);
@@ -316,15 +328,16 @@ __device__ __forceinline__ void store_rowT(bf16* __restrict__ base, long long rs
 }
 
 // ---- forward (MODE 0) and dQ backward (MODE 1): query on the lane ----
-template <int MODE>
+template <int MODE, int HD>
 __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                      const bf16* __restrict__ v, bf16* __restrict__ o,
                                                      const bf16* __restrict__ d_o, float* __restrict__ lse,
                                                      float* __restrict__ delta, bf16* __restrict__ dq, AttnParams p) {
     // forward: K by rows only, V transposed only.  dQ backward: K by rows AND transposed (dual image), V by rows only
     constexpr int KP = MODE == 0 ? PITCH : DUAL, VP = MODE == 0 ? VPITCH : PITCH;
-    __shared__ __attribute__((aligned(16))) char k_lds[KT * (KP == DUAL ? 128 : KP)];
-    __shared__ __attribute__((aligned(16))) char v_lds[KT * VP];
+    constexpr int NF = HD / 16, ND = HD / 32, NI = HD / 64;  // k-steps per row, 32-row d-tiles, 64-column LDS images
+    __shared__ __attribute__((aligned(16))) char k_lds[NI * img_bytes<KP>()];
+    __shared__ __attribute__((aligned(16))) char v_lds[NI * img_bytes<VP>()];
     __shared__ __attribute__((aligned(16))) float kbias_lds[KT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -332,20 +345,20 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
     const bool valid = t < p.T;
     const float c = p.scale * LOG2E;
 
-    bf16x8_t qf[4], dof[4];
+    bf16x8_t qf[NF], dof[NF];
     load_row_frags(qf, q + b * p.q_bs + h * HD, p.q_rs, t, valid, lane);
     float m = -INFINITY, l = 0.f, L2 = 0.f, dl = 0.f;
-    f32x16 acc[2];  // Oᵀ (MODE 0) or dQᵀ (MODE 1): [d-tile][d rows] x query lane
+    f32x16 acc[ND];  // Oᵀ (MODE 0) or dQᵀ (MODE 1): [d-tile][d rows] x query lane
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     if constexpr (MODE == 1) {
         load_row_frags(dof, d_o + b * p.do_bs + h * HD, p.do_rs, t, valid, lane);
-        bf16x8_t of[4];
+        bf16x8_t of[NF];
         load_row_frags(of, o + b * p.o_bs + h * HD, p.o_rs, t, valid, lane);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) dl += frag_dot(dof[kk], of[kk]);
+        for (int kk = 0; kk < NF; ++kk) dl += frag_dot(dof[kk], of[kk]);
         dl += __shfl_xor(dl, 32, 64);
         const long long row = ((long long)b * p.H + h) * p.T + t;
         if (valid) {
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
     const int wt0 = blockIdx.x * 128 + wave * 32;  // first query of this wave
     const bf16* kbase = k + b * p.k_bs + h * HD;
     const bf16* vbase = v + b * p.v_bs + h * HD;
-    uint4 kreg[2], vreg[2];
+    uint4 kreg[2 * NI], vreg[2 * NI];
     if (s_end > 0) {
         tile_g2r(kreg, kbase, p.k_rs, 0, p.S, tid);
         tile_g2r(vreg, vbase, p.v_rs, 0, p.S, tid);
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < NF; ++kk)
                 sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<KP>(k_lds, kb * 32, kk, lane), qf[kk],
                                                                  sc[kb], 0, 0, 0);
         }
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
             l = l * alpha + psum;
             m = mn;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
             // Oᵀ[d][query] += Vᵀ[d][key] · P[key][query]
@@ -441,7 +454,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
                 for (int s = 0; s < 2; ++s) {
                     bf16x8_t pf = acc_frag(sc[kb], s);
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
+                    for (int dt = 0; dt < ND; ++dt)
                         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<VP>(v_lds, kb * 32, s, dt * 32, lane),
                                                                           pf, acc[dt], 0, 0, 0);
                 }
@@ -453,7 +466,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dp[kb][r] = 0.f;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
+                for (int kk = 0; kk < NF; ++kk)
                     dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<VP>(v_lds, kb * 32, kk, lane), dof[kk],
                                                                      dp[kb], 0, 0, 0);
 #pragma unroll
@@ -469,7 +482,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
                 for (int s = 0; s < 2; ++s) {
                     bf16x8_t pf = acc_frag(sc[kb], s);
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
+                    for (int dt = 0; dt < ND; ++dt)
                         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             tr_frag<KP>(k_lds, kb * 32, s, dt * 32, lane), pf, acc[dt], 0, 0, 0);
                 }
@@ -486,13 +499,18 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
 }
 
 // ---- dK / dV backward: key on the lane ----
+// WHICH: 0 = dK and dV (head_dim 64); 1 = dV only, 2 = dK only (head_dim 128: two launches, the accumulators of both
+// would not fit the register file)
+template <int HD, int WHICH>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                            const bf16* __restrict__ v, const bf16* __restrict__ d_o,
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16* __restrict__ dk,
                                                            bf16* __restrict__ dv, AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char q_lds[KT * 128];   // dual-use images: read by rows and transposed
-    __shared__ __attribute__((aligned(16))) char do_lds[KT * 128];
+    constexpr int NF = HD / 16, ND = HD / 32, NI = HD / 64;
+    constexpr bool DO_V = WHICH != 2, DO_K = WHICH != 1;
+    __shared__ __attribute__((aligned(16))) char q_lds[NI * KT * 128];   // dual-use images: read by rows and transposed
+    __shared__ __attribute__((aligned(16))) char do_lds[NI * KT * 128];
     __shared__ __attribute__((aligned(16))) float l2_lds[KT], dl_lds[KT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -500,12 +518,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
     const bool kvalid = s < p.S && !(p.key_pad && p.key_pad[(long long)b * p.S + min(s, p.S - 1)]);
     const float c = p.scale * LOG2E;
 
-    bf16x8_t kf[4], vf[4];
+    bf16x8_t kf[NF], vf[NF];
     load_row_frags(kf, k + b * p.k_bs + h * HD, p.k_rs, s, s < p.S, lane);
     load_row_frags(vf, v + b * p.v_bs + h * HD, p.v_rs, s, s < p.S, lane);
-    f32x16 dka[2], dva[2];  // dKᵀ, dVᵀ: [d-tile][d rows] x key lane
+    f32x16 dka[ND], dva[ND];  // dKᵀ, dVᵀ: [d-tile][d rows] x key lane
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dka[dt][r] = dva[dt][r] = 0.f;
 
@@ -517,7 +535,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
     const float lane_bias = kvalid ? 0.f : -INFINITY;      // padding keys / keys past S: p = exp2(-inf) = 0
     const bf16* qbase = q + b * p.q_bs + h * HD;
     const bf16* dobase = d_o + b * p.do_bs + h * HD;
-    uint4 qreg[2], doreg[2];
+    uint4 qreg[2 * NI], doreg[2 * NI];
     if (t_begin < p.T) {
         tile_g2r(qreg, qbase, p.q_rs, t_begin, p.T, tid);
         tile_g2r(doreg, dobase, p.do_rs, t_begin, p.T, tid);
@@ -546,11 +564,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < NF; ++kk) {
                 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DUAL>(q_lds, qb * 32, kk, lane), kf[kk], sc, 0,
                                                              0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DUAL>(do_lds, qb * 32, kk, lane), vf[kk], dp,
-                                                             0, 0, 0);
+                if constexpr (DO_K)
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DUAL>(do_lds, qb * 32, kk, lane), vf[kk], dp,
+                                                                 0, 0, 0);
             }
             f32x16 ds;
 #pragma unroll
@@ -571,18 +590,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
             for (int st = 0; st < 2; ++st) {
                 bf16x8_t pf = acc_frag(sc, st), dsf = acc_frag(ds, st);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
+                for (int dt = 0; dt < ND; ++dt) {
                     // dVᵀ[d][key] += dOᵀ[d][query] · P[query][key] ;  dKᵀ[d][key] += Qᵀ[d][query] · dS[query][key]
-                    dva[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        tr_frag<DUAL>(do_lds, qb * 32, st, dt * 32, lane), pf, dva[dt], 0, 0, 0);
-                    dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        tr_frag<DUAL>(q_lds, qb * 32, st, dt * 32, lane), dsf, dka[dt], 0, 0, 0);
+                    if constexpr (DO_V)
+                        dva[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            tr_frag<DUAL>(do_lds, qb * 32, st, dt * 32, lane), pf, dva[dt], 0, 0, 0);
+                    if constexpr (DO_K)
+                        dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            tr_frag<DUAL>(q_lds, qb * 32, st, dt * 32, lane), dsf, dka[dt], 0, 0, 0);
                 }
             }
         }
     }
-    store_rowT(dk + b * p.dk_bs + h * HD, p.dk_rs, s, s < p.S, dka, p.scale, lane);
-    store_rowT(dv + b * p.dv_bs + h * HD, p.dv_rs, s, s < p.S, dva, 1.f, lane);
+    if constexpr (DO_K) store_rowT(dk + b * p.dk_bs + h * HD, p.dk_rs, s, s < p.S, dka, p.scale, lane);
+    if constexpr (DO_V) store_rowT(dv + b * p.dv_bs + h * HD, p.dv_rs, s, s < p.S, dva, 1.f, lane);
 }
 
 // ---- whole backward of one (batch, head) in one workgroup, for T <= 128 queries and S <= 128 keys ----
@@ -621,10 +642,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
     const int off = p.S - p.T;
 
     // ---- loads: Q, dO (+O for delta) tiles, the K tile (kept in registers until phase 2), own-key K/V fragments ----
-    const bf16* qbase = q + b * p.q_bs + h * HD;
-    const bf16* dobase = d_o + b * p.do_bs + h * HD;
-    const bf16* obase = o + b * p.o_bs + h * HD;
-    const bf16* kbase = k + b * p.k_bs + h * HD;
+    const bf16* qbase = q + b * p.q_bs + h * HD64;
+    const bf16* dobase = d_o + b * p.do_bs + h * HD64;
+    const bf16* obase = o + b * p.o_bs + h * HD64;
+    const bf16* kbase = k + b * p.k_bs + h * HD64;
     uint4 kreg[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -654,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
     const float lane_bias = kvalid ? 0.f : -INFINITY;
     bf16x8_t kf[4], vf[4];
     load_row_frags(kf, kbase, p.k_rs, s, s < p.S, lane);
-    load_row_frags(vf, v + b * p.v_bs + h * HD, p.v_rs, s, s < p.S, lane);
+    load_row_frags(vf, v + b * p.v_bs + h * HD64, p.v_rs, s, s < p.S, lane);
     f32x16 dka[2], dva[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -707,8 +728,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
             }
         }
     }
-    store_rowT(dk + b * p.dk_bs + h * HD, p.dk_rs, s, s < p.S, dka, p.scale, lane);
-    store_rowT(dv + b * p.dv_bs + h * HD, p.dv_rs, s, s < p.S, dva, 1.f, lane);
+    store_rowT(dk + b * p.dk_bs + h * HD64, p.dk_rs, s, s < p.S, dka, p.scale, lane);
+    store_rowT(dv + b * p.dv_bs + h * HD64, p.dv_rs, s, s < p.S, dva, 1.f, lane);
     __syncthreads();  // dSᵀ complete; the dO tile is dead
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -737,11 +758,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
                                                                   acc[dt], 0, 0, 0);
         }
     }
-    store_rowT(dq + b * p.dq_bs + h * HD, p.dq_rs, t, t < p.T, acc, p.scale, lane);
+    store_rowT(dq + b * p.dq_bs + h * HD64, p.dq_rs, t, t < p.T, acc, p.scale, lane);
 }
 
 int check_common(const AttnParams& p, int hd, int dtype, const char* who) {
-    PK_CHECK_ARG(hd == HD, "%s: head_dim %d not supported (64 only)", who, hd);
+    PK_CHECK_ARG(hd == 64 || hd == 128, "%s: head_dim %d not supported (64 or 128)", who, hd);
     PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16, "%s: dtype %d not supported", who, dtype);
     PK_CHECK_ARG(p.B >= 0 && p.H > 0 && p.T >= 0 && p.S >= 0, "%s: bad sizes", who);
     PK_CHECK_ARG(p.B <= 65535 && p.H <= 65535, "%s: B and H must be <= 65535", who);
@@ -769,12 +790,18 @@ extern "C" int pk_attn_fwd(const void* q, const void* k, const void* v, void* o,
     if (B == 0 || T == 0) return 0;
     dim3 grid((T + 127) / 128, H, B);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == PK_BF16)
-        hipLaunchKernelGGL((attn_q_kernel<0>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v,
-                           (bf16*)o, (const bf16*)nullptr, lse, (float*)nullptr, (bf16*)nullptr, p);
-    else
-        hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(128), 0, s, (const float*)q, (const float*)k,
-                           (const float*)v, (float*)o, lse, p);
+#define PK_FWD(D)                                                                                                      \
+    do {                                                                                                               \
+        if (dtype == PK_BF16)                                                                                          \
+            hipLaunchKernelGGL((attn_q_kernel<0, D>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,           \
+                               (const bf16*)v, (bf16*)o, (const bf16*)nullptr, lse, (float*)nullptr, (bf16*)nullptr, p); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((attn_fwd_f32_kernel<D>), grid, dim3(128), 0, s, (const float*)q, (const float*)k,      \
+                               (const float*)v, (float*)o, lse, p);                                                    \
+    } while (0)
+    if (hd == 64) PK_FWD(64);
+    else PK_FWD(128);
+#undef PK_FWD
     PK_LAUNCH_CHECK();
     return 0;
 }
@@ -803,7 +830,7 @@ extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const vo
     hipStream_t s = (hipStream_t)stream;
     dim3 gq((T + 127) / 128, H, B), gk((S + 127) / 128, H, B);
     static const bool no_fused = getenv("PK_ATTN_NO_FUSED_BWD") != nullptr;
-    if (dtype == PK_BF16 && T > 0 && S > 0 && T <= 128 && S <= 128 && !no_fused) {
+    if (dtype == PK_BF16 && hd == 64 && T > 0 && S > 0 && T <= 128 && S <= 128 && !no_fused) {
         static const int attr_rc = hipFuncSetAttribute((const void*)attn_bwd_fused128_kernel,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
         PK_CHECK_ARG(attr_rc == 0, "pk_attn_bwd: cannot reserve %d B of LDS", FUSED_LDS);
@@ -811,21 +838,42 @@ extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const vo
                            (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dq,
                            (bf16*)dk, (bf16*)dv, p);
     } else if (dtype == PK_BF16) {
-        if (T > 0)
-            hipLaunchKernelGGL((attn_q_kernel<1>), gq, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v,
-                               (bf16*)const_cast<void*>(o), (const bf16*)d_o, const_cast<float*>(lse), delta, (bf16*)dq, p);
+#define PK_DQ(D)                                                                                                    \
+    hipLaunchKernelGGL((attn_q_kernel<1, D>), gq, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v,  \
+                       (bf16*)const_cast<void*>(o), (const bf16*)d_o, const_cast<float*>(lse), delta, (bf16*)dq, p)
+#define PK_DKV(D, W)                                                                                               \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, W>), gk, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,           \
+                       (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dk, (bf16*)dv, p)
+        if (T > 0) {
+            if (hd == 64) PK_DQ(64);
+            else PK_DQ(128);
+        }
         PK_LAUNCH_CHECK();
-        if (S > 0)
-            hipLaunchKernelGGL(attn_bwd_dkv_kernel, gk, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,
-                               (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dk, (bf16*)dv, p);
+        if (S > 0) {
+            if (hd == 64) {
+                PK_DKV(64, 0);
+            } else {  // head_dim 128: dV and dK in two launches (each recomputes S; both accumulators do not fit)
+                PK_DKV(128, 1);
+                PK_LAUNCH_CHECK();
+                PK_DKV(128, 2);
+            }
+        }
+#undef PK_DQ
+#undef PK_DKV
     } else {
-        if (T > 0)
-            hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, gq, dim3(128), 0, s, (const float*)q, (const float*)k,
-                               (const float*)v, (const float*)o, (const float*)d_o, lse, delta, (float*)dq, p);
-        PK_LAUNCH_CHECK();
-        if (S > 0)
-            hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, gk, dim3(128), 0, s, (const float*)q, (const float*)k,
-                               (const float*)v, (const float*)d_o, lse, (const float*)delta, (float*)dk, (float*)dv, p);
+#define PK_BWD32(D)                                                                                                  \
+    do {                                                                                                             \
+        if (T > 0)                                                                                                   \
+            hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<D>), gq, dim3(128), 0, s, (const float*)q, (const float*)k,   \
+                               (const float*)v, (const float*)o, (const float*)d_o, lse, delta, (float*)dq, p);      \
+        if (S > 0)                                                                                                   \
+            hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<D>), gk, dim3(128), 0, s, (const float*)q, (const float*)k,  \
+                               (const float*)v, (const float*)d_o, lse, (const float*)delta, (float*)dk, (float*)dv, \
+                               p);                                                                                   \
+    } while (0)
+        if (hd == 64) PK_BWD32(64);
+        else PK_BWD32(128);
+#undef PK_BWD32
     }
     PK_LAUNCH_CHECK();
     return 0;

@@ -56,7 +56,8 @@ def build_plan(decoder) -> Optional[Plan]:
     from . import modules
     from .transformer import TransformerDecoderLayer
     cfg = decoder.cfg
-    if decoder.training or not decoder.embed_tokens.weight.is_cuda:
+    if (decoder.training or not decoder.embed_tokens.weight.is_cuda
+            or cfg.embed_dim != 64 * cfg.decoder_attention_heads):  # the native step is built for head_dim 64
         return None
     pos = decoder.embed_positions
     if not isinstance(pos, (modules.SinusoidalPositionalEmbedding, modules.LearnedPositionalEmbedding)):

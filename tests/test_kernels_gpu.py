@@ -263,6 +263,28 @@ def test_attention_fwd_bwd(F, dtype, B, H, T, S, causal, ragged):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,H,T,S,causal,ragged', [(2, 2, 70, 90, False, True), (2, 3, 128, 128, True, False),
+                                                     (1, 2, 1, 37, True, False), (2, 1, 200, 130, False, True)])
+def test_attention_head_dim_128(F, dtype, B, H, T, S, causal, ragged):
+    """transformer_small / nllb_3b3 (4 or 16 heads of 128): the same kernels instantiated for head_dim 128 (forward
+    and dQ with four d-tiles per wave; dV and dK in two launches), against the oracle's explicit softmax attention"""
+    D = H * 128
+    q, k, v, dy = (rnd((B, n, D), 20 + i, dtype) for i, n in enumerate((T, S, S, T)))
+    key_pad = None
+    if ragged:
+        lens = torch.tensor([S] + [max(1, S - 17 * (i + 1)) for i in range(B - 1)])
+        key_pad = O.len_to_mask(lens, S)
+    scale = 128 ** -0.5
+    refs = _attn_oracle(q.float(), k.float(), v.float(), H, key_pad, causal, scale, dy.float())
+    kp = key_pad.cuda() if key_pad is not None else None
+    o, lse = F.attn_fwd(q.cuda(), k.cuda(), v.cuda(), H, kp, causal, scale)
+    dq, dk, dv = F.attn_bwd(q.cuda(), k.cuda(), v.cuda(), o, dy.cuda(), lse, H, kp, causal, scale)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for got, want, name in zip((o, dq, dk, dv), refs, 'o dq dk dv'.split()):
+        assert rel_err(got, want) < tol, name
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_attention_fully_masked_rows_and_strided_qkv(F, dtype):
     """a batch row whose keys are all padding outputs zeros (reference: nan_to_num, modules.py:765); q/k/v are
     column slices of one fused (B, T, 3D) projection buffer"""

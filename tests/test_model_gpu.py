@@ -104,6 +104,11 @@ def test_lora_branches_fp32_vs_reference():
     assert any(str(n).endswith('fc2.lora.down.weight') for n in g['grad_names'])
 
 
+def test_heads_of_128_fp32_vs_reference():
+    """embed_dim 256 with 2 heads: the head_dim-128 instantiations of the attention kernels inside the whole model"""
+    _check_encdec('tiny_hd128')
+
+
 def test_mha_rotary_incremental_offsets():
     """rotary self-attention decoded one token at a time (offset = cached length) equals the full causal pass"""
     from pasero_amd.modules import MultiheadAttention
