@@ -81,15 +81,20 @@ int pk_residual_ln_bwd(const void* dy, const void* dz_extra, const void* z, cons
  *   s <= t + (S - T).  A query with every key masked outputs 0.  lse [B,H,T] fp32 (natural log, scaled scores). */
 int pk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const unsigned char* key_pad,
                 int B, int H, int T, int S, int hd, long long q_bs, long long q_rs, long long k_bs, long long k_rs,
-                long long v_bs, long long v_rs, long long o_bs, long long o_rs, int causal, float scale, int dtype,
+                long long v_bs, long long v_rs, long long o_bs, long long o_rs, int causal, float scale, float drop_p,
+                unsigned long long seed, unsigned long long offset, unsigned char* drop_mask, int dtype,
                 void* stream);
-/*   dq, dk, dv from d_o; `delta` [B,H,T] fp32 is scratch (rowsum(dO*O), produced and consumed inside the call) */
+/*   Attention-probability dropout (`dropout_p` of F.scaled_dot_product_attention, modules.py:707-720; the IWSLT2023
+ *   recipes train with attention_dropout 0.1): o = (dropout(softmax(..)) v), softmax denominator unaffected.  With
+ *   drop_p > 0 the forward call draws one keep bit per (query, key) from Philox(seed, offset) and stores them in
+ *   drop_mask [B][H][T][8*ceil(S/64)] bytes (bit s%8 of byte s/8 of a row); pk_attn_bwd takes the same buffer.
+ *   dq, dk, dv from d_o; `delta` [B,H,T] fp32 is scratch (rowsum(dO*O), produced and consumed inside the call) */
 int pk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                 float* delta, void* dq, void* dk, void* dv, const unsigned char* key_pad, int B, int H, int T, int S,
                 int hd, long long q_bs, long long q_rs, long long k_bs, long long k_rs, long long v_bs,
                 long long v_rs, long long o_bs, long long o_rs, long long do_bs, long long do_rs, long long dq_bs,
                 long long dq_rs, long long dk_bs, long long dk_rs, long long dv_bs, long long dv_rs, int causal,
-                float scale, int dtype, void* stream);
+                float scale, float drop_p, const unsigned char* drop_mask, int dtype, void* stream);
 
 /* ---- Token + positional embedding (K1): replaces Embedding.forward, `*= embed_scale`, `+= positions`, Dropout,
  * pasero/models/modules.py:916-933,435-457,467-484; pasero/models/transformer.py:727-744,866-878.

@@ -216,23 +216,29 @@ class AttentionFn(torch.autograd.Function):
         return a.size(-1), a, b, c
 
     @staticmethod
-    def forward(ctx, a, b, c, key_pad, num_heads: int, causal: bool, scale: float):
+    def forward(ctx, a, b, c, key_pad, num_heads: int, causal: bool, scale: float, p: float = 0.0):
         D, q, k, v = AttentionFn._split(a, b, c)
-        o, lse = F.attn_fwd(q, k, v, num_heads, key_pad, causal, scale)
-        ctx.num_heads, ctx.causal, ctx.scale = num_heads, causal, scale
-        ctx.save_for_backward(a, b, c, key_pad, o, lse)
+        mask = None
+        if p > 0:  # attention-probability dropout: the keep bits are drawn in the forward kernel and kept for backward
+            seed, offset = rng.next_offset()
+            o, lse, mask = F.attn_fwd(q, k, v, num_heads, key_pad, causal, scale, p, seed, offset)
+        else:
+            o, lse = F.attn_fwd(q, k, v, num_heads, key_pad, causal, scale)
+        ctx.num_heads, ctx.causal, ctx.scale, ctx.p = num_heads, causal, scale, p
+        ctx.save_for_backward(a, b, c, key_pad, o, lse, mask)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
-        a, b, c, key_pad, o, lse = ctx.saved_tensors
+        a, b, c, key_pad, o, lse, mask = ctx.saved_tensors
         D, q, k, v = AttentionFn._split(a, b, c)
         da = torch.empty_like(a)
         db = torch.empty_like(b) if b is not None else None
         dc = torch.empty_like(c) if c is not None else None
         _, dq, dk, dv = AttentionFn._split(da, db, dc)
-        F.attn_bwd(q, k, v, o, _contig(d_o), lse, ctx.num_heads, key_pad, ctx.causal, ctx.scale, dq=dq, dk=dk, dv=dv)
-        return da, db, dc, None, None, None, None
+        F.attn_bwd(q, k, v, o, _contig(d_o), lse, ctx.num_heads, key_pad, ctx.causal, ctx.scale, dq=dq, dk=dk, dv=dv,
+                   drop_p=ctx.p, drop_mask=mask)
+        return da, db, dc, None, None, None, None, None
 
 
 class ResidualLayerNormFn(torch.autograd.Function):

@@ -35,7 +35,25 @@ struct AttnParams {
     const unsigned char* key_pad;  // [B][S] or null
     int causal;
     float scale;
+    // attention-probability dropout (F.scaled_dot_product_attention(dropout_p=...), modules.py:707-720): the forward pass
+    // draws keep bits from Philox (element index = row * 8 * mask_pitch + key) and stores them, one bit per (query, key),
+    // rows of `mask_pitch` = 8 * ceil(S / 64) bytes; the backward kernels read the bits back
+    unsigned drop_thr;             // 0: no dropout
+    float drop_scale;              // 1 / (1 - p)
+    unsigned long long seed, offset;
+    unsigned char* drop_mask;      // [B][H][T][mask_pitch]
+    long long mask_pitch;
 };
+
+__device__ __forceinline__ bool drop_keep1(const AttnParams& p, long long row, int s) {
+    const unsigned long long idx = (unsigned long long)row * 8ull * p.mask_pitch + s;
+    Philox4 r = philox4x32_10(p.seed, p.offset, idx >> 2);
+    const unsigned w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
+    return w >= p.drop_thr;
+}
+__device__ __forceinline__ bool drop_bit(const AttnParams& p, long long row, int s) {
+    return (p.drop_mask[row * p.mask_pitch + (s >> 3)] >> (s & 7)) & 1;
+}
 
 __device__ __forceinline__ bool key_masked(const AttnParams& p, int b, int t, int s) {
     if (s >= p.S) return true;
@@ -64,6 +82,8 @@ __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restri
     }
     float m = -INFINITY, l = 0.f;
     const float c = p.scale * LOG2E;
+    const long long row = ((long long)b * p.H + h) * p.T + t;
+    unsigned mbyte = 0;
     for (int s0 = 0; s0 < p.S; s0 += F32_TILE) {
         __syncthreads();
         for (int i = threadIdx.x; i < F32_TILE * HD; i += 128) {
@@ -74,24 +94,35 @@ __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restri
         __syncthreads();
         for (int r = 0; r < F32_TILE; ++r) {
             int s = s0 + r;
-            if (!valid || key_masked(p, b, t, s)) continue;
+            if (!valid || s >= p.S) continue;
+            bool keep = true;
+            if (p.drop_thr) {  // keep bits of all S keys of this query, eight per byte
+                keep = drop_keep1(p, row, s);
+                mbyte |= (unsigned)keep << (s & 7);
+                if ((s & 7) == 7 || s == p.S - 1) {
+                    p.drop_mask[row * p.mask_pitch + (s >> 3)] = (unsigned char)mbyte;
+                    mbyte = 0;
+                }
+            }
+            if (key_masked(p, b, t, s)) continue;
             float dot = 0.f;
 #pragma unroll
             for (int d = 0; d < HD; ++d) dot += qr[d] * ks[r][d];
             float s2 = dot * c;
             float mn = fmaxf(m, s2);
             float alpha = exp2f(m - mn), pw = exp2f(s2 - mn);
-            l = l * alpha + pw;
+            l = l * alpha + pw;  // the softmax denominator does not see the dropout
+            const float pv = keep ? pw : 0.f;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) acc[d] = acc[d] * alpha + pw * vs[r][d];
+            for (int d = 0; d < HD; ++d) acc[d] = acc[d] * alpha + pv * vs[r][d];
             m = mn;
         }
     }
     if (!valid) return;
-    float inv = l > 0.f ? 1.f / l : 0.f;
+    float inv = (l > 0.f ? 1.f / l : 0.f) * (p.drop_thr ? p.drop_scale : 1.f);
 #pragma unroll
     for (int d = 0; d < HD; ++d) o[b * p.o_bs + (long long)t * p.o_rs + h * HD + d] = acc[d] * inv;
-    lse[((long long)b * p.H + h) * p.T + t] = l > 0.f ? (m + log2f(l)) * LN2 : 0.f;
+    lse[row] = l > 0.f ? (m + log2f(l)) * LN2 : 0.f;
 }
 
 // dQ (thread per query) + delta = rowsum(dO * O)
@@ -136,6 +167,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_f32_kernel(const float* __res
                 dp += dor[d] * vs[r][d];
             }
             float pw = exp2f(dot * c - L2);
+            if (p.drop_thr) dp = drop_bit(p, row, s) ? dp * p.drop_scale : 0.f;  // dP = M/(1-p) * (dO . V)
             float ds = pw * (dp - dl) * p.scale;
 #pragma unroll
             for (int d = 0; d < HD; ++d) acc[d] += ds * ks[r][d];
@@ -190,10 +222,16 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_f32_kernel(const float* __re
                 dp += dos[r][d] * vr[d];
             }
             float pw = exp2f(dot * c - ls[r]);
+            float pv = pw;
+            if (p.drop_thr) {
+                const bool keep = drop_bit(p, ((long long)b * p.H + h) * p.T + t, s);
+                pv = keep ? pw * p.drop_scale : 0.f;
+                dp = keep ? dp * p.drop_scale : 0.f;
+            }
             float ds = pw * (dp - dls[r]) * p.scale;
 #pragma unroll
             for (int d = 0; d < HD; ++d) {
-                dva[d] += pw * dos[r][d];
+                dva[d] += pv * dos[r][d];
                 dka[d] += ds * qs[r][d];
             }
         }
@@ -328,7 +366,7 @@ __device__ __forceinline__ void store_rowT(bf16* __restrict__ base, long long rs
 }
 
 // ---- forward (MODE 0) and dQ backward (MODE 1): query on the lane ----
-template <int MODE, int HD>
+template <int MODE, int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                      const bf16* __restrict__ v, bf16* __restrict__ o,
                                                      const bf16* __restrict__ d_o, float* __restrict__ lse,
@@ -441,8 +479,30 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
                     sc[kb][r] = pw;
                     psum += pw;
                 }
-            l = l * alpha + psum;
+            l = l * alpha + psum;  // the softmax denominator does not see the dropout
             m = mn;
+            if constexpr (DROP) {
+                // registers 4g..4g+3 of a block are 4 consecutive keys of this lane's query: one Philox draw each; the
+                // two half-waves (keys +0..3 / +4..7) merge their nibbles into the byte of the stored bit mask
+                const long long mrow = ((long long)b * p.H + h) * p.T + t;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int key0 = s0 + kb * 32 + 8 * g + 4 * (lane >> 5);
+                        bool keep[4];
+                        dropout_keep4(p.seed, p.offset, ((unsigned long long)mrow * 8ull * p.mask_pitch + key0) >> 2,
+                                      p.drop_thr, keep);
+                        unsigned nib = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            nib |= (unsigned)keep[j] << j;
+                            if (!keep[j]) sc[kb][4 * g + j] = 0.f;
+                        }
+                        const unsigned other = __shfl_xor(nib, 32, 64);
+                        if (valid && lane < 32) p.drop_mask[mrow * p.mask_pitch + ((s0 + kb * 32) >> 3) + g] = (unsigned char)(nib | (other << 4));
+                    }
+            }
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
@@ -469,6 +529,17 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
                 for (int kk = 0; kk < NF; ++kk)
                     dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<VP>(v_lds, kb * 32, kk, lane), dof[kk],
                                                                      dp[kb], 0, 0, 0);
+                if constexpr (DROP) {  // dP = M / (1 - p) * (dO . V): the stored keep bits of this query's keys
+                    const long long mrow = ((long long)b * p.H + h) * p.T + t;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        unsigned byte = valid ? p.drop_mask[mrow * p.mask_pitch + ((s0 + kb * 32) >> 3) + g] : 0u;
+                        byte >>= 4 * (lane >> 5);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            dp[kb][4 * g + j] = ((byte >> j) & 1) ? dp[kb][4 * g + j] * p.drop_scale : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float pw = __builtin_amdgcn_exp2f(sc[kb][r] - L2);  // masked: exp2(-inf) = 0
@@ -491,6 +562,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
     if constexpr (MODE == 0) {
         l += __shfl_xor(l, 32, 64);
         float inv = l > 0.f ? 1.f / l : 0.f;
+        if constexpr (DROP) inv *= p.drop_scale;
         store_rowT(o + b * p.o_bs + h * HD, p.o_rs, t, valid, acc, inv, lane);
         if (valid && lane < 32) lse[((long long)b * p.H + h) * p.T + t] = l > 0.f ? (m + log2f(l)) * LN2 : 0.f;
     } else {
@@ -501,7 +573,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
 // ---- dK / dV backward: key on the lane ----
 // WHICH: 0 = dK and dV (head_dim 64); 1 = dV only, 2 = dK only (head_dim 128: two launches, the accumulators of both
 // would not fit the register file)
-template <int HD, int WHICH>
+template <int HD, int WHICH, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                            const bf16* __restrict__ v, const bf16* __restrict__ d_o,
                                                            const float* __restrict__ lse,
@@ -582,8 +654,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
                     float x = fmaf(sc[4 * g + j], c, lane_bias) - (&l4.x)[j];
                     if (check) x = s > t0 + tl + j + off ? -INFINITY : x;
                     const float pw = __builtin_amdgcn_exp2f(x);
-                    sc[4 * g + j] = pw;
-                    ds[4 * g + j] = pw * (dp[4 * g + j] - (&d4.x)[j]);
+                    float pv = pw, dpv = dp[4 * g + j];
+                    if constexpr (DROP) {  // keep bit of (query t0+tl+j, this lane's key)
+                        const int tq = t0 + tl + j;
+                        const bool keep = tq < p.T && s < p.S && drop_bit(p, ((long long)b * p.H + h) * p.T + tq, s);
+                        pv = keep ? pw * p.drop_scale : 0.f;
+                        dpv = keep ? dpv * p.drop_scale : 0.f;
+                    }
+                    sc[4 * g + j] = pv;
+                    ds[4 * g + j] = pw * (dpv - (&d4.x)[j]);
                 }
             }
 #pragma unroll
@@ -626,6 +705,7 @@ __device__ __forceinline__ bf16x8_t ds_tr_frag(const char* lds, int row0, int s,
     return __builtin_bit_cast(bf16x8_t, f);
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
     const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v, const bf16* __restrict__ o,
     const bf16* __restrict__ d_o, const float* __restrict__ lse, float* __restrict__ delta, bf16* __restrict__ dq,
@@ -709,8 +789,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
                 float x = fmaf(sc[4 * g + j], c, lane_bias) - (&l4.x)[j];
                 if (check) x = s > tl + j + off ? -INFINITY : x;
                 const float pw = __builtin_amdgcn_exp2f(x);
-                sc[4 * g + j] = pw;
-                ds[4 * g + j] = pw * (dp[4 * g + j] - (&d4.x)[j]);
+                float pv = pw, dpv = dp[4 * g + j];
+                if constexpr (DROP) {
+                    const int tq = tl + j;
+                    const bool keep = tq < p.T && s < p.S && drop_bit(p, ((long long)b * p.H + h) * p.T + tq, s);
+                    pv = keep ? pw * p.drop_scale : 0.f;
+                    dpv = keep ? dpv * p.drop_scale : 0.f;
+                }
+                sc[4 * g + j] = pv;
+                ds[4 * g + j] = pw * (dpv - (&d4.x)[j]);
             }
             unsigned lo = (unsigned)f2bf(ds[4 * g]) | ((unsigned)f2bf(ds[4 * g + 1]) << 16);
             unsigned hi = (unsigned)f2bf(ds[4 * g + 2]) | ((unsigned)f2bf(ds[4 * g + 3]) << 16);
@@ -779,11 +866,21 @@ int check_common(const AttnParams& p, int hd, int dtype, const char* who) {
 extern "C" int pk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                            const unsigned char* key_pad, int B, int H, int T, int S, int hd, long long q_bs,
                            long long q_rs, long long k_bs, long long k_rs, long long v_bs, long long v_rs,
-                           long long o_bs, long long o_rs, int causal, float scale, int dtype, void* stream) {
+                           long long o_bs, long long o_rs, int causal, float scale, float drop_p,
+                           unsigned long long seed, unsigned long long offset, unsigned char* drop_mask, int dtype,
+                           void* stream) {
     AttnParams p = {};
     p.B = B; p.H = H; p.T = T; p.S = S;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.key_pad = key_pad; p.causal = causal; p.scale = scale;
+    PK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pk_attn_fwd: bad dropout %f", drop_p);
+    PK_CHECK_ARG(drop_p == 0.f || drop_mask, "pk_attn_fwd: dropout needs the drop_mask buffer");
+    if (drop_p > 0.f) {
+        p.drop_thr = dropout_threshold(drop_p);
+        p.drop_scale = 1.f / (1.f - drop_p);
+        p.seed = seed; p.offset = offset; p.drop_mask = drop_mask;
+        p.mask_pitch = 8LL * ((S + 63) / 64);
+    }
     if (int rc = check_common(p, hd, dtype, "pk_attn_fwd")) return rc;
     if (B == 0 || T == 0) return 0;
     PK_CHECK_ARG(q && k && v && o && lse, "pk_attn_fwd: null tensor");
@@ -792,8 +889,11 @@ extern "C" int pk_attn_fwd(const void* q, const void* k, const void* v, void* o,
     hipStream_t s = (hipStream_t)stream;
 #define PK_FWD(D)                                                                                                      \
     do {                                                                                                               \
-        if (dtype == PK_BF16)                                                                                          \
-            hipLaunchKernelGGL((attn_q_kernel<0, D>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,           \
+        if (dtype == PK_BF16 && p.drop_thr)                                                                            \
+            hipLaunchKernelGGL((attn_q_kernel<0, D, true>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,     \
+                               (const bf16*)v, (bf16*)o, (const bf16*)nullptr, lse, (float*)nullptr, (bf16*)nullptr, p); \
+        else if (dtype == PK_BF16)                                                                                     \
+            hipLaunchKernelGGL((attn_q_kernel<0, D, false>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,    \
                                (const bf16*)v, (bf16*)o, (const bf16*)nullptr, lse, (float*)nullptr, (bf16*)nullptr, p); \
         else                                                                                                           \
             hipLaunchKernelGGL((attn_fwd_f32_kernel<D>), grid, dim3(128), 0, s, (const float*)q, (const float*)k,      \
@@ -812,9 +912,18 @@ extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const vo
                            long long q_rs, long long k_bs, long long k_rs, long long v_bs, long long v_rs,
                            long long o_bs, long long o_rs, long long do_bs, long long do_rs, long long dq_bs,
                            long long dq_rs, long long dk_bs, long long dk_rs, long long dv_bs, long long dv_rs,
-                           int causal, float scale, int dtype, void* stream) {
+                           int causal, float scale, float drop_p, const unsigned char* drop_mask, int dtype,
+                           void* stream) {
     AttnParams p = {};
     p.B = B; p.H = H; p.T = T; p.S = S;
+    PK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pk_attn_bwd: bad dropout %f", drop_p);
+    PK_CHECK_ARG(drop_p == 0.f || drop_mask, "pk_attn_bwd: dropout needs the drop_mask of the forward call");
+    if (drop_p > 0.f) {
+        p.drop_thr = dropout_threshold(drop_p);
+        p.drop_scale = 1.f / (1.f - drop_p);
+        p.drop_mask = const_cast<unsigned char*>(drop_mask);
+        p.mask_pitch = 8LL * ((S + 63) / 64);
+    }
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.do_bs = do_bs; p.do_rs = do_rs; p.dq_bs = dq_bs; p.dq_rs = dq_rs; p.dk_bs = dk_bs; p.dk_rs = dk_rs;
     p.dv_bs = dv_bs; p.dv_rs = dv_rs;
@@ -831,19 +940,32 @@ extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const vo
     dim3 gq((T + 127) / 128, H, B), gk((S + 127) / 128, H, B);
     static const bool no_fused = getenv("PK_ATTN_NO_FUSED_BWD") != nullptr;
     if (dtype == PK_BF16 && hd == 64 && T > 0 && S > 0 && T <= 128 && S <= 128 && !no_fused) {
-        static const int attr_rc = hipFuncSetAttribute((const void*)attn_bwd_fused128_kernel,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
+        static const int attr_rc = [] {
+            int a = hipFuncSetAttribute((const void*)attn_bwd_fused128_kernel<false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
+            int b = hipFuncSetAttribute((const void*)attn_bwd_fused128_kernel<true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
+            return a ? a : b;
+        }();
         PK_CHECK_ARG(attr_rc == 0, "pk_attn_bwd: cannot reserve %d B of LDS", FUSED_LDS);
-        hipLaunchKernelGGL(attn_bwd_fused128_kernel, dim3(H, B), dim3(256), FUSED_LDS, s, (const bf16*)q,
-                           (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dq,
-                           (bf16*)dk, (bf16*)dv, p);
+        if (p.drop_thr)
+            hipLaunchKernelGGL(attn_bwd_fused128_kernel<true>, dim3(H, B), dim3(256), FUSED_LDS, s, (const bf16*)q,
+                               (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dq,
+                               (bf16*)dk, (bf16*)dv, p);
+        else
+            hipLaunchKernelGGL(attn_bwd_fused128_kernel<false>, dim3(H, B), dim3(256), FUSED_LDS, s, (const bf16*)q,
+                               (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dq,
+                               (bf16*)dk, (bf16*)dv, p);
     } else if (dtype == PK_BF16) {
-#define PK_DQ(D)                                                                                                    \
-    hipLaunchKernelGGL((attn_q_kernel<1, D>), gq, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v,  \
-                       (bf16*)const_cast<void*>(o), (const bf16*)d_o, const_cast<float*>(lse), delta, (bf16*)dq, p)
-#define PK_DKV(D, W)                                                                                               \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, W>), gk, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,           \
+#define PK_DQ_(D, DR)                                                                                                \
+    hipLaunchKernelGGL((attn_q_kernel<1, D, DR>), gq, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,               \
+                       (const bf16*)v, (bf16*)const_cast<void*>(o), (const bf16*)d_o, const_cast<float*>(lse), delta, \
+                       (bf16*)dq, p)
+#define PK_DQ(D) do { if (p.drop_thr) PK_DQ_(D, true); else PK_DQ_(D, false); } while (0)
+#define PK_DKV_(D, W, DR)                                                                                          \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, W, DR>), gk, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,       \
                        (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dk, (bf16*)dv, p)
+#define PK_DKV(D, W) do { if (p.drop_thr) PK_DKV_(D, W, true); else PK_DKV_(D, W, false); } while (0)
         if (T > 0) {
             if (hd == 64) PK_DQ(64);
             else PK_DQ(128);
@@ -859,7 +981,9 @@ extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const vo
             }
         }
 #undef PK_DQ
+#undef PK_DQ_
 #undef PK_DKV
+#undef PK_DKV_
     } else {
 #define PK_BWD32(D)                                                                                                  \
     do {                                                                                                             \

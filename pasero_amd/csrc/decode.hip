@@ -23,8 +23,8 @@ int pk_residual_ln_fwd(const void* x, const void* residual, const void* gamma, c
                        unsigned long long seed, unsigned long long offset, int dtype, void* stream);
 int pk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const unsigned char* key_pad,
                 int B, int H, int T, int S, int hd, long long q_bs, long long q_rs, long long k_bs, long long k_rs,
-                long long v_bs, long long v_rs, long long o_bs, long long o_rs, int causal, float scale, int dtype,
-                void* stream);
+                long long v_bs, long long v_rs, long long o_bs, long long o_rs, int causal, float scale, float drop_p,
+                unsigned long long seed, unsigned long long offset, unsigned char* drop_mask, int dtype, void* stream);
 int pk_embed_fwd(const long long* ids, const void* E, const void* pos, void* out, long long ntok, int Tlen, int d,
                  long long V, float scale, int pos_start, float drop_p, unsigned long long seed,
                  unsigned long long offset, int dtype, void* stream);
@@ -196,7 +196,7 @@ extern "C" int pk_decoder_step(const PkDecoderPlan* plan, const long long* ids, 
                                (float*)self_k[l], (float*)self_v[l], D, t, cap);
         PK_LAUNCH_CHECK();
         RC(pk_attn_fwd(s.qkv, self_k[l], self_v[l], s.o, s.lse, nullptr, B, H, 1, t + 1, 64, 3LL * D, 3LL * D, cap * D, D,
-                       cap * D, D, D, D, 0, scale, dt, stream));
+                       cap * D, D, D, D, 0, scale, 0.f, 0, 0, nullptr, dt, stream));
         RC(linear(s.o, w.out_w, w.out_b, s.q, D, D, PK_ACT_NONE));
         RC(block_end(s.q, w.ln1_g, w.ln1_b));
         // ---- cross-attention over the cached projections of the encoder output ----
@@ -204,7 +204,7 @@ extern "C" int pk_decoder_step(const PkDecoderPlan* plan, const long long* ids, 
         RC(linear(in, w.cq_w, w.cq_b, s.q, D, D, PK_ACT_NONE));
         const char* ckv = (const char*)cross_kv[l];
         RC(pk_attn_fwd(s.q, ckv, ckv + (size_t)D * es, s.o, s.lse, enc_mask, B, H, 1, S, 64, D, D, (long long)S * 2 * D,
-                       2LL * D, (long long)S * 2 * D, 2LL * D, D, D, 0, scale, dt, stream));
+                       2LL * D, (long long)S * 2 * D, 2LL * D, D, D, 0, scale, 0.f, 0, 0, nullptr, dt, stream));
         RC(linear(s.o, w.cout_w, w.cout_b, s.q, D, D, PK_ACT_NONE));
         RC(block_end(s.q, w.ln2_g, w.ln2_b));
         // ---- feed-forward ----

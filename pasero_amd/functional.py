@@ -114,27 +114,30 @@ def _bs_rs(t: Tensor):
 
 
 def attn_fwd(q: Tensor, k: Tensor, v: Tensor, num_heads: int, key_pad: Optional[Tensor], causal: bool,
-             scale: float):
-    """q (B,T,D), k/v (B,S,D) (views with arbitrary batch/row strides), D = num_heads*64.
-    Returns (o (B,T,D) contiguous, lse (B,H,T) fp32)."""
+             scale: float, drop_p: float = 0.0, seed: int = 0, offset: int = 0):
+    """q (B,T,D), k/v (B,S,D) (views with arbitrary batch/row strides), D = num_heads * head_dim (64 or 128).
+    Returns (o (B,T,D) contiguous, lse (B,H,T) fp32) — and, with drop_p > 0 (attention-probability dropout), the keep-bit
+    mask (B,H,T,8*ceil(S/64)) uint8 that attn_bwd needs."""
     require_gpu(q, k, v, key_pad)
     B, T, D = q.shape
     S = k.size(1)
     hd = D // num_heads
     o = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=q.device)
+    mask = torch.empty(B, num_heads, T, 8 * ((S + 63) // 64), dtype=torch.uint8, device=q.device) if drop_p > 0 else None
     if key_pad is not None:
         assert key_pad.dtype == torch.bool and key_pad.shape == (B, S) and key_pad.is_contiguous()
     L = lib.load()
     check(L.pk_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(key_pad), B, num_heads, T, S, hd,
-                        *_bs_rs(q), *_bs_rs(k), *_bs_rs(v), *_bs_rs(o), int(causal), float(scale), dtype_code(q),
-                        stream_ptr()), 'pk_attn_fwd')
-    return o, lse
+                        *_bs_rs(q), *_bs_rs(k), *_bs_rs(v), *_bs_rs(o), int(causal), float(scale), float(drop_p),
+                        int(seed), int(offset), ptr(mask), dtype_code(q), stream_ptr()), 'pk_attn_fwd')
+    return (o, lse, mask) if drop_p > 0 else (o, lse)
 
 
 def attn_bwd(q, k, v, o, d_o, lse, num_heads: int, key_pad, causal: bool, scale: float,
-             dq: Optional[Tensor] = None, dk: Optional[Tensor] = None, dv: Optional[Tensor] = None):
-    require_gpu(q, k, v, o, d_o, lse, key_pad)
+             dq: Optional[Tensor] = None, dk: Optional[Tensor] = None, dv: Optional[Tensor] = None,
+             drop_p: float = 0.0, drop_mask: Optional[Tensor] = None):
+    require_gpu(q, k, v, o, d_o, lse, key_pad, drop_mask)
     B, T, D = q.shape
     S = k.size(1)
     hd = D // num_heads
@@ -148,7 +151,7 @@ def attn_bwd(q, k, v, o, d_o, lse, num_heads: int, key_pad, causal: bool, scale:
     check(L.pk_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                         ptr(key_pad), B, num_heads, T, S, hd, *_bs_rs(q), *_bs_rs(k), *_bs_rs(v), *_bs_rs(o),
                         *_bs_rs(d_o), *_bs_rs(dq), *_bs_rs(dk), *_bs_rs(dv), int(causal), float(scale),
-                        dtype_code(q), stream_ptr()), 'pk_attn_bwd')
+                        float(drop_p), ptr(drop_mask), dtype_code(q), stream_ptr()), 'pk_attn_bwd')
     return dq, dk, dv
 
 

@@ -1,8 +1,8 @@
 """Host-side mirror of `pasero/models/modules.py` for the Transformer hot path: same class names, constructor
 arguments, parameter names/shapes (= checkpoint keys) and forward signatures, with every forward/backward routed to
-the HIP kernels of libpasero_hip.so.  Variants that are outside the hot-path scope (LoRA, tensor parallelism, ALiBi /
-T5 / rotary biases, grouped-query attention, attention-probability dropout) raise NotImplementedError loudly instead
-of silently falling back to eager PyTorch.
+the HIP kernels of libpasero_hip.so.  Variants that are outside the hot-path scope (tensor parallelism, ALiBi / T5
+biases, grouped-query attention, RMSNorm) raise NotImplementedError loudly instead of silently falling back to eager
+PyTorch.
 """
 import contextlib
 import functools
@@ -509,8 +509,7 @@ class MultiheadAttention(nn.Module):
             attn_mask = None  # padding is at the end: useless for causal attention (modules.py:602-605)
         if attn_mask is not None and attn_mask.dim() != 2:
             raise NotImplementedError('pasero_amd: (B,T,S) attention masks are not implemented')
-        if self.training and self.dropout > 0:
-            raise NotImplementedError('pasero_amd: attention-probability dropout (--attention-dropout) is not implemented')
+        drop = float(self.dropout) if self.training else 0.0  # attention-probability dropout (modules.py:707-720)
         B, T, D = query.shape
         H = self.num_heads
         scale = 1.0 / math.sqrt(self.head_dim) if self.scaled else 1.0
@@ -547,7 +546,7 @@ class MultiheadAttention(nn.Module):
                     k4, v4 = torch.cat([prev_k, k4], dim=1), torch.cat([prev_v, v4], dim=1)
                 state['key'], state['value'] = k4, v4
                 k, v = k4.reshape(B, -1, D), v4.reshape(B, -1, D)
-            attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale)
+            attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale, drop)
         elif state is not None:  # incremental decoding (inference): K/V cache of shape (B,S,H,hd) (modules.py:621-641)
             qkv = PackedLinearFn.apply(query, w, b, 3, None, q_w, k_w, v_w, q_b, k_b, v_b)
             qkv = rope(qkv, state['key'].size(1) if 'key' in state else 0)
@@ -566,16 +565,16 @@ class MultiheadAttention(nn.Module):
             attn = AttentionFn.apply(q, k.view(B, S, D), v.view(B, S, D), attn_mask, H, self.causal and T > 1, scale)
         elif key is query and value is query:
             qkv = rope(PackedLinearFn.apply(query, w, b, 3, link, q_w, k_w, v_w, q_b, k_b, v_b), 0)
-            attn = AttentionFn.apply(qkv, None, None, attn_mask, H, self.causal and T > 1, scale)
+            attn = AttentionFn.apply(qkv, None, None, attn_mask, H, self.causal and T > 1, scale, drop)
         elif key is value:
             q = LinearFn.apply(query, q_w, q_b, 'none', link)
             kv = PackedLinearFn.apply(key, w[D:], None if b is None else b[D:], 2, None, k_w, v_w, k_b, v_b)
-            attn = AttentionFn.apply(q, kv, None, attn_mask, H, self.causal and T > 1, scale)
+            attn = AttentionFn.apply(q, kv, None, attn_mask, H, self.causal and T > 1, scale, drop)
         else:
             q = LinearFn.apply(query, q_w, q_b, 'none', link)
             k = LinearFn.apply(key, k_w, k_b, 'none')
             v = LinearFn.apply(value, v_w, v_b, 'none')
-            attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale)
+            attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale, drop)
         attn = self.out_proj(attn)
         return attn, None
 

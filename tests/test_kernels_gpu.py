@@ -285,6 +285,59 @@ def test_attention_head_dim_128(F, dtype, B, H, T, S, causal, ragged):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,H,T,S,causal,ragged,hd', [(2, 2, 70, 90, False, True, 64), (2, 4, 128, 128, True, False, 64),
+                                                        (3, 2, 100, 128, False, True, 64), (1, 2, 130, 257, False, True, 64),
+                                                        (2, 2, 64, 100, False, True, 128)])
+def test_attention_probability_dropout(F, dtype, B, H, T, S, causal, ragged, hd):
+    """dropout_p of F.scaled_dot_product_attention (modules.py:707-720; attention_dropout 0.1 in the IWSLT2023 recipes):
+    the forward kernel draws the keep bits and stores them; with THOSE bits the outputs and all three gradients must
+    equal o = (softmax(s) * M / (1 - p)) v computed explicitly — the fused single-workgroup backward (T, S <= 128), the
+    general dQ / dKdV kernels and head_dim 128 all read the same mask.  Plus: keep rate, determinism, lse unaffected."""
+    pdrop, D = 0.25, H * hd
+    q, k, v, dy = (rnd((B, n, D), 50 + i, dtype) for i, n in enumerate((T, S, S, T)))
+    key_pad = None
+    if ragged:
+        lens = torch.tensor([S] + [max(2, S - 13 * (i + 1)) for i in range(B - 1)])
+        key_pad = O.len_to_mask(lens, S)
+    scale = hd ** -0.5
+    kp = key_pad.cuda() if key_pad is not None else None
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    o, lse, mask = F.attn_fwd(qc, kc, vc, H, kp, causal, scale, pdrop, 77, 5)
+    o0, lse0 = F.attn_fwd(qc, kc, vc, H, kp, causal, scale)
+    assert torch.equal(lse, lse0)  # the softmax statistics do not see the dropout
+    def unpack(m):  # (B,H,T,pitch) bytes -> (B,H,T,S) bool; bytes past ceil(S/8) are padding
+        return ((m[..., :, None] >> torch.arange(8, device='cuda', dtype=torch.uint8)) & 1).flatten(-2)[..., :S].bool()
+    bits = unpack(mask)
+    assert bits.shape == (B, H, T, S)
+    live = torch.ones(B, 1, T, S, dtype=torch.bool, device='cuda')  # bits of masked (query, key) pairs are never used
+    if kp is not None:
+        live = live & ~kp[:, None, None, :]
+    if causal:
+        live = live & ~torch.ones(T, S, device='cuda', dtype=torch.bool).triu(1 + S - T)
+    live = live.expand(B, H, T, S)
+    assert abs(bits[live].float().mean().item() - (1 - pdrop)) < 1e-2
+    _, _, mask_again = F.attn_fwd(qc, kc, vc, H, kp, causal, scale, pdrop, 77, 5)
+    _, _, mask_other = F.attn_fwd(qc, kc, vc, H, kp, causal, scale, pdrop, 77, 6)
+    assert torch.equal(bits[live], unpack(mask_again)[live]) and not torch.equal(bits[live], unpack(mask_other)[live])
+    # explicit reference with the kernel's own bits
+    qf, kf, vf = (t.float().cuda().view(B, -1, H, hd).transpose(1, 2).requires_grad_() for t in (q, k, v))
+    sc = (qf @ kf.transpose(-1, -2)) * scale
+    if key_pad is not None:
+        sc = sc.masked_fill(kp[:, None, None, :], float('-inf'))
+    if causal:
+        sc = sc.masked_fill(torch.ones(T, S, device='cuda', dtype=torch.bool).triu(1 + S - T), float('-inf'))
+    pr = torch.softmax(sc, -1)
+    ref = ((pr * bits / (1 - pdrop)) @ vf).transpose(1, 2).reshape(B, T, D)
+    ref.backward(dy.float().cuda())
+    back = lambda g: g.transpose(1, 2).reshape(B, -1, D)
+    dq, dk, dv = F.attn_bwd(qc, kc, vc, o, dy.cuda(), lse, H, kp, causal, scale, drop_p=pdrop, drop_mask=mask)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(o, ref.detach()) < tol
+    for got, want, name in ((dq, qf.grad, 'dq'), (dk, kf.grad, 'dk'), (dv, vf.grad, 'dv')):
+        assert rel_err(got, back(want)) < tol, name
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_attention_fully_masked_rows_and_strided_qkv(F, dtype):
     """a batch row whose keys are all padding outputs zeros (reference: nan_to_num, modules.py:765); q/k/v are
     column slices of one fused (B, T, 3D) projection buffer"""

@@ -52,7 +52,7 @@ def _check_encdec(name, full=True):
             ref = g['gradsample:' + n]
             typical = ref_norm / np.sqrt(gr.numel())
             err = np.abs(gr.reshape(-1)[::4099].cpu().numpy() - ref).max()
-            assert err <= 1e-2 * max(np.abs(ref).max(), typical) + 1e-7, n
+            assert err <= 1e-2 * max(np.abs(ref).max(), typical) + (atol if n.endswith('k_proj.bias') else 1e-7), n
     model.eval()
     with torch.no_grad():
         enc_out, enc_mask, _ = model.encoder(batch['encoder_input'], batch['encoder_input_length'])
@@ -434,3 +434,35 @@ def test_sequence_longer_than_the_positional_table_is_rejected_like_the_referenc
              'decoder_input': torch.full((1, n + 1), 5, device='cuda'), 'prompt_mask': torch.zeros(1, n + 1, dtype=torch.bool, device='cuda')}
     with pytest.raises(AssertionError, match='too long'):
         model(**batch)
+
+
+def test_attention_dropout_training_step():
+    """attention_dropout 0.1 (the IWSLT2023 recipes): the step runs through the dropout instantiations of the attention
+    kernels, is reproducible from the seed, differs from the dropout-free step and from another seed, and in eval mode
+    nothing is dropped"""
+    from pasero_amd import rng
+    from pasero_amd.modules import MultiheadAttention
+    g = load_golden('tiny_encdec_post')
+    cfg, model = build_model(g, torch.bfloat16, 'cuda')
+    batch = text_batch(g, 'cuda')
+    model.train()
+    base, _ = model(**batch)
+    for m in model.modules():
+        if isinstance(m, MultiheadAttention):
+            m.dropout = 0.1
+    out = []
+    for seed in (5, 5, 6):
+        rng.manual_seed(seed)
+        model.zero_grad(set_to_none=True)
+        loss, _ = model(**batch)
+        loss.backward()
+        gq = model.decoder.layers[0].encoder_attn.q_proj.weight.grad.float()
+        assert torch.isfinite(loss) and torch.isfinite(gq).all()
+        out.append((loss.item(), gq.norm().item()))
+    assert out[0] == out[1] and out[0] != out[2] and out[0][0] != base.item()
+    assert abs(out[0][0] - base.item()) < 0.2 * base.item()
+    model.eval()
+    with torch.no_grad():
+        a, _ = model(**batch)
+        b, _ = model(**batch)
+    assert a.item() == b.item() and abs(a.item() - base.item()) <= 1e-6 * base.item()
