@@ -96,6 +96,12 @@ int pk_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
                 long long dq_rs, long long dk_bs, long long dk_rs, long long dv_bs, long long dv_rs, int causal,
                 float scale, float drop_p, const unsigned char* drop_mask, int dtype, void* stream);
 
+/*   Attention weights softmax(q k^T * scale + masks) as a (B, T, H, S) tensor, fully masked rows = 0: what the reference's
+ *   explicit path returns for `return_attn` / return_layers (modules.py:742-771).  Not used in training. */
+int pk_attn_probs(const void* q, const void* k, void* probs, const unsigned char* key_pad, int B, int H, int T, int S,
+                  int hd, long long q_bs, long long q_rs, long long k_bs, long long k_rs, int causal, float scale,
+                  int dtype, void* stream);
+
 /* ---- Token + positional embedding (K1): replaces Embedding.forward, `*= embed_scale`, `+= positions`, Dropout,
  * pasero/models/modules.py:916-933,435-457,467-484; pasero/models/transformer.py:727-744,866-878.
  *   out[tok] = dropout( E[clip(ids[tok])] * scale + pos[pos_start + tok % Tlen] )      (pos may be NULL)

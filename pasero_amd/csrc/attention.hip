@@ -848,6 +848,53 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
     store_rowT(dq + b * p.dq_bs + h * HD64, p.dq_rs, t, t < p.T, acc, p.scale, lane);
 }
 
+// ---- attention weights (B, T, H, S) for `return_attn` / return_layers: modules.py:742-771 (fp32 softmax, nan_to_num) ----
+// Not on the training path (the flash kernels never materialise the weights): one thread per query row, two passes over
+// the keys (max / sum, then the normalised weights), K tiles staged in LDS as fp32.
+template <typename T, int HD>
+__global__ __launch_bounds__(128) void attn_probs_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                         T* __restrict__ probs, AttnParams p) {
+    __shared__ float ks[F32_TILE][HD + 1];
+    const int b = blockIdx.z, h = blockIdx.y, t = blockIdx.x * 128 + threadIdx.x;
+    const bool valid = t < p.T;
+    float qr[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) qr[d] = valid ? to_f32(q[b * p.q_bs + (long long)t * p.q_rs + h * HD + d]) : 0.f;
+    const float c = p.scale * LOG2E;
+    float m = -INFINITY, l = 0.f;
+    T* out = probs + (((long long)b * p.T + t) * p.H + h) * p.S;
+    for (int pass = 0; pass < 2; ++pass) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        for (int s0 = 0; s0 < p.S; s0 += F32_TILE) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < F32_TILE * HD; i += 128) {
+                int r = i / HD, d = i % HD, s = s0 + r;
+                ks[r][d] = s < p.S ? to_f32(k[b * p.k_bs + (long long)s * p.k_rs + h * HD + d]) : 0.f;
+            }
+            __syncthreads();
+            for (int r = 0; r < F32_TILE; ++r) {
+                const int s = s0 + r;
+                if (!valid || s >= p.S) continue;
+                const bool masked = key_masked(p, b, t, s);
+                float s2 = 0.f;
+                if (!masked) {
+#pragma unroll
+                    for (int d = 0; d < HD; ++d) s2 += qr[d] * ks[r][d];
+                    s2 *= c;
+                }
+                if (pass == 0) {
+                    if (masked) continue;
+                    const float mn = fmaxf(m, s2);
+                    l = l * exp2f(m - mn) + exp2f(s2 - mn);
+                    m = mn;
+                } else {
+                    out[s] = from_f32<T>(masked ? 0.f : exp2f(s2 - m) * inv);  // a fully masked row is all zeros
+                }
+            }
+        }
+    }
+}
+
 int check_common(const AttnParams& p, int hd, int dtype, const char* who) {
     PK_CHECK_ARG(hd == 64 || hd == 128, "%s: head_dim %d not supported (64 or 128)", who, hd);
     PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16, "%s: dtype %d not supported", who, dtype);
@@ -999,6 +1046,28 @@ extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const vo
         else PK_BWD32(128);
 #undef PK_BWD32
     }
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_attn_probs(const void* q, const void* k, void* probs, const unsigned char* key_pad, int B, int H, int T,
+                             int S, int hd, long long q_bs, long long q_rs, long long k_bs, long long k_rs, int causal,
+                             float scale, int dtype, void* stream) {
+    AttnParams p = {};
+    p.B = B; p.H = H; p.T = T; p.S = S;
+    p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs;
+    p.key_pad = key_pad; p.causal = causal; p.scale = scale;
+    PK_CHECK_ARG(hd == 64 || hd == 128, "pk_attn_probs: head_dim %d not supported (64 or 128)", hd);
+    PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16, "pk_attn_probs: dtype %d not supported", dtype);
+    PK_CHECK_ARG(B >= 0 && H > 0 && T >= 0 && S >= 0 && B <= 65535 && H <= 65535, "pk_attn_probs: bad sizes");
+    if (B == 0 || T == 0 || S == 0) return 0;
+    PK_CHECK_ARG(q && k && probs, "pk_attn_probs: null tensor");
+    dim3 grid((T + 127) / 128, H, B);
+    hipStream_t s = (hipStream_t)stream;
+#define PK_PR(TT, D) hipLaunchKernelGGL((attn_probs_kernel<TT, D>), grid, dim3(128), 0, s, (const TT*)q, (const TT*)k, (TT*)probs, p)
+    if (dtype == PK_BF16) { if (hd == 64) PK_PR(bf16, 64); else PK_PR(bf16, 128); }
+    else { if (hd == 64) PK_PR(float, 64); else PK_PR(float, 128); }
+#undef PK_PR
     PK_LAUNCH_CHECK();
     return 0;
 }

@@ -155,6 +155,18 @@ def attn_bwd(q, k, v, o, d_o, lse, num_heads: int, key_pad, causal: bool, scale:
     return dq, dk, dv
 
 
+def attn_probs(q: Tensor, k: Tensor, num_heads: int, key_pad: Optional[Tensor], causal: bool, scale: float) -> Tensor:
+    """attention weights (B, T, H, S) of q (B,T,D) against k (B,S,D) — the `return_attn` output of the reference"""
+    require_gpu(q, k, key_pad)
+    B, T, D = q.shape
+    S = k.size(1)
+    probs = torch.empty(B, T, num_heads, S, dtype=q.dtype, device=q.device)
+    L = lib.load()
+    check(L.pk_attn_probs(ptr(q), ptr(k), ptr(probs), ptr(key_pad), B, num_heads, T, S, D // num_heads, *_bs_rs(q),
+                          *_bs_rs(k), int(causal), float(scale), dtype_code(q), stream_ptr()), 'pk_attn_probs')
+    return probs
+
+
 def embed_fwd(ids: Tensor, E: Tensor, pos: Optional[Tensor], scale: float, pos_start: int, drop_p: float = 0.0,
               seed: int = 0, offset: int = 0) -> Tensor:
     """ids (B,T) int64 -> (B,T,d); pos: (P,d) table in E's dtype or None; rows pos_start.. are added"""

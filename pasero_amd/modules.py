@@ -502,9 +502,6 @@ class MultiheadAttention(nn.Module):
         Shape: query (B,T,D), key/value (B,S,D), attn_mask (B,S) bool with True at masked keys.
         Returns (attn (B,T,D), attn_weights or None)
         """
-        if return_attn:
-            raise NotImplementedError('pasero_amd: returning attention weights (return_layers) is not implemented '
-                                      'by the flash attention kernels')
         if attn_mask is not None and attn_mask.dim() == 2 and self.causal:
             attn_mask = None  # padding is at the end: useless for causal attention (modules.py:602-605)
         if attn_mask is not None and attn_mask.dim() != 2:
@@ -528,11 +525,12 @@ class MultiheadAttention(nn.Module):
 
         if self.rotary_embed is not None and not (key is query and value is query):
             raise NotImplementedError('pasero_amd: rotary embeddings are implemented for self-attention only')
-        if self.q_proj.lora is not None:
-            # LoRA branches on the projections (modules.py:67-100): three separate projections, each adding its own
-            # low-rank update; the fused packed projection is for the plain layer
+        weights = None
+        if self.q_proj.lora is not None or return_attn:
+            # LoRA branches on the projections (modules.py:67-100) / attention weights wanted (return_layers): three
+            # separate projections; the fused packed projection is for the plain layer
             if self.rotary_embed is not None:
-                raise NotImplementedError('pasero_amd: LoRA together with rotary embeddings is not implemented')
+                raise NotImplementedError('pasero_amd: LoRA / return_attn together with rotary embeddings is not implemented')
             q = self.q_proj(query, link=link)
             k = self.k_proj(key)
             v = self.v_proj(value)
@@ -547,6 +545,9 @@ class MultiheadAttention(nn.Module):
                 state['key'], state['value'] = k4, v4
                 k, v = k4.reshape(B, -1, D), v4.reshape(B, -1, D)
             attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale, drop)
+            if return_attn:  # (B,T,H,S) softmax weights before dropout, as the reference's explicit path returns them
+                with torch.no_grad():
+                    weights = F.attn_probs(q.detach(), k.detach(), H, attn_mask, self.causal and T > 1, scale)
         elif state is not None:  # incremental decoding (inference): K/V cache of shape (B,S,H,hd) (modules.py:621-641)
             qkv = PackedLinearFn.apply(query, w, b, 3, None, q_w, k_w, v_w, q_b, k_b, v_b)
             qkv = rope(qkv, state['key'].size(1) if 'key' in state else 0)
@@ -576,7 +577,7 @@ class MultiheadAttention(nn.Module):
             v = LinearFn.apply(value, v_w, v_b, 'none')
             attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale, drop)
         attn = self.out_proj(attn)
-        return attn, None
+        return attn, weights
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -48,6 +48,11 @@ def test_multihead_attention_vs_reference(variant):
     assert rel(q.grad, g[variant + ':dq']) < 1e-4
     if variant == 'cross':
         assert rel(kv.grad, g[variant + ':dkv']) < 1e-4
+    with torch.no_grad():  # return_attn: the (B,T,H,S) weights of the reference's explicit path (modules.py:742-771)
+        y2, w2 = mha(query=q, key=kv, value=kv, attn_mask=mask, return_attn=True)
+    assert w2.shape == g[variant + ':attn_weights'].shape
+    assert np.abs(w2.cpu().numpy() - g[variant + ':attn_weights']).max() < 1e-5
+    assert rel(y2, g[variant + ':y_return_attn']) < 1e-4
     for n, p in mha.named_parameters():
         ref = g[variant + ':grad:' + n]
         # the key bias shifts every score of a row by the same amount: its gradient is zero up to rounding
