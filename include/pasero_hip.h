@@ -8,7 +8,8 @@
  * Conventions
  *   - plain pointers + sizes only; every pointer is DEVICE memory unless stated; the caller allocates all outputs
  *     and workspaces; tensors are row-major and contiguous unless a leading dimension (ld*) is given.
- *   - `dtype`: PK_F32 or PK_BF16 selects the storage type of all T* tensors of the call (accumulation is always fp32).
+ *   - `dtype`: PK_F32, PK_BF16 or PK_F16 (the reference's default, config.py:518-523) selects the storage type of all
+ *     T* tensors of the call; accumulation is always fp32.
  *   - `stream` is a hipStream_t; all work is enqueued on it, nothing synchronises, nothing allocates: every call is
  *     hipGraph-capturable.
  *   - returns 0 on success, -1 on an argument error, or a hipError_t; pk_last_error() gives the message
@@ -25,7 +26,7 @@
 extern "C" {
 #endif
 
-enum { PK_F32 = 0, PK_BF16 = 1 };
+enum { PK_F32 = 0, PK_BF16 = 1, PK_F16 = 2 };
 /* pasero/models/modules.py:220-228 get_activation_fn */
 enum { PK_ACT_NONE = 0, PK_ACT_RELU = 1, PK_ACT_GELU = 2, PK_ACT_GELU_TANH = 3, PK_ACT_SILU = 4 };
 

@@ -6,6 +6,7 @@
 
 #define PK_F32 0
 #define PK_BF16 1
+#define PK_F16 2
 
 // activation ids (pasero/models/modules.py:220-228)
 #define PK_ACT_NONE 0
@@ -15,6 +16,7 @@
 #define PK_ACT_SILU 4
 
 typedef __hip_bfloat16 bf16;
+typedef _Float16 f16;  // IEEE half: the reference's default training dtype (config.py:518-523)
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA bf16 A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
@@ -49,9 +51,31 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return __bfloat162float(v); }
+template <> __device__ __forceinline__ float to_f32<f16>(f16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return __float2bfloat16(v); }
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
+
+// The two 16-bit storage types share every kernel: same bytes in memory, LDS and MFMA fragments; they differ in the
+// float <-> 16-bit conversion and in the MFMA instruction (v_mfma_f32_32x32x16_bf16 / _f16).
+template <typename T> struct H16;
+template <> struct H16<bf16> {
+    typedef __attribute__((ext_vector_type(8))) __bf16 vec;
+    static __device__ __forceinline__ unsigned short bits(float f) { return f2bf(f); }
+    static __device__ __forceinline__ float val(unsigned short u) { return bf2f(u); }
+    static __device__ __forceinline__ f32x16 mfma(vec a, vec b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct H16<f16> {
+    typedef __attribute__((ext_vector_type(8))) _Float16 vec;
+    static __device__ __forceinline__ unsigned short bits(float f) { return __builtin_bit_cast(unsigned short, (f16)f); }
+    static __device__ __forceinline__ float val(unsigned short u) { return (float)__builtin_bit_cast(f16, u); }
+    static __device__ __forceinline__ f32x16 mfma(vec a, vec b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
 
 // ---- 16-byte vector access: VEC<T> elements per 16 B ----
 template <typename T> struct Vec16;
@@ -74,6 +98,19 @@ template <> struct Vec16<bf16> {
         w = (i & 1) ? ((w & 0x0000ffffu) | (b << 16)) : ((w & 0xffff0000u) | b);
     }
 };
+template <> struct Vec16<f16> {
+    static constexpr int N = 8;
+    uint4 raw;
+    __device__ __forceinline__ float get(int i) const {
+        unsigned w = (&raw.x)[i >> 1];
+        return H16<f16>::val((unsigned short)((i & 1) ? (w >> 16) : (w & 0xffff)));
+    }
+    __device__ __forceinline__ void set(int i, float v) {
+        unsigned& w = (&raw.x)[i >> 1];
+        unsigned b = H16<f16>::bits(v);
+        w = (i & 1) ? ((w & 0x0000ffffu) | (b << 16)) : ((w & 0xffff0000u) | b);
+    }
+};
 template <typename T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
     Vec16<T> v;
     v.raw = *reinterpret_cast<const decltype(v.raw)*>(p);
@@ -82,6 +119,13 @@ template <typename T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
 template <typename T> __device__ __forceinline__ void store16(T* p, const Vec16<T>& v) {
     *reinterpret_cast<decltype(v.raw)*>(p) = v.raw;
 }
+
+// run `...` with T bound to the storage type of `dtype`
+#define PK_DTYPE_SWITCH(dtype, who, ...)                                   \
+    if (dtype == PK_BF16) { using T = bf16; __VA_ARGS__ }                  \
+    else if (dtype == PK_F16) { using T = f16; __VA_ARGS__ }               \
+    else if (dtype == PK_F32) { using T = float; __VA_ARGS__ }             \
+    else { PK_CHECK_ARG(false, "%s: dtype %d not supported", who, dtype); }
 
 // ---- wave (64 lanes) reductions ----
 __device__ __forceinline__ float wave_sum(float v) {

@@ -109,7 +109,7 @@ struct Scratch {
     size_t total;
 };
 Scratch carve(const PkDecoderPlan* p, int B, char* base) {
-    const size_t es = p->dtype == PK_BF16 ? 2 : 4;
+    const size_t es = p->dtype == PK_F32 ? 4 : 2;
     Scratch s;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* r = base ? base + off : nullptr; off += align256(bytes); return r; };
@@ -146,7 +146,7 @@ extern "C" int pk_decoder_step(const PkDecoderPlan* plan, const long long* ids, 
     PK_CHECK_ARG(plan && ids && self_k && self_v && cross_kv && scratch && logits, "pk_decoder_step: null argument");
     PK_CHECK_ARG(B > 0 && t >= 0 && t < cap && S > 0, "pk_decoder_step: bad sizes (B=%d t=%d cap=%lld S=%d)", B, t, cap, S);
     PK_CHECK_ARG(plan->d % 64 == 0 && plan->heads * 64 == plan->d, "pk_decoder_step: head_dim must be 64");
-    PK_CHECK_ARG(plan->dtype == PK_F32 || plan->dtype == PK_BF16, "pk_decoder_step: bad dtype");
+    PK_CHECK_ARG(plan->dtype == PK_F32 || plan->dtype == PK_BF16 || plan->dtype == PK_F16, "pk_decoder_step: bad dtype");
     Scratch s = carve(plan, B, (char*)scratch);
     PK_CHECK_ARG(scratch_bytes >= s.total, "pk_decoder_step: scratch too small (%zu < %zu)", scratch_bytes, s.total);
     const int D = plan->d, H = plan->heads, F = plan->ffn, dt = plan->dtype;
@@ -181,14 +181,14 @@ extern "C" int pk_decoder_step(const PkDecoderPlan* plan, const long long* ids, 
                               0.f, 0, 0, dt, stream));
         std::swap(x, xn);
     }
-    const size_t es = dt == PK_BF16 ? 2 : 4;
+    const size_t es = dt == PK_F32 ? 4 : 2;
     for (int l = 0; l < plan->n_layers; ++l) {
         const PkDecoderLayerWeights& w = plan->layers[l];
         const char* in;
         // ---- self-attention over the cache (keys 0..t) ----
         RC(block_in(w.ln1_g, w.ln1_b, &in));
         RC(linear(in, w.qkv_w, w.qkv_b, s.qkv, 3 * D, D, PK_ACT_NONE));
-        if (dt == PK_BF16)
+        if (dt != PK_F32)  // a 16-bit row copy: bf16 and fp16 alike
             hipLaunchKernelGGL((kv_append_kernel<bf16>), dim3(B), dim3(64), 0, st, (const bf16*)s.qkv, (bf16*)self_k[l],
                                (bf16*)self_v[l], D, t, cap);
         else
@@ -231,6 +231,8 @@ extern "C" int pk_argmax_rows(const void* x, long long rows, long long n, long l
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PK_BF16)
         hipLaunchKernelGGL((argmax_rows_kernel<bf16>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16*)x, ld, n, out, out_stride);
+    else if (dtype == PK_F16)
+        hipLaunchKernelGGL((argmax_rows_kernel<f16>), dim3((unsigned)rows), dim3(256), 0, st, (const f16*)x, ld, n, out, out_stride);
     else if (dtype == PK_F32)
         hipLaunchKernelGGL((argmax_rows_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)x, ld, n, out, out_stride);
     else PK_CHECK_ARG(false, "pk_argmax_rows: dtype %d not supported", dtype);

@@ -137,10 +137,6 @@ inline int grid_for(long long work, int per_block) {
 }
 }  // namespace
 
-#define PK_DTYPE_SWITCH(dtype, who, ...)                                   \
-    if (dtype == PK_BF16) { using T = bf16; __VA_ARGS__ }                  \
-    else if (dtype == PK_F32) { using T = float; __VA_ARGS__ }             \
-    else { PK_CHECK_ARG(false, "%s: dtype %d not supported", who, dtype); }
 
 extern "C" int pk_act_fwd(const void* x, void* out, long long n, int act, int dtype, void* stream) {
     PK_CHECK_ARG(x && out, "pk_act_fwd: null tensor");
@@ -262,7 +258,7 @@ extern "C" int pk_pad_rows(const void* src, int src_dtype, const long long* offs
     dim3 grid((unsigned)((long long)B * Tmax)), block(D >= 256 ? 256 : 64);
     hipStream_t s = (hipStream_t)stream;
 #define PK_PAD(S, T) hipLaunchKernelGGL((pad_rows_kernel<S, T>), grid, block, 0, s, (const S*)src, offsets, (T*)out, Tmax, D)
-    const int key = src_dtype * 10 + out_dtype;  // src: 0 f32, 1 bf16, 2 f16; out: 0 f32, 1 bf16
+    const int key = src_dtype * 10 + out_dtype;  // src / out: 0 f32, 1 bf16, 2 f16
     switch (key) {
         case 0: PK_PAD(float, float); break;
         case 1: PK_PAD(float, bf16); break;
@@ -270,6 +266,9 @@ extern "C" int pk_pad_rows(const void* src, int src_dtype, const long long* offs
         case 11: PK_PAD(bf16, bf16); break;
         case 20: PK_PAD(__half, float); break;
         case 21: PK_PAD(__half, bf16); break;
+        case 2: PK_PAD(float, f16); break;
+        case 12: PK_PAD(bf16, f16); break;
+        case 22: PK_PAD(__half, f16); break;
         default: PK_CHECK_ARG(false, "pk_pad_rows: dtypes (%d -> %d) not supported", src_dtype, out_dtype);
     }
 #undef PK_PAD

@@ -309,10 +309,6 @@ inline bool is_aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
 }  // namespace
 
-#define PK_DTYPE_SWITCH(dtype, who, ...)                                   \
-    if (dtype == PK_BF16) { using T = bf16; __VA_ARGS__ }                  \
-    else if (dtype == PK_F32) { using T = float; __VA_ARGS__ }             \
-    else { PK_CHECK_ARG(false, "%s: dtype %d not supported", who, dtype); }
 
 extern "C" int pk_embed_fwd(const long long* ids, const void* E, const void* pos, void* out, long long ntok, int Tlen,
                             int d, long long V, float scale, int pos_start, float drop_p, unsigned long long seed,
@@ -361,6 +357,9 @@ extern "C" int pk_embed_bwd(const long long* ids, const void* dout, void* dE, vo
     if (dtype == PK_BF16) {
         hipLaunchKernelGGL((f32_to_T_kernel<bf16>), dim3(grid_for(V * d, 1024)), dim3(256), 0, s, acc, (bf16*)dE,
                            V * d);
+        PK_LAUNCH_CHECK();
+    } else if (dtype == PK_F16) {
+        hipLaunchKernelGGL((f32_to_T_kernel<f16>), dim3(grid_for(V * d, 1024)), dim3(256), 0, s, acc, (f16*)dE, V * d);
         PK_LAUNCH_CHECK();
     }
     return 0;

@@ -21,6 +21,7 @@
 // private L2.
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -31,9 +32,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 extern "C" int pk_gemm256_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
                                  long long M, long long N, long long K, long long lda, long long ldb, int a_col,
-                                 int b_col, int kchunk, int splitk, EpiParams ep, void* stream);
+                                 int b_col, int kchunk, int splitk, EpiParams ep, int dtype, void* stream);
 extern "C" int pk_gemm_skinny_launch(const void* A, const void* B, void* C, long long M, long long N, long long K,
-                                     long long lda, long long ldb, EpiParams ep, void* stream);
+                                     long long lda, long long ldb, EpiParams ep, int dtype, void* stream);
 
 namespace {
 
@@ -53,6 +54,7 @@ template <> struct Traits<bf16> {
     static constexpr bool GLDS = true;
     static constexpr int NSTAGE = PK_NS;  // LDS-DMA ring: NSTAGE-1 K-tiles in flight under the MFMAs of the current one
 };
+template <> struct Traits<f16> : Traits<bf16> {};  // same bytes, same tiles; only the MFMA instruction differs
 template <> struct Traits<float> {
     static constexpr int BK = 16, EPV = 4, KSTEP = 2;
     static constexpr bool GLDS = false;
@@ -78,6 +80,7 @@ template <bool COL> struct TileGeom<bf16, COL> {
     }
     __device__ static __forceinline__ int offset(int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); }
 };
+template <bool COL> struct TileGeom<f16, COL> : TileGeom<bf16, COL> {};
 template <bool COL> struct TileGeom<float, COL> {
     static constexpr int ROWS = COL ? 16 : 128, COLS = COL ? 128 : 16;
     static constexpr int PITCH = COL ? 512 : 68;  // row form: 17 words, ds_read_b32 column reads conflict-free
@@ -295,8 +298,7 @@ __device__ __forceinline__ void fast_epilogue(const float* __restrict__ cs, T* _
         if constexpr (sizeof(T) == 2) {
             typedef __attribute__((ext_vector_type(8))) float f32x8;
             f32x8 f = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
-            bf16x8_t h = __builtin_convertvector(f, bf16x8_t);
-            o.raw = __builtin_bit_cast(uint4, h);
+            o.raw = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename H16<T>::vec));
         } else {
             o.raw = make_float4(x[0], x[1], x[2], x[3]);
         }
@@ -393,19 +395,19 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
         if constexpr (sizeof(T) == 2) {
             // fragment reads of k-step kk+1 are issued before the MFMAs of k-step kk (register double buffer)
             constexpr int NKK = TR::BK / TR::KSTEP;
-            bf16x8_t fa[2][2], fb[2][2];
+            typename H16<T>::vec fa[2][2], fb[2][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[0][i] = frag_bf16<A_COL>(sa, wm + 32 * i, 0, lane);
+            for (int i = 0; i < 2; ++i) fa[0][i] = __builtin_bit_cast(typename H16<T>::vec, frag_bf16<A_COL>(sa, wm + 32 * i, 0, lane));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[0][j] = frag_bf16<B_COL>(sb, wn + 32 * j, 0, lane);
+            for (int j = 0; j < 2; ++j) fb[0][j] = __builtin_bit_cast(typename H16<T>::vec, frag_bf16<B_COL>(sb, wn + 32 * j, 0, lane));
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
                 const int cur = kk & 1, nxt = cur ^ 1;
                 if (kk + 1 < NKK) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) fa[nxt][i] = frag_bf16<A_COL>(sa, wm + 32 * i, kk + 1, lane);
+                    for (int i = 0; i < 2; ++i) fa[nxt][i] = __builtin_bit_cast(typename H16<T>::vec, frag_bf16<A_COL>(sa, wm + 32 * i, kk + 1, lane));
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) fb[nxt][j] = frag_bf16<B_COL>(sb, wn + 32 * j, kk + 1, lane);
+                    for (int j = 0; j < 2; ++j) fb[nxt][j] = __builtin_bit_cast(typename H16<T>::vec, frag_bf16<B_COL>(sb, wn + 32 * j, kk + 1, lane));
                 }
 #if defined(PK_ABLATE) && PK_ABLATE == 2
 #pragma unroll
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = H16<T>::mfma(fa[cur][i], fb[cur][j], acc[i][j]);
 #endif
             }
         } else {
@@ -462,14 +464,14 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
             // Software pipeline across K-tiles: the fragments of (tile t+1, k-step 0) are read from LDS — and the DMA of
             // tile t+2 is issued — BEFORE the last 4 MFMAs of tile t, right behind the one barrier per tile, so neither the
             // LDS read latency nor the DMA issue sits in front of a tile's first MFMA.
-            bf16x8_t fa[2][2], fb[2][2];
+            typename H16<T>::vec fa[2][2], fb[2][2];
             dma(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[0][i] = frag_bf16<A_COL>(smem, wm + 32 * i, 0, lane);
+            for (int i = 0; i < 2; ++i) fa[0][i] = __builtin_bit_cast(typename H16<T>::vec, frag_bf16<A_COL>(smem, wm + 32 * i, 0, lane));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[0][j] = frag_bf16<B_COL>(smem + GA::BYTES, wn + 32 * j, 0, lane);
+            for (int j = 0; j < 2; ++j) fb[0][j] = __builtin_bit_cast(typename H16<T>::vec, frag_bf16<B_COL>(smem + GA::BYTES, wn + 32 * j, 0, lane));
             if (nk_dma > 1) dma(1);
             for (int kt = 0; kt < nk_dma; ++kt) {
                 const char* sa = smem + (kt & 1) * STAGE;
@@ -492,18 +494,18 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
                     const int cur = kk & 1, nxt = cur ^ 1;
                     if (kk + 1 < NKK) {
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) fa[nxt][i] = frag_bf16<A_COL>(sa, wm + 32 * i, kk + 1, lane);
+                        for (int i = 0; i < 2; ++i) fa[nxt][i] = __builtin_bit_cast(typename H16<T>::vec, frag_bf16<A_COL>(sa, wm + 32 * i, kk + 1, lane));
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) fb[nxt][j] = frag_bf16<B_COL>(sb, wn + 32 * j, kk + 1, lane);
+                        for (int j = 0; j < 2; ++j) fb[nxt][j] = __builtin_bit_cast(typename H16<T>::vec, frag_bf16<B_COL>(sb, wn + 32 * j, kk + 1, lane));
                     } else if (kt + 1 < nk_dma) {
                         // every LDS read of tile kt has returned, my pieces of tile kt+1 have landed
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                         const char* na = smem + ((kt + 1) & 1) * STAGE;
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) fa[nxt][i] = frag_bf16<A_COL>(na, wm + 32 * i, 0, lane);
+                        for (int i = 0; i < 2; ++i) fa[nxt][i] = __builtin_bit_cast(typename H16<T>::vec, frag_bf16<A_COL>(na, wm + 32 * i, 0, lane));
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) fb[nxt][j] = frag_bf16<B_COL>(na + GA::BYTES, wn + 32 * j, 0, lane);
+                        for (int j = 0; j < 2; ++j) fb[nxt][j] = __builtin_bit_cast(typename H16<T>::vec, frag_bf16<B_COL>(na + GA::BYTES, wn + 32 * j, 0, lane));
 #if !defined(PK_ABLATE) || PK_ABLATE != 1
                         if (kt + 2 < nk_dma) dma(kt + 2);  // into the stage tile kt just vacated
 #endif
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = H16<T>::mfma(fa[cur][i], fb[cur][j], acc[i][j]);
                 }
             }
             __syncthreads();
@@ -735,6 +737,7 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
     if (aligned(B, ldb)) flags |= 2;
     if (aligned(C, ep.ldc) && (!ep.preact || aligned(ep.preact, ep.ldpre))) flags |= 4;
     if (ep.aux && aligned(ep.aux, ep.ldaux)) flags |= 8;
+    constexpr int dtype16 = std::is_same<T, f16>::value ? PK_F16 : PK_BF16;  // (meaningful for the 16-bit types)
     int nt = (int)(((M + BM - 1) / BM) * ((N + BN - 1) / BN));
     int kchunk = (int)K;
     float* ws = nullptr;
@@ -743,7 +746,7 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         static const bool no_skinny = getenv("PK_GEMM_NO_SKINNY") != nullptr;
         // (every 64-row block re-reads its weight columns: only while that is cheaper than a tiled kernel's latency)
         if (!a_col && !b_col && (M <= 64 || (M <= 256 && N <= 8192)) && splitk <= 1 && !asum_out && !no_skinny) {
-            int rc = pk_gemm_skinny_launch(A, B, C, M, N, K, lda, ldb, ep, stream);
+            int rc = pk_gemm_skinny_launch(A, B, C, M, N, K, lda, ldb, ep, dtype16, stream);
             if (rc != 0) return rc == 1 ? 0 : rc;  // 1 = launched, 0 = not eligible, anything else = error
         }
         // 256x256-tile kernel (gemm256.hip): LDS-DMA only, so it needs 16-byte addressable operands, K in whole 64-tiles
@@ -774,9 +777,9 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
             if (sk > 0 && (tile_pref == 256 || fills)) {
                 float* w2 = sk > 1 ? (float*)workspace : nullptr;
                 float* asw = (sk > 1 && asum_out) ? w2 + (size_t)sk * M * N : nullptr;
-                GemmSample* sm = timing_begin(256, a_col, b_col, std::max(sk, 1), PK_BF16, M, N, K, stream);
+                GemmSample* sm = timing_begin(256, a_col, b_col, std::max(sk, 1), dtype16, M, N, K, stream);
                 int rc = pk_gemm256_launch(A, B, C, w2, asw, asum_out, M, N, K, lda, ldb, a_col, b_col, (int)per,
-                                           std::max(sk, 1), ep, stream);
+                                           std::max(sk, 1), ep, dtype16, stream);
                 timing_end(sm, stream);
                 if (rc != 1) return rc;
                 if (w2) {
@@ -812,7 +815,7 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
 #define PK_LAUNCH(AC, BC) \
     hipLaunchKernelGGL((gemm_kernel<T, AC, BC>), grid, block, 0, stream, a, b, c, ws, asum_ws, (T*)asum_out, M, N, K, \
                        lda, ldb, kchunk, ep, flags)
-    GemmSample* sm = timing_begin(128, a_col, b_col, splitk, sizeof(T) == 2 ? PK_BF16 : PK_F32, M, N, K, stream);
+    GemmSample* sm = timing_begin(128, a_col, b_col, splitk, sizeof(T) == 4 ? PK_F32 : dtype16, M, N, K, stream);
     if (!a_col && !b_col) PK_LAUNCH(false, false);
     else if (!a_col && b_col) PK_LAUNCH(false, true);
     else if (a_col && !b_col) PK_LAUNCH(true, false);
@@ -840,7 +843,7 @@ extern "C" int pk_gemm(const void* A, const void* B, void* C, const void* bias, 
     PK_CHECK_ARG(A && B && C, "pk_gemm: null operand");
     PK_CHECK_ARG(!asum_out || a_col, "pk_gemm: asum_out (fused bias gradient) needs A in col form");
     PK_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "pk_gemm: negative size");
-    PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16, "pk_gemm: dtype %d not supported", dtype);
+    PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16 || dtype == PK_F16, "pk_gemm: dtype %d not supported", dtype);
     PK_CHECK_ARG(mode >= 0 && mode <= 3, "pk_gemm: bad epilogue mode %d", mode);
     PK_CHECK_ARG(mode == 0 || aux, "pk_gemm: epilogue mode %d needs aux", mode);
     PK_CHECK_ARG(((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31), "pk_gemm: too many tiles");
@@ -852,6 +855,8 @@ extern "C" int pk_gemm(const void* A, const void* B, void* C, const void* bias, 
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PK_BF16)
         return launch_gemm<bf16>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
+    if (dtype == PK_F16)
+        return launch_gemm<f16>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
     return launch_gemm<float>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
 }
 

@@ -80,15 +80,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 }
 
 // one 64-row pass of the epilogue: thread t owns 16-byte chunk t % 32 of rows t / 32 + 16*it
-template <int ACT, int MODE, int NW>
-__device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, bf16* __restrict__ C, const EpiParams& ep,
+template <typename T, int ACT, int MODE, int NW>
+__device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, T* __restrict__ C, const EpiParams& ep,
                                               long long mh, long long n0, long long M, long long N, int tid) {
     const int col = (tid & 31) * 8, r0 = tid >> 5;
     const long long gn = n0 + col;
     if (gn + 8 > N) return;
     float b[8];
     if (MODE != 2 && ep.bias) {
-        Vec16<bf16> bv = load16<bf16>(reinterpret_cast<const bf16*>(ep.bias) + gn);
+        Vec16<T> bv = load16<T>(reinterpret_cast<const T*>(ep.bias) + gn);
 #pragma unroll
         for (int e = 0; e < 8; ++e) b[e] = bv.get(e);
     } else {
@@ -97,12 +97,12 @@ __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, bf16
     }
     const float alpha = ep.alpha;
     constexpr int RS = NW * 2, NIT = 64 / RS;  // rows per sweep of the workgroup, sweeps per 64-row pass
-    Vec16<bf16> av[NIT];
+    Vec16<T> av[NIT];
     if (MODE != 0) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const long long gm = mh + r0 + RS * it;
-            if (gm < M) av[it] = load16<bf16>(reinterpret_cast<const bf16*>(ep.aux) + gm * ep.ldaux + gn);
+            if (gm < M) av[it] = load16<T>(reinterpret_cast<const T*>(ep.aux) + gm * ep.ldaux + gn);
         }
     }
 #pragma unroll
@@ -126,18 +126,18 @@ __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, bf16
         }
         typedef __attribute__((ext_vector_type(8))) float f32x8;
         f32x8 f = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
-        Vec16<bf16> o;
-        o.raw = __builtin_bit_cast(uint4, __builtin_convertvector(f, bf16x8_t));
-        store16<bf16>(C + gm * ep.ldc + gn, o);
+        Vec16<T> o;
+        o.raw = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename H16<T>::vec));
+        store16<T>(C + gm * ep.ldc + gn, o);
     }
 }
 
 // everything after the K loop (all LDS stages are free): fused bias-gradient column sums, then four 64-row passes of the
 // accumulators through the fp32 staging buffer with the fused epilogue (or raw split-K slabs)
-template <bool A_COL, int NW>
+template <typename T, bool A_COL, int NW>
 __device__ __forceinline__ void finish_tile(char* smem, f32x16 (&acc)[4][16 / NW], float (&asum)[8], bool do_asum,
-                                            bf16* __restrict__ C, float* __restrict__ ws, float* __restrict__ asum_ws,
-                                            bf16* __restrict__ asum_out, long long M, long long N, long long m0,
+                                            T* __restrict__ C, float* __restrict__ ws, float* __restrict__ asum_ws,
+                                            T* __restrict__ asum_out, long long M, long long N, long long m0,
                                             long long n0, int kslab, const EpiParams& ep) {
     constexpr int WAVES_N = NW / 2, TJ = 16 / NW, RS = NW * 2, NIT = 64 / RS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -153,7 +153,7 @@ __device__ __forceinline__ void finish_tile(char* smem, f32x16 (&acc)[4][16 / NW
 #pragma unroll
                 for (int r = 0; r < RS; ++r) s += red[r * BM + tid];
                 if (asum_ws) asum_ws[(long long)kslab * M + m0 + tid] = s;
-                else asum_out[m0 + tid] = __float2bfloat16(s);
+                else asum_out[m0 + tid] = from_f32<T>(s);
             }
             __syncthreads();
         }
@@ -192,23 +192,23 @@ __device__ __forceinline__ void finish_tile(char* smem, f32x16 (&acc)[4][16 / NW
                 }
             }
         } else if (ep.mode == 0) {
-            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 0, NW>(cs, C, ep, mh, n0, M, N, tid);
-            else epilogue_pass<PK_ACT_NONE, 0, NW>(cs, C, ep, mh, n0, M, N, tid);
+            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 0, NW>(cs, C, ep, mh, n0, M, N, tid);
+            else epilogue_pass<T, PK_ACT_NONE, 0, NW>(cs, C, ep, mh, n0, M, N, tid);
         } else if (ep.mode == 1) {
-            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 1, NW>(cs, C, ep, mh, n0, M, N, tid);
-            else epilogue_pass<PK_ACT_NONE, 1, NW>(cs, C, ep, mh, n0, M, N, tid);
+            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 1, NW>(cs, C, ep, mh, n0, M, N, tid);
+            else epilogue_pass<T, PK_ACT_NONE, 1, NW>(cs, C, ep, mh, n0, M, N, tid);
         } else {
-            if (ep.act == PK_ACT_RELU) epilogue_pass<PK_ACT_RELU, 2, NW>(cs, C, ep, mh, n0, M, N, tid);
-            else epilogue_pass<PK_ACT_NONE, 2, NW>(cs, C, ep, mh, n0, M, N, tid);
+            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 2, NW>(cs, C, ep, mh, n0, M, N, tid);
+            else epilogue_pass<T, PK_ACT_NONE, 2, NW>(cs, C, ep, mh, n0, M, N, tid);
         }
         if (p < 3) __syncthreads();
     }
 }
 
-template <bool A_COL, bool B_COL, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
-                                                        bf16* __restrict__ C, float* __restrict__ ws,
-                                                        float* __restrict__ asum_ws, bf16* __restrict__ asum_out,
+template <typename T, bool A_COL, bool B_COL, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm256_kernel(const T* __restrict__ A, const T* __restrict__ B,
+                                                        T* __restrict__ C, float* __restrict__ ws,
+                                                        float* __restrict__ asum_ws, T* __restrict__ asum_out,
                                                         long long M, long long N, long long K, long long lda,
                                                         long long ldb, int kchunk, EpiParams ep) {
     using GA = G2<A_COL>;
@@ -249,20 +249,20 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
     auto dma = [&](int kt) {
         long long k0 = kbeg + (long long)kt * BK;
         char* s = smem + (kt & 1) * STAGE;
-        if constexpr (A_COL) tile_glds<true, NW>(s, A, lda, k0, m0, kend, M, wave, lane);
-        else tile_glds<false, NW>(s, A, lda, m0, k0, M, kend, wave, lane);
-        if constexpr (B_COL) tile_glds<true, NW>(s + OP_BYTES, B, ldb, k0, n0, kend, N, wave, lane);
-        else tile_glds<false, NW>(s + OP_BYTES, B, ldb, n0, k0, N, kend, wave, lane);
+        if constexpr (A_COL) tile_glds<true, NW>(s, (const bf16*)A, lda, k0, m0, kend, M, wave, lane);
+        else tile_glds<false, NW>(s, (const bf16*)A, lda, m0, k0, M, kend, wave, lane);
+        if constexpr (B_COL) tile_glds<true, NW>(s + OP_BYTES, (const bf16*)B, ldb, k0, n0, kend, N, wave, lane);
+        else tile_glds<false, NW>(s + OP_BYTES, (const bf16*)B, ldb, n0, k0, N, kend, wave, lane);
     };
     if (nk > 0) {
-        bf16x8_t fa[2][4], fb[2][TJ];
+        typename H16<T>::vec fa[2][4], fb[2][TJ];
         dma(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[0][i] = frag<A_COL>(smem, wm + 32 * i, 0, lane);
+        for (int i = 0; i < 4; ++i) fa[0][i] = __builtin_bit_cast(typename H16<T>::vec, frag<A_COL>(smem, wm + 32 * i, 0, lane));
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) fb[0][j] = frag<B_COL>(smem + OP_BYTES, wn + 32 * j, 0, lane);
+        for (int j = 0; j < TJ; ++j) fb[0][j] = __builtin_bit_cast(typename H16<T>::vec, frag<B_COL>(smem + OP_BYTES, wn + 32 * j, 0, lane));
         if (nk > 1) dma(1);
         // One K-tile.  NEXT: another tile follows (barrier + its first fragments behind this tile's k-step NKK-2);
         // DMA: the tile after that is still to be issued.  Compile-time flags keep every k-step in one basic block,
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
                 if (do_asum) {  // thread owns column chunk tid % 32 of the [64][256] A tile, rows tid / 32 + RS i
 #pragma unroll
                     for (int i = 0; i < NIT; ++i) {
-                        Vec16<bf16> v;
+                        Vec16<T> v;
                         v.raw = *reinterpret_cast<const uint4*>(sa + GA::offset((tid >> 5) + RS * i, tid & 31));
 #pragma unroll
                         for (int e = 0; e < 8; ++e) asum[e] += v.get(e);
@@ -287,17 +287,17 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
                 const int cur = kk & 1, nxt = cur ^ 1;
                 if (kk + 1 < NKK) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) fa[nxt][i] = frag<A_COL>(sa, wm + 32 * i, kk + 1, lane);
+                    for (int i = 0; i < 4; ++i) fa[nxt][i] = __builtin_bit_cast(typename H16<T>::vec, frag<A_COL>(sa, wm + 32 * i, kk + 1, lane));
 #pragma unroll
-                    for (int j = 0; j < TJ; ++j) fb[nxt][j] = frag<B_COL>(sb, wn + 32 * j, kk + 1, lane);
+                    for (int j = 0; j < TJ; ++j) fb[nxt][j] = __builtin_bit_cast(typename H16<T>::vec, frag<B_COL>(sb, wn + 32 * j, kk + 1, lane));
                 } else if constexpr (NEXT) {
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile kt+1 landed, LDS reads returned
                     __builtin_amdgcn_s_barrier();
                     const char* na = smem + ((kt + 1) & 1) * STAGE;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) fa[nxt][i] = frag<A_COL>(na, wm + 32 * i, 0, lane);
+                    for (int i = 0; i < 4; ++i) fa[nxt][i] = __builtin_bit_cast(typename H16<T>::vec, frag<A_COL>(na, wm + 32 * i, 0, lane));
 #pragma unroll
-                    for (int j = 0; j < TJ; ++j) fb[nxt][j] = frag<B_COL>(na + OP_BYTES, wn + 32 * j, 0, lane);
+                    for (int j = 0; j < TJ; ++j) fb[nxt][j] = __builtin_bit_cast(typename H16<T>::vec, frag<B_COL>(na + OP_BYTES, wn + 32 * j, 0, lane));
 #if !defined(PK_ABLATE256) || PK_ABLATE256 != 1
                     if constexpr (DMA) dma(kt + 2);
 #endif
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = H16<T>::mfma(fa[cur][i], fb[cur][j], acc[i][j]);
 #ifndef PK_NO_SCHED
                 // Instruction order of this k-step, pinned: hipcc otherwise sinks the next step's fragment reads to
                 // just in front of their first use (lgkmcnt(0) then stalls every wave for an LDS round trip, several
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
     }
     __syncthreads();
 
-    finish_tile<A_COL, NW>(smem, acc, asum, do_asum, C, ws, asum_ws, asum_out, M, N, m0, n0, kslab, ep);
+    finish_tile<T, A_COL, NW>(smem, acc, asum, do_asum, C, ws, asum_ws, asum_out, M, N, m0, n0, kslab, ep);
 }
 
 }  // namespace
@@ -347,29 +347,30 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const bf16* __restrict
 // uses the 128x128 kernel), or a negative / hip error code.
 extern "C" int pk_gemm256_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
                                  long long M, long long N, long long K, long long lda, long long ldb, int a_col,
-                                 int b_col, int kchunk, int splitk, EpiParams ep, void* stream) {
+                                 int b_col, int kchunk, int splitk, EpiParams ep, int dtype, void* stream) {
     // 8 waves of 128x64 (default), or 4 waves of 128x128 with the accumulators in AGPRs (PK_GEMM256_NW=4): half the LDS
     // fragment traffic per MFMA but half the waves to hide prologue / epilogue.  Measured: K = 2048 row,row 887 vs 811
     // TFLOP/s in isolation, K = 512 shapes and col-form operands 5-10 % slower, no difference in the training step.
     static const int nw = getenv("PK_GEMM256_NW") ? atoi(getenv("PK_GEMM256_NW")) : 8;
     dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN) * splitk)), block(nw * 64);
     hipStream_t s = (hipStream_t)stream;
-    const bf16* a = (const bf16*)A;
-    const bf16* b = (const bf16*)B;
-#define PK_L(AC, BC)                                                                                                  \
-    do {                                                                                                              \
-        if (nw == 4)                                                                                                  \
-            hipLaunchKernelGGL((gemm256_kernel<AC, BC, 4>), grid, block, 0, s, a, b, (bf16*)C, ws, asum_ws,           \
-                               (bf16*)asum_out, M, N, K, lda, ldb, kchunk, ep);                                       \
-        else                                                                                                          \
-            hipLaunchKernelGGL((gemm256_kernel<AC, BC, 8>), grid, block, 0, s, a, b, (bf16*)C, ws, asum_ws,           \
-                               (bf16*)asum_out, M, N, K, lda, ldb, kchunk, ep);                                       \
+#define PK_K(TT, AC, BC, W)                                                                                        \
+    hipLaunchKernelGGL((gemm256_kernel<TT, AC, BC, W>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, ws,  \
+                       asum_ws, (TT*)asum_out, M, N, K, lda, ldb, kchunk, ep)
+#define PK_L(AC, BC)                                                       \
+    do {                                                                   \
+        if (dtype == PK_F16) {                                             \
+            if (nw == 4) PK_K(f16, AC, BC, 4); else PK_K(f16, AC, BC, 8);  \
+        } else {                                                           \
+            if (nw == 4) PK_K(bf16, AC, BC, 4); else PK_K(bf16, AC, BC, 8); \
+        }                                                                  \
     } while (0)
     if (!a_col && !b_col) PK_L(false, false);
     else if (!a_col && b_col) PK_L(false, true);
     else if (a_col && !b_col) PK_L(true, false);
     else PK_L(true, true);
 #undef PK_L
+#undef PK_K
     PK_LAUNCH_CHECK();
     return 1;
 }

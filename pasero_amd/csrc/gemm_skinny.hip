@@ -12,21 +12,21 @@
 #include "common.h"
 #include "gemm_epi.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
 namespace {
 
 constexpr int SK_BM = 64, SK_BN = 32, SK_WAVES = 4, SK_PITCH = SK_BN + 1;
 
-__device__ __forceinline__ bf16x8_t ldfrag(const bf16* __restrict__ p, bool ok) {
+template <typename T>
+__device__ __forceinline__ typename H16<T>::vec ldfrag(const T* __restrict__ p, bool ok) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (ok) v = *reinterpret_cast<const uint4*>(p);
-    return __builtin_bit_cast(bf16x8_t, v);
+    return __builtin_bit_cast(typename H16<T>::vec, v);
 }
 
-template <int ACT, int MODE>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
-                                                          bf16* __restrict__ C, long long M, long long N, long long K,
+template <typename T, int ACT, int MODE>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                          T* __restrict__ C, long long M, long long N, long long K,
                                                           long long lda, long long ldb, EpiParams ep) {
     __shared__ float red[SK_WAVES][SK_BM][SK_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -34,15 +34,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
     const long long n0 = (long long)blockIdx.x * SK_BN, m0 = (long long)blockIdx.y * SK_BM;
     const long long kq = K / SK_WAVES, kb = wave * kq;  // the launcher guarantees K % 64 == 0
     const bool okb = n0 + r < N, oka0 = m0 + r < M, oka1 = m0 + 32 + r < M;
-    const bf16* pa0 = A + (m0 + r) * lda + kb + 8 * h;
-    const bf16* pa1 = pa0 + 32 * lda;
-    const bf16* pb = W + (n0 + r) * ldb + kb + 8 * h;
+    const T* pa0 = A + (m0 + r) * lda + kb + 8 * h;
+    const T* pa1 = pa0 + 32 * lda;
+    const T* pb = W + (n0 + r) * ldb + kb + 8 * h;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
     constexpr int U = 8;  // k-steps per batch: 24 x 16-byte loads per lane in flight
     for (long long k = 0; k < kq; k += 16 * U) {
-        bf16x8_t fa0[U], fa1[U], fb[U];
+        typename H16<T>::vec fa0[U], fa1[U], fb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool in = k + 16 * u < kq;
@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[u], fb[u], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[u], fb[u], acc1, 0, 0, 0);
+            acc0 = H16<T>::mfma(fa0[u], fb[u], acc0);
+            acc1 = H16<T>::mfma(fa1[u], fb[u], acc1);
         }
     }
 #pragma unroll
@@ -71,23 +71,23 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e)
         v[e] = (red[0][row][c0 + e] + red[1][row][c0 + e]) + (red[2][row][c0 + e] + red[3][row][c0 + e]);
-    Vec16<bf16> bv, av;
+    Vec16<T> bv, av;
     const bool full = gn + 8 <= N;
-    if (ep.bias && full) bv = load16<bf16>(reinterpret_cast<const bf16*>(ep.bias) + gn);
-    if (MODE == 1 && full) av = load16<bf16>(reinterpret_cast<const bf16*>(ep.aux) + gm * ep.ldaux + gn);
-    Vec16<bf16> o;
+    if (ep.bias && full) bv = load16<T>(reinterpret_cast<const T*>(ep.bias) + gn);
+    if (MODE == 1 && full) av = load16<T>(reinterpret_cast<const T*>(ep.aux) + gm * ep.ldaux + gn);
+    Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float y = v[e] * ep.alpha;
-        if (ep.bias) y += full ? bv.get(e) : (gn + e < N ? to_f32(reinterpret_cast<const bf16*>(ep.bias)[gn + e]) : 0.f);
+        if (ep.bias) y += full ? bv.get(e) : (gn + e < N ? to_f32(reinterpret_cast<const T*>(ep.bias)[gn + e]) : 0.f);
         y = act_fwd(ACT, y);
-        if (MODE == 1) y += full ? av.get(e) : (gn + e < N ? to_f32(reinterpret_cast<const bf16*>(ep.aux)[gm * ep.ldaux + gn + e]) : 0.f);
+        if (MODE == 1) y += full ? av.get(e) : (gn + e < N ? to_f32(reinterpret_cast<const T*>(ep.aux)[gm * ep.ldaux + gn + e]) : 0.f);
         o.set(e, y);
     }
     if (full) {
-        store16<bf16>(C + gm * ep.ldc + gn, o);
+        store16<T>(C + gm * ep.ldc + gn, o);
     } else {
-        for (int e = 0; e < 8 && gn + e < N; ++e) C[gm * ep.ldc + gn + e] = from_f32<bf16>(o.get(e));
+        for (int e = 0; e < 8 && gn + e < N; ++e) C[gm * ep.ldc + gn + e] = from_f32<T>(o.get(e));
     }
 }
 
@@ -95,19 +95,22 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
 
 // Returns 1 if launched, 0 if the call is not eligible (the caller falls through to the tiled kernels).
 extern "C" int pk_gemm_skinny_launch(const void* A, const void* B, void* C, long long M, long long N, long long K,
-                                     long long lda, long long ldb, EpiParams ep, void* stream) {
+                                     long long lda, long long ldb, EpiParams ep, int dtype, void* stream) {
     const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) && lda % 8 == 0 &&
                          ldb % 8 == 0 && ep.ldc % 8 == 0 && (!ep.bias || (uintptr_t)ep.bias % 16 == 0) &&
                          (ep.mode != 1 || ((uintptr_t)ep.aux % 16 == 0 && ep.ldaux % 8 == 0));
     if (!aligned || M > 256 || K % 64 != 0 || K <= 0 || ep.preact || ep.mode > 1) return 0;
     dim3 grid((unsigned)((N + SK_BN - 1) / SK_BN), (unsigned)((M + SK_BM - 1) / SK_BM)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    const bf16* a = (const bf16*)A;
-    const bf16* b = (const bf16*)B;
-#define SK_L(ACT)                                                                                                    \
-    do {                                                                                                             \
-        if (ep.mode == 0) hipLaunchKernelGGL((gemm_skinny_kernel<ACT, 0>), grid, block, 0, s, a, b, (bf16*)C, M, N, K, lda, ldb, ep); \
-        else hipLaunchKernelGGL((gemm_skinny_kernel<ACT, 1>), grid, block, 0, s, a, b, (bf16*)C, M, N, K, lda, ldb, ep);              \
+#define SK_T(TT, ACT, MD) \
+    hipLaunchKernelGGL((gemm_skinny_kernel<TT, ACT, MD>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, M, N, K, lda, ldb, ep)
+#define SK_L(ACT)                                                       \
+    do {                                                                \
+        if (dtype == PK_F16) {                                          \
+            if (ep.mode == 0) SK_T(f16, ACT, 0); else SK_T(f16, ACT, 1); \
+        } else {                                                        \
+            if (ep.mode == 0) SK_T(bf16, ACT, 0); else SK_T(bf16, ACT, 1); \
+        }                                                               \
     } while (0)
     switch (ep.act) {
         case PK_ACT_NONE: SK_L(PK_ACT_NONE); break;
@@ -118,6 +121,7 @@ extern "C" int pk_gemm_skinny_launch(const void* A, const void* B, void* C, long
         default: return 0;
     }
 #undef SK_L
+#undef SK_T
     PK_LAUNCH_CHECK();
     return 1;
 }

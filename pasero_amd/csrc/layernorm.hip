@@ -355,6 +355,8 @@ extern "C" int pk_residual_ln_fwd(const void* x, const void* residual, const voi
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PK_BF16)
         return launch_fwd<bf16>(x, residual, gamma, beta, z_out, y_out, mean, rstd, rows, d, eps, drop_p, seed, offset, s);
+    if (dtype == PK_F16)
+        return launch_fwd<f16>(x, residual, gamma, beta, z_out, y_out, mean, rstd, rows, d, eps, drop_p, seed, offset, s);
     if (dtype == PK_F32)
         return launch_fwd<float>(x, residual, gamma, beta, z_out, y_out, mean, rstd, rows, d, eps, drop_p, seed, offset, s);
     PK_CHECK_ARG(false, "pk_residual_ln_fwd: dtype %d not supported", dtype);
@@ -379,6 +381,9 @@ extern "C" int pk_residual_ln_bwd(const void* dy, const void* dz_extra, const vo
     if (dtype == PK_BF16)
         return launch_bwd<bf16>(dy, dz_extra, z, gamma, mean, rstd, dres_out, dx_out, dgamma, dbeta, (float*)workspace,
                                 ws_bytes, rows, d, drop_p, seed, offset, s);
+    if (dtype == PK_F16)
+        return launch_bwd<f16>(dy, dz_extra, z, gamma, mean, rstd, dres_out, dx_out, dgamma, dbeta, (float*)workspace,
+                               ws_bytes, rows, d, drop_p, seed, offset, s);
     if (dtype == PK_F32)
         return launch_bwd<float>(dy, dz_extra, z, gamma, mean, rstd, dres_out, dx_out, dgamma, dbeta,
                                  (float*)workspace, ws_bytes, rows, d, drop_p, seed, offset, s);

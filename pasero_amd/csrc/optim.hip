@@ -110,6 +110,7 @@ extern "C" int pk_mt_sqnorm(const long long* table, int ntensors, const int* chu
     MTList L = make_list(table, ntensors, chunk_tensor, chunk_start);
     if (nchunks > 0) {
         if (dtype == PK_BF16) hipLaunchKernelGGL((mt_sqnorm_kernel<bf16>), dim3(nchunks), dim3(256), 0, s, L, partial);
+        else if (dtype == PK_F16) hipLaunchKernelGGL((mt_sqnorm_kernel<f16>), dim3(nchunks), dim3(256), 0, s, L, partial);
         else if (dtype == PK_F32) hipLaunchKernelGGL((mt_sqnorm_kernel<float>), dim3(nchunks), dim3(256), 0, s, L, partial);
         else PK_CHECK_ARG(false, "pk_mt_sqnorm: dtype %d not supported", dtype);
         PK_LAUNCH_CHECK();
@@ -132,6 +133,9 @@ extern "C" int pk_mt_adam(const long long* table, int ntensors, const int* chunk
     MTList L = make_list(table, ntensors, chunk_tensor, chunk_start);
     if (dtype == PK_BF16)
         hipLaunchKernelGGL((mt_adam_kernel<bf16>), dim3(nchunks), dim3(256), 0, s, L, gnorm, scale, max_norm, lr, beta1,
+                           beta2, eps, weight_decay, bc1, bc2_sqrt);
+    else if (dtype == PK_F16)
+        hipLaunchKernelGGL((mt_adam_kernel<f16>), dim3(nchunks), dim3(256), 0, s, L, gnorm, scale, max_norm, lr, beta1,
                            beta2, eps, weight_decay, bc1, bc2_sqrt);
     else if (dtype == PK_F32)
         hipLaunchKernelGGL((mt_adam_kernel<float>), dim3(nchunks), dim3(256), 0, s, L, gnorm, scale, max_norm, lr,

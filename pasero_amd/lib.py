@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PASERO_HIP_LIB') or os.path.join(_HERE, 'libpasero_hip.so')  # env: diagnostic builds
 
-PK_F32, PK_BF16 = 0, 1
+PK_F32, PK_BF16, PK_F16 = 0, 1, 2
 ACT = {'none': 0, None: 0, 'relu': 1, 'gelu': 2, 'gelu_tanh': 3, 'geglu': 3, 'swiglu': 4, 'silu': 4}
 
 P, I, F, LL, SZ, ULL = c_void_p, c_int, c_float, c_longlong, c_size_t, c_ulonglong
@@ -90,7 +90,9 @@ def dtype_code(t: torch.Tensor) -> int:
         return PK_F32
     if t.dtype == torch.bfloat16:
         return PK_BF16
-    raise TypeError(f'pasero_amd kernels support float32 and bfloat16, got {t.dtype}')
+    if t.dtype == torch.float16:
+        return PK_F16
+    raise TypeError(f'pasero_amd kernels support float32, bfloat16 and float16, got {t.dtype}')
 
 
 def ptr(t):
