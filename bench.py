@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='c2_base_bf16', choices=list(WORKLOADS))
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--force-ddp', action='store_true',
                     help='rehearsal: run the bucketed all-reduce path even on one rank (exercises RCCL on a 1-GPU box)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' to rehearse)")
@@ -216,7 +216,7 @@ def main():
 
     cfg_name, V, B, S, T = WORKLOADS[args.workload]
     cfg = getattr(C, cfg_name)()  # dropout 0.1, label smoothing 0.1: the training configuration
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
     torch.manual_seed(1234)  # identical random-init weights on every rank
     model = Transformer(cfg, C.DistributedConfig(dp_size=world, dp_rank=rank), C.SyntheticTask(V))
     model = model.to(dtype).to(device)

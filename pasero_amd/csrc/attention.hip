@@ -260,11 +260,18 @@ template <int P> __device__ __forceinline__ int lds_off(int row, int ch) {
         return row * P + ch * 16;
 }
 constexpr int KT = 64;       // rows (keys or queries) staged per LDS tile
+// T = bf16 or f16: fragments travel as raw 8 x 16-bit vectors; only the MFMA instruction and the conversions differ
+template <typename T>
+__device__ __forceinline__ f32x16 mm(bf16x8_t a, bf16x8_t b, f32x16 c) {
+    typedef typename H16<T>::vec V;
+    return H16<T>::mfma(__builtin_bit_cast(V, a), __builtin_bit_cast(V, b), c);
+}
 // A [64 rows][head_dim] tile is head_dim / 64 images side by side (each 64 columns wide, laid out as above)
 template <int P> constexpr int img_bytes() { return KT * (P == DUAL ? 128 : P); }
 
 // stage a [64 rows][64 cols] bf16 tile (rows r0.., row limit `lim`, zero fill) into LDS with the given pitch
-__device__ __forceinline__ void stage_tile(char* lds, int pitch, const bf16* __restrict__ base, long long rs, int r0,
+template <typename T>
+__device__ __forceinline__ void stage_tile(char* lds, int pitch, const T* __restrict__ base, long long rs, int r0,
                                            int lim, int tid) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -277,8 +284,8 @@ __device__ __forceinline__ void stage_tile(char* lds, int pitch, const bf16* __r
 }
 
 // the same in two halves, so the next tile's global loads fly under the current tile's MFMAs
-template <int NR>  // NR = 2 * head_dim / 64 chunks of 16 B per thread
-__device__ __forceinline__ void tile_g2r(uint4 (&regs)[NR], const bf16* __restrict__ base, long long rs, int r0, int lim,
+template <int NR, typename T>  // NR = 2 * head_dim / 64 chunks of 16 B per thread
+__device__ __forceinline__ void tile_g2r(uint4 (&regs)[NR], const T* __restrict__ base, long long rs, int r0, int lim,
                                          int tid) {
     constexpr int CPR = 4 * NR;  // 16-B chunks per row
 #pragma unroll
@@ -321,17 +328,18 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* lds, int row0, int s, in
     return __builtin_bit_cast(bf16x8_t, f);
 }
 // accumulator registers 8s..8s+7 of a 32x32 tile -> bf16 B/A operand of k-step s
+template <typename T>
 __device__ __forceinline__ bf16x8_t acc_frag(const f32x16& a, int s) {
     s16x8 f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (short)f2bf(a[8 * s + j]);
+    for (int j = 0; j < 8; ++j) f[j] = (short)H16<T>::bits(a[8 * s + j]);
     return __builtin_bit_cast(bf16x8_t, f);
 }
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // global row fragment (rows beyond `lim` read as zero): lane (r, h) row row0 + r, d = 16kk + 8h .. +7
-template <int NF>
-__device__ __forceinline__ void load_row_frags(bf16x8_t (&f)[NF], const bf16* __restrict__ base, long long rs, int row,
+template <int NF, typename T>
+__device__ __forceinline__ void load_row_frags(bf16x8_t (&f)[NF], const T* __restrict__ base, long long rs, int row,
                                                bool valid, int lane) {
 #pragma unroll
     for (int kk = 0; kk < NF; ++kk) {
@@ -341,17 +349,18 @@ __device__ __forceinline__ void load_row_frags(bf16x8_t (&f)[NF], const bf16* __
     }
 }
 
+template <typename T>
 __device__ __forceinline__ float frag_dot(const bf16x8_t& a, const bf16x8_t& b) {
     s16x8 x = __builtin_bit_cast(s16x8, a), y = __builtin_bit_cast(s16x8, b);
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += bf2f((unsigned short)x[j]) * bf2f((unsigned short)y[j]);
+    for (int j = 0; j < 8; ++j) s += H16<T>::val((unsigned short)x[j]) * H16<T>::val((unsigned short)y[j]);
     return s;
 }
 
 // write a transposed accumulator pair Xᵀ[d][row-on-lane] (2 d-tiles) as bf16 rows: lane (r, h) owns row `row`
-template <int ND>
-__device__ __forceinline__ void store_rowT(bf16* __restrict__ base, long long rs, int row, bool valid,
+template <int ND, typename T>
+__device__ __forceinline__ void store_rowT(T* __restrict__ base, long long rs, int row, bool valid,
                                            const f32x16 (&acc)[ND], float mul, int lane) {
     if (!valid) return;
 #pragma unroll
@@ -359,18 +368,18 @@ __device__ __forceinline__ void store_rowT(bf16* __restrict__ base, long long rs
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             int d = dt * 32 + 8 * g + 4 * (lane >> 5);
-            unsigned lo = (unsigned)f2bf(acc[dt][4 * g] * mul) | ((unsigned)f2bf(acc[dt][4 * g + 1] * mul) << 16);
-            unsigned hi = (unsigned)f2bf(acc[dt][4 * g + 2] * mul) | ((unsigned)f2bf(acc[dt][4 * g + 3] * mul) << 16);
+            unsigned lo = (unsigned)H16<T>::bits(acc[dt][4 * g] * mul) | ((unsigned)H16<T>::bits(acc[dt][4 * g + 1] * mul) << 16);
+            unsigned hi = (unsigned)H16<T>::bits(acc[dt][4 * g + 2] * mul) | ((unsigned)H16<T>::bits(acc[dt][4 * g + 3] * mul) << 16);
             *reinterpret_cast<uint2*>(base + (long long)row * rs + d) = make_uint2(lo, hi);
         }
 }
 
 // ---- forward (MODE 0) and dQ backward (MODE 1): query on the lane ----
-template <int MODE, int HD, bool DROP>
-__global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
-                                                     const bf16* __restrict__ v, bf16* __restrict__ o,
-                                                     const bf16* __restrict__ d_o, float* __restrict__ lse,
-                                                     float* __restrict__ delta, bf16* __restrict__ dq, AttnParams p) {
+template <typename T, int MODE, int HD, bool DROP>
+__global__ __launch_bounds__(256) void attn_q_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                     const T* __restrict__ v, T* __restrict__ o,
+                                                     const T* __restrict__ d_o, float* __restrict__ lse,
+                                                     float* __restrict__ delta, T* __restrict__ dq, AttnParams p) {
     // forward: K by rows only, V transposed only.  dQ backward: K by rows AND transposed (dual image), V by rows only
     constexpr int KP = MODE == 0 ? PITCH : DUAL, VP = MODE == 0 ? VPITCH : PITCH;
     constexpr int NF = HD / 16, ND = HD / 32, NI = HD / 64;  // k-steps per row, 32-row d-tiles, 64-column LDS images
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
         bf16x8_t of[NF];
         load_row_frags(of, o + b * p.o_bs + h * HD, p.o_rs, t, valid, lane);
 #pragma unroll
-        for (int kk = 0; kk < NF; ++kk) dl += frag_dot(dof[kk], of[kk]);
+        for (int kk = 0; kk < NF; ++kk) dl += frag_dot<T>(dof[kk], of[kk]);
         dl += __shfl_xor(dl, 32, 64);
         const long long row = ((long long)b * p.H + h) * p.T + t;
         if (valid) {
@@ -411,8 +420,8 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
     int s_end = p.S;
     if (p.causal) s_end = min(p.S, blockIdx.x * 128 + 128 + off);
     const int wt0 = blockIdx.x * 128 + wave * 32;  // first query of this wave
-    const bf16* kbase = k + b * p.k_bs + h * HD;
-    const bf16* vbase = v + b * p.v_bs + h * HD;
+    const T* kbase = k + b * p.k_bs + h * HD;
+    const T* vbase = v + b * p.v_bs + h * HD;
     uint4 kreg[2 * NI], vreg[2 * NI];
     if (s_end > 0) {
         tile_g2r(kreg, kbase, p.k_rs, 0, p.S, tid);
@@ -444,8 +453,8 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
             for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < NF; ++kk)
-                sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<KP>(k_lds, kb * 32, kk, lane), qf[kk],
-                                                                 sc[kb], 0, 0, 0);
+                sc[kb] = mm<T>(row_frag<KP>(k_lds, kb * 32, kk, lane), qf[kk],
+                                                                 sc[kb]);
         }
         // scale + key bias (exp2 domain): registers 4g..4g+3 of a block are 4 consecutive keys -> one 16-B bias read
         float tmax = -INFINITY;
@@ -512,11 +521,11 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    bf16x8_t pf = acc_frag(sc[kb], s);
+                    bf16x8_t pf = acc_frag<T>(sc[kb], s);
 #pragma unroll
                     for (int dt = 0; dt < ND; ++dt)
-                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<VP>(v_lds, kb * 32, s, dt * 32, lane),
-                                                                          pf, acc[dt], 0, 0, 0);
+                        acc[dt] = mm<T>(tr_frag<VP>(v_lds, kb * 32, s, dt * 32, lane),
+                                                                          pf, acc[dt]);
                 }
         } else {
             // dPᵀ[key][query] = V[key][:] · dO[query][:]
@@ -527,8 +536,8 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
                 for (int r = 0; r < 16; ++r) dp[kb][r] = 0.f;
 #pragma unroll
                 for (int kk = 0; kk < NF; ++kk)
-                    dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<VP>(v_lds, kb * 32, kk, lane), dof[kk],
-                                                                     dp[kb], 0, 0, 0);
+                    dp[kb] = mm<T>(row_frag<VP>(v_lds, kb * 32, kk, lane), dof[kk],
+                                                                     dp[kb]);
                 if constexpr (DROP) {  // dP = M / (1 - p) * (dO . V): the stored keep bits of this query's keys
                     const long long mrow = ((long long)b * p.H + h) * p.T + t;
 #pragma unroll
@@ -551,11 +560,11 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    bf16x8_t pf = acc_frag(sc[kb], s);
+                    bf16x8_t pf = acc_frag<T>(sc[kb], s);
 #pragma unroll
                     for (int dt = 0; dt < ND; ++dt)
-                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            tr_frag<KP>(k_lds, kb * 32, s, dt * 32, lane), pf, acc[dt], 0, 0, 0);
+                        acc[dt] = mm<T>(
+                            tr_frag<KP>(k_lds, kb * 32, s, dt * 32, lane), pf, acc[dt]);
                 }
         }
     }
@@ -573,12 +582,12 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16* __restrict__ q,
 // ---- dK / dV backward: key on the lane ----
 // WHICH: 0 = dK and dV (head_dim 64); 1 = dV only, 2 = dK only (head_dim 128: two launches, the accumulators of both
 // would not fit the register file)
-template <int HD, int WHICH, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
-                                                           const bf16* __restrict__ v, const bf16* __restrict__ d_o,
+template <typename T, int HD, int WHICH, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                           const T* __restrict__ v, const T* __restrict__ d_o,
                                                            const float* __restrict__ lse,
-                                                           const float* __restrict__ delta, bf16* __restrict__ dk,
-                                                           bf16* __restrict__ dv, AttnParams p) {
+                                                           const float* __restrict__ delta, T* __restrict__ dk,
+                                                           T* __restrict__ dv, AttnParams p) {
     constexpr int NF = HD / 16, ND = HD / 32, NI = HD / 64;
     constexpr bool DO_V = WHICH != 2, DO_K = WHICH != 1;
     __shared__ __attribute__((aligned(16))) char q_lds[NI * KT * 128];   // dual-use images: read by rows and transposed
@@ -605,8 +614,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
     if (p.causal) t_begin = max(0, (int)(blockIdx.x * 128) - off) / KT * KT;
     const int ws0 = blockIdx.x * 128 + wave * 32;          // first key of this wave
     const float lane_bias = kvalid ? 0.f : -INFINITY;      // padding keys / keys past S: p = exp2(-inf) = 0
-    const bf16* qbase = q + b * p.q_bs + h * HD;
-    const bf16* dobase = d_o + b * p.do_bs + h * HD;
+    const T* qbase = q + b * p.q_bs + h * HD;
+    const T* dobase = d_o + b * p.do_bs + h * HD;
     uint4 qreg[2 * NI], doreg[2 * NI];
     if (t_begin < p.T) {
         tile_g2r(qreg, qbase, p.q_rs, t_begin, p.T, tid);
@@ -637,11 +646,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
             for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < NF; ++kk) {
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DUAL>(q_lds, qb * 32, kk, lane), kf[kk], sc, 0,
-                                                             0, 0);
+                sc = mm<T>(row_frag<DUAL>(q_lds, qb * 32, kk, lane), kf[kk], sc);
                 if constexpr (DO_K)
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DUAL>(do_lds, qb * 32, kk, lane), vf[kk], dp,
-                                                                 0, 0, 0);
+                    dp = mm<T>(row_frag<DUAL>(do_lds, qb * 32, kk, lane), vf[kk], dp);
             }
             f32x16 ds;
 #pragma unroll
@@ -667,16 +674,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                bf16x8_t pf = acc_frag(sc, st), dsf = acc_frag(ds, st);
+                bf16x8_t pf = acc_frag<T>(sc, st), dsf = acc_frag<T>(ds, st);
 #pragma unroll
                 for (int dt = 0; dt < ND; ++dt) {
                     // dVᵀ[d][key] += dOᵀ[d][query] · P[query][key] ;  dKᵀ[d][key] += Qᵀ[d][query] · dS[query][key]
                     if constexpr (DO_V)
-                        dva[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            tr_frag<DUAL>(do_lds, qb * 32, st, dt * 32, lane), pf, dva[dt], 0, 0, 0);
+                        dva[dt] = mm<T>(
+                            tr_frag<DUAL>(do_lds, qb * 32, st, dt * 32, lane), pf, dva[dt]);
                     if constexpr (DO_K)
-                        dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            tr_frag<DUAL>(q_lds, qb * 32, st, dt * 32, lane), dsf, dka[dt], 0, 0, 0);
+                        dka[dt] = mm<T>(
+                            tr_frag<DUAL>(q_lds, qb * 32, st, dt * 32, lane), dsf, dka[dt]);
                 }
             }
         }
@@ -705,11 +712,11 @@ __device__ __forceinline__ bf16x8_t ds_tr_frag(const char* lds, int row0, int s,
     return __builtin_bit_cast(bf16x8_t, f);
 }
 
-template <bool DROP>
+template <typename T, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
-    const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v, const bf16* __restrict__ o,
-    const bf16* __restrict__ d_o, const float* __restrict__ lse, float* __restrict__ delta, bf16* __restrict__ dq,
-    bf16* __restrict__ dk, bf16* __restrict__ dv, AttnParams p) {
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ o,
+    const T* __restrict__ d_o, const float* __restrict__ lse, float* __restrict__ delta, T* __restrict__ dq,
+    T* __restrict__ dk, T* __restrict__ dv, AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char fused_lds[];
     char* q_lds = fused_lds;                    // [128 queries] dual image
     char* do_lds = fused_lds + 2 * KT * 128;    // [128 queries] dual image; reused for the K tile in phase 2
@@ -722,10 +729,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
     const int off = p.S - p.T;
 
     // ---- loads: Q, dO (+O for delta) tiles, the K tile (kept in registers until phase 2), own-key K/V fragments ----
-    const bf16* qbase = q + b * p.q_bs + h * HD64;
-    const bf16* dobase = d_o + b * p.do_bs + h * HD64;
-    const bf16* obase = o + b * p.o_bs + h * HD64;
-    const bf16* kbase = k + b * p.k_bs + h * HD64;
+    const T* qbase = q + b * p.q_bs + h * HD64;
+    const T* dobase = d_o + b * p.do_bs + h * HD64;
+    const T* obase = o + b * p.o_bs + h * HD64;
+    const T* kbase = k + b * p.k_bs + h * HD64;
     uint4 kreg[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -740,7 +747,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
         if (r < p.S) kreg[i] = *reinterpret_cast<const uint4*>(kbase + (long long)r * p.k_rs + ch * 8);
         *reinterpret_cast<uint4*>(q_lds + lds_off<DUAL>(r, ch)) = qv;
         *reinterpret_cast<uint4*>(do_lds + lds_off<DUAL>(r, ch)) = dov;
-        float part = frag_dot(__builtin_bit_cast(bf16x8_t, dov), __builtin_bit_cast(bf16x8_t, ov));
+        float part = frag_dot<T>(__builtin_bit_cast(bf16x8_t, dov), __builtin_bit_cast(bf16x8_t, ov));
         part += __shfl_xor(part, 1);
         part += __shfl_xor(part, 2);
         part += __shfl_xor(part, 4);  // the 8 lanes of a row
@@ -775,8 +782,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
         for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DUAL>(q_lds, t0, kk, lane), kf[kk], sc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DUAL>(do_lds, t0, kk, lane), vf[kk], dp, 0, 0, 0);
+            sc = mm<T>(row_frag<DUAL>(q_lds, t0, kk, lane), kf[kk], sc);
+            dp = mm<T>(row_frag<DUAL>(do_lds, t0, kk, lane), vf[kk], dp);
         }
         f32x16 ds;
 #pragma unroll
@@ -799,19 +806,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
                 sc[4 * g + j] = pv;
                 ds[4 * g + j] = pw * (dpv - (&d4.x)[j]);
             }
-            unsigned lo = (unsigned)f2bf(ds[4 * g]) | ((unsigned)f2bf(ds[4 * g + 1]) << 16);
-            unsigned hi = (unsigned)f2bf(ds[4 * g + 2]) | ((unsigned)f2bf(ds[4 * g + 3]) << 16);
+            unsigned lo = (unsigned)H16<T>::bits(ds[4 * g]) | ((unsigned)H16<T>::bits(ds[4 * g + 1]) << 16);
+            unsigned hi = (unsigned)H16<T>::bits(ds[4 * g + 2]) | ((unsigned)H16<T>::bits(ds[4 * g + 3]) << 16);
             *reinterpret_cast<uint2*>(ds_lds + ds_off(s, tl)) = make_uint2(lo, hi);
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            bf16x8_t pf = acc_frag(sc, st), dsf = acc_frag(ds, st);
+            bf16x8_t pf = acc_frag<T>(sc, st), dsf = acc_frag<T>(ds, st);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                dva[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DUAL>(do_lds, t0, st, dt * 32, lane), pf,
-                                                                  dva[dt], 0, 0, 0);
-                dka[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DUAL>(q_lds, t0, st, dt * 32, lane), dsf,
-                                                                  dka[dt], 0, 0, 0);
+                dva[dt] = mm<T>(tr_frag<DUAL>(do_lds, t0, st, dt * 32, lane), pf,
+                                                                  dva[dt]);
+                dka[dt] = mm<T>(tr_frag<DUAL>(q_lds, t0, st, dt * 32, lane), dsf,
+                                                                  dka[dt]);
             }
         }
     }
@@ -841,8 +848,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
             bf16x8_t dsf = ds_tr_frag(ds_lds, kb * 32, st, wave * 32, lane);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DUAL>(do_lds, kb * 32, st, dt * 32, lane), dsf,
-                                                                  acc[dt], 0, 0, 0);
+                acc[dt] = mm<T>(tr_frag<DUAL>(do_lds, kb * 32, st, dt * 32, lane), dsf,
+                                                                  acc[dt]);
         }
     }
     store_rowT(dq + b * p.dq_bs + h * HD64, p.dq_rs, t, t < p.T, acc, p.scale, lane);
@@ -897,10 +904,10 @@ __global__ __launch_bounds__(128) void attn_probs_kernel(const T* __restrict__ q
 
 int check_common(const AttnParams& p, int hd, int dtype, const char* who) {
     PK_CHECK_ARG(hd == 64 || hd == 128, "%s: head_dim %d not supported (64 or 128)", who, hd);
-    PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16, "%s: dtype %d not supported", who, dtype);
+    PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16 || dtype == PK_F16, "%s: dtype %d not supported", who, dtype);
     PK_CHECK_ARG(p.B >= 0 && p.H > 0 && p.T >= 0 && p.S >= 0, "%s: bad sizes", who);
     PK_CHECK_ARG(p.B <= 65535 && p.H <= 65535, "%s: B and H must be <= 65535", who);
-    if (dtype == PK_BF16) {
+    if (dtype != PK_F32) {
         PK_CHECK_ARG(p.q_rs % 8 == 0 && p.k_rs % 8 == 0 && p.v_rs % 8 == 0 && p.o_rs % 8 == 0 && p.q_bs % 8 == 0 &&
                          p.k_bs % 8 == 0 && p.v_bs % 8 == 0 && p.o_bs % 8 == 0,
                      "%s: bf16 strides must be multiples of 8 elements", who);
@@ -934,20 +941,26 @@ extern "C" int pk_attn_fwd(const void* q, const void* k, const void* v, void* o,
     if (B == 0 || T == 0) return 0;
     dim3 grid((T + 127) / 128, H, B);
     hipStream_t s = (hipStream_t)stream;
-#define PK_FWD(D)                                                                                                      \
-    do {                                                                                                               \
-        if (dtype == PK_BF16 && p.drop_thr)                                                                            \
-            hipLaunchKernelGGL((attn_q_kernel<0, D, true>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,     \
-                               (const bf16*)v, (bf16*)o, (const bf16*)nullptr, lse, (float*)nullptr, (bf16*)nullptr, p); \
-        else if (dtype == PK_BF16)                                                                                     \
-            hipLaunchKernelGGL((attn_q_kernel<0, D, false>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,    \
-                               (const bf16*)v, (bf16*)o, (const bf16*)nullptr, lse, (float*)nullptr, (bf16*)nullptr, p); \
-        else                                                                                                           \
-            hipLaunchKernelGGL((attn_fwd_f32_kernel<D>), grid, dim3(128), 0, s, (const float*)q, (const float*)k,      \
-                               (const float*)v, (float*)o, lse, p);                                                    \
+#define PK_FWD16(TT, D)                                                                                              \
+    do {                                                                                                             \
+        if (p.drop_thr)                                                                                              \
+            hipLaunchKernelGGL((attn_q_kernel<TT, 0, D, true>), grid, dim3(256), 0, s, (const TT*)q, (const TT*)k,   \
+                               (const TT*)v, (TT*)o, (const TT*)nullptr, lse, (float*)nullptr, (TT*)nullptr, p);     \
+        else                                                                                                         \
+            hipLaunchKernelGGL((attn_q_kernel<TT, 0, D, false>), grid, dim3(256), 0, s, (const TT*)q, (const TT*)k,  \
+                               (const TT*)v, (TT*)o, (const TT*)nullptr, lse, (float*)nullptr, (TT*)nullptr, p);     \
+    } while (0)
+#define PK_FWD(D)                                                                                                    \
+    do {                                                                                                             \
+        if (dtype == PK_BF16) PK_FWD16(bf16, D);                                                                     \
+        else if (dtype == PK_F16) PK_FWD16(f16, D);                                                                  \
+        else                                                                                                         \
+            hipLaunchKernelGGL((attn_fwd_f32_kernel<D>), grid, dim3(128), 0, s, (const float*)q, (const float*)k,    \
+                               (const float*)v, (float*)o, lse, p);                                                  \
     } while (0)
     if (hd == 64) PK_FWD(64);
     else PK_FWD(128);
+#undef PK_FWD16
 #undef PK_FWD
     PK_LAUNCH_CHECK();
     return 0;
@@ -978,7 +991,7 @@ extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const vo
     if (int rc = check_common(p, hd, dtype, "pk_attn_bwd")) return rc;
     if (B == 0) return 0;
     PK_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv, "pk_attn_bwd: null tensor");
-    if (dtype == PK_BF16)
+    if (dtype != PK_F32)
         PK_CHECK_ARG(do_rs % 8 == 0 && dq_rs % 8 == 0 && dk_rs % 8 == 0 && dv_rs % 8 == 0 && do_bs % 8 == 0 &&
                          dq_bs % 8 == 0 && dk_bs % 8 == 0 && dv_bs % 8 == 0,
                      "pk_attn_bwd: bf16 strides must be multiples of 8 elements");
@@ -986,32 +999,36 @@ extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const vo
     hipStream_t s = (hipStream_t)stream;
     dim3 gq((T + 127) / 128, H, B), gk((S + 127) / 128, H, B);
     static const bool no_fused = getenv("PK_ATTN_NO_FUSED_BWD") != nullptr;
-    if (dtype == PK_BF16 && hd == 64 && T > 0 && S > 0 && T <= 128 && S <= 128 && !no_fused) {
+    const bool half = dtype != PK_F32;
+#define PK_T16(...) do { if (dtype == PK_F16) { using TT = f16; __VA_ARGS__; } else { using TT = bf16; __VA_ARGS__; } } while (0)
+    if (half && hd == 64 && T > 0 && S > 0 && T <= 128 && S <= 128 && !no_fused) {
         static const int attr_rc = [] {
-            int a = hipFuncSetAttribute((const void*)attn_bwd_fused128_kernel<false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
-            int b = hipFuncSetAttribute((const void*)attn_bwd_fused128_kernel<true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
-            return a ? a : b;
+            int rc = 0;
+            const void* fns[] = {(const void*)attn_bwd_fused128_kernel<bf16, false>, (const void*)attn_bwd_fused128_kernel<bf16, true>,
+                                 (const void*)attn_bwd_fused128_kernel<f16, false>, (const void*)attn_bwd_fused128_kernel<f16, true>};
+            for (const void* f : fns) {
+                int e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
+                if (e) rc = e;
+            }
+            return rc;
         }();
         PK_CHECK_ARG(attr_rc == 0, "pk_attn_bwd: cannot reserve %d B of LDS", FUSED_LDS);
-        if (p.drop_thr)
-            hipLaunchKernelGGL(attn_bwd_fused128_kernel<true>, dim3(H, B), dim3(256), FUSED_LDS, s, (const bf16*)q,
-                               (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dq,
-                               (bf16*)dk, (bf16*)dv, p);
-        else
-            hipLaunchKernelGGL(attn_bwd_fused128_kernel<false>, dim3(H, B), dim3(256), FUSED_LDS, s, (const bf16*)q,
-                               (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dq,
-                               (bf16*)dk, (bf16*)dv, p);
-    } else if (dtype == PK_BF16) {
+#define PK_FUSED(DR)                                                                                                   \
+    PK_T16(hipLaunchKernelGGL((attn_bwd_fused128_kernel<TT, DR>), dim3(H, B), dim3(256), FUSED_LDS, s, (const TT*)q,   \
+                              (const TT*)k, (const TT*)v, (const TT*)o, (const TT*)d_o, lse, delta, (TT*)dq, (TT*)dk, \
+                              (TT*)dv, p))
+        if (p.drop_thr) PK_FUSED(true);
+        else PK_FUSED(false);
+#undef PK_FUSED
+    } else if (half) {
 #define PK_DQ_(D, DR)                                                                                                \
-    hipLaunchKernelGGL((attn_q_kernel<1, D, DR>), gq, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,               \
-                       (const bf16*)v, (bf16*)const_cast<void*>(o), (const bf16*)d_o, const_cast<float*>(lse), delta, \
-                       (bf16*)dq, p)
+    PK_T16(hipLaunchKernelGGL((attn_q_kernel<TT, 1, D, DR>), gq, dim3(256), 0, s, (const TT*)q, (const TT*)k,        \
+                              (const TT*)v, (TT*)const_cast<void*>(o), (const TT*)d_o, const_cast<float*>(lse), delta, \
+                              (TT*)dq, p))
 #define PK_DQ(D) do { if (p.drop_thr) PK_DQ_(D, true); else PK_DQ_(D, false); } while (0)
-#define PK_DKV_(D, W, DR)                                                                                          \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, W, DR>), gk, dim3(256), 0, s, (const bf16*)q, (const bf16*)k,       \
-                       (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dk, (bf16*)dv, p)
+#define PK_DKV_(D, W, DR)                                                                                            \
+    PK_T16(hipLaunchKernelGGL((attn_bwd_dkv_kernel<TT, D, W, DR>), gk, dim3(256), 0, s, (const TT*)q, (const TT*)k,  \
+                              (const TT*)v, (const TT*)d_o, lse, (const float*)delta, (TT*)dk, (TT*)dv, p))
 #define PK_DKV(D, W) do { if (p.drop_thr) PK_DKV_(D, W, true); else PK_DKV_(D, W, false); } while (0)
         if (T > 0) {
             if (hd == 64) PK_DQ(64);
@@ -1046,6 +1063,7 @@ extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const vo
         else PK_BWD32(128);
 #undef PK_BWD32
     }
+#undef PK_T16
     PK_LAUNCH_CHECK();
     return 0;
 }
@@ -1058,7 +1076,7 @@ extern "C" int pk_attn_probs(const void* q, const void* k, void* probs, const un
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs;
     p.key_pad = key_pad; p.causal = causal; p.scale = scale;
     PK_CHECK_ARG(hd == 64 || hd == 128, "pk_attn_probs: head_dim %d not supported (64 or 128)", hd);
-    PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16, "pk_attn_probs: dtype %d not supported", dtype);
+    PK_CHECK_ARG(dtype == PK_F32 || dtype == PK_BF16 || dtype == PK_F16, "pk_attn_probs: dtype %d not supported", dtype);
     PK_CHECK_ARG(B >= 0 && H > 0 && T >= 0 && S >= 0 && B <= 65535 && H <= 65535, "pk_attn_probs: bad sizes");
     if (B == 0 || T == 0 || S == 0) return 0;
     PK_CHECK_ARG(q && k && probs, "pk_attn_probs: null tensor");
@@ -1066,6 +1084,7 @@ extern "C" int pk_attn_probs(const void* q, const void* k, void* probs, const un
     hipStream_t s = (hipStream_t)stream;
 #define PK_PR(TT, D) hipLaunchKernelGGL((attn_probs_kernel<TT, D>), grid, dim3(128), 0, s, (const TT*)q, (const TT*)k, (TT*)probs, p)
     if (dtype == PK_BF16) { if (hd == 64) PK_PR(bf16, 64); else PK_PR(bf16, 128); }
+    else if (dtype == PK_F16) { if (hd == 64) PK_PR(f16, 64); else PK_PR(f16, 128); }
     else { if (hd == 64) PK_PR(float, 64); else PK_PR(float, 128); }
 #undef PK_PR
     PK_LAUNCH_CHECK();

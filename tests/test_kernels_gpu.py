@@ -235,7 +235,7 @@ ATTN_CASES = [
 ]
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('B,H,T,S,causal,ragged', ATTN_CASES)
 def test_attention_fwd_bwd(F, dtype, B, H, T, S, causal, ragged):
     D = H * 64
@@ -254,7 +254,7 @@ def test_attention_fwd_bwd(F, dtype, B, H, T, S, causal, ragged):
     o, lse = F.attn_fwd(q.cuda(), k.cuda(), v.cuda(), H, kp, causal, scale)
     # fp32: exact arithmetic, different summation order.  bf16: P and dS are rounded to bf16 for the MFMA
     # (relative 2^-8), outputs rounded to bf16.
-    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    tol = 1e-5 if dtype == torch.float32 else (2e-2 if dtype == torch.bfloat16 else 3e-3)  # fp16: 2^-11 storage
     assert rel_err(o, o_ref) < tol
     dq, dk, dv = F.attn_bwd(q.cuda(), k.cuda(), v.cuda(), o, dy.cuda(), lse, H, kp, causal, scale)
     assert rel_err(dq, dq_ref) < tol

@@ -466,3 +466,36 @@ def test_attention_dropout_training_step():
         a, _ = model(**batch)
         b, _ = model(**batch)
     assert a.item() == b.item() and abs(a.item() - base.item()) <= 1e-6 * base.item()
+
+
+@pytest.mark.parametrize('name', ['tiny_encdec_post', 'tiny_encdec_pre', 'base_c1'])
+def test_fp16_model_vs_reference(name):
+    """float16 — the reference's default `--dtype` (config.py:518-523): the same kernels with the f16 MFMA and
+    conversions; 2^-11 relative per rounding -> loss within 3e-3 of the fp32 reference, total gradient norm within 2 %,
+    every gradient finite (no loss scaling needed at these magnitudes), greedy argmax of the tiny models unchanged"""
+    g = load_golden(name)
+    cfg, model = build_model(g, torch.float16, 'cuda')
+    model.train()
+    batch = text_batch(g, 'cuda')
+    loss, logs = model(**batch)
+    loss.backward()
+    ref_loss = float(g['loss'])
+    assert loss.dtype == torch.float32
+    assert abs(loss.item() - ref_loss) <= 3e-3 * abs(ref_loss)
+    assert logs['num_tokens'] == int(g['logs_num_tokens'])
+    grads = dict(model.named_parameters())
+    assert all(p.grad.dtype == torch.float16 and torch.isfinite(p.grad.float()).all() for p in grads.values())
+    tot_ref = float(np.sqrt((g['grad_norms'] ** 2).sum()))
+    tot = float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in grads.values())).item())
+    assert abs(tot - tot_ref) <= 2e-2 * tot_ref
+    # and the native decoding step in fp16
+    model.eval()
+    with torch.no_grad():
+        enc_out, enc_mask, _ = model.encoder(batch['encoder_input'], batch['encoder_input_length'])
+        tokens = batch['decoder_input'].clamp(min=2)
+        state = {}
+        lg, _ = model.decoder(enc_out, enc_mask, tokens[:, :2], state=state)
+        lg2, _ = model.decoder(enc_out, enc_mask, tokens[:, 2:3], state=state)
+        full, _ = model.decoder(enc_out, enc_mask, tokens[:, :3])
+    assert '_pk_decode' in state
+    assert (lg2[:, -1].float() - full[:, -1].float()).abs().max().item() <= 2e-2 * full[:, -1].float().abs().max().item()
