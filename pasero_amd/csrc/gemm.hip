@@ -6,8 +6,8 @@
 // k contiguous ("row" form) or with its m/n index contiguous ("col" form).
 //
 // gfx950 design: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, each 64x64 = 2x2 MFMA 32x32 tiles),
-// bf16: v_mfma_f32_32x32x16_bf16, BK = 64; f32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), BK = 16.
-// bf16 staging is LDS-DMA: `global_load_lds_dwordx4` writes each wave-instruction's 64 x 16 B straight into a linear
+// bf16 / fp16: v_mfma_f32_32x32x16_{bf16,f16}, BK = 64; f32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), BK = 16.
+// 16-bit staging is LDS-DMA: `global_load_lds_dwordx4` writes each wave-instruction's 64 x 16 B straight into a linear
 // 1-KiB piece of the LDS tile (no VGPR round trip, no ds_write), the next K-tile's DMA is in flight under the current
 // tile's MFMAs (double-buffered LDS, one vmcnt(0)+barrier per K-step).  Because the DMA destination is lane-linear, the
 // bank-conflict swizzle is applied to the per-lane SOURCE address and undone on the read: row-form tiles
@@ -52,7 +52,7 @@ template <typename T> struct Traits;
 template <> struct Traits<bf16> {
     static constexpr int BK = PK_BK, EPV = 8, KSTEP = 16;
     static constexpr bool GLDS = true;
-    static constexpr int NSTAGE = PK_NS;  // LDS-DMA ring: NSTAGE-1 K-tiles in flight under the MFMAs of the current one
+    static constexpr int NSTAGE = PK_NS;  // LDS stages (the pipelined loop below is written for 2)
 };
 template <> struct Traits<f16> : Traits<bf16> {};  // same bytes, same tiles; only the MFMA instruction differs
 template <> struct Traits<float> {
@@ -438,9 +438,8 @@ __global__ __launch_bounds__(NTHREADS, PK_OCC) void gemm_kernel(
     };
 
     // ---- main loop ----
-    // bf16, 16-byte addressable operands: the K-tiles that are full in k go through a 4-stage LDS-DMA ring with counted
-    // vmcnt waits and raw barriers (a __syncthreads() would drain the DMA queue): tile kt+3 is issued right after the
-    // barrier that retires tile kt-1's stage, so up to 3 tiles (24 KiB per workgroup) stay in flight under the MFMAs.
+    // 16-bit types, 16-byte addressable operands: the K-tiles that are full in k are staged by LDS-DMA into a double
+    // buffer, with an explicit vmcnt(0) and a raw barrier per tile (a __syncthreads() would drain the DMA queue too early)
     const bool dma_ok = TR::GLDS && a_vec && b_vec && (M % TR::EPV == 0 || !A_COL) && (N % TR::EPV == 0 || !B_COL);
 #if defined(PK_ABLATE) && PK_ABLATE == 5
     const int nk_dma = 0;
