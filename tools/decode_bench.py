@@ -19,7 +19,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--src-len', type=int, default=64)
     ap.add_argument('--steps', type=int, default=64)
-    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--config', default='TransformerConfig')
     ap.add_argument('--no-cross-cache', action='store_true')
     args = ap.parse_args()
@@ -30,7 +30,7 @@ def main():
     cfg = getattr(C, args.config)()
     torch.manual_seed(0)
     model = Transformer(cfg, C.DistributedConfig(), C.SyntheticTask(V))
-    model = model.to(torch.bfloat16 if args.dtype == 'bf16' else torch.float32).cuda().eval()
+    model = model.to({'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]).cuda().eval()
     if args.no_cross_cache:
         os.environ['PASERO_NO_CROSS_KV_CACHE'] = '1'
     b = paramgen.make_text_batch(1, args.batch, args.src_len, 4, V, ragged=True)
