@@ -119,7 +119,7 @@ CFG_KEYS = [
     'decoder_embed_norm', 'encoder_positional_encoding', 'decoder_positional_encoding',
     'positional_encoding_shift', 'scale_embed', 'encoder_max_len', 'decoder_max_len', 'shared_embeddings',
     'tied_output_projection', 'rope_base', 'input_dim', 'conv_input_dim', 'conv_channels', 'conv_kernel_sizes',
-    'conv_strides', 'conv_activation', 'norm_eps', 'padding_idx', 'eos_idx', 'bos_idx',
+    'conv_strides', 'conv_activation', 'norm_eps', 'padding_idx', 'eos_idx', 'bos_idx', 'attention_key_bias',
 ]
 
 
@@ -355,7 +355,8 @@ def gen_speech():
                                 conv_strides=[1, 2], conv_activation='gelu', encoder_prenorm=True,
                                 decoder_prenorm=True, activation_fn='gelu', scale_embed=False,
                                 encoder_positional_encoding='learned', decoder_positional_encoding='learned',
-                                positional_encoding_shift=0, encoder_max_len=64, decoder_max_len=32)),
+                                positional_encoding_shift=0, encoder_max_len=64, decoder_max_len=32,
+                                attention_key_bias=False)),
         ('speech_iwslt', dict(input_dim=96, conv_input_dim=80, conv_channels=256, conv_kernel_sizes=[5],
                               conv_strides=[2], conv_activation='glu', encoder_prenorm=True,
                               decoder_prenorm=True, encoder_max_len=64, decoder_max_len=32)),

@@ -164,6 +164,10 @@ class WhisperConfig(TransformerConfig):          # config.py:2540-2560
     conv_activation: str = 'gelu'
     encoder_max_len: int = 3000
     decoder_max_len: int = 448
+    attention_key_bias: bool = False
+    padding_idx: int = 50256
+    eos_idx: int = 50257
+    bos_idx: int = 50258
 
 
 @dataclass
