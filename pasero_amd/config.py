@@ -14,10 +14,20 @@ CONFIGS = {}
 
 
 def register_model(*names):
-    """same role as pasero.config.register_model (config.py:91-101)"""
+    """same role as pasero.config.register_model (config.py:91-101).  Inside the reference tree (`pasero` importable)
+    the class is ALSO entered in the reference's own registry, so that `pasero.config.get_architecture` — what
+    `pasero-train` / `pasero-decode` call — resolves 'transformer' / 'adapter_transformer' to the classes of this package
+    once `pasero_amd` has been imported."""
     def wrapper(cls):
         for name in names:
             MODELS[name] = cls
+        try:
+            from pasero.config import register_model as reference_register  # type: ignore
+        except Exception:  # stand-alone (tests, bench.py, the GPU box)
+            reference_register = None
+        if reference_register is not None:
+            for name in names:
+                reference_register(name)(cls)
         return cls
     return wrapper
 

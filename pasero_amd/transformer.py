@@ -24,10 +24,7 @@ from .modules import Embedding, Identity
 from .autograd import (FFNFn, GatedFFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn,
                        AddPositionsFn, LinearFn, ResidualLink)
 
-try:  # inside the reference tree: register under the reference's own registry (config.py:91-122)
-    from pasero.config import register_model  # type: ignore
-except Exception:  # stand-alone
-    from .config import register_model
+from .config import register_model  # also enters the reference's registry when `pasero` is importable
 
 logger = logging.getLogger('models')
 LN2 = math.log(2)

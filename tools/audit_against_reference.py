@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Build-container audit of the drop-in boundary against the REAL reference tree (/root/reference, read-only):
+  1. every `cfg.<attr>` / `dist_cfg.<attr>` pasero_amd reads exists on the reference's configuration classes;
+  2. every preset in pasero_amd/config.py has the reference's defaults (pasero/config.py MODEL_CONFIGS);
+  3. with the reference's own configuration objects and registry, `get_architecture` resolves to the pasero_amd classes
+     and their state_dict names/shapes equal the reference model's.
+No forward pass runs (there is no GPU here and pasero_amd has no CPU path).  Exit code 0 = clean.
+Test infrastructure only; the reference never travels to the GPU box, so this runs only where /root/reference exists.
+"""
+import dataclasses
+import glob
+import os
+import re
+import sys
+import types
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+sys.dont_write_bytecode = True
+
+
+def import_reference():
+    # the two third-party imports absent from the image, stubbed as in oracle/make_golden.py
+    sb, sbm = types.ModuleType('sacrebleu'), types.ModuleType('sacrebleu.metrics')
+    sbm.METRICS = {'BLEU': type('B', (), {'TOKENIZERS': {}})}
+    sb.metrics = sbm
+    sys.modules['sacrebleu'], sys.modules['sacrebleu.metrics'] = sb, sbm
+    names = ['stopes', 'stopes.pipelines', 'stopes.pipelines.monolingual', 'stopes.pipelines.monolingual.utils',
+             'stopes.pipelines.monolingual.utils.text_normalizer']
+    for n in names:
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules[names[-1]].remove_non_printing_char = lambda s: s
+    sys.modules[names[-1]].replace_unicode_punct = lambda s: s
+    sys.path.insert(0, REF)
+    sys.path.insert(0, REPO)
+    from pasero import config as RC
+    from pasero.models import transformer as RT, adapters as RA
+    return RC, RT, RA
+
+
+class FakeTask:
+    freeze_encoder_embed_mask = None
+
+    def __init__(self, enc, dec):
+        self.encoder_num_embeddings, self.decoder_num_embeddings = enc, dec
+
+
+def main() -> int:
+    RC, RT, RA = import_reference()
+    import pasero_amd.config as MC
+    import pasero_amd.transformer   # noqa: F401  registers 'transformer' in the reference's registry
+    import pasero_amd.adapters      # noqa: F401  registers 'adapter_transformer' (after the reference's own import)
+    problems = []
+
+    used, dused = set(), set()
+    for f in glob.glob(os.path.join(REPO, 'pasero_amd', '*.py')):
+        src = open(f).read()
+        dused |= set(re.findall(r'\bdist_cfg\.(\w+)', src))
+        if not f.endswith('config.py'):
+            used |= set(re.findall(r'\bcfg\.(\w+)', src))
+    ref_cfg, ref_dist = RC.AdapterTransformerConfig(), RC.DistributedConfig()
+    problems += [f'cfg.{a} is read but the reference configuration has no such field' for a in sorted(used)
+                 if not hasattr(ref_cfg, a)]
+    problems += [f'dist_cfg.{a} is read but the reference has no such field' for a in sorted(dused)
+                 if not hasattr(ref_dist, a)]
+
+    task_defaults = ('label_smoothing', 'model_type', 'decoder_max_len')  # set per task (config.py:1146-1153,1241-1272)
+    for name, mine_cls in MC.CONFIGS.items():
+        ref_cls = RC.MODEL_CONFIGS.get(name)
+        if ref_cls is None:
+            problems.append(f'preset {name} does not exist in the reference')
+            continue
+        r, m = ref_cls(), mine_cls()
+        for f in dataclasses.fields(m):
+            if f.name not in task_defaults and getattr(r, f.name, '<missing>') != getattr(m, f.name):
+                problems.append(f'preset {name}.{f.name}: {getattr(m, f.name)!r} here, '
+                                f'{getattr(r, f.name, "<missing>")!r} in the reference')
+
+    def sig(model):
+        return [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+
+    cases = [
+        (RC.TransformerSmallConfig, dict(shared_embeddings=False), FakeTask(300, 400), RT.Transformer),
+        (RC.MBARTConfig, dict(encoder_layers=2, decoder_layers=2), FakeTask(1000, 1000), RT.Transformer),
+        (RC.WhisperConfig, dict(encoder_layers=2, decoder_layers=2), FakeTask(0, 51865), RT.Transformer),
+        (RC.AdapterTransformerConfig, dict(encoder_adapters=['a'], decoder_adapters=['a', 'b']), FakeTask(500, 500),
+         RA.AdapterTransformer),
+        (RC.TransformerConfig, dict(lora_rank=4, encoder_layers=1, decoder_layers=1), FakeTask(200, 200), RT.Transformer),
+    ]
+    for cfg_cls, kw, task, ref_model_cls in cases:
+        cfg = cfg_cls(**kw)
+        cfg.label_smoothing = 0.1 if cfg.label_smoothing is None else cfg.label_smoothing
+        cfg.model_type = cfg.model_type or 'encoder_decoder'
+        cfg.decoder_max_len = cfg.decoder_max_len or 256
+        arch = RC.get_architecture(cfg)
+        if not arch.__module__.startswith('pasero_amd'):
+            problems.append(f'{cfg_cls.__name__}: the reference registry resolves to {arch.__module__}.{arch.__name__}')
+            continue
+        ours = arch(cfg, RC.DistributedConfig(), task)
+        theirs = ref_model_cls(cfg, RC.DistributedConfig(), task)
+        if sig(ours) != sig(theirs):
+            problems.append(f'{cfg_cls.__name__}: state_dict names/shapes differ from {ref_model_cls.__name__}')
+        frozen = lambda m: sorted(k for k, p in m.named_parameters() if not p.requires_grad)  # noqa: E731
+        if frozen(ours) != frozen(theirs):
+            problems.append(f'{cfg_cls.__name__}: the set of frozen parameters differs')
+    for p in problems:
+        print('AUDIT:', p)
+    print(f'audit_against_reference: {len(problems)} problem(s), {len(used)} cfg fields, {len(MC.CONFIGS)} presets, '
+          f'{len(cases)} model layouts')
+    return 1 if problems else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
