@@ -63,7 +63,9 @@ int pk_gemm_timing_read(int i, int* kernel, int* a_col, int* b_col, int* splitk,
 /* ---- Residual + dropout + LayerNorm (K4): replaces `residual + dropout(x)` followed by nn.LayerNorm,
  * pasero/models/transformer.py:1043-1054,1073-1086 (encoder), :1322-1339,1389-1407 (decoder), :941-947 (Norm).
  *   z = (residual ? residual : 0) + dropout(x)          -> z_out (optional)
- *   y = (z - mean) * rstd * gamma + beta                -> y_out, mean[rows], rstd[rows]   (only if gamma != NULL) */
+ *   y = (z - mean) * rstd * gamma + beta                -> y_out, mean[rows], rstd[rows]   (only if gamma != NULL)
+ *   mean == NULL selects RMSNorm (pasero/models/modules.py:192-202): y = z * rsqrt(mean(z^2) + eps) * gamma in fp32,
+ *   beta must be NULL; pk_residual_ln_bwd with mean == NULL is its backward (dbeta must be NULL). */
 int pk_residual_ln_fwd(const void* x, const void* residual, const void* gamma, const void* beta, void* z_out,
                        void* y_out, float* mean, float* rstd, long long rows, int d, float eps, float drop_p,
                        unsigned long long seed, unsigned long long offset, int dtype, void* stream);

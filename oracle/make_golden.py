@@ -120,6 +120,7 @@ CFG_KEYS = [
     'positional_encoding_shift', 'scale_embed', 'encoder_max_len', 'decoder_max_len', 'shared_embeddings',
     'tied_output_projection', 'rope_base', 'input_dim', 'conv_input_dim', 'conv_channels', 'conv_kernel_sizes',
     'conv_strides', 'conv_activation', 'norm_eps', 'padding_idx', 'eos_idx', 'bos_idx', 'attention_key_bias',
+    'has_bias', 'rms_norm',
 ]
 
 
@@ -306,6 +307,16 @@ def gen_tiny_swiglu():
                encoder_prenorm=True, decoder_prenorm=True)
 
 
+def gen_tiny_rms():
+    """llama-style parameterisation of the encoder-decoder: RMSNorm (modules.py:192-202), pre-norm, rotary positions,
+    SwiGLU, no biases anywhere"""
+    gen_encdec('tiny_encdec_rms', V=83, B=3, S=9, T=6, seed=18,
+               embed_dim=128, encoder_ffn_dim=192, decoder_ffn_dim=192, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=2, decoder_layers=1, dropout=0.0, activation_fn='swiglu',
+               encoder_prenorm=True, decoder_prenorm=True, rms_norm=True, has_bias=False, norm_eps=1e-6,
+               encoder_positional_encoding='rotary', decoder_positional_encoding='rotary')
+
+
 def gen_ce():
     """Transformer.compute_loss (transformer.py:324-380): label-smoothed CE, sum reduction, pad ignored,
     logs in bits"""
@@ -474,6 +485,7 @@ GENERATORS = {
     'mha_rotary': gen_mha_rotary,
     'tiny_encdec_rotary': gen_tiny_rotary,
     'tiny_encdec_swiglu': gen_tiny_swiglu,
+    'tiny_encdec_rms': gen_tiny_rms,
     'ce_ls': gen_ce,
     'sinpos': gen_sinpos,
     'speech': gen_speech,

@@ -69,6 +69,13 @@ def layer_norm(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float) ->
     return y if bias is None else y + bias
 
 
+def rms_norm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
+    """models/modules.py:192-202 RMSNorm.forward — no centring, fp32 arithmetic, result cast back to x's dtype"""
+    xf = x.float()
+    y = xf * torch.rsqrt((xf * xf).mean(-1, keepdim=True) + eps) * weight
+    return y.to(x.dtype)
+
+
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
     """models/modules.py:92-96 (no LoRA): y = x Wᵀ + b"""
     y = x @ weight.t()
@@ -213,6 +220,8 @@ def _rope(cfg, kind):
 
 
 def _ln(P, prefix, x, cfg):
+    if getattr(cfg, 'rms_norm', False):  # models/transformer.py:941-947: RMSNorm instead of nn.LayerNorm
+        return rms_norm(x, P[prefix + '.weight'], cfg.norm_eps)
     return layer_norm(x, P[prefix + '.weight'], P.get(prefix + '.bias'), cfg.norm_eps)
 
 

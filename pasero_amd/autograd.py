@@ -3,6 +3,7 @@
 on the hot path.
 """
 import math
+import threading
 from typing import Optional
 
 import torch
@@ -10,6 +11,34 @@ from torch import Tensor
 
 from . import functional as F
 from . import rng
+
+
+class _Outer(threading.local):
+    grad = True
+
+
+_outer = _Outer()
+
+
+class Function(torch.autograd.Function):
+    """torch.autograd.Function that knows whether a backward pass can follow.  `ctx.needs_input_grad` only mirrors the
+    inputs' `requires_grad` flags — it stays True for parameters under `torch.no_grad()` — and grad mode is always off
+    inside `forward`, so `apply` records the caller's grad mode and `wants_grad(ctx)` combines the two.  Forward passes
+    use it to skip everything that only a backward pass needs (saved pre-activations, z = x + residual, dropout masks,
+    and the gradient GEMMs the fused vocabulary cross-entropy runs in its forward) at inference."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        prev, _outer.grad = _outer.grad, torch.is_grad_enabled()
+        try:
+            return super().apply(*args, **kwargs)
+        finally:
+            _outer.grad = prev
+
+
+def wants_grad(ctx) -> tuple:
+    """per input: a gradient may be asked for later (requires_grad AND the caller's grad mode is on)"""
+    return tuple(bool(f) and _outer.grad for f in ctx.needs_input_grad)
 
 
 def _2d(x: Tensor) -> Tensor:
@@ -61,14 +90,14 @@ def _wgrad(dy2d: Tensor, x2d: Tensor, want_w: bool, want_b: bool):
     return None, (F.colsum(dy2d) if want_b else None)
 
 
-class LinearFn(torch.autograd.Function):
+class LinearFn(Function):
     """y = act(x Wᵀ + b)   (pasero/models/modules.py:92-96 + the activation that follows fc1)"""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act: str = 'none', link=None):
         ctx.link = link
         x2 = _2d(_contig(x))
-        need_pre = act not in ('none', 'relu') and any(ctx.needs_input_grad)
+        need_pre = act not in ('none', 'relu') and any(wants_grad(ctx))
         pre = torch.empty(x2.size(0), weight.size(0), dtype=x.dtype, device=x.device) if need_pre else None
         y = F.gemm(x2, weight, bias=bias, act=act, preact=pre)
         ctx.act = act
@@ -95,7 +124,7 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-class FFNFn(torch.autograd.Function):
+class FFNFn(Function):
     """y = fc2(act(fc1(x)))   (pasero/models/transformer.py:999-1019, 1224-1244; no fc3, no activation dropout).
     Backward fuses act'(.) into the epilogue of the dH = dY·W2 GEMM."""
 
@@ -103,7 +132,7 @@ class FFNFn(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2, b2, act: str, link=None):
         ctx.link = link
         x2 = _2d(_contig(x))
-        grad = any(ctx.needs_input_grad)  # (grad mode is always off inside Function.forward)
+        grad = any(wants_grad(ctx))
         need_pre = grad and act not in ('none', 'relu')
         pre = torch.empty(x2.size(0), w1.size(0), dtype=x.dtype, device=x.device) if need_pre else None
         h = F.gemm(x2, w1, bias=b1, act=act, preact=pre)
@@ -128,7 +157,7 @@ class FFNFn(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2, None, None
 
 
-class GatedFFNFn(torch.autograd.Function):
+class GatedFFNFn(Function):
     """y = fc2( act(fc1 x) * fc3 x )   (SwiGLU / GEGLU, pasero/models/transformer.py:1011-1018): the gate product is the
     epilogue of the fc1 GEMM (mode 3), its backward one elementwise kernel"""
 
@@ -162,7 +191,7 @@ class GatedFFNFn(torch.autograd.Function):
         return dx, dw1, db1, dw3, db3, dw2, db2, None, None
 
 
-class PackedLinearFn(torch.autograd.Function):
+class PackedLinearFn(Function):
     """y = x · W_flatᵀ + b_flat where W_flat [n*D, K] is the flat arena holding `n` projection weights back to back
     (q|k|v or k|v, pasero/models/modules.py:610-615).  ONE GEMM reads x once; the gradient of each nn.Parameter is the
     matching slice of one flat gradient GEMM.  `params` = n weights followed by n biases (or None)."""
@@ -198,7 +227,7 @@ class PackedLinearFn(torch.autograd.Function):
         return (dx, None, None, None, None, *grads)
 
 
-class AttentionFn(torch.autograd.Function):
+class AttentionFn(Function):
     """softmax(q kᵀ * scale + masks) v on projection outputs, without reshapes or transposes:
        self-attention:  a = packed (B,T,3D) [q|k|v], b = c = None      -> backward returns one (B,T,3D) tensor
        cross-attention: a = q (B,T,D), b = packed (B,S,2D) [k|v], c = None
@@ -241,19 +270,19 @@ class AttentionFn(torch.autograd.Function):
         return da, db, dc, None, None, None, None, None
 
 
-class ResidualLayerNormFn(torch.autograd.Function):
+class ResidualLayerNormFn(Function):
     """y = LayerNorm(residual + dropout(x)) in one pass (post-norm blocks, pasero/models/transformer.py:1043-1048);
-    with residual=None and p=0 it is a plain LayerNorm."""
+    with residual=None and p=0 it is a plain LayerNorm; `rms` makes the normalisation an RMSNorm (modules.py:192-202)."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps: float, p: float, link=None):
+    def forward(ctx, x, residual, gamma, beta, eps: float, p: float, link=None, rms: bool = False):
         ctx.link = link if (link is not None and residual is not None and residual.requires_grad) else None
         x = _contig(x)
         residual = _contig(residual) if residual is not None else None
         seed, offset = rng.next_offset() if p > 0 else (0, 0)
         fused = residual is not None or p > 0
         y, z, mean, rstd = F.residual_ln_fwd(x, residual, gamma, beta, eps, p, seed, offset,
-                                             want_z=fused and any(ctx.needs_input_grad))
+                                             want_z=fused and any(wants_grad(ctx)), rms=rms)
         ctx.p, ctx.seed, ctx.offset = p, seed, offset
         ctx.has_res, ctx.has_beta = residual is not None, beta is not None
         ctx.save_for_backward(z if fused else x, gamma, mean, rstd)
@@ -274,10 +303,10 @@ class ResidualLayerNormFn(torch.autograd.Function):
             ctx.link.dres = dres
             dres = None
         return (dx if need_dx else None, dres if ctx.has_res else None, dgamma,
-                dbeta if ctx.has_beta else None, None, None, None)
+                dbeta if ctx.has_beta else None, None, None, None, None)
 
 
-class AdapterFn(torch.autograd.Function):
+class AdapterFn(Function):
     """y = res + s · up(act(down(LN(x))))   — the bottleneck adapter of Bapna et al. and, without LayerNorm / biases /
     activation and with `res` = the frozen layer's output, LoRA (pasero/models/modules.py:248-370 AdapterLayer.forward,
     :67-100 Linear.forward).  Three launches forward (LayerNorm, down-projection with the activation in its epilogue,
@@ -287,7 +316,7 @@ class AdapterFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, ln_w, ln_b, eps: float, down_w, down_b, up_w, up_b, act: str, scaling: float):
         x2 = _2d(_contig(x))
-        grad = any(ctx.needs_input_grad)
+        grad = any(wants_grad(ctx))
         if ln_w is not None:
             h, _, mean, rstd = F.residual_ln_fwd(x2, None, ln_w, ln_b, eps, want_z=False)
         else:
@@ -351,7 +380,7 @@ class AdapterFn(torch.autograd.Function):
                 ddown_w, ddown_b, dup_w, dup_b, None, None)
 
 
-class ResidualDropoutFn(torch.autograd.Function):
+class ResidualDropoutFn(Function):
     """z = residual + dropout(x)   (pre-norm blocks: pasero/models/transformer.py:1043-1044,1049-1050)"""
 
     @staticmethod
@@ -371,7 +400,7 @@ class ResidualDropoutFn(torch.autograd.Function):
         return dx, dz, None
 
 
-class DropoutFn(torch.autograd.Function):
+class DropoutFn(Function):
     """nn.Dropout with a regenerable Philox mask"""
 
     @staticmethod
@@ -385,7 +414,7 @@ class DropoutFn(torch.autograd.Function):
         return F.dropout(_contig(dy), ctx.p, ctx.seed, ctx.offset), None
 
 
-class EmbeddingFn(torch.autograd.Function):
+class EmbeddingFn(Function):
     """dropout(E[ids] * scale + pos[pos_start : pos_start+T])
     (pasero/models/modules.py:916-933; pasero/models/transformer.py:727-744, 866-878)"""
 
@@ -424,7 +453,7 @@ def _ce_chunk_rows(rows: int, V: int, itemsize: int, budget_bytes: int = 128 << 
     return min(rows, per)
 
 
-class VocabCrossEntropyFn(torch.autograd.Function):
+class VocabCrossEntropyFn(Function):
     """Tied vocabulary projection + label-smoothed cross-entropy, chunked over rows so the (rows, V) logits never
     exist as a whole (pasero/models/modules.py:935-947 + pasero/models/transformer.py:354-380).
     Returns sums = [loss, nll_loss, num_tokens] (fp32, device).  Only sums[0] is differentiable.
@@ -436,7 +465,7 @@ class VocabCrossEntropyFn(torch.autograd.Function):
         x2 = _2d(_contig(x))
         tgt = _contig(target).view(-1)
         rows, V = x2.size(0), weight.size(0)
-        grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        grad = any(wants_grad(ctx)[:2])
         row_loss = torch.empty(rows, dtype=torch.float32, device=x.device)
         row_nll = torch.empty(rows, dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x2) if grad else None
@@ -472,7 +501,7 @@ class VocabCrossEntropyFn(torch.autograd.Function):
         return gx, gw, None, None, None
 
 
-class ActivationFn(torch.autograd.Function):
+class ActivationFn(Function):
     """stand-alone activation (non-fused fallback of pasero/models/modules.py:220-228)"""
 
     @staticmethod
@@ -488,7 +517,7 @@ class ActivationFn(torch.autograd.Function):
         return F.act_bwd(_contig(dy), x, ctx.act), None
 
 
-class GLUFn(torch.autograd.Function):
+class GLUFn(Function):
     """nn.GLU over the channel (last) dim of a channels-last tensor (pasero/models/modules.py:802)"""
 
     @staticmethod
@@ -503,7 +532,7 @@ class GLUFn(torch.autograd.Function):
         return F.glu_bwd(_contig(dy), x)
 
 
-class Conv1dChannelsLastFn(torch.autograd.Function):
+class Conv1dChannelsLastFn(Function):
     """nn.Conv1d(C_in, C_out, k, stride, padding) + optional activation on a channels-last (B, L, C_in) input
     (pasero/models/modules.py:793-799,829-833) as an implicit GEMM: with R = ceil((L+2p)/stride) rows per batch, row r
     of the im2col matrix is the contiguous window x_pad[b, r*stride : r*stride+k, :] — a strided VIEW (lda =
@@ -520,7 +549,7 @@ class Conv1dChannelsLastFn(torch.autograd.Function):
         xp[:B * Lp].view(B, Lp, C)[:, padding:padding + L] = x
         A = torch.as_strided(xp, (B * R, k * C), (stride * C, 1))
         wr = weight.permute(0, 2, 1).reshape(O, k * C).contiguous()  # [o][(j, c)]
-        need_pre = act != 'none' and any(ctx.needs_input_grad)
+        need_pre = act != 'none' and any(wants_grad(ctx))
         pre = torch.empty(B * R, O, dtype=x.dtype, device=x.device) if need_pre else None
         y = F.gemm(A, wr, bias=bias, act=act, preact=pre)
         ctx.geom = (B, L, C, O, k, stride, padding, Lout, R)
@@ -549,7 +578,7 @@ class Conv1dChannelsLastFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
-class AddPositionsFn(torch.autograd.Function):
+class AddPositionsFn(Function):
     """dropout(x * scale + pos[pos_start : pos_start+T]) for dense (speech) encoder inputs
     (pasero/models/transformer.py:739-744)"""
 
@@ -577,7 +606,7 @@ class AddPositionsFn(torch.autograd.Function):
         return dx, dpos, None, None, None
 
 
-class CrossEntropyFn(torch.autograd.Function):
+class CrossEntropyFn(Function):
     """Label-smoothed cross-entropy on materialised logits (the reference API `compute_loss(logits, target, ...)`,
     pasero/models/transformer.py:324-380).  Returns sums = [loss, nll_loss, num_tokens]."""
 
@@ -588,7 +617,7 @@ class CrossEntropyFn(torch.autograd.Function):
         rows = lg.size(0)
         row_loss = torch.empty(rows, dtype=torch.float32, device=lg.device)
         row_nll = torch.empty(rows, dtype=torch.float32, device=lg.device)
-        grad = ctx.needs_input_grad[0]
+        grad = wants_grad(ctx)[0]
         dl = torch.empty_like(lg) if grad else None
         F.ce_rows(lg, tgt, padding_idx, eps, row_loss, row_nll, dlogits=dl)
         ctx.shape = logits.shape
@@ -602,7 +631,7 @@ class CrossEntropyFn(torch.autograd.Function):
         return F.scale(dl, _contig(dsums)[:1].float()).view(ctx.shape), None, None, None
 
 
-class RotaryFn(torch.autograd.Function):
+class RotaryFn(Function):
     """RoPE on the q|k part of a packed projection (pasero/models/modules.py:982-1025); backward = inverse rotation"""
 
     @staticmethod

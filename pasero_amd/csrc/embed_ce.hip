@@ -105,6 +105,15 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, l
     const bool active = tgt != pad_idx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float lse = 0.f;
+    // dlogits may alias logits (the fused vocabulary loss works in place): everything a thread reads from x after the
+    // workgroup barrier must be its OWN chunk.  The target logit is therefore fetched here, before any store — read
+    // after the barrier it raced with the wave that overwrites that column with its gradient (seen as one row's nll
+    // off by several nats, once in ~30 runs).
+    float x_tgt = 0.f;
+    if (active && tid == 0) {
+        long long tc = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
+        x_tgt = to_f32<T>(x[tc]);
+    }
     if (active || row_lse) {
         float m = -INFINITY, s = 0.f, tot = 0.f;
         const long long nvec = vec_ok ? V / EPV : 0;
@@ -146,8 +155,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, l
         if (tid == 0) {
             if (row_lse) row_lse[row] = lse;
             if (active) {
-                long long tc = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
-                float nll = lse - to_f32<T>(x[tc]);
+                float nll = lse - x_tgt;
                 float smooth = lse - bc[1] / (float)V;
                 row_nll[row] = nll;
                 row_loss[row] = eps > 0.f ? (1.f - eps) * nll + eps * smooth : nll;

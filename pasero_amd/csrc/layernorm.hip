@@ -4,8 +4,10 @@
 // HBM-bound: one wave (64 lanes) owns one row, each lane keeps its 16-byte chunks of the row in registers, so a row
 // is read exactly once; mean / variance are wave-shuffle reductions in fp32 (two-pass variance, like aten).
 // The dropout mask is regenerated from (seed, offset, element index) in the backward pass, never stored.
-// dgamma / dbeta: per-lane running sums over a wave's rows, one LDS reduction per workgroup, then fp32 atomic adds
-// (256-byte wave-instructions, ~4 KiB per workgroup) into a [2][d] accumulator and a tiny conversion kernel.
+// dgamma / dbeta: per-lane running sums over a wave's rows, one LDS reduction per workgroup into the workgroup's own
+// [2][d] fp32 slab, then a column-parallel reduction kernel over the slabs (no atomics).
+// RMSNorm (pasero/models/modules.py:192-202: y = x * rsqrt(mean(x^2) + eps) * weight, computed in fp32) is the same
+// kernels with the mean fixed at 0: the C ABI selects it with mean == NULL (then beta must be NULL too).
 #include "common.h"
 
 namespace {
@@ -71,7 +73,8 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
                     sum += v[i][e];
                 }
         }
-        float mu = wave_sum(sum) * inv_d;
+        const bool rms = mean_out == nullptr;
+        float mu = rms ? 0.f : wave_sum(sum) * inv_d;
         float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
         }
         float rstd = rsqrtf(wave_sum(sq) * inv_d + eps);
         if (lane == 0) {
-            mean_out[row] = mu;
+            if (!rms) mean_out[row] = mu;
             rstd_out[row] = rstd;
         }
 #pragma unroll
@@ -135,8 +138,9 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
     const long long row_step = (long long)gridDim.x * ROWS_PER_BLOCK;
     Vec16<T> dv_n[NCH], zv_n[NCH];
     float mu_n = 0.f, rs_n = 0.f;
+    const bool rms = mean == nullptr;  // RMSNorm: xhat = z * rstd, no mean-of-gradient term
     auto fetch = [&](long long row) {
-        mu_n = mean[row];
+        mu_n = rms ? 0.f : mean[row];
         rs_n = rstd[row];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
                     for (int e = 0; e < EPV; ++e) g[i][e] = xh[i][e] = 0.f;
                 }
             }
-            s1 = wave_sum(s1) * inv_d;
+            s1 = rms ? 0.f : wave_sum(s1) * inv_d;
             s2 = wave_sum(s2) * inv_d;
         }
 #pragma unroll
@@ -348,7 +352,8 @@ extern "C" int pk_residual_ln_fwd(const void* x, const void* residual, const voi
                                   int dtype, void* stream) {
     if (rows == 0) return 0;
     PK_CHECK_ARG(x, "pk_residual_ln_fwd: x is null");
-    PK_CHECK_ARG(!gamma || (y_out && mean && rstd), "pk_residual_ln_fwd: gamma given but y/mean/rstd missing");
+    PK_CHECK_ARG(!gamma || (y_out && rstd), "pk_residual_ln_fwd: gamma given but y/rstd missing");
+    PK_CHECK_ARG(!gamma || mean || !beta, "pk_residual_ln_fwd: RMSNorm (mean == NULL) has no beta");
     PK_CHECK_ARG(gamma || z_out, "pk_residual_ln_fwd: nothing to compute");
     PK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pk_residual_ln_fwd: bad dropout %f", drop_p);
     if (rows == 0) return 0;
@@ -373,7 +378,8 @@ extern "C" int pk_residual_ln_bwd(const void* dy, const void* dz_extra, const vo
                                   void* dgamma, void* dbeta, void* workspace, size_t ws_bytes, long long rows,
                                   int d, float drop_p, unsigned long long seed, unsigned long long offset,
                                   int dtype, void* stream) {
-    PK_CHECK_ARG(!gamma || (dy && z && mean && rstd), "pk_residual_ln_bwd: LN inputs missing");
+    PK_CHECK_ARG(!gamma || (dy && z && rstd), "pk_residual_ln_bwd: LN inputs missing");
+    PK_CHECK_ARG(!gamma || mean || !dbeta, "pk_residual_ln_bwd: RMSNorm (mean == NULL) has no beta gradient");
     PK_CHECK_ARG(gamma || dz_extra, "pk_residual_ln_bwd: nothing to compute");
     PK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pk_residual_ln_bwd: bad dropout %f", drop_p);
     if (rows == 0) return 0;

@@ -61,8 +61,10 @@ def choose_splitk(M: int, N: int, K: int, target_blocks: int = 512) -> int:
 
 
 def residual_ln_fwd(x: Tensor, residual: Optional[Tensor], gamma: Optional[Tensor], beta: Optional[Tensor],
-                    eps: float, drop_p: float = 0.0, seed: int = 0, offset: int = 0, want_z: bool = True):
-    """z = residual + dropout(x); y = LN(z).  Returns (y or None, z or None, mean, rstd)."""
+                    eps: float, drop_p: float = 0.0, seed: int = 0, offset: int = 0, want_z: bool = True,
+                    rms: bool = False):
+    """z = residual + dropout(x); y = LN(z), or RMSNorm(z) with `rms` (then mean is None and beta must be None).
+    Returns (y or None, z or None, mean, rstd)."""
     require_gpu(x, residual, gamma, beta)
     d = x.size(-1)
     rows = x.numel() // d
@@ -71,7 +73,8 @@ def residual_ln_fwd(x: Tensor, residual: Optional[Tensor], gamma: Optional[Tenso
     z = torch.empty_like(x) if (want_z or gamma is None) else None
     mean = rstd = None
     if gamma is not None:
-        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        assert not (rms and beta is not None)
+        mean = None if rms else torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     L = lib.load()
     check(L.pk_residual_ln_fwd(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(z), ptr(y), ptr(mean), ptr(rstd),

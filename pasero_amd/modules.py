@@ -105,12 +105,20 @@ class WrappableLayerNorm(LayerNorm):
 
 
 class RMSNorm(nn.Module):
+    """modules.py:192-202 — x * rsqrt(mean(x^2) + eps) * weight, computed in fp32 whatever the storage type: the
+    wave-per-row LayerNorm kernel with the mean fixed at 0"""
+
     def __init__(self, dim: int, eps: float = 1e-6):
         super().__init__()
-        raise NotImplementedError('pasero_amd: RMSNorm (decoder-only LLM configs) is outside the hot-path scope')
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x: Tensor) -> Tensor:
+        return ResidualLayerNormFn.apply(x, None, self.weight, None, self.eps, 0.0, None, True)
 
 
-WrappableRMSNorm = RMSNorm
+class WrappableRMSNorm(RMSNorm):
+    pass
 
 
 class Dropout(nn.Dropout):

@@ -43,7 +43,7 @@ def len_to_mask(lengths: LongTensor, size: Optional[int] = None) -> BoolTensor:
 
 def _norm_cls(cfg, wrappable: bool = False):
     if cfg.rms_norm:
-        return modules.RMSNorm
+        return modules.WrappableRMSNorm if wrappable else modules.RMSNorm
     if cfg.norm_bias:
         return modules.WrappableLayerNorm if wrappable else modules.LayerNorm
     return modules.LayerNormWithoutBias

@@ -187,6 +187,27 @@ def test_layernorm_fwd_bwd(F, dtype, rows, d):
     assert rel_err(dres2, xz.grad + extra.float()) < tol
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('rows,d', [(7, 128), (1000, 512), (5, 2048), (3, 520)])
+def test_rmsnorm_fwd_bwd(F, dtype, rows, d):
+    """RMSNorm = the same kernels with mean == NULL (pasero/models/modules.py:192-202)"""
+    x = rnd((rows, d), 26, dtype) + 0.5  # a non-zero mean, so that a wrongly centred kernel fails
+    gamma = (1 + 0.1 * rnd((d,), 27, torch.float32)).to(dtype)
+    dy = rnd((rows, d), 28, dtype)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    x32, g32 = x.float().requires_grad_(), gamma.float().requires_grad_()
+    y_ref = O.rms_norm(x32, g32, 1e-6)
+    y_ref.backward(dy.float())
+    y, _, mean, rstd = F.residual_ln_fwd(x.cuda(), None, gamma.cuda(), None, 1e-6, want_z=False, rms=True)
+    assert mean is None
+    assert rel_err(y, y_ref.detach()) < tol
+    dx, _, dgamma, dbeta = F.residual_ln_bwd(dy.cuda(), None, x.cuda(), gamma.cuda(), None, rstd, want_dres=True,
+                                             want_dx=False, want_param_grads=True, has_beta=False)
+    assert dbeta is None
+    assert rel_err(dx, x32.grad) < tol
+    assert rel_err(dgamma, g32.grad) < tol
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_dropout_residual_ln_mask_consistency(F, dtype):
     """dropout inside the fused kernel: keep-rate ~ 1-p, kept values scaled by 1/(1-p), and the backward pass

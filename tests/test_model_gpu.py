@@ -87,6 +87,12 @@ def test_tiny_swiglu_prenorm_fp32_vs_reference():
     _check_encdec('tiny_encdec_swiglu')
 
 
+def test_tiny_rmsnorm_rotary_swiglu_no_bias_fp32_vs_reference():
+    """llama-style parameterisation of the encoder-decoder: RMSNorm (the LayerNorm kernel with the mean fixed at 0),
+    rotary positions, SwiGLU, no bias on any projection"""
+    _check_encdec('tiny_encdec_rms')
+
+
 def test_adapter_transformer_frozen_backbone_fp32_vs_reference():
     """adapter_transformer (pasero/models/adapters.py): bottleneck adapters after every layer, only they are trained;
     loss, every adapter gradient, logits and argmax against the real reference; frozen parameters get no gradient"""
@@ -382,6 +388,33 @@ def test_argmax_rows_first_maximum():
     want = x.float().argmax(-1)
     want[5] = 0
     assert torch.equal(out[:, 0], want) and out[3, 0] == 100 and (out[:, 1] == -1).all()
+
+
+def test_inference_runs_no_backward_only_work():
+    """`ctx.needs_input_grad` stays True for parameters under torch.no_grad(): the forward passes must look at the
+    caller's grad mode instead (pasero_amd.autograd.wants_grad), or scoring at inference would run the gradient GEMMs of
+    the fused vocabulary loss and write every z = x + residual.  Counted with the library's own GEMM sampler."""
+    from pasero_amd import lib
+    g = load_golden('tiny_encdec_post')
+    cfg, model = build_model(g, torch.float32, 'cuda')
+    batch = text_batch(g, 'cuda')
+    L = lib.load()
+
+    def gemm_calls(fn):
+        lib.check(L.pk_gemm_timing_start(4096, 1), 'pk_gemm_timing_start')
+        out = fn()
+        torch.cuda.synchronize()
+        return L.pk_gemm_timing_stop(), out
+
+    model.eval()
+    with torch.no_grad():
+        n_eval, (loss_eval, _) = gemm_calls(lambda: model(**batch))
+    n_train_fwd, (loss_train, _) = gemm_calls(lambda: model(**batch))
+    # per encoder layer qkv, out, fc1, fc2; per decoder layer qkv, out, q, kv, out, fc1, fc2; + the vocabulary projection
+    forward_gemms = 4 * cfg.encoder_layers + 7 * cfg.decoder_layers + 1
+    assert n_eval == forward_gemms
+    assert n_train_fwd == forward_gemms + 2  # dX and dW of the fused loss, made while the logits chunk is cache-resident
+    assert loss_eval.item() == loss_train.item()
 
 
 def test_edge_cases_empty_single_token_and_all_pad_targets():

@@ -80,6 +80,10 @@ def test_tiny_encdec_swiglu_prenorm():
     _run_encdec('tiny_encdec_swiglu')
 
 
+def test_tiny_encdec_rmsnorm_rotary_swiglu_no_bias():
+    _run_encdec('tiny_encdec_rms')
+
+
 def test_mha_rotary_full_and_incremental():
     g = load_golden('mha_rotary')
     d, H, B, T = (int(g[k]) for k in 'dHBT')
