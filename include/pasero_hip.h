@@ -44,6 +44,7 @@ const char* pk_last_error(void);
  *   mode 2: C = v * act'(aux)        (backward through the activation; aux = pre-activation, or post- for ReLU)
  *   mode 3: C = act(v + bias) * aux  (gated FFN: SwiGLU / GEGLU, pasero/models/transformer.py:1013-1016)
  *   splitk > 1: K is cut into `splitk` slices reduced through `workspace` (>= splitk*M*(N+1)*4 bytes), deterministic.
+ *   aux may alias C (accumulate in place: every element of aux is read by the thread that stores it).
  *   asum_out (optional, needs a_col = 1): asum_out[m] = sum_k A(m,k) — the bias gradient db = colsum(dY) comes out of
  *   the weight-gradient GEMM that already streams dY, instead of a separate pass over it. */
 int pk_gemm(const void* A, const void* B, void* C, const void* bias, const void* aux, void* preact, long long M,

@@ -129,6 +129,27 @@ def test_gemm_splitk(F, dtype, splitk):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('a_col,b_col', [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize('M,N,K,splitk', [(130, 70, 100, 1), (48, 512, 512, 1), (1024, 1024, 512, 1),
+                                          (512, 512, 2048, 4), (200, 264, 1100, 2)])
+def test_gemm_accumulates_in_place(F, dtype, a_col, b_col, M, N, K, splitk):
+    """C = A·B + C with aux aliasing out (the fused loss accumulates dW across row chunks, the gated FFN adds its
+    second dX): every kernel variant (skinny, 128- and 256-tiles, split-K reduce) must read an element of aux in the
+    thread that writes it, and the result must not depend on when other workgroups store"""
+    A = rnd((K, M) if a_col else (M, K), 31, dtype)
+    B = rnd((K, N) if b_col else (N, K), 32, dtype)
+    acc = rnd((M, N), 33, dtype)
+    ref = (A.double().t() if a_col else A.double()) @ (B.double() if b_col else B.double().t()) + acc.double()
+    tol = 2e-5 if dtype == torch.float32 else 6e-3
+    out = acc.cuda()
+    got = F.gemm(A.cuda(), B.cuda(), a_col=a_col, b_col=b_col, aux=out, mode=1, out=out, splitk=splitk)
+    assert got.data_ptr() == out.data_ptr()
+    assert rel_err(out, ref) < tol
+    sep = F.gemm(A.cuda(), B.cuda(), a_col=a_col, b_col=b_col, aux=acc.cuda(), mode=1, splitk=splitk)
+    assert torch.equal(sep, out)  # bitwise the same as with separate buffers
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('splitk', [1, 7])
 @pytest.mark.parametrize('M,N,K', [(192, 160, 4100), (2048, 512, 3000), (130, 70, 100)])
 def test_gemm_fused_bias_gradient(F, dtype, splitk, M, N, K):
