@@ -258,8 +258,25 @@ def checkpoint_wrapper(module: nn.Module, activate: bool = True) -> nn.Module:
     """modules.py:386-391"""
     if activate:
         from torch.utils.checkpoint import checkpoint
-        module._no_ckpt_forward = module.forward
-        module.forward = functools.partial(checkpoint, module._no_ckpt_forward, use_reentrant=False)
+        from . import rng
+        module._no_ckpt_forward = inner = module.forward
+
+        def forward(*args, **kwargs):
+            # Dropout masks here are functions of (seed, offset) handed out by pasero_amd.rng, not of torch's generator:
+            # the recomputation in the backward pass must replay the offsets of the first run (what torch's
+            # preserve_rng_state does for the reference), then put the stream back where the step had got to.
+            entry = rng.get_state()
+
+            def run(*a, **k):
+                now = rng.get_state()
+                rng.set_state(entry)
+                try:
+                    return inner(*a, **k)
+                finally:  # (the recomputation may be cut short once every saved tensor has been rebuilt)
+                    if now != entry:  # this was the recomputation
+                        rng.set_state(now)
+            return checkpoint(run, *args, use_reentrant=False, preserve_rng_state=False, **kwargs)
+        module.forward = forward
     return module
 
 

@@ -390,6 +390,34 @@ def test_argmax_rows_first_maximum():
     assert torch.equal(out[:, 0], want) and out[3, 0] == 100 and (out[:, 1] == -1).all()
 
 
+def test_activation_checkpointing_replays_the_dropout_masks():
+    """cfg.checkpoint_activations (modules.py:386-391): layers are recomputed in the backward pass; with dropout on, the
+    recomputation has to draw the masks of the first run — loss and every gradient equal the non-checkpointed step"""
+    from pasero_amd import rng
+    from pasero_amd.config import DistributedConfig, SyntheticTask
+    from pasero_amd.transformer import Transformer
+    from model_utils import load_paramgen
+    g = load_golden('tiny_encdec_post')
+    results = []
+    for ckpt in (False, True):
+        cfg = build_cfg(g)
+        cfg.dropout, cfg.attention_dropout, cfg.checkpoint_activations = 0.2, 0.1, ckpt
+        model = Transformer(cfg, DistributedConfig(), SyntheticTask(int(g['V'])))
+        load_paramgen(model, int(g['seed']))
+        model = model.cuda().train()
+        rng.manual_seed(77)
+        loss, _ = model(**text_batch(g, 'cuda'))
+        loss.backward()
+        results.append((loss.item(), {n: p.grad.clone() for n, p in model.named_parameters()}, rng.get_state()))
+    (l0, g0, s0), (l1, g1, s1) = results
+    assert l0 == l1 and s0 == s1  # same masks in the forward pass, and the offset stream ends at the same place
+    for n in g0:
+        if 'embed_tokens' in n:   # fp32 atomics: summation order varies from run to run
+            assert rel(g1[n], g0[n]) < 1e-5, n
+        else:
+            assert torch.equal(g0[n], g1[n]), n
+
+
 def test_inference_runs_no_backward_only_work():
     """`ctx.needs_input_grad` stays True for parameters under torch.no_grad(): the forward passes must look at the
     caller's grad mode instead (pasero_amd.autograd.wants_grad), or scoring at inference would run the gradient GEMMs of
