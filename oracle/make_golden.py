@@ -120,7 +120,7 @@ CFG_KEYS = [
     'positional_encoding_shift', 'scale_embed', 'encoder_max_len', 'decoder_max_len', 'shared_embeddings',
     'tied_output_projection', 'rope_base', 'input_dim', 'conv_input_dim', 'conv_channels', 'conv_kernel_sizes',
     'conv_strides', 'conv_activation', 'norm_eps', 'padding_idx', 'eos_idx', 'bos_idx', 'attention_key_bias',
-    'has_bias', 'rms_norm',
+    'has_bias', 'rms_norm', 'norm_bias', 'scale_attn', 'prompt_loss', 'shared_norm',
 ]
 
 
@@ -136,12 +136,12 @@ def cfg_json(cfg):
 
 
 # ----------------------------------------------------------------------------------------------------------
-def gen_encdec(name, V, B, S, T, seed, store_grads='full', arch='transformer', **overrides):
+def gen_encdec(name, V, B, S, T, seed, store_grads='full', arch='transformer', prompt_cols=0, **overrides):
     """Whole Transformer.forward + backward (transformer.py:227-380), encoder (698-752), decoder (831-898)"""
     cfg, model = build_model(V, arch=arch, **overrides)
     names_shapes = load_params(model, seed)
     model.train()  # dropout probabilities are 0 in every fixture config, so train() == eval() numerically
-    batch = paramgen.make_text_batch(seed, B, S, T, V)
+    batch = paramgen.make_text_batch(seed, B, S, T, V, prompt_cols=prompt_cols)
     tb = {k: t(v) for k, v in batch.items()}
     loss, logs = model(**tb)
     loss.backward()
@@ -151,6 +151,11 @@ def gen_encdec(name, V, B, S, T, seed, store_grads='full', arch='transformer', *
         'logs_num_tokens': logs['num_tokens'], 'logs_num_lines': logs['num_lines'],
         **names_shapes_arrays(names_shapes),
     }
+    if prompt_cols:
+        out['prompt_cols'] = prompt_cols
+    for k in ('prompt_nll_loss', 'num_prompt_tokens'):  # the two-part loss of cfg.prompt_loss != 1 (transformer.py:283-321)
+        if k in logs:
+            out['logs_' + k] = logs[k]
     grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
     out['frozen_names'] = np.array([k for k, p in model.named_parameters() if not p.requires_grad] or [''])
     out['grad_names'] = np.array(list(grads))
@@ -315,6 +320,23 @@ def gen_tiny_rms():
                decoder_attention_heads=2, encoder_layers=2, decoder_layers=1, dropout=0.0, activation_fn='swiglu',
                encoder_prenorm=True, decoder_prenorm=True, rms_norm=True, has_bias=False, norm_eps=1e-6,
                encoder_positional_encoding='rotary', decoder_positional_encoding='rotary')
+
+
+def gen_tiny_opts():
+    """configuration switches of the base path that no other fixture turns: untied output projection, separate
+    encoder / decoder embeddings, LayerNorm without bias, unscaled attention scores, the two-part prompt loss
+    (transformer.py:283-321) — and pre-norm layers sharing one norm (shared_norm), no biases, prompt tokens unscored"""
+    gen_encdec('tiny_opts_a', V=89, B=4, S=8, T=7, seed=19, prompt_cols=2,
+               embed_dim=128, encoder_ffn_dim=128, decoder_ffn_dim=192, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=1, decoder_layers=2, dropout=0.0, activation_fn='gelu',
+               shared_embeddings=False, tied_output_projection=False, norm_bias=False, scale_attn=False,
+               prompt_loss=0.5)
+    gen_encdec('tiny_opts_b', V=97, B=4, S=9, T=6, seed=20, prompt_cols=3,
+               embed_dim=128, encoder_ffn_dim=192, decoder_ffn_dim=128, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=2, decoder_layers=1, dropout=0.0,
+               encoder_prenorm=True, decoder_prenorm=True, shared_norm=True, has_bias=False, prompt_loss=0.0,
+               scale_embed=False, label_smoothing=0.0, decoder_positional_encoding='learned',
+               encoder_embed_norm=True)
 
 
 def gen_ce():
@@ -486,6 +508,7 @@ GENERATORS = {
     'tiny_encdec_rotary': gen_tiny_rotary,
     'tiny_encdec_swiglu': gen_tiny_swiglu,
     'tiny_encdec_rms': gen_tiny_rms,
+    'tiny_opts': gen_tiny_opts,
     'ce_ls': gen_ce,
     'sinpos': gen_sinpos,
     'speech': gen_speech,

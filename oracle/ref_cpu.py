@@ -219,6 +219,15 @@ def _rope(cfg, kind):
     return float(getattr(cfg, 'rope_base', 10000)) if kind == 'rotary' else None
 
 
+def _scaled(cfg) -> bool:
+    return bool(getattr(cfg, 'scale_attn', True))  # modules.py:654: scores are divided by sqrt(head_dim) unless disabled
+
+
+def _final_norm(cfg, prefix):
+    # transformer.py:977-980,1202-1205: with shared_norm the layer's last norm IS its first one
+    return prefix + ('.self_attn_layer_norm' if getattr(cfg, 'shared_norm', False) else '.final_layer_norm')
+
+
 def _ln(P, prefix, x, cfg):
     if getattr(cfg, 'rms_norm', False):  # models/transformer.py:941-947: RMSNorm instead of nn.LayerNorm
         return rms_norm(x, P[prefix + '.weight'], cfg.norm_eps)
@@ -240,16 +249,16 @@ def encoder_layer(P: dict, prefix: str, x: Tensor, pad_mask: Tensor, cfg) -> Ten
     if pre:
         x = _ln(P, prefix + '.self_attn_layer_norm', x, cfg)
     x, _ = multihead_attention(P, prefix + '.self_attn', x, x, x, cfg.encoder_attention_heads, pad_mask,
-                               rope_base=_rope(cfg, cfg.encoder_positional_encoding))
+                               scaled=_scaled(cfg), rope_base=_rope(cfg, cfg.encoder_positional_encoding))
     x = res + x
     if not pre:
         x = _ln(P, prefix + '.self_attn_layer_norm', x, cfg)
     res = x
     if pre:
-        x = _ln(P, prefix + '.final_layer_norm', x, cfg)
+        x = _ln(P, _final_norm(cfg, prefix), x, cfg)
     x = res + _ffn(P, prefix, x, cfg)
     if not pre:
-        x = _ln(P, prefix + '.final_layer_norm', x, cfg)
+        x = _ln(P, _final_norm(cfg, prefix), x, cfg)
     return x
 
 
@@ -267,7 +276,7 @@ def decoder_layer(P: dict, prefix: str, x: Tensor, enc_out: Tensor, enc_mask: Te
         key = f'dec_{layer_id}_self_attn_'
         sa_state = {k[len(key):]: v for k, v in state.items() if k.startswith(key)}
     x, _ = multihead_attention(P, prefix + '.self_attn', x, x, x, H, None, causal=True, state=sa_state,
-                               rope_base=_rope(cfg, cfg.decoder_positional_encoding))
+                               scaled=_scaled(cfg), rope_base=_rope(cfg, cfg.decoder_positional_encoding))
     if sa_state:
         state.update({f'dec_{layer_id}_self_attn_{k}': v for k, v in sa_state.items()})
     x = res + x
@@ -276,16 +285,16 @@ def decoder_layer(P: dict, prefix: str, x: Tensor, enc_out: Tensor, enc_mask: Te
     res = x
     if pre:
         x = _ln(P, prefix + '.encoder_attn_layer_norm', x, cfg)
-    x, _ = multihead_attention(P, prefix + '.encoder_attn', x, enc_out, enc_out, H, enc_mask)
+    x, _ = multihead_attention(P, prefix + '.encoder_attn', x, enc_out, enc_out, H, enc_mask, scaled=_scaled(cfg))
     x = res + x
     if not pre:
         x = _ln(P, prefix + '.encoder_attn_layer_norm', x, cfg)
     res = x
     if pre:
-        x = _ln(P, prefix + '.final_layer_norm', x, cfg)
+        x = _ln(P, _final_norm(cfg, prefix), x, cfg)
     x = res + _ffn(P, prefix, x, cfg)
     if not pre:
-        x = _ln(P, prefix + '.final_layer_norm', x, cfg)
+        x = _ln(P, _final_norm(cfg, prefix), x, cfg)
     return x
 
 
@@ -363,20 +372,31 @@ def decoder(P: dict, cfg, enc_out: Tensor, enc_mask: Tensor, decoder_input: Tens
 
 def transformer_forward(P: dict, cfg, encoder_input: Tensor, encoder_input_length: Tensor,
                         decoder_input: Tensor, prompt_mask: Optional[Tensor] = None, **unused):
-    """models/transformer.py:227-283 + compute_loss :324-380 (prompt_loss == 1.0).
+    """models/transformer.py:227-321 + compute_loss :324-380.
     Returns (loss tensor, logs dict with loss/nll_loss in bits, num_tokens, num_lines)."""
     target = decoder_input[:, 1:]
     dec_in = decoder_input[:, :-1]
     enc_out, enc_mask = encoder(P, cfg, encoder_input, encoder_input_length)
     logits = decoder(P, cfg, enc_out, enc_mask, dec_in)
-    loss, nll, ntok = label_smoothed_ce(logits.reshape(-1, logits.size(-1)), target.reshape(-1),
-                                        cfg.padding_idx, cfg.label_smoothing or 0.0)
-    logs = {
-        'loss': loss.item() / LN2,
-        'nll_loss': nll.item() / LN2,
-        'num_tokens': int(ntok),
-        'num_lines': target.size(0),
-    }
+
+    def ce(tgt):
+        loss, nll, ntok = label_smoothed_ce(logits.reshape(-1, logits.size(-1)), tgt.reshape(-1),
+                                            cfg.padding_idx, cfg.label_smoothing or 0.0)
+        return loss, {'loss': loss.item() / LN2, 'nll_loss': nll.item() / LN2, 'num_tokens': int(ntok),
+                      'num_lines': target.size(0)}
+    scale = getattr(cfg, 'prompt_loss', 1.0)
+    if scale == 1.0:
+        return ce(target)
+    # transformer.py:283-321: generated tokens at weight 1, prompt tokens at weight `prompt_loss`
+    pmask = prompt_mask[:, 1:]
+    loss, logs = ce(target.masked_fill(pmask, cfg.padding_idx))
+    if scale > 0:
+        p_loss, p_logs = ce(target.masked_fill(~pmask, cfg.padding_idx))
+        logs['prompt_nll_loss'] = p_logs['nll_loss']
+        logs['loss'] = logs['loss'] + scale * p_logs['loss']
+        logs['num_tokens'] += p_logs['num_tokens']
+        logs['num_prompt_tokens'] = p_logs['num_tokens']
+        loss = loss + scale * p_loss
     return loss, logs
 
 

@@ -41,7 +41,7 @@ def make_state_dict(seed: int, names_shapes) -> dict:
 
 
 def make_text_batch(seed: int, B: int, S: int, T: int, V: int, ragged: bool = True,
-                    pad: int = 1, eos: int = 2, min_frac: float = 0.5) -> dict:
+                    pad: int = 1, eos: int = 2, min_frac: float = 0.5, prompt_cols: int = 0) -> dict:
     """Synthetic padded (B, S) / (B, T+1) batch following SURVEY §8d: ids ~ U[4, V), last source token and
     first/last decoder tokens = EOS/BOS (2), pad = 1, `prompt_mask[:, 0] = True`.
     `decoder_input` has T+1 columns (BOS + T targets) like the batches of `pasero/tasks/task.py:564-571`."""
@@ -64,6 +64,9 @@ def make_text_batch(seed: int, B: int, S: int, T: int, V: int, ragged: bool = Tr
         dec[b, tlen[b] + 1:] = pad
     prompt_mask = np.zeros((B, T + 1), dtype=bool)
     prompt_mask[:, 0] = True
+    for b in range(B):  # `prompt_cols`: odd rows carry a prompt of up to that many target tokens (cfg.prompt_loss cases)
+        if prompt_cols and b % 2 == 1:
+            prompt_mask[b, : 1 + min(prompt_cols, max(0, tlen[b] - 1))] = True
     return {
         'encoder_input': enc,
         'encoder_input_length': slen.astype(np.int64),

@@ -45,7 +45,9 @@ def oracle_state(g, cfg):
 
 
 def text_batch(g, device='cpu'):
-    b = paramgen.make_text_batch(int(g['seed']), int(g['B']), int(g['S']), int(g['T']), int(g['V']))
+    prompt_cols = int(g['prompt_cols']) if 'prompt_cols' in getattr(g, 'files', g) else 0
+    b = paramgen.make_text_batch(int(g['seed']), int(g['B']), int(g['S']), int(g['T']), int(g['V']),
+                                 prompt_cols=prompt_cols)
     return {k: torch.from_numpy(v).to(device) for k, v in b.items()}
 
 

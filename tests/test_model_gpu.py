@@ -34,6 +34,10 @@ def _check_encdec(name, full=True):
     assert abs(logs['loss'] - float(g['logs_loss'])) <= 1e-4 * abs(float(g['logs_loss']))
     assert abs(logs['nll_loss'] - float(g['logs_nll_loss'])) <= 1e-4 * abs(float(g['logs_nll_loss']))
     assert logs['num_tokens'] == int(g['logs_num_tokens']) and logs['num_lines'] == int(g['logs_num_lines'])
+    for k in ('prompt_nll_loss', 'num_prompt_tokens'):  # the two-part loss of cfg.prompt_loss != 1
+        assert (k in logs) == ('logs_' + k in g.files)
+        if k in logs:
+            assert abs(logs[k] - float(g['logs_' + k])) <= 1e-4 * abs(float(g['logs_' + k])), k
     grads = dict(model.named_parameters())
     for n, ref_norm in zip(g['grad_names'], g['grad_norms']):
         n = str(n)
@@ -91,6 +95,14 @@ def test_tiny_rmsnorm_rotary_swiglu_no_bias_fp32_vs_reference():
     """llama-style parameterisation of the encoder-decoder: RMSNorm (the LayerNorm kernel with the mean fixed at 0),
     rotary positions, SwiGLU, no bias on any projection"""
     _check_encdec('tiny_encdec_rms')
+
+
+@pytest.mark.parametrize('name', ['tiny_opts_a', 'tiny_opts_b'])
+def test_configuration_switches_fp32_vs_reference(name):
+    """(a) untied output projection, separate encoder / decoder embeddings, LayerNorm without bias, unscaled attention
+    scores, prompt tokens scored at weight 0.5 (the non-fused two-pass loss, transformer.py:283-321);
+    (b) pre-norm layers sharing one norm, no biases, prompt tokens unscored, no label smoothing, embedding LayerNorm"""
+    _check_encdec(name)
 
 
 def test_adapter_transformer_frozen_backbone_fp32_vs_reference():
