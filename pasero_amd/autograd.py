@@ -27,10 +27,21 @@ class Function(torch.autograd.Function):
     use it to skip everything that only a backward pass needs (saved pre-activations, z = x + residual, dropout masks,
     and the gradient GEMMs the fused vocabulary cross-entropy runs in its forward) at inference."""
 
+    _keep_fp32 = ()  # positions of tensor arguments that stay fp32 under autocast (e.g. rotary tables)
+
     @classmethod
     def apply(cls, *args, **kwargs):
         prev, _outer.grad = _outer.grad, torch.is_grad_enabled()
         try:
+            if torch.is_autocast_enabled('cuda'):
+                # `--amp` (pasero/training.py:27-31,379): fp32 parameters, 16-bit compute.  Same contract as
+                # torch.amp.custom_fwd(cast_inputs=...): fp32 CUDA tensors are cast on the way in (the casts stay in
+                # the autograd graph, so parameter gradients come back in fp32) and the kernels run in that type.
+                dt = torch.get_autocast_dtype('cuda')
+                args = tuple(a.to(dt) if (torch.is_tensor(a) and a.is_cuda and a.dtype == torch.float32
+                                          and i not in cls._keep_fp32) else a for i, a in enumerate(args))
+                with torch.autocast('cuda', enabled=False):
+                    return super().apply(*args, **kwargs)
             return super().apply(*args, **kwargs)
         finally:
             _outer.grad = prev
@@ -633,6 +644,7 @@ class CrossEntropyFn(Function):
 
 class RotaryFn(Function):
     """RoPE on the q|k part of a packed projection (pasero/models/modules.py:982-1025); backward = inverse rotation"""
+    _keep_fp32 = (1, 2)  # the cos / sin tables
 
     @staticmethod
     def forward(ctx, x, cos_t, sin_t, ncols: int, pos_offset: int):

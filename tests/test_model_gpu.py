@@ -574,6 +574,43 @@ def test_fp16_model_vs_reference(name):
     assert (lg2[:, -1].float() - full[:, -1].float()).abs().max().item() <= 2e-2 * full[:, -1].float().abs().max().item()
 
 
+@pytest.mark.parametrize('name', ['tiny_encdec_post', 'tiny_encdec_rms', 'speech_whisper'])
+def test_amp_autocast_fp32_parameters_fp16_compute(name):
+    """`--amp` (pasero/training.py:27-31,107-112,379): torch.autocast(float16) around the forward pass of an fp32 model.
+    The custom functions follow the custom_fwd contract — fp32 tensors are cast on the way in, the kernels run in fp16,
+    parameter gradients come back in fp32"""
+    g = load_golden(name)
+    cfg, model = build_model(g, torch.float32, 'cuda')
+    model.train()
+    if name.startswith('speech'):
+        seed, B, S, T, V = (int(g[k]) for k in ('seed', 'B', 'S', 'T', 'V'))
+        feats = torch.from_numpy(paramgen.make_array(seed, name + '.feats', (B, S, cfg.input_dim)))
+        lens = torch.from_numpy(g['lens'])
+        for b in range(B):
+            feats[b, lens[b]:] = 0
+        tb = paramgen.make_text_batch(seed, B, 4, T, V)
+        batch = dict(encoder_input=feats.cuda(), encoder_input_length=lens.cuda(),
+                     decoder_input=torch.from_numpy(tb['decoder_input']).cuda(),
+                     prompt_mask=torch.from_numpy(tb['prompt_mask']).cuda())
+    else:
+        batch = text_batch(g, 'cuda')
+    with torch.autocast('cuda', dtype=torch.float16):
+        enc_out, _, _ = model.encoder(batch['encoder_input'], batch['encoder_input_length'])
+        loss, logs = model(**batch)
+    assert enc_out.dtype == torch.float16       # the kernels really ran in 16 bits
+    loss.backward()
+    ref_loss = float(g['loss'])
+    assert loss.dtype == torch.float32
+    assert abs(loss.item() - ref_loss) <= 3e-3 * abs(ref_loss)
+    assert logs['num_tokens'] == int(g['logs_num_tokens'])
+    grads = dict(model.named_parameters())
+    assert all(p.dtype == torch.float32 and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all()
+               for p in grads.values())
+    tot_ref = float(np.sqrt((g['grad_norms'] ** 2).sum()))
+    tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in grads.values())).item())
+    assert abs(tot - tot_ref) <= 2e-2 * tot_ref
+
+
 def test_lora_weights_merge_into_the_linear_layers_at_inference():
     """transformer.py:484-497: at inference the low-rank updates are folded into the weights when the checkpoint is loaded
     (cfg.lora_rank is reset to 0 by setup_for_inference) — the merged model must compute what the LoRA model computes"""
