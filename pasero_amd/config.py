@@ -293,3 +293,10 @@ class SyntheticTask:
         self.encoder_num_embeddings = encoder_num_embeddings
         self.decoder_num_embeddings = (
             encoder_num_embeddings if decoder_num_embeddings is None else decoder_num_embeddings)
+
+    # vocabulary re-mapping when fine-tuning a model trained with other dictionaries (pasero/tasks/task.py): identity
+    def remap_encoder_embed(self, embed):
+        return embed
+
+    def remap_decoder_embed(self, embed):
+        return embed

@@ -197,16 +197,35 @@ class Transformer(EncoderDecoder):
 
     # ---- checkpoint plumbing the Trainer touches (training.py:135-148,622-623,797-800,926) ----
     def remap_state_dict(self, state_dict: dict) -> None:
+        """:382-417 — one-off conversions when fine-tuning another model: vocabulary re-mapping of the embedding-shaped
+        tensors by the task, and `--shift-{encoder,decoder}-layers` (training only)"""
         for name, fn in (('encoder.embed_tokens.weight', 'remap_encoder_embed'),
-                         ('decoder.embed_tokens.weight', 'remap_decoder_embed')):
-            if name in state_dict and hasattr(self.task, fn):
+                         ('decoder.embed_tokens.weight', 'remap_decoder_embed'),
+                         ('decoder.output_projection.weight', 'remap_decoder_embed')):
+            if name in state_dict:
                 state_dict[name] = getattr(self.task, fn)(state_dict[name])
+        import re
+        for component in ('encoder', 'decoder'):
+            shift = getattr(self.cfg, f'shift_{component}_layers', 0)
+            if not (self.training and shift):
+                continue
+            pattern = re.compile(rf'{component}\.layers\.(\d+)\.')
+            renamed = {}
+            for key, value in state_dict.items():
+                m = pattern.match(key)
+                if m:
+                    key = f'{component}.layers.{int(m.group(1)) + shift}.' + key[m.end():]
+                renamed[key] = value
+            state_dict.clear()
+            state_dict.update(renamed)
 
     def update_state_dict(self, state_dict: dict) -> None:
-        """:419-497 restricted to what applies here: shared-embedding aliases, fairseq `in_proj` split, stale keys"""
+        """:419-497: stale fairseq / HuggingFace keys, shared-embedding aliases, fairseq `in_proj` split, HF's name for
+        the decoder's last norm, the frozen-embedding copy, LoRA (new branches when training, merged at inference)"""
         for k in list(state_dict):
             if k.endswith('.version'):
                 state_dict.pop(k)
+        state_dict.pop('lm_head.weight', None)
         enc, dec = 'encoder.embed_tokens.weight', 'decoder.embed_tokens.weight'
         if enc in state_dict and dec not in state_dict:
             state_dict[dec] = state_dict[enc]
@@ -224,6 +243,13 @@ class Transformer(EncoderDecoder):
                 dim = param.size(0) // 3
                 for i, s in enumerate(['.q_proj.', '.k_proj.', '.v_proj.']):
                     state_dict[name.replace('.in_proj_', s)] = param[dim * i:dim * (i + 1)]
+            else:  # (HuggingFace checkpoints call the decoder's last norm `final_layer_norm`)
+                state_dict[name.replace('decoder.final_layer_norm.', 'decoder.layer_norm.')] = state_dict.pop(name)
+        frozen = 'encoder.embed_tokens.frozen_embedding.weight'
+        if self.task.freeze_encoder_embed_mask is not None:
+            state_dict[frozen] = state_dict[enc]
+        else:
+            state_dict.pop(frozen, None)
         if self.cfg.lora_rank and self.training:  # :479-482: new LoRA branches start from their random init
             modules.add_missing_parameters(self, state_dict, r'.*\.lora\..*')
         if not self.training:  # :484-497: at inference the low-rank updates are merged into the linear weights
@@ -263,6 +289,8 @@ class Transformer(EncoderDecoder):
         key = 'decoder.embed_tokens.weight'
         if key in state_dict and state_dict[key].numel() == 0:
             state_dict.pop(key)
+        state_dict.pop('encoder.embed_tokens.frozen_embedding.weight', None)
+        state_dict.pop('decoder.embed_tokens.frozen_embedding.weight', None)
 
     def parallelize(self, devices) -> None:
         assert not self.training

@@ -45,6 +45,84 @@ class FakeTask:
         self.encoder_num_embeddings, self.decoder_num_embeddings = enc, dec
 
 
+def state_dict_plumbing(RC, RT):
+    """remap_state_dict / update_state_dict / clean_state_dict (transformer.py:382-497,584-592) applied by the reference
+    model and by ours to the same synthetic checkpoints must leave the same keys and values, and ours must then load
+    strictly"""
+    import copy
+    import torch
+    import pasero_amd.transformer as T
+    problems = []
+
+    class Task(FakeTask):
+        def remap_encoder_embed(self, e): return e * 2
+        def remap_decoder_embed(self, e): return e * 3
+
+    def small(**kw):
+        cfg = RC.TransformerConfig(embed_dim=128, encoder_ffn_dim=64, decoder_ffn_dim=64, encoder_attention_heads=2,
+                                   decoder_attention_heads=2, encoder_layers=2, decoder_layers=2, **kw)
+        cfg.label_smoothing, cfg.model_type, cfg.decoder_max_len = 0.1, 'encoder_decoder', 64
+        return cfg
+
+    def stale_checkpoint(model):
+        """what old fairseq / HuggingFace checkpoints look like"""
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        for layer in ('encoder.layers.0.self_attn', 'decoder.layers.1.encoder_attn'):
+            for kind in ('weight', 'bias'):
+                parts = [sd.pop(f'{layer}.{p}_proj.{kind}') for p in 'qkv']
+                sd[f'{layer}.in_proj_{kind}'] = torch.cat(parts)
+        sd['decoder.version'] = torch.tensor([3.0])
+        sd['lm_head.weight'] = torch.zeros(3, 3)
+        sd.pop('decoder.embed_tokens.weight', None)
+        if 'decoder.layer_norm.weight' in sd:
+            for kind in ('weight', 'bias'):
+                sd[f'decoder.final_layer_norm.{kind}'] = sd.pop(f'decoder.layer_norm.{kind}')
+        if model.cfg.tied_output_projection:
+            sd['decoder.output_projection.weight'] = torch.zeros(5, 128)
+        sd['encoder.embed_tokens.frozen_embedding.weight'] = torch.zeros(2, 2)
+        return sd
+
+    cases = [('post-norm, training', small(), True), ('pre-norm, inference', small(encoder_prenorm=True,
+             decoder_prenorm=True), False), ('untied, unshared', small(tied_output_projection=False,
+             shared_embeddings=False), True), ('lora training', small(lora_rank=4), True),
+             ('lora inference', small(lora_rank=4), False), ('shifted layers', small(), True)]
+    for tag, cfg, training in cases:
+        if tag == 'shifted layers':
+            cfg.shift_encoder_layers, cfg.shift_decoder_layers = 1, 0
+        torch.manual_seed(0)
+        ref = RT.Transformer(cfg, RC.DistributedConfig(), Task(50, 50)).train(training)
+        ours = T.Transformer(cfg, RC.DistributedConfig(), Task(50, 50)).train(training)
+        ours.load_state_dict(ref.state_dict())
+        base = stale_checkpoint(ref)
+        if tag.startswith('lora') and training:  # a checkpoint of the backbone only: LoRA parameters are new
+            base = {k: v for k, v in base.items() if '.lora.' not in k}
+        a, b = copy.deepcopy(base), copy.deepcopy(base)
+        for model, sd in ((ref, a), (ours, b)):
+            model.remap_state_dict(sd)
+            model.update_state_dict(sd)
+        if set(a) != set(b):
+            problems.append(f'state dict plumbing [{tag}]: keys differ: only reference {sorted(set(a) - set(b))[:5]}, '
+                            f'only ours {sorted(set(b) - set(a))[:5]}')
+            continue
+        lora_new = tag == 'lora training'
+        bad = [k for k in a if a[k].shape != b[k].shape or
+               (not (lora_new and '.lora.' in k) and not torch.allclose(a[k].float(), b[k].float(), atol=1e-6))]
+        if bad:
+            problems.append(f'state dict plumbing [{tag}]: values differ for {bad[:5]}')
+        if tag != 'shifted layers':
+            ref.load_state_dict(a, strict=True)
+            try:
+                ours.load_state_dict(b, strict=True)
+            except Exception as e:  # noqa: BLE001
+                problems.append(f'state dict plumbing [{tag}]: strict load fails: {str(e)[:300]}')
+        a, b = dict(ref.state_dict()), dict(ours.state_dict())
+        ref.clean_state_dict(a)
+        ours.clean_state_dict(b)
+        if set(a) != set(b):
+            problems.append(f'clean_state_dict [{tag}]: keys differ')
+    return problems
+
+
 def main() -> int:
     RC, RT, RA = import_reference()
     import pasero_amd.config as MC
@@ -103,6 +181,7 @@ def main() -> int:
         frozen = lambda m: sorted(k for k, p in m.named_parameters() if not p.requires_grad)  # noqa: E731
         if frozen(ours) != frozen(theirs):
             problems.append(f'{cfg_cls.__name__}: the set of frozen parameters differs')
+    problems += state_dict_plumbing(RC, RT)
     for p in problems:
         print('AUDIT:', p)
     print(f'audit_against_reference: {len(problems)} problem(s), {len(used)} cfg fields, {len(MC.CONFIGS)} presets, '
