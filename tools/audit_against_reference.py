@@ -120,6 +120,64 @@ def state_dict_plumbing(RC, RT):
         ours.clean_state_dict(b)
         if set(a) != set(b):
             problems.append(f'clean_state_dict [{tag}]: keys differ')
+    problems += adapter_plumbing(RC, Task)
+    return problems
+
+
+def adapter_plumbing(RC, Task):
+    """AdapterTransformer.update_state_dict / clean_state_dict (adapters.py:144-166): new adapters keep their
+    initialisation when training on a backbone checkpoint, adapters the model does not hold are parked in
+    `extra_adapters` and written back by clean_state_dict, missing adapters are disabled at inference"""
+    import copy
+    import torch
+    from pasero.models import adapters as RA
+    import pasero_amd.adapters as A
+    problems = []
+
+    def cfg_for(enc, dec):
+        cfg = RC.AdapterTransformerConfig(embed_dim=128, encoder_ffn_dim=64, decoder_ffn_dim=64,
+                                          encoder_attention_heads=2, decoder_attention_heads=2, encoder_layers=2,
+                                          decoder_layers=1, encoder_adapters=enc, decoder_adapters=dec)
+        cfg.label_smoothing, cfg.model_type, cfg.decoder_max_len = 0.1, 'encoder_decoder', 64
+        return cfg
+
+    torch.manual_seed(1)
+    donor = RA.AdapterTransformer(cfg_for(['a', 'x'], ['a', 'x']), RC.DistributedConfig(), Task(40, 40))
+    full = {k: v.clone() for k, v in donor.state_dict().items()}
+    backbone = {k: v for k, v in full.items() if '.adapters.' not in k}
+    for tag, enc, dec, training, ckpt in (('new adapters on a backbone', ['a'], ['a', 'b'], True, backbone),
+                                          ('checkpoint holds other adapters', ['a'], ['a'], True, full),
+                                          ('inference with a subset', ['a'], ['x', 'zz'], False, full)):
+        cfg = cfg_for(enc, dec)
+        ref = RA.AdapterTransformer(cfg, RC.DistributedConfig(), Task(40, 40)).train(training)
+        ours = A.AdapterTransformer(cfg, RC.DistributedConfig(), Task(40, 40)).train(training)
+        ours.load_state_dict(ref.state_dict())
+        a, b = copy.deepcopy(ckpt), copy.deepcopy(ckpt)
+        ref.update_state_dict(a)
+        ours.update_state_dict(b)
+        if set(a) != set(b):
+            problems.append(f'adapter plumbing [{tag}]: keys differ: only reference {sorted(set(a) - set(b))[:4]}, '
+                            f'only ours {sorted(set(b) - set(a))[:4]}')
+            continue
+        bad = [k for k in a if not torch.equal(a[k], b[k])]
+        if bad:
+            problems.append(f'adapter plumbing [{tag}]: values differ for {bad[:4]}')
+        if sorted(ref.extra_adapters) != sorted(ours.extra_adapters):
+            problems.append(f'adapter plumbing [{tag}]: extra_adapters differ')
+        ref.load_state_dict(a, strict=True)
+        try:
+            ours.load_state_dict(b, strict=True)
+        except Exception as e:  # noqa: BLE001
+            problems.append(f'adapter plumbing [{tag}]: strict load fails: {str(e)[:300]}')
+            continue
+        a, b = dict(ref.state_dict()), dict(ours.state_dict())
+        ref.clean_state_dict(a)
+        ours.clean_state_dict(b)
+        if set(a) != set(b):
+            problems.append(f'adapter clean_state_dict [{tag}]: keys differ: {sorted(set(a) ^ set(b))[:6]}')
+        frozen = lambda m: sorted(k for k, p in m.named_parameters() if not p.requires_grad)  # noqa: E731
+        if frozen(ref) != frozen(ours):
+            problems.append(f'adapter plumbing [{tag}]: frozen parameter sets differ after loading')
     return problems
 
 
