@@ -454,6 +454,64 @@ def gen_greedy():
          n_steps=len(steps), **names_shapes_arrays(names_shapes))
 
 
+def gen_beam():
+    """decoding.beam_search (decoding.py:1225-1657) as a TRACE: what the search feeds the decoder at every step
+    (tokens, incremental `state`) and the beam re-ordering it applies to the state (`Decoder.reorder_state`, including the
+    steps where finished sentences leave the batch), with the last-position logits the reference decoder returned.
+    The GPU test replays the trace through pasero_amd's decoder and `reorder_state`; the search itself stays the
+    reference's Python."""
+    V, B, S, K, max_out = 61, 4, 7, 3, 10
+    cfg, model = build_model(V, embed_dim=128, encoder_ffn_dim=128, decoder_ffn_dim=128,
+                             encoder_attention_heads=2, decoder_attention_heads=2, encoder_layers=1,
+                             decoder_layers=2, dropout=0.0)
+    for seed in range(40, 80):  # first seed whose search drops finished sentences from the batch on the way
+        names_shapes = load_params(model, seed)
+        model.eval()
+        batch = paramgen.make_text_batch(seed, B, S, 5, V)
+        trace = {'dec_in': [], 'logits': [], 'reorder': [], 'rows': []}
+        dec = model.decoder
+        inner_forward = dec.forward
+
+        def spy_forward(encoder_out, encoder_mask, decoder_input, **kw):
+            out = inner_forward(encoder_out, encoder_mask, decoder_input, **kw)
+            trace['dec_in'].append(npy(decoder_input))
+            trace['logits'].append(npy(out[0][:, -1].float()))
+            trace['rows'].append(encoder_out.size(0))
+            return out
+        inner_reorder = transformer.Decoder.reorder_state
+
+        def spy_reorder(state, indices):
+            trace['reorder'].append(npy(indices))
+            return inner_reorder(state, indices)
+        dec.forward = spy_forward
+        decoding.Decoder.reorder_state = staticmethod(spy_reorder)
+        try:
+            with torch.no_grad():
+                enc_out, enc_mask, _ = model.encoder(t(batch['encoder_input']), t(batch['encoder_input_length']))
+                # decoder_input given explicitly: EnsembleDecoder has no `bos_idx` (decoding.py:1305 would raise)
+                bos = torch.full((B, 1), cfg.bos_idx, dtype=torch.long)
+                hyps = decoding.beam_search(dec, enc_out, enc_mask, max_out, K, {}, decoder_input=bos)
+        finally:
+            dec.forward = inner_forward
+            decoding.Decoder.reorder_state = staticmethod(inner_reorder)
+        shrinks = len(set(trace['rows'])) > 1
+        print(f'seed {seed}: {len(trace["dec_in"])} decoder calls, rows per call {trace["rows"]}')
+        if shrinks and len(trace['dec_in']) >= 5:
+            break
+    else:
+        raise RuntimeError('no seed gave a search with a shrinking batch')
+    out = {'cfg': cfg_json(cfg), 'V': V, 'B': B, 'S': S, 'K': K, 'seed': seed, 'max_output_len': max_out,
+           'n_calls': len(trace['dec_in']), 'n_reorders': len(trace['reorder']), **names_shapes_arrays(names_shapes)}
+    for i, (d, lg) in enumerate(zip(trace['dec_in'], trace['logits'])):
+        out[f'dec_in_{i}'] = d
+        out[f'logits_{i}'] = lg
+    for i, r in enumerate(trace['reorder']):
+        out[f'reorder_{i}'] = r
+    for b, nbest in enumerate(hyps):
+        out[f'best_{b}'] = npy(nbest[0]['tokens'])
+    save('beam_trace', **out)
+
+
 def gen_optim():
     """K9 ("next" row): optimization.Adam.step (optimization.py:56-149), clip_grad_norm_ (390-427),
     LRScheduler inverse-sqrt (21-52)"""
@@ -513,6 +571,7 @@ GENERATORS = {
     'sinpos': gen_sinpos,
     'speech': gen_speech,
     'greedy_decode': gen_greedy,
+    'beam_trace': gen_beam,
     'adam_step': gen_optim,
     'logmel': gen_logmel,
 }

@@ -388,6 +388,44 @@ def test_native_decoding_step_matches_per_op_path(name, dtype, monkeypatch):
         assert x.shape == y.shape and (x - y).abs().max().item() <= tol * y.abs().max().item()
 
 
+@pytest.mark.parametrize('native', [True, False])
+def test_beam_search_trace_replay(native, monkeypatch):
+    """tests/golden/beam_trace.npz: what the reference's beam_search (decoding.py:1225-1657) fed ITS decoder at every
+    step of a real search — tokens, incremental state, and the beam re-ordering of the state, including the step where
+    a finished sentence leaves the batch (12 -> 9 rows) — with the logits it got back.  Replayed here through
+    pasero_amd's decoder and `Decoder.reorder_state`, with the native decoding step and with the per-op path:
+    same last-position logits at every step (fp32, 2e-5 of the range) and the same best next token"""
+    from pasero_amd.transformer import Decoder
+    g = load_golden('beam_trace')
+    cfg, model = build_model(g, torch.float32, 'cuda')
+    model.eval()
+    if not native:
+        monkeypatch.setenv('PASERO_NO_NATIVE_DECODE', '1')
+    B, S, V, K, seed = (int(g[k]) for k in ('B', 'S', 'V', 'K', 'seed'))
+    b = paramgen.make_text_batch(seed, B, S, 5, V)
+    with torch.no_grad():
+        enc_out, enc_mask, _ = model.encoder(torch.from_numpy(b['encoder_input']).cuda(),
+                                             torch.from_numpy(b['encoder_input_length']).cuda())
+        enc_out, enc_mask = enc_out.repeat_interleave(K, dim=0), enc_mask.repeat_interleave(K, dim=0)
+        state, engaged, rows = {}, False, []
+        for i in range(int(g['n_calls'])):
+            dec_in = torch.from_numpy(g[f'dec_in_{i}']).cuda()
+            assert dec_in.size(0) == enc_out.size(0)
+            rows.append(dec_in.size(0))
+            logits, _ = model.decoder(enc_out, enc_mask, dec_in, state=state)
+            engaged |= '_pk_decode' in state
+            want = torch.from_numpy(g[f'logits_{i}']).cuda()
+            got = logits[:, -1].float()
+            assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item(), i
+            assert torch.equal(got.argmax(-1), want.argmax(-1)), i
+            if i < int(g['n_reorders']):
+                idx = torch.from_numpy(g[f'reorder_{i}']).cuda()
+                enc_out, enc_mask = enc_out.index_select(0, idx), enc_mask.index_select(0, idx)
+                Decoder.reorder_state(state, idx)
+    assert len(set(rows)) > 1          # the trace does contain a shrinking batch
+    assert engaged == native
+
+
 def test_argmax_rows_first_maximum():
     import ctypes
     from pasero_amd import lib
