@@ -201,3 +201,42 @@ def test_fullsize_cross_entropy_gradient_rows_sum_to_zero():
     sums3 = F.ce_finalize(row_loss, row_nll, target, 1)
     assert int(sums3[2].item()) == int((target != 1).sum())
     assert abs(sums3[1].item() - row_nll.double().sum().item()) <= 1e-5 * row_nll.double().sum().item()
+
+
+@pytest.mark.parametrize('vocab,layers,b', [(70376, 2, 64), (256206, 1, 32)])
+def test_c3_c5_vocabularies_chunked_loss(vocab, layers, b, monkeypatch):
+    """BASELINE configs C3 (transformer_big, V = 70376) and C5 (NLLB, V = 256206) at their widths (d = 1024, 16 heads,
+    S = T = 128) with fewer layers: the fused vocabulary loss walks the rows in logits chunks sized for the Infinity
+    Cache — the result must not depend on the chunking, and stays additive over the batch"""
+    from pasero_amd import autograd
+    from pasero_amd.config import TransformerBigConfig, DistributedConfig, SyntheticTask
+    from pasero_amd.transformer import Transformer
+    import paramgen
+    cfg = TransformerBigConfig(encoder_layers=layers, decoder_layers=layers, dropout=0.0)
+    torch.manual_seed(3)
+    model = Transformer(cfg, DistributedConfig(), SyntheticTask(vocab)).to(torch.bfloat16).cuda().train()
+    batch = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(9, b, 128, 128, vocab).items()}
+    watch = ['encoder.embed_tokens.weight', 'decoder.layers.0.fc1.weight']
+
+    def step(rows=slice(None)):
+        model.zero_grad(set_to_none=True)
+        loss, logs = model(**{k: v[rows].contiguous() for k, v in batch.items()})
+        loss.backward()
+        params = dict(model.named_parameters())
+        return loss.item(), logs['num_tokens'], {n: params[n].grad.float().clone() for n in watch}
+
+    chunks = []
+    real = autograd._ce_chunk_rows
+    monkeypatch.setattr(autograd, '_ce_chunk_rows', lambda *a, **k: chunks.append(real(*a, **k)) or chunks[-1])
+    full, ntok, g = step()
+    assert chunks[-1] < b * 128, 'the default budget should already split these rows into several chunks'
+    h1, n1, g1 = step(slice(0, b // 2))
+    h2, n2, g2 = step(slice(b // 2, b))
+    assert ntok == n1 + n2 and abs(full - (h1 + h2)) <= 1e-5 * abs(full)
+    for n in watch:
+        assert (g[n] - (g1[n] + g2[n])).abs().max().item() <= 2e-2 * g[n].abs().max().item(), n
+    monkeypatch.setattr(autograd, '_ce_chunk_rows', lambda rows, V, itemsize, budget_bytes=0: min(rows, 640))
+    small, ntok2, gs = step()   # many small chunks (640 rows: not a multiple of the 256-row tiles)
+    assert ntok2 == ntok and abs(small - full) <= 1e-6 * abs(full)   # per-row losses are the same numbers
+    for n in watch:  # the gradient chunks are rounded to bf16 before they are summed: more chunks, more roundings
+        assert (gs[n] - g[n]).abs().max().item() <= 2e-2 * g[n].abs().max().item(), n
