@@ -112,28 +112,113 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
 
 // dz = LN_bwd(dy) (+ dz_extra);  dres_out = dz;  dx_out = dz * keep * scale;  partial dgamma/dbeta per block
 template <typename T, int NCH>
-__global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
+__global__ __launch_bounds__(256, NCH == 4 ? 3 : NCH == 8 ? 2 : 1) void residual_ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ dz_extra, const T* __restrict__ z, const T* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dres_out, T* __restrict__ dx_out,
     float* __restrict__ partials /* [gridDim.x][2][d], every workgroup writes its slab */, long long rows, int d, unsigned thr, float drop_scale,
     unsigned long long seed, unsigned long long offset) {
     constexpr int EPV = 16 / sizeof(T);
+    // Wide rows (d > 1024 for 16-bit types): with gamma, the products dy*gamma and the normalised row all held in
+    // registers next to the dgamma / dbeta sums, a wave needs 290-512 registers and runs alone on its SIMD (2.0 TB/s
+    // at d = 2048, 1.3 at 4096).  The LEAN form keeps only the sums and the packed dy / z chunks: gamma is re-read
+    // (L1-resident) and dy*gamma, xhat are recomputed in the second pass; no next-row prefetch, occupancy hides it.
+    constexpr bool LEAN = NCH >= 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunks = d / EPV;
     const float inv_d = 1.f / (float)d;
-    float dg[NCH][EPV], db[NCH][EPV], gm[NCH][EPV];
+    float dg[NCH][EPV], db[NCH][EPV], gm[LEAN ? 1 : NCH][EPV];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         int ch = lane + 64 * i;
         Vec16<T> gv;
-        if (gamma && ch < nchunks) gv = load16<T>(gamma + ch * EPV);
+        if (!LEAN && gamma && ch < nchunks) gv = load16<T>(gamma + ch * EPV);
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
             dg[i][e] = 0.f;
             db[i][e] = 0.f;
-            gm[i][e] = (gamma && ch < nchunks) ? gv.get(e) : 0.f;
+            if constexpr (!LEAN) gm[i][e] = (gamma && ch < nchunks) ? gv.get(e) : 0.f;
         }
     }
+    if constexpr (LEAN) {
+        const bool rms_l = mean == nullptr;
+        for (long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + wave; row < rows;
+             row += (long long)gridDim.x * ROWS_PER_BLOCK) {
+            Vec16<T> dvc[NCH], zvc[NCH];
+            float mu = 0.f, rs = 0.f, s1 = 0.f, s2 = 0.f;
+            if (gamma) {
+                mu = rms_l ? 0.f : mean[row];
+                rs = rstd[row];
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    int ch = lane + 64 * i;
+                    if (ch < nchunks) {
+                        long long off = row * d + (long long)ch * EPV;
+                        dvc[i] = load16<T>(dy + off);
+                        zvc[i] = load16<T>(z + off);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    int ch = lane + 64 * i;
+                    if (ch < nchunks) {
+                        Vec16<T> gv = load16<T>(gamma + ch * EPV);
+#pragma unroll
+                        for (int e = 0; e < EPV; ++e) {
+                            float dyv = dvc[i].get(e);
+                            float xhat = (zvc[i].get(e) - mu) * rs;
+                            float gg = dyv * gv.get(e);
+                            s1 += gg;
+                            s2 += gg * xhat;
+                            dg[i][e] += dyv * xhat;
+                            db[i][e] += dyv;
+                        }
+                    }
+                }
+                s1 = rms_l ? 0.f : wave_sum(s1) * inv_d;
+                s2 = wave_sum(s2) * inv_d;
+            }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                int ch = lane + 64 * i;
+                if (ch < nchunks) {
+                    long long off = row * d + (long long)ch * EPV;
+                    float dz[EPV];
+                    Vec16<T> ev, gv;
+                    if (dz_extra) ev = load16<T>(dz_extra + off);
+                    if (gamma) gv = load16<T>(gamma + ch * EPV);
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) {
+                        float t = 0.f;
+                        if (gamma) {  // same expressions as the first pass, so the two passes agree bit for bit
+                            float xhat = (zvc[i].get(e) - mu) * rs;
+                            float gg = dvc[i].get(e) * gv.get(e);
+                            t = rs * (gg - s1 - xhat * s2);
+                        }
+                        if (dz_extra) t += ev.get(e);
+                        dz[e] = t;
+                    }
+                    if (dres_out) {
+                        Vec16<T> o;
+#pragma unroll
+                        for (int e = 0; e < EPV; ++e) o.set(e, dz[e]);
+                        store16<T>(dres_out + off, o);
+                    }
+                    if (dx_out) {
+                        bool keep[EPV];
+                        if (thr) {
+#pragma unroll
+                            for (int e = 0; e < EPV; e += 4)
+                                dropout_keep4(seed, offset, (unsigned long long)(off + e) >> 2, thr, keep + e);
+                        }
+                        Vec16<T> o;
+#pragma unroll
+                        for (int e = 0; e < EPV; ++e) o.set(e, thr ? (keep[e] ? dz[e] * drop_scale : 0.f) : dz[e]);
+                        store16<T>(dx_out + off, o);
+                    }
+                }
+            }
+        }
+    } else {
     // the loads of the wave's next row are issued before the reductions of the current one (a wave walks ~8 rows)
     const long long row_step = (long long)gridDim.x * ROWS_PER_BLOCK;
     Vec16<T> dv_n[NCH], zv_n[NCH];
@@ -228,6 +313,7 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(
             }
         }
     }
+    }  // !LEAN
     if (!partials) return;
     // 4 waves -> one partial per workgroup, written to the workgroup's own slab.  (fp32 atomics into one [2][d] row were
     // the slowest part of this kernel: a thousand workgroups adding to the same 2*d addresses serialise at the memory
@@ -279,7 +365,16 @@ __global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* __rest
     if (r == 0 && col < d) out[col] = from_f32<T>(red[0][c]);
 }
 
-constexpr int LN_BWD_MAX_BLOCKS = 1024;
+// backward grid: every workgroup writes a [2][d] fp32 slab of partial dgamma / dbeta sums that the reduction kernel
+// reads back, so the slab traffic grows with blocks * d.  Measured best (32768 * 512 elements, bf16, us incl. the
+// reduction kernel): d = 512: 1024 workgroups (27.7 vs 31.2 at 512); d = 1024..4096: 512 (29.6 / 37.4 / 36.0 / 50.9 vs
+// 31.9 / 42.0 / 41.5 / 63.4 at 1024).
+inline int ln_bwd_max_blocks(int d) {
+    static const int forced = getenv("PK_LN_BWD_BLOCKS") ? atoi(getenv("PK_LN_BWD_BLOCKS")) : 0;  // (experiments)
+    if (forced > 0) return forced;
+    return d <= 512 ? 1024 : 512;
+}
+
 inline int ln_grid(long long rows) {
     long long blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
@@ -319,7 +414,7 @@ int launch_bwd(const void* dy, const void* dz_extra, const void* z, const void* 
     float scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
     int nch = (d / EPV + 63) / 64;
     int nblocks = ln_grid(rows);
-    if (nblocks > LN_BWD_MAX_BLOCKS) nblocks = LN_BWD_MAX_BLOCKS;  // 16 waves/CU stream at HBM rate
+    if (nblocks > ln_bwd_max_blocks(d)) nblocks = ln_bwd_max_blocks(d);
     bool want_pg = gamma && (dgamma || dbeta);
     if (want_pg) {
         size_t need = (size_t)nblocks * 2 * d * sizeof(float);
@@ -369,7 +464,7 @@ extern "C" int pk_residual_ln_fwd(const void* x, const void* residual, const voi
 
 extern "C" size_t pk_residual_ln_bwd_workspace(long long rows, int d) {
     long long blocks = ln_grid(rows);
-    if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
+    if (blocks > ln_bwd_max_blocks(d)) blocks = ln_bwd_max_blocks(d);
     return (size_t)blocks * 2 * d * sizeof(float);
 }
 

@@ -176,8 +176,10 @@ def test_gemm_strided_views(F):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('rows,d', [(7, 128), (1000, 512), (33, 1024), (5, 2048), (3, 520)])
+@pytest.mark.parametrize('rows,d', [(7, 128), (1000, 512), (33, 1024), (5, 2048), (3, 520), (2100, 1280), (9, 4096)])
 def test_layernorm_fwd_bwd(F, dtype, rows, d):
+    if dtype == torch.float32 and d > 2048:
+        pytest.skip('the backward kernel keeps a row in registers: fp32 rows up to 2048 (rejected loudly beyond)')
     x = rnd((rows, d), 20, dtype)
     res = rnd((rows, d), 21, dtype)
     gamma = (1 + 0.1 * rnd((d,), 22, torch.float32)).to(dtype)
