@@ -454,6 +454,37 @@ def gen_greedy():
          n_steps=len(steps), **names_shapes_arrays(names_shapes))
 
 
+def gen_return_layers():
+    """`return_layers` of the encoder / decoder (transformer.py:698-752,831-898; layers :1030-1099,1263-1417): hidden
+    states after a layer ('enc_0', 'dec_1') and attention weights ('enc_0_self_attn', 'dec_0_self_attn',
+    'dec_1_cross_attn'), full pass and one incremental step"""
+    V, B, S, T, seed = 71, 3, 8, 6, 23
+    cfg, model = build_model(V, embed_dim=128, encoder_ffn_dim=128, decoder_ffn_dim=128, encoder_attention_heads=2,
+                             decoder_attention_heads=2, encoder_layers=2, decoder_layers=2, dropout=0.0)
+    names_shapes = load_params(model, seed)
+    model.eval()
+    batch = paramgen.make_text_batch(seed, B, S, T, V)
+    enc_names = ['enc_0', 'enc_1_self_attn']
+    dec_names = ['dec_1', 'dec_0_self_attn', 'dec_1_cross_attn']
+    out = {'cfg': cfg_json(cfg), 'V': V, 'B': B, 'S': S, 'T': T, 'seed': seed, 'enc_names': np.array(enc_names),
+           'dec_names': np.array(dec_names), **names_shapes_arrays(names_shapes)}
+    with torch.no_grad():
+        enc_out, enc_mask, enc_layers = model.encoder(t(batch['encoder_input']), t(batch['encoder_input_length']),
+                                                      return_layers=enc_names)
+        dec_in = t(batch['decoder_input'])[:, :-1]
+        logits, dec_layers = model.decoder(enc_out, enc_mask, dec_in, return_layers=dec_names)
+        assert sorted(enc_layers) == sorted(enc_names) and sorted(dec_layers) == sorted(dec_names)
+        for k, v in {**enc_layers, **dec_layers}.items():
+            out['full:' + k] = npy(v)
+        out['logits'] = npy(logits)
+        state = {}
+        model.decoder(enc_out, enc_mask, dec_in[:, :3], state=state)
+        _, step_layers = model.decoder(enc_out, enc_mask, dec_in[:, 3:4], state=state, return_layers=dec_names)
+        for k, v in step_layers.items():
+            out['step:' + k] = npy(v)
+    save('return_layers', **out)
+
+
 def gen_beam():
     """decoding.beam_search (decoding.py:1225-1657) as a TRACE: what the search feeds the decoder at every step
     (tokens, incremental `state`) and the beam re-ordering it applies to the state (`Decoder.reorder_state`, including the
@@ -572,6 +603,7 @@ GENERATORS = {
     'speech': gen_speech,
     'greedy_decode': gen_greedy,
     'beam_trace': gen_beam,
+    'return_layers': gen_return_layers,
     'adam_step': gen_optim,
     'logmel': gen_logmel,
 }

@@ -426,6 +426,39 @@ def test_beam_search_trace_replay(native, monkeypatch):
     assert engaged == native
 
 
+def test_return_layers_hidden_states_and_attention_weights():
+    """`return_layers` (transformer.py:698-752,831-898): hidden states after chosen layers and (B,T,H,S) attention
+    weights of chosen attention blocks, for a full pass and for one incremental step (where the native decoding step
+    must stand aside, the per-op path produces the weights) — against the real reference"""
+    g = load_golden('return_layers')
+    cfg, model = build_model(g, torch.float32, 'cuda')
+    model.eval()
+    batch = text_batch(g, 'cuda')
+    enc_names, dec_names = [str(n) for n in g['enc_names']], [str(n) for n in g['dec_names']]
+    with torch.no_grad():
+        enc_out, enc_mask, enc_layers = model.encoder(batch['encoder_input'], batch['encoder_input_length'],
+                                                      return_layers=enc_names)
+        dec_in = batch['decoder_input'][:, :-1]
+        logits, dec_layers = model.decoder(enc_out, enc_mask, dec_in, return_layers=dec_names)
+        assert sorted(enc_layers) == sorted(enc_names) and sorted(dec_layers) == sorted(dec_names)
+        for k, v in {**enc_layers, **dec_layers}.items():
+            want = g['full:' + k]
+            assert tuple(v.shape) == want.shape, k
+            assert rel(v, want) < 2e-5, k
+        assert rel(logits, g['logits']) < 2e-5
+        state = {}
+        model.decoder(enc_out, enc_mask, dec_in[:, :3], state=state)
+        _, step_layers = model.decoder(enc_out, enc_mask, dec_in[:, 3:4], state=state, return_layers=dec_names)
+        assert sorted(step_layers) == sorted(dec_names)
+        for k, v in step_layers.items():
+            want = g['step:' + k]
+            assert tuple(v.shape) == want.shape, k
+            assert rel(v, want) < 2e-5, k
+        # without return_layers nothing is collected
+        _, none = model.decoder(enc_out, enc_mask, dec_in)
+        assert none == {}
+
+
 def test_argmax_rows_first_maximum():
     import ctypes
     from pasero_amd import lib
