@@ -1,8 +1,8 @@
 """Host-side mirror of `pasero/models/modules.py` for the Transformer hot path: same class names, constructor
 arguments, parameter names/shapes (= checkpoint keys) and forward signatures, with every forward/backward routed to
 the HIP kernels of libpasero_hip.so.  Variants that are outside the hot-path scope (tensor parallelism, ALiBi / T5
-biases, grouped-query attention, RMSNorm) raise NotImplementedError loudly instead of silently falling back to eager
-PyTorch.
+biases, grouped-query attention, sliding windows) raise NotImplementedError loudly instead of silently falling back to
+eager PyTorch.
 """
 import contextlib
 import functools
