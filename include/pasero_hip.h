@@ -164,12 +164,13 @@ int pk_logmel(const float* wav, const long long* wav_len, long long wav_stride, 
               size_t ws_bytes, int B, void* stream);
 
 /* ---- Rotary position embedding (RoPE) on a packed projection output: replaces RotaryEmbedding.forward,
- * pasero/models/modules.py:982-1025 (GPT-J style halves: rotate(x) = cat(-x2, x1), head_dim 64).
- *   x, y: (rows, ld) with `total_cols` used columns; the first `ncols` columns (q|k heads of 64) are rotated by the
- *   angle of position pos_offset + row % Tlen, the rest (v) is copied.  cos_t / sin_t: fp32 [max_pos][32] tables.
- *   inverse = 1 applies the transposed rotation (backward pass).  y must not alias x. */
+ * pasero/models/modules.py:982-1025 (GPT-J style halves: rotate(x) = cat(-x2, x1), head_dim 64 or 128).
+ *   x, y: (rows, ld) with `total_cols` used columns; the first `ncols` columns (q|k heads of head_dim) are rotated by
+ *   the angle of position pos_offset + row % Tlen, the rest (v) is copied.  cos_t / sin_t: fp32
+ *   [max_pos][head_dim / 2] tables.  inverse = 1 applies the transposed rotation (backward pass).  y must not alias x. */
 int pk_rope(const void* x, void* y, long long rows, int Tlen, long long ld, int ncols, int total_cols,
-            const float* cos_t, const float* sin_t, int max_pos, int pos_offset, int inverse, int dtype, void* stream);
+            const float* cos_t, const float* sin_t, int max_pos, int pos_offset, int inverse, int head_dim, int dtype,
+            void* stream);
 
 /* ---- "Next" row: fused gradient normalisation + global-norm clipping + Adam over all parameters.
  * Replaces the per-parameter Python loops of Trainer.train_step (pasero/training.py:455-482), clip_grad_norm_

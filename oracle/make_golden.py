@@ -339,6 +339,15 @@ def gen_tiny_opts():
                encoder_embed_norm=True)
 
 
+def gen_tiny_hd128_rotary():
+    """heads of 128 with rotary positions (the llama-style head size), RMSNorm, SwiGLU, no biases"""
+    gen_encdec('tiny_hd128_rotary', V=67, B=3, S=9, T=7, seed=24,
+               embed_dim=256, encoder_ffn_dim=192, decoder_ffn_dim=192, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=1, decoder_layers=1, dropout=0.0, activation_fn='swiglu',
+               encoder_prenorm=True, decoder_prenorm=True, rms_norm=True, has_bias=False, norm_eps=1e-6,
+               encoder_positional_encoding='rotary', decoder_positional_encoding='rotary')
+
+
 def gen_ce():
     """Transformer.compute_loss (transformer.py:324-380): label-smoothed CE, sum reduction, pad ignored,
     logs in bits"""
@@ -598,6 +607,7 @@ GENERATORS = {
     'tiny_encdec_swiglu': gen_tiny_swiglu,
     'tiny_encdec_rms': gen_tiny_rms,
     'tiny_opts': gen_tiny_opts,
+    'tiny_hd128_rotary': gen_tiny_hd128_rotary,
     'ce_ls': gen_ce,
     'sinpos': gen_sinpos,
     'speech': gen_speech,

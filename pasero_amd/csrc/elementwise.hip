@@ -98,12 +98,12 @@ __global__ __launch_bounds__(256) void col2im1d_kernel(const T* __restrict__ dA,
 
 // rotary position embedding on the first `ncols` columns of each row (heads of 64: q|k of a packed projection):
 //   y[i] = x[i] cos_i - x[i+32] sin_i ;  y[i+32] = x[i+32] cos_i + x[i] sin_i       (i < 32, angle = pos * inv_freq_i)
-// inverse = 1 rotates by -angle (the backward pass).  cos/sin: fp32 tables [max_pos][32].
+// inverse = 1 rotates by -angle (the backward pass).  cos/sin: fp32 tables [max_pos][head_dim / 2].
 template <typename T>
 __global__ __launch_bounds__(256) void rope_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows, int Tlen,
                                                    long long ld, int ncols, int total_cols,
                                                    const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                   int pos_offset, int inverse) {
+                                                   int pos_offset, int inverse, int hd) {
     constexpr int EPV = 16 / sizeof(T);
     const int cpr = total_cols / EPV;  // 16-byte chunks per row
     const long long total = rows * cpr;
@@ -112,15 +112,16 @@ __global__ __launch_bounds__(256) void rope_kernel(const T* __restrict__ x, T* _
         const int col = (int)(i % cpr) * EPV;
         Vec16<T> v = load16<T>(x + row * ld + col);
         if (col < ncols) {
-            const int d = col & 63;            // position inside the head
-            const int lo = d & 31;             // frequency index of element 0 of this chunk
-            const bool upper = d >= 32;
-            Vec16<T> w = load16<T>(x + row * ld + (upper ? col - 32 : col + 32));  // the partner half
+            const int half = hd >> 1;
+            const int d = col & (hd - 1);      // position inside the head
+            const int lo = d & (half - 1);     // frequency index of element 0 of this chunk
+            const bool upper = d >= half;
+            Vec16<T> w = load16<T>(x + row * ld + (upper ? col - half : col + half));  // the partner half
             const int pos = pos_offset + (int)(row % Tlen);
             Vec16<T> o;
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
-                float c = cos_t[pos * 32 + lo + e], sn = sin_t[pos * 32 + lo + e];
+                float c = cos_t[pos * half + lo + e], sn = sin_t[pos * half + lo + e];
                 if (inverse) sn = -sn;
                 float a = v.get(e), b = w.get(e);
                 o.set(e, upper ? a * c + b * sn : a * c - b * sn);
@@ -198,17 +199,18 @@ extern "C" int pk_col2im1d(const void* dA, void* dx, int B, int L, int C, int R,
 }
 
 extern "C" int pk_rope(const void* x, void* y, long long rows, int Tlen, long long ld, int ncols, int total_cols,
-                       const float* cos_t, const float* sin_t, int max_pos, int pos_offset, int inverse, int dtype,
-                       void* stream) {
+                       const float* cos_t, const float* sin_t, int max_pos, int pos_offset, int inverse, int head_dim,
+                       int dtype, void* stream) {
     PK_CHECK_ARG(x && y && cos_t && sin_t, "pk_rope: null tensor");
     PK_CHECK_ARG(x != y, "pk_rope: in-place rotation is not supported (partner halves are read from x)");
-    PK_CHECK_ARG(ncols % 64 == 0 && ncols <= total_cols && total_cols % 8 == 0 && ld % 8 == 0, "pk_rope: bad column layout");
+    PK_CHECK_ARG(head_dim == 64 || head_dim == 128, "pk_rope: head_dim %d (64 or 128)", head_dim);
+    PK_CHECK_ARG(ncols % head_dim == 0 && ncols <= total_cols && total_cols % 8 == 0 && ld % 8 == 0, "pk_rope: bad column layout");
     PK_CHECK_ARG(Tlen > 0 && pos_offset >= 0 && pos_offset + Tlen <= max_pos, "pk_rope: positions exceed the cos/sin table");
     if (rows == 0) return 0;
     PK_DTYPE_SWITCH(dtype, "pk_rope", {
         hipLaunchKernelGGL((rope_kernel<T>), dim3(grid_for(rows * (total_cols / (16 / (int)sizeof(T))), 512)), dim3(256),
                            0, (hipStream_t)stream, (const T*)x, (T*)y, rows, Tlen, ld, ncols, total_cols, cos_t, sin_t,
-                           pos_offset, inverse);
+                           pos_offset, inverse, head_dim);
     })
     PK_LAUNCH_CHECK();
     return 0;

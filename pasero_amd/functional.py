@@ -338,14 +338,15 @@ def log_mel(wav: Tensor, wav_len: Optional[Tensor] = None) -> Tensor:
 
 
 def rope(x: Tensor, cos_t: Tensor, sin_t: Tensor, ncols: int, pos_offset: int, inverse: bool = False) -> Tensor:
-    """x (B, T, C) contiguous packed projection; rotates the first `ncols` columns (heads of 64), copies the rest"""
+    """x (B, T, C) contiguous packed projection; rotates the first `ncols` columns (heads of 2 * cos_t.size(1) = 64 or
+    128), copies the rest"""
     require_gpu(x, cos_t, sin_t)
     B, T, C = x.shape
     assert x.is_contiguous() and cos_t.dtype == torch.float32 and cos_t.is_contiguous() and sin_t.is_contiguous()
-    assert cos_t.shape == sin_t.shape and cos_t.size(1) == 32
+    assert cos_t.shape == sin_t.shape and cos_t.size(1) in (32, 64)
     y = torch.empty_like(x)
     check(lib.load().pk_rope(ptr(x), ptr(y), B * T, T, C, int(ncols), C, ptr(cos_t), ptr(sin_t), cos_t.size(0),
-                             int(pos_offset), int(inverse), dtype_code(x), stream_ptr()), 'pk_rope')
+                             int(pos_offset), int(inverse), 2 * cos_t.size(1), dtype_code(x), stream_ptr()), 'pk_rope')
     return y
 
 

@@ -457,8 +457,6 @@ class MultiheadAttention(nn.Module):
         self.head_dim = embed_dim // num_heads
         if self.head_dim not in (64, 128):
             raise NotImplementedError(f'pasero_amd: attention kernels are built for head_dim 64 and 128, got {self.head_dim}')
-        if self.head_dim != 64 and positional_encoding == 'rotary':
-            raise NotImplementedError('pasero_amd: rotary embeddings are implemented for head_dim 64 only')
         self.kv_dim = self.q_dim = embed_dim
         self.scaled = scaled
         self.has_bias = has_bias

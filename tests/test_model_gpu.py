@@ -97,6 +97,11 @@ def test_tiny_rmsnorm_rotary_swiglu_no_bias_fp32_vs_reference():
     _check_encdec('tiny_encdec_rms')
 
 
+def test_heads_of_128_with_rotary_positions_fp32_vs_reference():
+    """RoPE on heads of 128 (the llama-style head size) together with RMSNorm / SwiGLU / no biases"""
+    _check_encdec('tiny_hd128_rotary')
+
+
 @pytest.mark.parametrize('name', ['tiny_opts_a', 'tiny_opts_b'])
 def test_configuration_switches_fp32_vs_reference(name):
     """(a) untied output projection, separate encoder / decoder embeddings, LayerNorm without bias, unscaled attention

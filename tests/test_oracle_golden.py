@@ -92,6 +92,10 @@ def test_tiny_encdec_rmsnorm_rotary_swiglu_no_bias():
     _run_encdec('tiny_encdec_rms')
 
 
+def test_tiny_heads_of_128_rotary():
+    _run_encdec('tiny_hd128_rotary')
+
+
 @pytest.mark.parametrize('name', ['tiny_opts_a', 'tiny_opts_b'])
 def test_tiny_configuration_switches(name):
     """untied projection / unshared embeddings / LayerNorm without bias / unscaled scores / prompt_loss 0.5 (a);
