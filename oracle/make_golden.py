@@ -218,6 +218,14 @@ def gen_tiny_lora():
                encoder_prenorm=True, decoder_prenorm=True, activation_fn='gelu')
 
 
+def gen_tiny_lora_rotary():
+    """LoRA branches together with rotary positions: the rotation is applied to the separate q / k projections"""
+    gen_encdec('tiny_lora_rotary', V=71, B=3, S=7, T=6, seed=25,
+               embed_dim=128, encoder_ffn_dim=160, decoder_ffn_dim=160, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=1, decoder_layers=1, dropout=0.0, lora_rank=4, lora_alpha=8,
+               encoder_positional_encoding='rotary', decoder_positional_encoding='rotary')
+
+
 def gen_tiny_hd128():
     """heads of 128 (transformer_small = transformer_iwslt_de_en: 4 x 128; nllb_3b3: 16 x 128)"""
     gen_encdec('tiny_hd128', V=79, B=3, S=9, T=7, seed=17,
@@ -467,9 +475,15 @@ def gen_return_layers():
     """`return_layers` of the encoder / decoder (transformer.py:698-752,831-898; layers :1030-1099,1263-1417): hidden
     states after a layer ('enc_0', 'dec_1') and attention weights ('enc_0_self_attn', 'dec_0_self_attn',
     'dec_1_cross_attn'), full pass and one incremental step"""
+    _gen_return_layers('return_layers')
+    _gen_return_layers('return_layers_rotary', encoder_positional_encoding='rotary',
+                       decoder_positional_encoding='rotary')
+
+
+def _gen_return_layers(name, **overrides):
     V, B, S, T, seed = 71, 3, 8, 6, 23
     cfg, model = build_model(V, embed_dim=128, encoder_ffn_dim=128, decoder_ffn_dim=128, encoder_attention_heads=2,
-                             decoder_attention_heads=2, encoder_layers=2, decoder_layers=2, dropout=0.0)
+                             decoder_attention_heads=2, encoder_layers=2, decoder_layers=2, dropout=0.0, **overrides)
     names_shapes = load_params(model, seed)
     model.eval()
     batch = paramgen.make_text_batch(seed, B, S, T, V)
@@ -491,7 +505,7 @@ def gen_return_layers():
         _, step_layers = model.decoder(enc_out, enc_mask, dec_in[:, 3:4], state=state, return_layers=dec_names)
         for k, v in step_layers.items():
             out['step:' + k] = npy(v)
-    save('return_layers', **out)
+    save(name, **out)
 
 
 def gen_beam():
@@ -600,6 +614,7 @@ GENERATORS = {
     'base_c1': gen_base_c1,
     'tiny_adapter': gen_tiny_adapter,
     'tiny_lora': gen_tiny_lora,
+    'tiny_lora_rotary': gen_tiny_lora_rotary,
     'tiny_hd128': gen_tiny_hd128,
     'mha': gen_mha,
     'mha_rotary': gen_mha_rotary,

@@ -431,6 +431,10 @@ class Embedding(nn.Embedding):
 # ------------------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------------------
+def _contiguous(t: Tensor) -> Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
 class MultiheadAttention(nn.Module):
     """modules.py:487-771.  q/k/v projections live in one flat [3D, D] arena (the three nn.Parameters are views of
     it, names and shapes unchanged) so self-attention runs ONE projection GEMM that reads x once, and the attention
@@ -552,11 +556,14 @@ class MultiheadAttention(nn.Module):
         if self.q_proj.lora is not None or return_attn:
             # LoRA branches on the projections (modules.py:67-100) / attention weights wanted (return_layers): three
             # separate projections; the fused packed projection is for the plain layer
-            if self.rotary_embed is not None:
-                raise NotImplementedError('pasero_amd: LoRA / return_attn together with rotary embeddings is not implemented')
             q = self.q_proj(query, link=link)
             k = self.k_proj(key)
             v = self.v_proj(value)
+            if self.rotary_embed is not None:  # modules.py:621-623: the new q and k rows, at their absolute positions
+                offset = state['key'].size(1) if (state is not None and 'key' in state) else 0
+                cos_t, sin_t = self.rotary_embed.tables(offset + T, q.device)
+                q = RotaryFn.apply(_contiguous(q), cos_t, sin_t, D, offset)
+                k = RotaryFn.apply(_contiguous(k), cos_t, sin_t, D, offset)
             if state is not None:
                 k4, v4 = k.reshape(B, -1, H, self.head_dim), v.reshape(B, -1, H, self.head_dim)
                 if 'key' in state:

@@ -127,6 +127,11 @@ def test_lora_branches_fp32_vs_reference():
     assert any(str(n).endswith('fc2.lora.down.weight') for n in g['grad_names'])
 
 
+def test_lora_with_rotary_positions_fp32_vs_reference():
+    """the separate-projection attention path (LoRA) with RoPE applied to its q and k outputs"""
+    _check_encdec('tiny_lora_rotary')
+
+
 def test_heads_of_128_fp32_vs_reference():
     """embed_dim 256 with 2 heads: the head_dim-128 instantiations of the attention kernels inside the whole model"""
     _check_encdec('tiny_hd128')
@@ -431,11 +436,12 @@ def test_beam_search_trace_replay(native, monkeypatch):
     assert engaged == native
 
 
-def test_return_layers_hidden_states_and_attention_weights():
+@pytest.mark.parametrize('fixture', ['return_layers', 'return_layers_rotary'])
+def test_return_layers_hidden_states_and_attention_weights(fixture):
     """`return_layers` (transformer.py:698-752,831-898): hidden states after chosen layers and (B,T,H,S) attention
     weights of chosen attention blocks, for a full pass and for one incremental step (where the native decoding step
     must stand aside, the per-op path produces the weights) — against the real reference"""
-    g = load_golden('return_layers')
+    g = load_golden(fixture)
     cfg, model = build_model(g, torch.float32, 'cuda')
     model.eval()
     batch = text_batch(g, 'cuda')
