@@ -763,7 +763,12 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
             // Measured in the training step after the slab-major walk: C2 19.95 vs 20.16 ms, transformer_big 74.5 vs
             // 79.0 ms in favour of the 256 kernel.  PK_GEMM_SK256=2 keeps split-K on the 128 kernel, =1 caps the factor.
             static const int sk_mode = [] { const char* e = getenv("PK_GEMM_SK256"); return e ? atoi(e) : 0; }();
-            if (splitk > 1 && sk_mode == 2) sk = 0;
+            static const int sk_min_tiles = [] { const char* e = getenv("PK_GEMM_SK256_MIN_TILES"); return e ? atoi(e) : 8; }();
+            // fewer than 8 output tiles (the d x d weight gradients of the base model: 4) would be cut into 64 K = 512
+            // slices, all prologue / epilogue, and 64 fp32 slabs to reduce: on 128-tiles with 32 slices the step gains
+            // 1 % (19.99 -> 19.76 ms); from 12 tiles up (qkv, fc1/fc2 gradients) the 256 kernel wins (threshold 16: 14.27
+            // vs 14.00 ms of GEMM time per step)
+            if (splitk > 1 && (sk_mode == 2 || t256 < sk_min_tiles)) sk = 0;
             else if (splitk > 1) {  // the caller allows split-K: re-derive the factor for 256-tiles (~1 workgroup per CU)
                 sk = (int)std::max(1LL, std::min((long long)(256 / std::max(1LL, t256)), K / 512));
                 sk = std::min(sk, 2 * splitk);  // the caller sized the workspace for twice its own factor

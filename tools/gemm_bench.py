@@ -20,6 +20,7 @@ SHAPES = {
     'fc1_dx': (32768, 512, 2048, False, True, 1),
     'fc2_dx': (32768, 2048, 512, False, True, 1),
     'qkv_dx': (32768, 512, 1536, False, True, 1),
+    'out_dx': (32768, 512, 512, False, True, 1),
     'fc1_dw': (2048, 512, 32768, True, True, 0),
     'out_dw': (512, 512, 32768, True, True, 0),
     'qkv_dw': (1536, 512, 32768, True, True, 0),
