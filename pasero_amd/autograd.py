@@ -461,6 +461,9 @@ def _ce_chunk_rows(rows: int, V: int, itemsize: int, budget_bytes: int = 128 << 
     writes it, the CE kernel that rewrites it in place and the two gradient GEMMs that read it"""
     per = max(1, budget_bytes // (V * itemsize))
     per = max(128, (per // 128) * 128)
+    if per >= 2048:  # whole waves of 256-row tiles over the 256 CUs: 8320 rows are 33 tile rows, 8192 are 32 (C2: the
+        per = (per // 2048) * 2048  # chunk GEMMs lose a fifth of their rate to the one tile row too many; same-box
+        # A/B of the C2 step: 19.22-19.33 vs 19.37-19.57 ms)
     return min(rows, per)
 
 
@@ -493,10 +496,11 @@ class VocabCrossEntropyFn(Function):
             if grad:
                 # dX chunk: few output tiles (chunk rows x d) but a vocabulary-long contraction -> split-K
                 F.gemm(lg, weight, b_col=True, out=dx[r0:r1], splitk=F.choose_splitk(r1 - r0, x2.size(1), V))
+                sk = F.choose_splitk(V, x2.size(1), r1 - r0)  # (V x d) output, contraction over the chunk's rows
                 if dw is None:
-                    dw = F.gemm(lg, x2[r0:r1], a_col=True, b_col=True)
+                    dw = F.gemm(lg, x2[r0:r1], a_col=True, b_col=True, splitk=sk)
                 else:
-                    F.gemm(lg, x2[r0:r1], a_col=True, b_col=True, aux=dw, mode=1, out=dw)
+                    F.gemm(lg, x2[r0:r1], a_col=True, b_col=True, aux=dw, mode=1, out=dw, splitk=sk)
         sums = F.ce_finalize(row_loss, row_nll, tgt, padding_idx)
         ctx.x_shape = x.shape
         if grad:
