@@ -89,6 +89,7 @@ class ResidualLink:
 def _dx_gemm(dy2d: Tensor, weight: Tensor, link, **kw) -> Tensor:
     """dX = dY · W (+ parked residual gradient)"""
     dres = link.take() if link is not None else None
+    kw.setdefault('splitk', F.choose_splitk(dy2d.size(0), weight.size(1), weight.size(0)))
     if dres is not None:
         return F.gemm(dy2d, weight, b_col=True, aux=_2d(dres), mode=1, **kw)
     return F.gemm(dy2d, weight, b_col=True, **kw)

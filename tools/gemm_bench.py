@@ -40,6 +40,15 @@ SHAPES = {
     'big_qkv_dw_sk4': (3072, 1024, 32768, True, True, 4),
     'big_out_dw_sk8': (1024, 1024, 32768, True, True, 8),
     'big_out_dw_sk16': (1024, 1024, 32768, True, True, 16),
+    # NLLB-1.3B shapes at C5 (d = 1024, f = 8192, 8192 rows per step)
+    'nllb_fc1_dw_sk1': (8192, 1024, 8192, True, True, 1),
+    'nllb_fc1_dw_sk2': (8192, 1024, 8192, True, True, 2),
+    'nllb_fc2_dw_sk1': (1024, 8192, 8192, True, True, 1),
+    'nllb_fc2_dw_sk2': (1024, 8192, 8192, True, True, 2),
+    'nllb_fc1_dx': (8192, 1024, 8192, False, True, 1),
+    'nllb_fc1_dx_sk2': (8192, 1024, 8192, False, True, 2),
+    'nllb_fc2_fwd': (8192, 1024, 8192, False, False, 1),
+    'nllb_fc2_fwd_sk2': (8192, 1024, 8192, False, False, 2),
 }
 
 
