@@ -753,7 +753,8 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         static const int tile_pref = [] { const char* e = getenv("PK_GEMM_TILE"); return e ? atoi(e) : 0; }();
         const bool simple = !ep.preact && (ep.act == PK_ACT_NONE || ep.act == PK_ACT_RELU) && (flags & 4) &&
                             (!ep.bias || ((uintptr_t)ep.bias % 16) == 0) && (ep.mode == 0 || (flags & 8)) && ep.mode < 3;
-        const bool addr_ok = (flags & 1) && (flags & 2) && (!a_col || M % 8 == 0) && (!b_col || N % 8 == 0) &&
+        const bool addr_ok = (flags & 1) && (flags & 2) && (!a_col || M % 8 == 0 || lda >= ((M + 7) & ~7LL)) &&
+                             (!b_col || N % 8 == 0) &&
                              N % 8 == 0 && K % 64 == 0 && K > 0;
         const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
         if (simple && addr_ok && tile_pref != 128 && M >= 256 && N >= 256) {

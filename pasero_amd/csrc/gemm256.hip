@@ -249,7 +249,9 @@ __global__ __launch_bounds__(NW * 64) void gemm256_kernel(const T* __restrict__ 
     auto dma = [&](int kt) {
         long long k0 = kbeg + (long long)kt * BK;
         char* s = smem + (kt & 1) * STAGE;
-        if constexpr (A_COL) tile_glds<true, NW>(s, (const bf16*)A, lda, k0, m0, kend, M, wave, lane);
+        // (col form with M % 8 != 0: the host only sends it here when the rows are padded, lda >= M rounded up to 8 —
+        // the chunk straddling the edge is then read whole; its pad columns feed output rows >= M, which are not stored)
+        if constexpr (A_COL) tile_glds<true, NW>(s, (const bf16*)A, lda, k0, m0, kend, (M + 7) & ~7LL, wave, lane);
         else tile_glds<false, NW>(s, (const bf16*)A, lda, m0, k0, M, kend, wave, lane);
         if constexpr (B_COL) tile_glds<true, NW>(s + OP_BYTES, (const bf16*)B, ldb, k0, n0, kend, N, wave, lane);
         else tile_glds<false, NW>(s + OP_BYTES, (const bf16*)B, ldb, n0, k0, N, kend, wave, lane);

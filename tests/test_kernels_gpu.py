@@ -163,6 +163,25 @@ def test_gemm_fused_bias_gradient(F, dtype, splitk, M, N, K):
     assert rel_err(db, dY.double().sum(0)) < tol
 
 
+@pytest.mark.parametrize('M,pad', [(1030, 2), (2051, 5), (262, 10)])
+def test_gemm_col_form_rows_not_a_multiple_of_8(F, M, pad):
+    """weight gradient of the vocabulary projection: A = dlogits (rows, V) in col form with V % 8 != 0 (NLLB: 256206),
+    rows padded to a 16-byte multiple.  The 256-tile kernel reads the chunk that straddles the edge whole; the pad
+    columns (poisoned here with NaN) only feed output rows that are not stored"""
+    K, N = 4096, 512
+    buf = torch.full((K, M + pad), float('nan'), dtype=torch.bfloat16)
+    A = rnd((K, M), 51, torch.bfloat16)
+    buf[:, :M] = A
+    B = rnd((K, N), 52, torch.bfloat16)
+    a = buf.cuda()[:, :M]
+    assert a.stride(0) == M + pad and (M + pad) % 8 == 0 and M % 8 != 0
+    ref = A.double().t() @ B.double()
+    for sk in (1, 32):  # 128-tile kernel / 256-tile kernel with split-K
+        out = F.gemm(a, B.cuda(), a_col=True, b_col=True, splitk=sk)
+        assert torch.isfinite(out.float()).all()
+        assert rel_err(out, ref) < 6e-3
+
+
 def test_gemm_strided_views(F):
     """q/k/v-style column slices and a padded leading dimension"""
     M, N, K = 96, 64, 128
