@@ -31,6 +31,24 @@ class Adam(torch.optim.Optimizer):
             st['exp_avg_sq'] = torch.zeros_like(p, dtype=torch.float32)
         return st
 
+    def load_state_dict(self, state_dict) -> None:
+        """torch.optim.Optimizer.load_state_dict casts floating-point state to the dtype of its parameter: with bf16 /
+        fp16 parameters the fp32 moments would come back in 16 bits (and half as large as the kernels assume).  The
+        moments are taken from the checkpoint as they are, in fp32, on the parameter's device — the reference guards
+        its optimizer against the same cast (pasero/optimization.py:151-164)."""
+        super().load_state_dict(state_dict)
+        saved = state_dict['state']
+        old_ids = [i for g in state_dict['param_groups'] for i in g['params']]
+        params = [p for g in self.param_groups for p in g['params']]
+        for old_id, p in zip(old_ids, params):
+            src = saved.get(old_id)
+            if not src:
+                continue
+            st = self.state[p]
+            for k in ('exp_avg', 'exp_avg_sq'):
+                st[k] = src[k].detach().to(device=p.device, dtype=torch.float32).contiguous().clone()
+            st['step'] = int(src['step'])
+
     def _chunks(self, key, params):
         plan = self._plan.get(key)
         if plan is None:
@@ -64,6 +82,13 @@ class Adam(torch.optim.Optimizer):
                     if not (p.is_contiguous() and p.grad.is_contiguous()):
                         raise RuntimeError('pasero_amd.optim.Adam needs contiguous parameters and gradients')
                 states = [self._state(p) for p in params]
+                for p, st in zip(params, states):  # the kernels index the moments as fp32 arrays of p.numel() elements
+                    for k in ('exp_avg', 'exp_avg_sq'):
+                        m = st[k]
+                        if not (m.dtype == torch.float32 and m.numel() == p.numel() and m.device == p.device
+                                and m.is_contiguous()):
+                            raise RuntimeError(f'pasero_amd.optim.Adam: state {k} must be a contiguous fp32 tensor of the '
+                                               f"parameter's size on its device (got {m.dtype}, {tuple(m.shape)}, {m.device})")
                 ct, cs, partial, numel = self._chunks((gi, dt, tuple(id(p) for p in params)), params)
                 table = torch.tensor([p.data_ptr() for p in params] + [p.grad.data_ptr() for p in params]
                                      + [s['exp_avg'].data_ptr() for s in states]

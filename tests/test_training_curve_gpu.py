@@ -78,3 +78,61 @@ def test_loss_curve_matches_cpu_reference(name):
     bf16 = _hip_curve(g, torch.bfloat16)
     for s, (a, r) in enumerate(zip(bf16, ref)):
         assert abs(a - r) <= 3e-2 * abs(r), (s, a, r)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_checkpoint_resume_continues_the_same_trajectory(dtype):
+    """training.py:622-623,797-800,899-926: model and optimizer state dicts saved after 3 steps (through clean_state_dict,
+    to the CPU, as the Trainer writes them), loaded into a fresh model + optimizer (update_state_dict, strict load) —
+    steps 4-6 (dropout on, so the dropout offsets must resume too) give the losses of the uninterrupted run"""
+    import copy
+    import io
+    from pasero_amd import rng
+    from pasero_amd.optim import Adam
+    g = load_golden('tiny_encdec_post')
+    batches = [{k: torch.from_numpy(x).cuda() for k, x in b.items()} for b in _batches(g)[:6]]
+
+    def fresh():
+        cfg, model = build_model(g, dtype, 'cuda')
+        cfg.dropout = 0.1
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.1
+        model.train()
+        return model, Adam(model.parameters(), lr=LR, betas=BETAS, eps=EPS, weight_decay=0.01)
+
+    def run(model, opt, bs):
+        out = []
+        for b in bs:
+            model.zero_grad(set_to_none=True)
+            loss, logs = model(**b)
+            loss.backward()
+            opt.fused_step(1.0 / logs['num_tokens'], CLIP)
+            out.append(loss.item())
+        return out
+
+    rng.manual_seed(9)
+    model, opt = fresh()
+    straight = run(model, opt, batches)
+
+    rng.manual_seed(9)
+    model, opt = fresh()
+    first = run(model, opt, batches[:3])
+    msd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.clean_state_dict(msd)
+    buf = io.BytesIO()
+    torch.save({'model': msd, 'optimizer': opt.state_dict(), 'rng': rng.get_state()}, buf)
+    del model, opt
+    buf.seek(0)
+    ckpt = torch.load(buf, map_location='cpu', weights_only=False)
+    model2, opt2 = fresh()
+    sd = copy.copy(ckpt['model'])
+    model2.update_state_dict(sd)
+    model2.load_state_dict(sd, strict=True)
+    opt2.load_state_dict(ckpt['optimizer'])
+    rng.set_state(ckpt['rng'])
+    rest = run(model2, opt2, batches[3:])
+    # (not bit for bit: the embedding gradient is summed with fp32 atomics, whose order varies from run to run)
+    close = lambda a, b: all(abs(x - y) <= 1e-5 * abs(y) for x, y in zip(a, b))  # noqa: E731
+    assert close(first, straight[:3])
+    assert close(rest, straight[3:]), (rest, straight[3:])
