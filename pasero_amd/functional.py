@@ -10,6 +10,16 @@ from . import lib
 from .lib import ACT, check, dtype_code, ptr, require_gpu, stream_ptr
 
 
+def _same(ref: Tensor, *tensors, what: str) -> None:
+    """The kernels index every tensor of a call with ONE element type and trust the sizes they are given: a tensor of
+    another dtype would be read with the wrong stride — or past its end (an fp32 LayerNorm weight next to bf16
+    activations, optimizer moments cast to 16 bits).  Checked here, on the host, for every multi-tensor entry point."""
+    for t in tensors:
+        if t is not None and t.dtype != ref.dtype:
+            raise TypeError(f'pasero_amd: {what}: tensors of dtype {t.dtype} and {ref.dtype} in one kernel call '
+                            f'(cast the module with .to(dtype), or run under torch.autocast)')
+
+
 def _ld(t: Tensor) -> int:
     assert t.dim() == 2 and (t.stride(1) == 1 or t.size(1) == 1), 'operand must be 2-D with unit inner stride'
     return t.stride(0) if t.size(0) > 1 else max(t.size(1), t.stride(0))
@@ -73,6 +83,8 @@ def residual_ln_fwd(x: Tensor, residual: Optional[Tensor], gamma: Optional[Tenso
     d = x.size(-1)
     rows = x.numel() // d
     assert x.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.shape == x.shape))
+    _same(x, residual, gamma, beta, what='residual_ln_fwd')
+    assert all(t is None or (t.numel() == d and t.is_contiguous()) for t in (gamma, beta))
     y = torch.empty_like(x) if gamma is not None else None
     z = torch.empty_like(x) if (want_z or gamma is None) else None
     mean = rstd = None
@@ -97,7 +109,11 @@ def residual_ln_bwd(dy: Optional[Tensor], dz_extra: Optional[Tensor], z: Optiona
     d = ref.size(-1)
     rows = ref.numel() // d
     for t in (dy, dz_extra, z):
-        assert t is None or t.is_contiguous()
+        assert t is None or (t.is_contiguous() and t.numel() == ref.numel())
+    _same(ref, dy, dz_extra, z, gamma, what='residual_ln_bwd')
+    assert gamma is None or (gamma.numel() == d and gamma.is_contiguous())
+    for t in (mean, rstd):
+        assert t is None or (t.dtype == torch.float32 and t.numel() == rows and t.is_contiguous())
     dres = torch.empty_like(ref) if want_dres else None
     dx = torch.empty_like(ref) if want_dx else None
     dgamma = dbeta = None
@@ -129,6 +145,8 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, num_heads: int, key_pad: Optional[
     B, T, D = q.shape
     S = k.size(1)
     hd = D // num_heads
+    _same(q, k, v, what='attn_fwd')
+    assert k.shape == (B, S, D) and v.shape == (B, S, D)
     o = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=q.device)
     mask = torch.empty(B, num_heads, T, 8 * ((S + 63) // 64), dtype=torch.uint8, device=q.device) if drop_p > 0 else None
@@ -150,6 +168,14 @@ def attn_bwd(q, k, v, o, d_o, lse, num_heads: int, key_pad, causal: bool, scale:
     hd = D // num_heads
     if d_o.stride(2) != 1:
         d_o = d_o.contiguous()
+    _same(q, k, v, o, d_o, dq, dk, dv, what='attn_bwd')
+    assert k.shape == (B, S, D) and v.shape == (B, S, D) and o.shape == (B, T, D) and d_o.shape == (B, T, D)
+    assert lse.dtype == torch.float32 and lse.shape == (B, num_heads, T) and lse.is_contiguous()
+    if key_pad is not None:
+        assert key_pad.dtype == torch.bool and key_pad.shape == (B, S) and key_pad.is_contiguous()
+    if drop_p > 0:
+        assert drop_mask is not None and drop_mask.dtype == torch.uint8 and drop_mask.is_contiguous() \
+            and drop_mask.shape == (B, num_heads, T, 8 * ((S + 63) // 64))
     dq = torch.empty(B, T, D, dtype=q.dtype, device=q.device) if dq is None else dq
     dk = torch.empty(B, S, D, dtype=q.dtype, device=q.device) if dk is None else dk
     dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device) if dv is None else dv
@@ -167,6 +193,10 @@ def attn_probs(q: Tensor, k: Tensor, num_heads: int, key_pad: Optional[Tensor], 
     require_gpu(q, k, key_pad)
     B, T, D = q.shape
     S = k.size(1)
+    _same(q, k, what='attn_probs')
+    assert k.shape == (B, S, D)
+    if key_pad is not None:
+        assert key_pad.dtype == torch.bool and key_pad.shape == (B, S) and key_pad.is_contiguous()
     probs = torch.empty(B, T, num_heads, S, dtype=q.dtype, device=q.device)
     L = lib.load()
     check(L.pk_attn_probs(ptr(q), ptr(k), ptr(probs), ptr(key_pad), B, num_heads, T, S, D // num_heads, *_bs_rs(q),
@@ -211,7 +241,8 @@ def embed_bwd(ids: Tensor, dout: Tensor, V: int, pad_idx: int, scale: float, dro
               offset: int = 0) -> Tensor:
     require_gpu(ids, dout)
     d = dout.size(-1)
-    assert dout.is_contiguous() and ids.is_contiguous()
+    assert dout.is_contiguous() and ids.is_contiguous() and ids.dtype == torch.int64
+    assert dout.numel() == ids.numel() * d
     dE = torch.empty(V, d, dtype=dout.dtype, device=dout.device)
     ws, ws_bytes = None, 0
     if dout.dtype != torch.float32:
@@ -230,6 +261,10 @@ def ce_rows(logits: Tensor, target: Tensor, pad_idx: int, eps: float, row_loss: 
     require_gpu(logits, target, dlogits)
     rows, V = logits.shape
     assert target.dtype == torch.int64 and target.is_contiguous() and target.numel() == rows
+    _same(logits, dlogits, what='ce_rows')
+    assert dlogits is None or dlogits.shape == logits.shape
+    for t in (row_loss, row_nll, row_lse):
+        assert t is None or (t.dtype == torch.float32 and t.numel() == rows and t.is_contiguous() and t.is_cuda)
     L = lib.load()
     check(L.pk_ce_rows(ptr(logits), _ld(logits), ptr(target), ptr(dlogits), _ld(dlogits) if dlogits is not None else 0,
                        ptr(row_loss), ptr(row_nll), ptr(row_lse), rows, V, int(pad_idx), float(eps or 0.0),
@@ -237,6 +272,10 @@ def ce_rows(logits: Tensor, target: Tensor, pad_idx: int, eps: float, row_loss: 
 
 
 def ce_finalize(row_loss: Tensor, row_nll: Tensor, target: Tensor, pad_idx: int) -> Tensor:
+    n = target.numel()
+    assert target.dtype == torch.int64 and target.is_contiguous()
+    for t in (row_loss, row_nll):
+        assert t.dtype == torch.float32 and t.numel() == n and t.is_contiguous()
     sums = torch.empty(3, dtype=torch.float32, device=row_loss.device)
     L = lib.load()
     check(L.pk_ce_finalize(ptr(row_loss), ptr(row_nll), ptr(target), target.numel(), int(pad_idx), ptr(sums),
@@ -270,6 +309,7 @@ def scale(x: Tensor, dev_scalar: Optional[Tensor], host_scalar: float = 1.0, out
     require_gpu(x, dev_scalar)
     assert x.is_contiguous()
     out = torch.empty_like(x) if out is None else out
+    assert out.dtype == x.dtype and out.numel() == x.numel() and out.is_contiguous()
     if dev_scalar is not None:
         assert dev_scalar.dtype == torch.float32 and dev_scalar.numel() == 1
     L = lib.load()
@@ -288,7 +328,8 @@ def act_fwd(x: Tensor, act: str) -> Tensor:
 
 def act_bwd(dy: Tensor, x: Tensor, act: str) -> Tensor:
     require_gpu(dy, x)
-    assert x.is_contiguous() and dy.is_contiguous()
+    assert x.is_contiguous() and dy.is_contiguous() and dy.numel() == x.numel()
+    _same(x, dy, what='act_bwd')
     out = torch.empty_like(x)
     check(lib.load().pk_act_bwd(ptr(dy), ptr(x), ptr(out), x.numel(), ACT[act], dtype_code(x), stream_ptr()),
           'pk_act_bwd')
@@ -306,7 +347,8 @@ def glu_fwd(x: Tensor) -> Tensor:
 
 def glu_bwd(dy: Tensor, x: Tensor) -> Tensor:
     require_gpu(dy, x)
-    assert x.is_contiguous() and dy.is_contiguous()
+    assert x.is_contiguous() and dy.is_contiguous() and 2 * dy.numel() == x.numel()
+    _same(x, dy, what='glu_bwd')
     C = x.size(-1) // 2
     dx = torch.empty_like(x)
     check(lib.load().pk_glu_bwd(ptr(dy), ptr(x), ptr(dx), x.numel() // (2 * C), C, dtype_code(x), stream_ptr()),
@@ -357,7 +399,8 @@ def rope(x: Tensor, cos_t: Tensor, sin_t: Tensor, ncols: int, pos_offset: int, i
 def gated_act_bwd(dh: Tensor, z: Tensor, u: Tensor, act: str):
     """h = act(z) * u  ->  (dz, du)"""
     require_gpu(dh, z, u)
-    assert dh.is_contiguous() and z.is_contiguous() and u.is_contiguous()
+    assert dh.is_contiguous() and z.is_contiguous() and u.is_contiguous() and dh.numel() == z.numel() == u.numel()
+    _same(z, dh, u, what='gated_act_bwd')
     dz, du = torch.empty_like(z), torch.empty_like(u)
     check(lib.load().pk_gated_act_bwd(ptr(dh), ptr(z), ptr(u), ptr(dz), ptr(du), z.numel(), ACT[act], dtype_code(z),
                                       stream_ptr()), 'pk_gated_act_bwd')

@@ -597,3 +597,32 @@ def test_fused_adam_bf16_scale_and_state_layout():
     st = opt.state[pb]
     assert set(st) == {'step', 'exp_avg', 'exp_avg_sq'} and st['step'] == 1
     assert st['exp_avg'].dtype == torch.float32 and rel_err(st['exp_avg'], m) < 1e-6 and rel_err(st['exp_avg_sq'], v) < 1e-6
+
+
+def test_mixed_dtypes_and_wrong_sizes_are_refused_on_the_host(F):
+    """the kernels trust the element type and sizes they are told: an fp32 LayerNorm weight next to bf16 activations,
+    int32 token ids or 16-bit optimizer moments would be read with the wrong stride or past their end — refused before
+    any launch"""
+    x = torch.randn(8, 128, device='cuda').bfloat16()
+    g32 = torch.ones(128, device='cuda')
+    with pytest.raises(TypeError):
+        F.residual_ln_fwd(x, None, g32, None, 1e-5)
+    with pytest.raises(AssertionError):
+        F.residual_ln_fwd(x, None, g32.bfloat16()[:64].contiguous(), None, 1e-5)
+    q = torch.randn(2, 4, 64, device='cuda').bfloat16()
+    with pytest.raises(TypeError):
+        F.attn_fwd(q, q.float(), q, 1, None, False, 0.125)
+    logits = torch.randn(4, 32, device='cuda').bfloat16()
+    rl, rn = torch.empty(4, device='cuda'), torch.empty(4, device='cuda')
+    with pytest.raises(AssertionError):
+        F.ce_rows(logits, torch.zeros(4, dtype=torch.int32, device='cuda'), 1, 0.1, rl, rn)
+    with pytest.raises(AssertionError):
+        F.ce_rows(logits, torch.zeros(4, dtype=torch.int64, device='cuda'), 1, 0.1, rl[:3], rn)
+    from pasero_amd.optim import Adam
+    p = torch.nn.Parameter(torch.randn(64, 64, device='cuda').bfloat16())
+    opt = Adam([p], lr=1e-3)
+    p.grad = torch.randn_like(p)
+    opt.step()
+    opt.state[p]['exp_avg'] = opt.state[p]['exp_avg'].bfloat16()  # what torch's load_state_dict would have done
+    with pytest.raises(RuntimeError, match='fp32'):
+        opt.step()
