@@ -44,11 +44,19 @@ class Plan:
 
     def __init__(self, c_plan, c_layers, keep, fingerprint, cross_w):
         self.c_plan, self.c_layers, self.keep, self.fingerprint, self.cross_w = c_plan, c_layers, keep, fingerprint, cross_w
+        self.full = None
 
 
 def _fingerprint(decoder):
     w = decoder.embed_tokens.weight
     return (w.data_ptr(), w.dtype, str(w.device), decoder.layers[0].fc1.weight.data_ptr())
+
+
+def _full_fingerprint(decoder):
+    """every parameter's address and type: the plan holds raw pointers, so a parameter whose storage was replaced
+    (`p.data = ...`, a partial `.to()`) must invalidate it.  ~30 us: checked once per sentence batch, the cheap
+    fingerprint above at every step."""
+    return tuple((p.data_ptr(), p.dtype) for p in decoder.parameters())
 
 
 def build_plan(decoder) -> Optional[Plan]:
@@ -115,7 +123,14 @@ def build_plan(decoder) -> Optional[Plan]:
     p.final_ln_b = None if isinstance(final_ln, modules.Identity) else ptr(final_ln.bias)
     p.out_w = ptr(out_w)
     p.layers = ctypes.cast(c_layers, ctypes.POINTER(PkDecoderLayerWeights))
-    return Plan(p, c_layers, keep, _fingerprint(decoder), [cw for _, cw in layers])
+    keep += [t for vals, _ in layers for t in vals if t is not None] + [E, out_w]  # the pointers stay valid
+    keep += [t for m in (embed_ln, final_ln) if not isinstance(m, modules.Identity) for t in (m.weight, m.bias)]
+    dtypes = {t.dtype for t in keep if t is not None and t.is_floating_point()}
+    if len(dtypes) != 1:
+        return None  # mixed parameter dtypes (e.g. fp32 LayerNorm weights in a bf16 model): per-op path, which refuses loudly
+    plan = Plan(p, c_layers, keep, _fingerprint(decoder), [cw for _, cw in layers])
+    plan.full = _full_fingerprint(decoder)
+    return plan
 
 
 _plans = weakref.WeakKeyDictionary()  # decoder -> (fingerprint, training), Plan | None
@@ -238,6 +253,11 @@ def try_step(decoder, encoder_out: Tensor, encoder_mask: Optional[Tensor], decod
     if cache is None:
         if first not in state or encoder_out is None or state[first].size(1) != state['offset']:
             return None
+        if plan.full != _full_fingerprint(decoder):  # some parameter moved since the plan was built
+            _plans.pop(decoder, None)
+            plan = get_plan(decoder)
+            if plan is None:
+                return None
         cache = DecodeCache(decoder, plan, encoder_out, encoder_mask, state)
         state[DecodeCache.KEY] = cache
     max_len = decoder.layers[0].self_attn.max_len

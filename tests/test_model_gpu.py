@@ -398,6 +398,40 @@ def test_native_decoding_step_matches_per_op_path(name, dtype, monkeypatch):
         assert x.shape == y.shape and (x - y).abs().max().item() <= tol * y.abs().max().item()
 
 
+def test_native_decoding_plan_follows_replaced_parameters(monkeypatch):
+    """the native step holds raw pointers to the weights: in-place updates are seen as they are; a parameter whose
+    storage is REPLACED between two sentences (p.data = ...) must invalidate the plan — and a model left with mixed
+    parameter dtypes must fall back to the per-op path, which refuses it loudly"""
+    g = load_golden('tiny_encdec_post')
+    cfg, model = build_model(g, torch.float32, 'cuda')
+    model.eval()
+    B, S, V = int(g['B']), int(g['S']), int(g['V'])
+    b = paramgen.make_text_batch(int(g['seed']), B, S, 8, V)
+    with torch.no_grad():
+        enc_out, enc_mask, _ = model.encoder(torch.from_numpy(b['encoder_input']).cuda(),
+                                             torch.from_numpy(b['encoder_input_length']).cuda())
+    tokens = torch.from_numpy(b['decoder_input']).cuda().clamp(min=2)
+    before, st = _decode_logits(model, enc_out, enc_mask, tokens)
+    assert '_pk_decode' in st
+    w = model.decoder.layers[1].fc2.weight
+    with torch.no_grad():
+        w.mul_(1.5)                                   # in place: same storage
+    inplace, _ = _decode_logits(model, enc_out, enc_mask, tokens)
+    w.data = (w.data / 1.5).clone()                   # new storage, original values
+    replaced, st = _decode_logits(model, enc_out, enc_mask, tokens)
+    assert '_pk_decode' in st
+    monkeypatch.setenv('PASERO_NO_NATIVE_DECODE', '1')
+    per_op, _ = _decode_logits(model, enc_out, enc_mask, tokens)
+    monkeypatch.delenv('PASERO_NO_NATIVE_DECODE')
+    assert (inplace[-1] - before[-1]).abs().max().item() > 1e-3       # the in-place update was seen
+    for a, r0, r1 in zip(replaced, before, per_op):
+        assert (a - r0).abs().max().item() <= 2e-5 * r0.abs().max().item()
+        assert (a - r1).abs().max().item() <= 2e-5 * r1.abs().max().item()
+    model.decoder.layers[0].self_attn_layer_norm.double()              # one module in another dtype
+    with pytest.raises((TypeError, AssertionError)):
+        _decode_logits(model, enc_out, enc_mask, tokens)
+
+
 @pytest.mark.parametrize('native', [True, False])
 def test_beam_search_trace_replay(native, monkeypatch):
     """tests/golden/beam_trace.npz: what the reference's beam_search (decoding.py:1225-1657) fed ITS decoder at every
