@@ -23,6 +23,10 @@ SHAPES = {
     'out_dx': (32768, 512, 512, False, True, 1),
     'fc1_dw': (2048, 512, 32768, True, True, 0),
     'out_dw': (512, 512, 32768, True, True, 0),
+    'out_dw_sk8': (512, 512, 32768, True, True, 8),
+    'out_dw_sk16': (512, 512, 32768, True, True, 16),
+    'out_dw_sk32': (512, 512, 32768, True, True, 32),
+    'out_dw_sk64': (512, 512, 32768, True, True, 64),
     'qkv_dw': (1536, 512, 32768, True, True, 0),
     'fc2_dw': (512, 2048, 32768, True, True, 0),
     'big_4k': (4096, 4096, 4096, False, False, 1),
