@@ -240,6 +240,35 @@ def test_greedy_decode_incremental_state():
     assert (tokens.numpy() == g['tokens']).all()
 
 
+def test_beam_search_trace_replay_through_the_oracle():
+    """tests/golden/beam_trace.npz (what the reference's beam_search fed its decoder, and the reorderings of the
+    incremental state — decoding.py:1225-1657, Decoder.reorder_state) replayed through the oracle's incremental decoder:
+    the last-position logits of every step match, including after the batch shrinks"""
+    g = load_golden('beam_trace')
+    cfg = golden_cfg(g)
+    seed, B, S, V, K = (int(g[k]) for k in ('seed', 'B', 'S', 'V', 'K'))
+    P = _state(g, seed)
+    if cfg.shared_embeddings:
+        P['decoder.embed_tokens.weight'] = P['encoder.embed_tokens.weight']
+    batch = paramgen.make_text_batch(seed, B, S, 5, V)
+    with torch.no_grad():
+        enc_out, enc_mask = O.encoder(P, cfg, torch.from_numpy(batch['encoder_input']),
+                                      torch.from_numpy(batch['encoder_input_length']))
+        enc_out, enc_mask = enc_out.repeat_interleave(K, dim=0), enc_mask.repeat_interleave(K, dim=0)
+        state = {}
+        for i in range(int(g['n_calls'])):
+            dec_in = torch.from_numpy(g[f'dec_in_{i}'])
+            logits = O.decoder(P, cfg, enc_out, enc_mask, dec_in, state=state)[:, -1]
+            close(logits.numpy(), g[f'logits_{i}'], rtol=2e-5)
+            assert (logits.argmax(-1).numpy() == g[f'logits_{i}'].argmax(-1)).all()
+            if i < int(g['n_reorders']):
+                idx = torch.from_numpy(g[f'reorder_{i}'])
+                enc_out, enc_mask = enc_out.index_select(0, idx), enc_mask.index_select(0, idx)
+                for k, v in list(state.items()):  # Decoder.reorder_state (transformer.py): every tensor of the state
+                    if torch.is_tensor(v):
+                        state[k] = v.index_select(0, idx)
+
+
 def test_adam_and_clip():
     g = load_golden('adam_step')
     n, steps = int(g['n']), int(g['steps'])
