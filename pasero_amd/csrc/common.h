@@ -119,6 +119,13 @@ template <typename T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
 template <typename T> __device__ __forceinline__ void store16(T* p, const Vec16<T>& v) {
     *reinterpret_cast<decltype(v.raw)*>(p) = v.raw;
 }
+// streaming store (`nt`): for outputs no later instruction of this kernel reads — the next kernel finds them in HBM /
+// Infinity Cache either way, and the L2 keeps the operand tiles that ARE re-read.  Measured on the 256-tile GEMM
+// epilogue: C2 step 18.74 -> 18.41 ms (same box, 4 alternations).
+template <typename T> __device__ __forceinline__ void store16_nt(T* p, const Vec16<T>& v) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v.raw), reinterpret_cast<u32x4*>(p));
+}
 
 // run `...` with T bound to the storage type of `dtype`
 #define PK_DTYPE_SWITCH(dtype, who, ...)                                   \

@@ -302,7 +302,7 @@ __device__ __forceinline__ void fast_epilogue(const float* __restrict__ cs, T* _
         } else {
             o.raw = make_float4(x[0], x[1], x[2], x[3]);
         }
-        store16<T>(cp + (long long)i * RPT * ep.ldc, o);
+        store16_nt<T>(cp + (long long)i * RPT * ep.ldc, o);
     }
 }
 
@@ -672,7 +672,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) o.set(e, v[e] * ep.alpha);
             }
-            store16<T>(C + gm * ep.ldc + gn, o);
+            store16_nt<T>(C + gm * ep.ldc + gn, o);
         }
         return;
     }

@@ -128,7 +128,7 @@ __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, T* _
         f32x8 f = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
         Vec16<T> o;
         o.raw = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename H16<T>::vec));
-        store16<T>(C + gm * ep.ldc + gn, o);
+        store16_nt<T>(C + gm * ep.ldc + gn, o);
     }
 }
 
