@@ -370,15 +370,26 @@ __device__ __forceinline__ float frag_dot(const bf16x8_t& a, const bf16x8_t& b) 
 template <int ND, typename T>
 __device__ __forceinline__ void store_rowT(T* __restrict__ base, long long rs, int row, bool valid,
                                            const f32x16 (&acc)[ND], float mul, int lane) {
-    if (!valid) return;
+    // lanes l and l + 32 own the same row: columns [8g, 8g+4) and [8g+4, 8g+8) of every group g.  They swap one piece
+    // per pair of groups so that each writes 16 contiguous bytes (lane l: group 2j whole, lane l + 32: group 2j + 1)
+    const int h = lane >> 5;
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            int d = dt * 32 + 8 * g + 4 * (lane >> 5);
-            unsigned lo = (unsigned)H16<T>::bits(acc[dt][4 * g] * mul) | ((unsigned)H16<T>::bits(acc[dt][4 * g + 1] * mul) << 16);
-            unsigned hi = (unsigned)H16<T>::bits(acc[dt][4 * g + 2] * mul) | ((unsigned)H16<T>::bits(acc[dt][4 * g + 3] * mul) << 16);
-            *reinterpret_cast<uint2*>(base + (long long)row * rs + d) = make_uint2(lo, hi);
+        for (int j = 0; j < 2; ++j) {
+            unsigned lo[2], hi[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int g = 2 * j + q;
+                lo[q] = (unsigned)H16<T>::bits(acc[dt][4 * g] * mul) | ((unsigned)H16<T>::bits(acc[dt][4 * g + 1] * mul) << 16);
+                hi[q] = (unsigned)H16<T>::bits(acc[dt][4 * g + 2] * mul) | ((unsigned)H16<T>::bits(acc[dt][4 * g + 3] * mul) << 16);
+            }
+            const unsigned send_lo = h ? lo[0] : lo[1], send_hi = h ? hi[0] : hi[1];
+            const unsigned recv_lo = __shfl_xor(send_lo, 32), recv_hi = __shfl_xor(send_hi, 32);
+            // h = 0: group 2j = {own cols 0-3, partner's cols 4-7};  h = 1: group 2j + 1 = {partner's cols 0-3, own cols 4-7}
+            const uint4 v = h ? make_uint4(recv_lo, recv_hi, lo[1], hi[1]) : make_uint4(lo[0], hi[0], recv_lo, recv_hi);
+            const int d = dt * 32 + 8 * (2 * j + h);
+            if (valid) *reinterpret_cast<uint4*>(base + (long long)row * rs + d) = v;
         }
 }
 
