@@ -5,6 +5,11 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks itself (one process per GPU, like
+the reference's own `pasero-train`, cli/train.py:705-727): before anything touches the GPU the parent spawns
+`python -m torch.distributed.run ... bench.py <same arguments>` as a child, passes its output through and exits with
+its return code.
+
 One "step" = one pass of the hot path over one synthetic batch per GPU: Transformer.forward (encoder, decoder, fused
 tied-projection + label-smoothed CE, the logs' device->host copy) + loss.backward() + (N > 1) the bucketed gradient
 all-reduce over RCCL, i.e. what `Trainer.train_step` does between `zero_grad` and the optimizer (pasero/training.py:
@@ -48,8 +53,8 @@ WORKLOADS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='c2_base_bf16', choices=list(WORKLOADS))
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--force-ddp', action='store_true',
@@ -58,7 +63,27 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true', help='skip the per-launch HIP-event instrumentation')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
+    ap.add_argument('--rehearse-cpu', action='store_true',
+                    help='CPU rehearsal of the multi-rank plumbing (launcher, rendezvous, reducer, fused logs '
+                         'all-reduce, timing protocol, JSON): a small torch MLP stands in for the HIP model, which has '
+                         'no CPU path.  The line it prints is marked "rehearsal" and is not a measurement.')
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`--gpus N` without a launcher: start N ranks (one process per GPU) as a CHILD torch.distributed.run and return
+    its exit code.  Nothing in this process has touched the GPU yet (and nothing is exec'ed)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
 
 
 def synthetic_batch(B, S, T, V, seed, device):
@@ -189,14 +214,69 @@ def count_flops(cfg, B: int, S: int, T: int, V: int) -> float:
     return 3.0 * (enc + dec + B * T * 2 * d * V)
 
 
+def rehearse_cpu(args, rank: int, world: int):
+    """CPU rehearsal of everything around the HIP model in a multi-rank run: rendezvous, the bucketed reducer, the
+    fused logs all-reduce, the barrier / max-over-ranks timing protocol and rank 0's JSON line.  Not a measurement."""
+    import torch.distributed as dist
+    import torch.nn as nn
+    from pasero_amd.ddp import DistributedDataParallel, reduce_logs
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(1234)
+    net = nn.Sequential(nn.Linear(64, 256), nn.ReLU(), nn.Linear(256, 64))
+    ddp = DistributedDataParallel(net, bucket_cap_mb=0.02) if world > 1 else net
+    x = torch.randn(32, 64, generator=torch.Generator().manual_seed(1 + rank))
+    tokens_per_step = 32
+
+    def step():
+        for p in net.parameters():
+            p.grad = None
+        ddp(x).pow(2).sum().backward()
+        return reduce_logs({'loss': 1.0, 'nll_loss': 1.0, 'num_tokens': tokens_per_step, 'num_lines': 1})
+
+    def fence():
+        if dist.is_initialized():
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    tokens = 0
+    for _ in range(args.steps):
+        tokens += step()['num_tokens']  # already the sum over the ranks
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank == 0:
+        print(json.dumps({'metric': 'target tokens/sec (fwd+bwd), Transformer-base d=512', 'value': tokens / elapsed,
+                          'unit': 'target tokens/s', 'n_gpus': world, 'rccl_ranks': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'rehearsal': 'CPU/gloo stand-in model: plumbing only, NOT a measurement',
+                          'config': {'workload': 'rehearsal', 'tokens_per_rank_per_step': tokens_per_step,
+                                     'parallelism': f'dp{world}'}}))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run '
-                         f'--nproc-per-node {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.rehearse_cpu:
+        return rehearse_cpu(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
     ndev = torch.cuda.device_count()
@@ -213,7 +293,7 @@ def main():
 
     from pasero_amd import config as C, rng
     from pasero_amd.transformer import Transformer
-    from pasero_amd.ddp import DistributedDataParallel
+    from pasero_amd.ddp import DistributedDataParallel, reduce_logs
 
     cfg_name, V, B, S, T = WORKLOADS[args.workload]
     cfg = getattr(C, cfg_name)()  # dropout 0.1, label smoothing 0.1: the training configuration
@@ -241,7 +321,9 @@ def main():
             batch['encoder_input'] = PF.log_mel(wav).to(dtype)
         loss, logs = ddp(**batch)
         loss.backward()
-        return logs['num_tokens']
+        if dist.is_initialized():  # Trainer.train_step's per-step log exchange (training.py:431), as ONE all-reduce
+            logs = reduce_logs(logs)
+        return logs['num_tokens']  # N > 1: already the sum over the ranks
 
     def fence():
         if dist.is_initialized():
@@ -265,9 +347,6 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-        n = torch.tensor([tokens], dtype=torch.float64, device=device)
-        dist.all_reduce(n, op=dist.ReduceOp.SUM)
-        tokens = n.item()
 
     if rank == 0:
         # SURVEY §8d algorithmic FLOPs of one fwd+bwd batch (speech: the encoder runs on the S/2 subsampled positions;
@@ -278,6 +357,8 @@ def main():
             'value': tokens / elapsed,
             'unit': 'target tokens/s',
             'n_gpus': world,
+            'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
+            'tokens_per_rank_per_step': tokens / world / args.steps,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
@@ -289,7 +370,7 @@ def main():
             'config': {'workload': f'{args.workload}: {cfg_name} V={V}, per-GPU batch (B,S,T)=({B},{S},{T}), '
                                    f'dropout {cfg.dropout}, label smoothing {cfg.label_smoothing}, full-length rows',
                        'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}',
-                       'step': 'forward + backward' + (' + bucketed RCCL all-reduce' if world > 1 else ''),
+                       'step': 'forward + backward' + (' + bucketed RCCL all-reduce + fused logs all-reduce' if world > 1 else ''),
                        'algorithmic_tflop_per_step_per_gpu': step_flops / 1e12,
                        'model_tflops_per_gpu': step_flops * args.steps / elapsed / 1e12,
                        'mfma_peak_fraction_whole_step': step_flops * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS},

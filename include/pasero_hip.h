@@ -177,14 +177,23 @@ int pk_rope(const void* x, void* y, long long rows, int Tlen, long long ld, int 
  * (pasero/optimization.py:390-427) and Adam.step (pasero/optimization.py:56-149; fp32 moments, bf16 params updated
  * through fp32).  `table` (device int64): [param ptrs | grad ptrs | exp_avg ptrs | exp_avg_sq ptrs | numel], each
  * `ntensors` long; the chunk list maps workgroup -> (tensor, start), pk_mt_chunk_size() elements per chunk.
- *   pk_mt_sqnorm: gnorm_out[0] = scale * sqrt(sum ||g||^2)       (`partial`: nchunks floats of scratch)
- *   pk_mt_adam  : g' = g * scale * min(1, max_norm / (gnorm + 1e-6)) (max_norm <= 0: no clipping); Adam update of m, v, p */
+ *   pk_mt_sqnorm: partial[0..nchunks) = chunk sums of squares of this table's gradients; with `gnorm_out`:
+ *                 gnorm_out[0] = scale * sqrt(sum partial_all[0..n_all)) — ONE norm over every table (parameter group,
+ *                 dtype) whose partials earlier calls left in `partial_all`, like the reference's clip_grad_norm_
+ *   pk_mt_adam  : g' = g * scale * min(1, max_norm / (gnorm + 1e-6)) (max_norm <= 0: no clipping); Adam update of m, v, p.
+ *                 `bias_corr` (device fp32 [2 * ntensors]: 1 - beta1^step_t | sqrt(1 - beta2^step_t)) carries the
+ *                 reference's per-parameter `state['step']` (optimization.py:120-125); NULL: every tensor at `step`.
+ *   pk_mt_copy  : dst_t = src_t for every tensor; `table` = [src ptrs | dst ptrs | numel].  The gradient pack of a
+ *                 data-parallel bucket (the reducer that replaces torch DDP's, pasero/training.py:243-250). */
 int pk_mt_chunk_size(void);
 int pk_mt_sqnorm(const long long* table, int ntensors, const int* chunk_tensor, const long long* chunk_start, int nchunks,
-                 float scale, float* partial, float* gnorm_out, int dtype, void* stream);
+                 float scale, float* partial, const float* partial_all, int n_all, float* gnorm_out, int dtype,
+                 void* stream);
 int pk_mt_adam(const long long* table, int ntensors, const int* chunk_tensor, const long long* chunk_start, int nchunks,
                const float* gnorm, float scale, float max_norm, float lr, float beta1, float beta2, float eps,
-               float weight_decay, int step, int dtype, void* stream);
+               float weight_decay, int step, const float* bias_corr, int dtype, void* stream);
+int pk_mt_copy(const long long* table, int ntensors, const int* chunk_tensor, const long long* chunk_start, int nchunks,
+               int dtype, void* stream);
 
 /* gated activation backward (SwiGLU / GEGLU FFN, transformer.py:1013-1016): h = act(z) * u
  *   dz = dh * u * act'(z)      du = dh * act(z) */

@@ -76,10 +76,15 @@ class ResidualLink:
     consumed x) adds it in the epilogue of its dX GEMM (mode 1).  That removes the engine's separate `dx_f + dres`
     accumulation kernel (a 3-tensor elementwise pass per sub-block).  Valid because the block-end backward always runs
     before f's first op (data dependency) and x has no other consumer inside the block."""
-    __slots__ = ('dres',)
+    __slots__ = ('dres', 'attached')
 
     def __init__(self):
         self.dres = None
+        self.attached = False  # set by the forward of the GEMM function that will add `dres` in its dX epilogue
+
+    def attach(self):
+        self.attached = True
+        return self
 
     def take(self):
         d, self.dres = self.dres, None
@@ -107,7 +112,7 @@ class LinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, act: str = 'none', link=None):
-        ctx.link = link
+        ctx.link = link.attach() if (link is not None and ctx.needs_input_grad[0]) else None
         x2 = _2d(_contig(x))
         need_pre = act not in ('none', 'relu') and any(wants_grad(ctx))
         pre = torch.empty(x2.size(0), weight.size(0), dtype=x.dtype, device=x.device) if need_pre else None
@@ -142,7 +147,7 @@ class FFNFn(Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, act: str, link=None):
-        ctx.link = link
+        ctx.link = link.attach() if (link is not None and ctx.needs_input_grad[0]) else None
         x2 = _2d(_contig(x))
         grad = any(wants_grad(ctx))
         need_pre = grad and act not in ('none', 'relu')
@@ -175,7 +180,7 @@ class GatedFFNFn(Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w3, b3, w2, b2, act: str, link=None):
-        ctx.link = link
+        ctx.link = link.attach() if (link is not None and ctx.needs_input_grad[0]) else None
         x2 = _2d(_contig(x))
         u = F.gemm(x2, w3, bias=b3)
         z = torch.empty(x2.size(0), w1.size(0), dtype=x.dtype, device=x.device)
@@ -210,7 +215,7 @@ class PackedLinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, w_flat, b_flat, n: int, link, *params):
-        ctx.link = link
+        ctx.link = link.attach() if (link is not None and ctx.needs_input_grad[0]) else None
         x2 = _2d(_contig(x))
         y = F.gemm(x2, w_flat, bias=b_flat)
         ctx.n = n
@@ -288,7 +293,9 @@ class ResidualLayerNormFn(Function):
 
     @staticmethod
     def forward(ctx, x, residual, gamma, beta, eps: float, p: float, link=None, rms: bool = False):
-        ctx.link = link if (link is not None and residual is not None and residual.requires_grad) else None
+        # (a link no GEMM picked up — a sub-block path that does not forward it — must not swallow the gradient)
+        ctx.link = link if (link is not None and link.attached and residual is not None
+                            and residual.requires_grad) else None
         x = _contig(x)
         residual = _contig(residual) if residual is not None else None
         seed, offset = rng.next_offset() if p > 0 else (0, 0)

@@ -1,16 +1,26 @@
 """Data-parallel gradient reduction for one-process-per-GPU training: a drop-in for the
 `torch.nn.parallel.DistributedDataParallel(model, device_ids=[..], broadcast_buffers=False,
 gradient_as_bucket_view=True)` wrap of the reference Trainer (pasero/training.py:243-250), with the same surface the
-Trainer touches (`.module`, `__call__`, `.no_sync()`, `.parameters()`, `.train()/.eval()`, `.state_dict()`).
+Trainer touches (`.module`, `__call__`, `.no_sync()`, `.parameters()`, `.train()/.eval()`, `.state_dict()`), plus
+`reduce_logs`, the ONE small all-reduce that replaces the per-step `utils.gather_dict` / `all_gather_object` of the
+training logs (pasero/utils.py:93-104, called at pasero/training.py:431,538).
 
 Design for 8 x MI355X over xGMI (RCCL):
   * parameters are grouped, in REVERSE registration order (≈ the order autograd produces their gradients: decoder top
-    -> encoder bottom -> shared embedding last), into flat buckets of `bucket_cap_mb` (16 MiB: the last, non-overlapped all-reduce of a step stays short);
-  * a post-accumulate hook per parameter marks it ready; when a bucket is complete its gradients are packed into the
-    flat buffer with one multi-tensor copy and ONE all-reduce (average) is launched on a dedicated communication stream
-    that waits on the compute stream's event — the collective overlaps the rest of backward;
-  * at the end of backward (autograd engine callback) the compute stream waits for the communication stream and every
-    `param.grad` is re-pointed at its slice of the reduced bucket (no copy back);
+    -> encoder bottom -> shared embedding last), into flat buckets of `bucket_cap_mb` (16 MiB: the last, non-overlapped
+    all-reduce of a step stays short);
+  * a post-accumulate hook per parameter marks it ready; a bucket is launched when it is complete AND every bucket
+    before it has been launched (every rank issues the same sequence of collectives, whatever order its gradients
+    arrive in — torch's Reducer does the same): its gradients are packed into the flat buffer by one multi-tensor HIP
+    kernel (`pk_mt_copy`) and ONE all-reduce (average) is launched on a dedicated communication stream that waits on
+    the compute stream's event — the collective overlaps the rest of backward;
+  * at the end of backward (autograd engine callback) the remaining buckets are flushed in order, the compute stream
+    waits for the communication stream and every `param.grad` is re-pointed at its slice of the reduced bucket (no
+    copy back);
+  * `find_unused_parameters` (set by AdapterTransformer: ranks may use different adapters in one step, adapters.py:
+    232-301): nothing is launched before the end of backward; a bitmap of the parameters that received a gradient is
+    all-reduced first, parameters no rank used keep `.grad = None` (the reference's optimizer then skips them, like
+    after torch DDP), locally unused ones contribute zeros;
   * `no_sync()` skips the reduction for gradient accumulation (training.py:392-408): only the last micro-batch reduces.
 Semantics follow torch DDP: gradients are AVERAGED over ranks, so `Trainer.train_step`'s `grad *= dp_size/num_tokens`
 normalisation (training.py:455-477) stays unchanged.
@@ -18,7 +28,7 @@ Works with any torch.distributed backend ('nccl' = RCCL on ROCm; 'gloo' on CPU f
 """
 import contextlib
 import os
-from typing import List, Optional
+from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -27,7 +37,7 @@ from torch.autograd import Variable
 
 
 class _Bucket:
-    __slots__ = ('params', 'offsets', 'flat', 'pending', 'work', 'dtype', 'numel')
+    __slots__ = ('params', 'offsets', 'flat', 'pending', 'ready', 'launched', 'work', 'dtype', 'numel', 'plan')
 
     def __init__(self, params: List[nn.Parameter]):
         self.params = params
@@ -40,7 +50,10 @@ class _Bucket:
         self.numel = n
         self.flat = torch.zeros(n, dtype=self.dtype, device=params[0].device)
         self.pending = 0
+        self.ready = [False] * len(params)
+        self.launched = False
         self.work = None
+        self.plan = None  # chunk list of the pack kernel (device tensors), built at the first pack
 
     def view(self, i: int) -> torch.Tensor:
         p = self.params[i]
@@ -61,8 +74,8 @@ class DistributedDataParallel(nn.Module):
         self._reduce_enabled = self.world_size > 1 or (dist.is_initialized()
                                                         and os.environ.get('PASERO_DDP_FORCE_REDUCE') == '1')
         self.require_backward_grad_sync = True
-        ignore = set(getattr(module, '_ddp_params_and_buffers_to_ignore', []))
-        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and n not in ignore]
+        self._ignore = set(getattr(module, '_ddp_params_and_buffers_to_ignore', []))
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and n not in self._ignore]
         self._params = [p for _, p in named]
         self._is_cuda = bool(self._params) and self._params[0].is_cuda
         self._comm_stream = torch.cuda.Stream() if self._is_cuda else None
@@ -70,9 +83,10 @@ class DistributedDataParallel(nn.Module):
         self._where = {}
         self._build_buckets(int(bucket_cap_mb * (1 << 20)))
         self._callback_queued = False
+        self._next = 0  # first bucket not launched yet
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(p)) for p in self._params]
         if self.world_size > 1:
-            self._broadcast_parameters()
+            self._broadcast_state()
 
     # ---- setup ----
     def _build_buckets(self, cap_bytes: int) -> None:
@@ -86,42 +100,102 @@ class DistributedDataParallel(nn.Module):
             cur_bytes += nbytes
         if cur:
             self._buckets.append(_Bucket(cur))
-        for b in self._buckets:
+        for bi, b in enumerate(self._buckets):
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
 
     @torch.no_grad()
-    def _broadcast_parameters(self) -> None:
-        """rank 0's parameters (and buffers) are the starting point on every rank, like torch DDP's constructor"""
-        for b in self._buckets:
-            flat = torch.cat([p.detach().reshape(-1) for p in b.params])
+    def _broadcast_state(self, chunk_bytes: int = 64 << 20) -> None:
+        """rank 0's parameters — trainable AND frozen — and buffers are the starting point on every rank, like torch
+        DDP's constructor (`_sync_module_states`); entries of `_ddp_params_and_buffers_to_ignore` are left alone.  Sent
+        in flat chunks of one dtype (≤ 64 MiB), so no second copy of the whole model is ever alive."""
+        seen, tensors = set(), []
+        for name, t in list(self.module.named_parameters()) + list(self.module.named_buffers()):
+            if name in self._ignore or t.data_ptr() in seen or t.numel() == 0:
+                continue
+            seen.add(t.data_ptr())  # tied tensors (shared embeddings) travel once
+            tensors.append(t.detach())
+        group: List[torch.Tensor] = []
+        size = 0
+
+        def flush():
+            if not group:
+                return
+            flat = torch.cat([t.reshape(-1) for t in group])
             dist.broadcast(flat, 0, group=self.process_group)
             off = 0
-            for p in b.params:
-                p.copy_(flat[off: off + p.numel()].view_as(p))
-                off += p.numel()
+            for t in group:
+                t.copy_(flat[off: off + t.numel()].view_as(t))
+                off += t.numel()
+            group.clear()
+
+        for t in tensors:
+            nbytes = t.numel() * t.element_size()
+            if group and (t.dtype != group[0].dtype or t.device != group[0].device or size + nbytes > chunk_bytes):
+                flush()
+                size = 0
+            group.append(t)
+            size += nbytes
+        flush()
 
     # ---- backward-time machinery ----
+    def _reset(self) -> None:
+        """state of one backward pass; also called from `forward`, so a backward that raised half-way (the Trainer's OOM
+        path, training.py:411-420, retries with a dummy batch) leaves nothing behind"""
+        self._callback_queued = False
+        self._next = 0
+        for b in self._buckets:
+            b.pending = len(b.params)
+            b.ready = [False] * len(b.params)
+            b.launched = False
+            if b.work is not None:  # a collective of the aborted step: every rank issued it, let it finish
+                b.work.wait()
+                b.work = None
+
     def _make_hook(self, p: nn.Parameter):
         def hook(param):
             if not self._reduce_enabled or not self.require_backward_grad_sync:
                 return
             if not self._callback_queued:
+                self._reset()
                 self._callback_queued = True
-                for b in self._buckets:
-                    b.pending = len(b.params)
                 Variable._execution_engine.queue_callback(self._finalize)
-            bucket, _ = self._where[p]
-            bucket.pending -= 1
-            if bucket.pending == 0:
-                self._reduce(bucket)
+            bucket, i = self._where[p]
+            if not bucket.ready[i]:
+                bucket.ready[i] = True
+                bucket.pending -= 1
+            if not self.find_unused_parameters:
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self) -> None:
+        """launch, in bucket order, every complete bucket whose predecessors have all been launched"""
+        while self._next < len(self._buckets) and self._buckets[self._next].pending == 0:
+            self._reduce(self._buckets[self._next])
+            self._next += 1
+
+    @torch.no_grad()
+    def _pack(self, b: _Bucket) -> None:
+        idx = [i for i, p in enumerate(b.params) if p.grad is not None]
+        if len(idx) < len(b.params):
+            b.flat.zero_()  # parameters without a gradient on this rank contribute zeros
+        if not idx:
+            return
+        views = [b.view(i) for i in idx]
+        grads = [b.params[i].grad for i in idx]
+        if self._is_cuda and all(g.is_contiguous() and g.dtype == b.dtype for g in grads):
+            from . import functional as PF
+            key = tuple(idx)
+            if b.plan is None or b.plan[0] != key:
+                b.plan = (key, PF.mt_copy_plan([v.numel() for v in views], b.flat.device))
+            PF.mt_copy(grads, views, b.plan[1])
+        else:  # CPU (gloo tests) or exotic gradient layouts
+            torch._foreach_copy_(views, grads)
 
     @torch.no_grad()
     def _reduce(self, b: _Bucket) -> None:
-        views = [b.view(i) for i in range(len(b.params))]
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
-        torch._foreach_copy_(views, grads)  # one multi-tensor pack into the flat bucket
+        self._pack(b)
+        b.launched = True
         if self._is_cuda:
             ready = torch.cuda.current_stream().record_event()
             with torch.cuda.stream(self._comm_stream):
@@ -135,18 +209,23 @@ class DistributedDataParallel(nn.Module):
         if backend == 'nccl':  # RCCL averages in the collective: no extra pass over the bucket
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.process_group, async_op=True)
         else:
+            b.flat.div_(self.world_size)  # (gloo has no AVG; pre-scaling keeps one pass and the same sum)
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
 
     @torch.no_grad()
     def _finalize(self) -> None:
-        """autograd engine callback at the end of backward: flush incomplete buckets (unused parameters), wait for the
-        collectives and re-point `.grad` at the reduced bucket slices"""
+        """autograd engine callback at the end of backward: flush the remaining buckets in order (unused parameters),
+        wait for the collectives and re-point `.grad` at the reduced bucket slices"""
         self._callback_queued = False
-        for b in self._buckets:
-            if b.pending > 0:  # some parameters received no gradient this step
-                b.pending = 0
-                self._reduce(b)
-        backend = dist.get_backend(self.process_group)
+        used_anywhere = None
+        if self.find_unused_parameters:
+            used = torch.tensor([float(r) for b in self._buckets for r in b.ready], dtype=torch.float32,
+                                device=self._buckets[0].flat.device)
+            dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.process_group)
+            used_anywhere = used.bool().tolist()
+        for b in self._buckets[self._next:]:
+            self._reduce(b)
+        self._next = len(self._buckets)
         for b in self._buckets:
             if b.work is not None:
                 if self._is_cuda:
@@ -155,16 +234,22 @@ class DistributedDataParallel(nn.Module):
                 else:
                     b.work.wait()
                 b.work = None
-                if backend != 'nccl':
-                    b.flat.div_(self.world_size)
         if self._is_cuda:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
+        k = 0
         for b in self._buckets:
             for i, p in enumerate(b.params):
-                p.grad = b.view(i)
+                if used_anywhere is not None:
+                    keep = used_anywhere[k]  # no rank produced a gradient: leave None, like torch DDP does
+                else:
+                    keep = b.ready[i]  # (without find_unused_parameters every rank uses the same parameters)
+                p.grad = b.view(i) if keep else None
+                k += 1
 
     # ---- the surface the Trainer uses ----
     def forward(self, *args, **kwargs):
+        if self._callback_queued and torch.is_grad_enabled():
+            self._reset()  # the previous backward never reached its end-of-backward callback
         return self.module(*args, **kwargs)
 
     @contextlib.contextmanager
@@ -181,3 +266,47 @@ class DistributedDataParallel(nn.Module):
 
     def load_state_dict(self, *args, **kwargs):
         return self.module.load_state_dict(*args, **kwargs)
+
+
+# ---- the training logs: one fused all-reduce instead of all_gather_object -------------------------------------------
+LOG_KEYS = ('loss', 'nll_loss', 'num_tokens', 'num_lines')
+_STATUS_LEVELS = (2, 3, 4)  # Status.FINISHED / INTERRUPTED / FAILED (pasero/training.py:36-40); RUNNING = 1
+
+
+def reduce_logs(logs: dict, keys: Sequence[str] = LOG_KEYS, group=None, device=None) -> dict:
+    """Drop-in for `utils.gather_dict(cfg, logs)` as `Trainer.train_step` / `valid_step` use it (pasero/utils.py:93-104;
+    pasero/training.py:429-446,538): the per-rank log values are SUMMED over the ranks and the job status takes the
+    WORST value (`Status.__iadd__`, training.py:46-53).  The reference pickles a dict on every rank and all-gathers the
+    pickles through the GPU (two collectives, a host sync and a pickle round trip per step); here the values travel as
+    ONE small fp64 tensor in ONE all-reduce(SUM): [the `keys`..., #ranks with status >= 2, >= 3, >= 4] — the maximum of
+    the statuses is rebuilt from the counts.  A rank with fewer keys (the dummy-batch path passes `{}`,
+    training.py:536-537) contributes zeros; keys outside `keys` are refused rather than dropped silently.
+    Integer entries stay integers (`num_tokens`, `num_lines`: exact below 2**53)."""
+    extra = [k for k in logs if k not in keys and k != 'status']
+    if extra:
+        raise KeyError(f'reduce_logs: keys {extra} are not in the fixed layout {tuple(keys)}; pass keys=...')
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return dict(logs)
+    status = logs.get('status')
+    level = int(getattr(status, 'value', status)) if status is not None else 1
+    vals = [float(logs.get(k, 0)) for k in keys] + [float(level >= s) for s in _STATUS_LEVELS]
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else 'cpu'
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    out_vals = t.tolist()  # the one device -> host copy of the step's logs
+    out = {}
+    for k, v in zip(keys, out_vals):
+        if k in logs:
+            is_int = isinstance(logs[k], int) and not isinstance(logs[k], bool)
+        else:
+            is_int = k.startswith('num_')
+        out[k] = int(round(v)) if is_int else v
+    if status is not None or any(out_vals[len(keys):]):
+        worst = 1 + sum(1 for c in out_vals[len(keys):] if c > 0)
+        if hasattr(status, 'value'):
+            status.value = max(int(status.value), worst)  # in place, like `Status.__iadd__`
+            out['status'] = status
+        else:
+            out['status'] = worst
+    return out

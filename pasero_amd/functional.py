@@ -420,3 +420,30 @@ def argmax_rows(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     check(L.pk_argmax_rows(ptr(x), rows, n, _ld(x), ptr(out), out.stride(0) if rows > 1 else 1, dtype_code(x),
                            stream_ptr()), 'pk_argmax_rows')
     return out
+
+
+def mt_copy_plan(numels, device):
+    """chunk list (device tensors) of a multi-tensor copy over tensors of `numels` elements (pk_mt_copy)"""
+    chunk = lib.load().pk_mt_chunk_size()
+    ct, cs = [], []
+    for i, n in enumerate(numels):
+        for start in range(0, n, chunk):
+            ct.append(i)
+            cs.append(start)
+    return (torch.tensor(ct, dtype=torch.int32, device=device), torch.tensor(cs, dtype=torch.int64, device=device),
+            list(numels))
+
+
+def mt_copy(srcs, dsts, plan) -> None:
+    """dsts[i] <- srcs[i] for every pair, in one launch (the gradient pack of a data-parallel bucket, ddp.py)"""
+    ct, cs, numels = plan
+    if not srcs:
+        return
+    require_gpu(*srcs, *dsts)
+    for s, d, n in zip(srcs, dsts, numels):
+        assert s.dtype == dsts[0].dtype and d.dtype == dsts[0].dtype and s.numel() == n and d.numel() == n
+        assert s.is_contiguous() and d.is_contiguous()
+    table = torch.tensor([s.data_ptr() for s in srcs] + [d.data_ptr() for d in dsts] + numels,
+                         dtype=torch.int64).to(dsts[0].device, non_blocking=True)
+    check(lib.load().pk_mt_copy(ptr(table), len(srcs), ptr(ct), ptr(cs), ct.numel(), dtype_code(dsts[0]),
+                                stream_ptr()), 'pk_mt_copy')

@@ -51,8 +51,9 @@ SIGNATURES = {
     'pk_gated_act_bwd': (I, [P, P, P, P, P, LL, I, I, P]),
     'pk_rope': (I, [P, P, LL, I, LL, I, I, P, P, I, I, I, I, I, P]),
     'pk_mt_chunk_size': (I, []),
-    'pk_mt_sqnorm': (I, [P, I, P, P, I, F, P, P, I, P]),
-    'pk_mt_adam': (I, [P, I, P, P, I, P, F, F, F, F, F, F, F, I, I, P]),
+    'pk_mt_sqnorm': (I, [P, I, P, P, I, F, P, P, I, P, I, P]),
+    'pk_mt_adam': (I, [P, I, P, P, I, P, F, F, F, F, F, F, F, I, P, I, P]),
+    'pk_mt_copy': (I, [P, I, P, P, I, I, P]),
     'pk_logmel_workspace': (SZ, [I]),
     'pk_logmel': (I, [P, P, LL, P, P, SZ, I, P]),
 }

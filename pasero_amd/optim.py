@@ -22,6 +22,8 @@ class Adam(torch.optim.Optimizer):
                  weight_decay: float = 0.01, optimizer_states_as_fp32: bool = True, **kwargs):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._plan = {}
+        self._partial = None
+        self._keepalive = None
 
     def _state(self, p):
         st = self.state[p]
@@ -61,53 +63,82 @@ class Adam(torch.optim.Optimizer):
                     cs.append(start)
             dev = params[0].device
             plan = (torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(cs, dtype=torch.int64, device=dev),
-                    torch.empty(max(len(ct), 1), dtype=torch.float32, device=dev),
-                    torch.tensor([p.numel() for p in params], dtype=torch.int64))
+                    [p.numel() for p in params])
             self._plan[key] = plan
         return plan
 
+    def _check(self, p, st):
+        if not p.is_cuda:
+            raise RuntimeError('pasero_amd.optim.Adam needs CUDA/HIP parameters (no CPU fallback)')
+        if not (p.is_contiguous() and p.grad.is_contiguous()):
+            raise RuntimeError('pasero_amd.optim.Adam needs contiguous parameters and gradients')
+        for k in ('exp_avg', 'exp_avg_sq'):  # the kernels index the moments as fp32 arrays of p.numel() elements
+            m = st[k]
+            if not (m.dtype == torch.float32 and m.numel() == p.numel() and m.device == p.device and m.is_contiguous()):
+                raise RuntimeError(f'pasero_amd.optim.Adam: state {k} must be a contiguous fp32 tensor of the '
+                                   f"parameter's size on its device (got {m.dtype}, {tuple(m.shape)}, {m.device})")
+
     @torch.no_grad()
     def fused_step(self, scale: float = 1.0, max_norm: float = 0.0) -> Optional[torch.Tensor]:
+        """One optimizer step over every parameter that has a gradient.  Like the reference: ONE gradient norm over all
+        of them (`clip_grad_norm_`, optimization.py:390-427) whatever their group or dtype, parameters without a
+        gradient are skipped and keep their own `state['step']` (optimization.py:72-76,120), and each parameter's bias
+        correction uses its own step count."""
+        import numpy as np
         L = lib.load()
-        gnorm_out = None
+        tables = []  # one per (param_group, dtype): the kernels are typed
         for gi, group in enumerate(self.param_groups):
             by_dtype = {}
             for p in group['params']:
                 if p.grad is not None:
                     by_dtype.setdefault(p.dtype, []).append(p)
             for dt, params in by_dtype.items():
-                for p in params:
-                    if not p.is_cuda:
-                        raise RuntimeError('pasero_amd.optim.Adam needs CUDA/HIP parameters (no CPU fallback)')
-                    if not (p.is_contiguous() and p.grad.is_contiguous()):
-                        raise RuntimeError('pasero_amd.optim.Adam needs contiguous parameters and gradients')
                 states = [self._state(p) for p in params]
-                for p, st in zip(params, states):  # the kernels index the moments as fp32 arrays of p.numel() elements
-                    for k in ('exp_avg', 'exp_avg_sq'):
-                        m = st[k]
-                        if not (m.dtype == torch.float32 and m.numel() == p.numel() and m.device == p.device
-                                and m.is_contiguous()):
-                            raise RuntimeError(f'pasero_amd.optim.Adam: state {k} must be a contiguous fp32 tensor of the '
-                                               f"parameter's size on its device (got {m.dtype}, {tuple(m.shape)}, {m.device})")
-                ct, cs, partial, numel = self._chunks((gi, dt, tuple(id(p) for p in params)), params)
-                table = torch.tensor([p.data_ptr() for p in params] + [p.grad.data_ptr() for p in params]
-                                     + [s['exp_avg'].data_ptr() for s in states]
-                                     + [s['exp_avg_sq'].data_ptr() for s in states] + numel.tolist(),
-                                     dtype=torch.int64).to(params[0].device, non_blocking=True)
-                n = len(params)
-                gnorm = torch.empty(1, dtype=torch.float32, device=params[0].device)
-                code = dtype_code(params[0])
-                check(L.pk_mt_sqnorm(ptr(table), n, ptr(ct), ptr(cs), ct.numel(), float(scale), ptr(partial),
-                                     ptr(gnorm), code, stream_ptr()), 'pk_mt_sqnorm')
-                for s in states:
-                    s['step'] += 1
-                b1, b2 = group['betas']
-                check(L.pk_mt_adam(ptr(table), n, ptr(ct), ptr(cs), ct.numel(), ptr(gnorm), float(scale),
-                                   float(max_norm), float(group['lr']), float(b1), float(b2), float(group['eps']),
-                                   float(group['weight_decay']), int(states[0]['step']), code, stream_ptr()),
-                      'pk_mt_adam')
-                gnorm_out = gnorm if gnorm_out is None else torch.sqrt(gnorm_out ** 2 + gnorm ** 2)
-        return gnorm_out
+                for p, st in zip(params, states):
+                    self._check(p, st)
+                tables.append((group, params, states, self._chunks((gi, dt, tuple(id(p) for p in params)), params)))
+        if not tables:
+            return None
+        dev = tables[0][1][0].device
+        n_all = sum(t[3][0].numel() for t in tables)
+        if self._partial is None or self._partial.numel() < n_all or self._partial.device != dev:
+            self._partial = torch.empty(max(n_all, 1), dtype=torch.float32, device=dev)
+        gnorm = torch.empty(1, dtype=torch.float32, device=dev)
+        # ONE host->device upload for all tables: per table [p | g | m | v | numel] int64 then [bc1 | bc2_sqrt] fp32
+        blobs, offs = [], []
+        off = 0
+        for group, params, states, (ct, cs, numel) in tables:
+            b1, b2 = group['betas']
+            for st in states:
+                st['step'] += 1
+            n = len(params)
+            ptrs = np.array([p.data_ptr() for p in params] + [p.grad.data_ptr() for p in params]
+                            + [st['exp_avg'].data_ptr() for st in states]
+                            + [st['exp_avg_sq'].data_ptr() for st in states] + numel, dtype=np.int64)
+            steps = np.array([st['step'] for st in states], dtype=np.float64)
+            bc = np.concatenate([1.0 - b1 ** steps, np.sqrt(1.0 - b2 ** steps)]).astype(np.float32)
+            blob = np.concatenate([ptrs.view(np.uint8), bc.view(np.uint8)])
+            blob = np.concatenate([blob, np.zeros((-blob.size) % 16, np.uint8)])
+            offs.append((off, off + 5 * n * 8))
+            off += blob.size
+            blobs.append(blob)
+        table = torch.from_numpy(np.concatenate(blobs)).to(dev, non_blocking=True)
+        base = table.data_ptr()
+        done = 0
+        for i, (group, params, states, (ct, cs, numel)) in enumerate(tables):
+            last = i == len(tables) - 1
+            check(L.pk_mt_sqnorm(base + offs[i][0], len(params), ptr(ct), ptr(cs), ct.numel(), float(scale),
+                                 self._partial.data_ptr() + 4 * done, ptr(self._partial), n_all,
+                                 ptr(gnorm) if last else None, dtype_code(params[0]), stream_ptr()), 'pk_mt_sqnorm')
+            done += ct.numel()
+        for i, (group, params, states, (ct, cs, numel)) in enumerate(tables):
+            b1, b2 = group['betas']
+            check(L.pk_mt_adam(base + offs[i][0], len(params), ptr(ct), ptr(cs), ct.numel(), ptr(gnorm), float(scale),
+                               float(max_norm), float(group['lr']), float(b1), float(b2), float(group['eps']),
+                               float(group['weight_decay']), 0, base + offs[i][1], dtype_code(params[0]),
+                               stream_ptr()), 'pk_mt_adam')
+        self._keepalive = table  # the launches read it asynchronously
+        return gnorm
 
     @torch.no_grad()
     def step(self, closure=None):

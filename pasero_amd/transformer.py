@@ -469,7 +469,7 @@ class _LayerBase(nn.Module):
         if not (self.training and self.activation_dropout.p > 0):
             return FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
                                self.activation_fn.name, link)
-        y = self.activation_dropout(self.activation_fn(self.fc1(x)))
+        y = self.activation_dropout(self.activation_fn(self.fc1(x, link=link)))
         return self.fc2(y)
 
     def _residual(self, x: Tensor, residual: Tensor) -> Tensor:

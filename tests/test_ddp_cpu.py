@@ -96,3 +96,161 @@ def test_ddp_gloo_world2():
     for r in range(world):
         bad = [k for k, v in ret[r].items() if not v]
         assert not bad, f'rank {r}: {bad}'
+
+
+# ---- rank-divergent parameter use (adapters), frozen parameters and buffers, an aborted backward, the logs -----------
+class AdapterNet(nn.Module):
+    """a shared trunk + one adapter per 'language': a rank only runs the adapter of its own batch
+    (pasero/models/adapters.py:232-301 — why AdapterTransformer asks for find_unused_parameters)"""
+
+    def __init__(self):
+        super().__init__()
+        self.trunk = nn.Linear(8, 8)
+        self.adapters = nn.ModuleDict({k: nn.Linear(8, 8) for k in ('de', 'fr', 'never')})
+        self.frozen = nn.Linear(8, 8)
+        self.frozen.requires_grad_(False)
+        self.register_buffer('table', torch.randn(5, 3))
+
+    def forward(self, x, lang):
+        return self.adapters[lang](torch.relu(self.frozen(self.trunk(x)))).pow(2).sum()
+
+
+def _worker_unused(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pasero_amd.ddp import DistributedDataParallel, reduce_logs
+    out = {}
+    torch.manual_seed(100 + rank)
+    net = AdapterNet()
+    ddp = DistributedDataParallel(net, bucket_cap_mb=0.0002, find_unused_parameters=True)
+    assert len(ddp._buckets) >= 4
+    # construction: rank 0's frozen parameters and buffers arrive too
+    for name, t in list(net.named_parameters()) + list(net.named_buffers()):
+        t0 = t.detach().clone()
+        dist.broadcast(t0, 0)
+        out[f'bcast:{name}'] = torch.equal(t0, t.detach())
+    torch.manual_seed(7)
+    full = torch.randn(4, 8)
+    mine = full[2 * rank: 2 * rank + 2]
+    lang = ('de', 'fr')[rank]
+    ref = AdapterNet()
+    ref.load_state_dict(net.state_dict())
+    (ref(full[:2], 'de') + ref(full[2:], 'fr')).backward()
+    ddp(mine, lang).backward()
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        if not p.requires_grad:
+            continue
+        if n.startswith('adapters.never'):
+            out[n] = p.grad is None  # unused on every rank: untouched, the optimizer skips it
+        else:
+            out[n] = p.grad is not None and torch.allclose(p.grad, q.grad / world, rtol=1e-5, atol=1e-6)
+    # a backward that dies half-way (the Trainer's OOM path) must not poison the next step
+    for p in net.parameters():
+        p.grad = None
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('out of memory (simulated)')
+
+    try:
+        h = net.adapters[lang](Boom.apply(torch.relu(net.frozen(net.trunk(mine)))))
+        h.pow(2).sum().backward()
+        out['boom_raised'] = False
+    except RuntimeError:
+        out['boom_raised'] = True
+    for p in net.parameters():
+        p.grad = None
+    ddp(mine, lang).backward()
+    out['after_abort'] = torch.allclose(net.trunk.weight.grad, ref.trunk.weight.grad / world, rtol=1e-5, atol=1e-6)
+
+    # the training logs: one all-reduce in place of utils.gather_dict
+    class Status:
+        def __init__(self, value):
+            self.value = value
+
+    st = Status(1 if rank == 0 else 3)
+    logs = reduce_logs({'loss': 1.5 + rank, 'nll_loss': 1.0 + rank, 'num_tokens': 100 + rank, 'num_lines': 4,
+                        'status': st})
+    out['logs'] = (abs(logs['loss'] - 4.0) < 1e-12 and abs(logs['nll_loss'] - 3.0) < 1e-12
+                   and logs['num_tokens'] == 201 and isinstance(logs['num_tokens'], int) and logs['num_lines'] == 8
+                   and logs['status'] is st and st.value == 3)
+    # a rank without a batch passes {} (training.py:536-537)
+    logs2 = reduce_logs({} if rank == 1 else {'loss': 2.0, 'nll_loss': 1.0, 'num_tokens': 7, 'num_lines': 1})
+    out['logs_ragged'] = logs2['num_tokens'] == 7 and abs(logs2['loss'] - 2.0) < 1e-12 and 'status' not in logs2
+    try:
+        reduce_logs({'loss': 1.0, 'moe_aux': 2.0})
+        out['logs_refuse'] = False
+    except KeyError:
+        out['logs_refuse'] = True
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _worker_order(rank, world, port, ret):
+    """gradients arrive in a different order on each rank: the collectives must still be issued in bucket order"""
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pasero_amd.ddp import DistributedDataParallel
+
+    class Two(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(6, 6)
+            self.b = nn.Linear(6, 6)
+
+        def forward(self, x, first):
+            # two independent branches: which gradient is ready first depends on the graph order, i.e. on the rank
+            ya, yb = self.a(x).pow(2).sum(), self.b(x).pow(3).sum()
+            return (ya + yb) if first else (yb + ya)
+
+    torch.manual_seed(3)
+    net = Two()
+    ddp = DistributedDataParallel(net, bucket_cap_mb=0.0001)
+    order = []
+    orig = ddp._all_reduce_avg
+    ddp._all_reduce_avg = lambda b: (order.append(ddp._buckets.index(b)), orig(b))[1]
+    x = torch.randn(3, 6, generator=torch.Generator().manual_seed(rank))
+    ddp(x, rank == 0).backward()
+    ref = Two()
+    ref.load_state_dict(net.state_dict())
+    xs = [torch.randn(3, 6, generator=torch.Generator().manual_seed(r)) for r in range(world)]
+    sum(ref(xx, True) for xx in xs).backward()
+    ret[rank] = {'in_order': order == sorted(order) and len(order) == len(ddp._buckets),
+                 'grads': all(torch.allclose(p.grad, q.grad / world, rtol=1e-5, atol=1e-6)
+                              for p, q in zip(net.parameters(), ref.parameters()))}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(worker, world=2, timeout=120):
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+        assert p.exitcode == 0, f'worker exited with {p.exitcode}'
+    for r in range(world):
+        bad = [k for k, v in ret[r].items() if not v]
+        assert not bad, f'rank {r}: {bad}'
+
+
+def test_ddp_rank_divergent_adapters_frozen_state_abort_and_logs():
+    _run(_worker_unused)
+
+
+def test_ddp_collectives_are_issued_in_bucket_order():
+    _run(_worker_order)

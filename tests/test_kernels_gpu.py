@@ -599,6 +599,45 @@ def test_fused_adam_bf16_scale_and_state_layout():
     assert st['exp_avg'].dtype == torch.float32 and rel_err(st['exp_avg'], m) < 1e-6 and rel_err(st['exp_avg_sq'], v) < 1e-6
 
 
+def test_fused_adam_one_global_norm_and_per_parameter_steps():
+    """two parameter groups, fp32 and bf16 parameters, one parameter without a gradient at the second step: the clip
+    coefficient comes from ONE norm over every gradient (optimization.py:404-424), a parameter that skipped a step keeps
+    its own `state['step']` and bias correction (optimization.py:72-76,120-127), its moments untouched"""
+    from pasero_amd.optim import Adam
+    shapes = [(64, 40), (300,), (128, 96), (1000,)]
+    dts = [torch.float32, torch.bfloat16, torch.bfloat16, torch.float32]
+    p0 = [rnd(s, 200 + i, torch.float32).to(dt) for i, (s, dt) in enumerate(zip(shapes, dts))]
+    params = [torch.nn.Parameter(p.clone().cuda()) for p in p0]
+    opt = Adam([{'params': params[:2], 'lr': 1e-2}, {'params': params[2:], 'lr': 5e-3, 'weight_decay': 0.0}],
+               betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    ref_p = [p.float() for p in p0]
+    ref_m = [torch.zeros_like(p) for p in ref_p]
+    ref_v = [torch.zeros_like(p) for p in ref_p]
+    ref_step = [0] * 4
+    lr, wd = [1e-2, 1e-2, 5e-3, 5e-3], [0.01, 0.01, 0.0, 0.0]
+    for s in range(3):
+        active = [0, 1, 2, 3] if s != 1 else [0, 2, 3]  # parameter 1 gets no gradient at step 1
+        grads = {i: rnd(shapes[i], 300 + 10 * s + i, torch.float32).to(dts[i]) * 3.0 for i in active}
+        for i, p in enumerate(params):
+            p.grad = grads[i].cuda() if i in grads else None
+        gnorm = opt.fused_step(scale=0.5, max_norm=1.0)
+        total = torch.sqrt(sum((grads[i].double() * 0.5).pow(2).sum() for i in active))
+        assert abs(gnorm.item() - total.item()) <= 1e-5 * total.item()
+        coef = 0.5 * min(1.0, 1.0 / (total.item() + 1e-6))
+        for i in active:
+            ref_step[i] += 1
+            ref_p[i], ref_m[i], ref_v[i] = O.adam_step(ref_p[i], grads[i].float() * coef, ref_m[i], ref_v[i],
+                                                       ref_step[i], lr[i], 0.9, 0.98, 1e-8, wd[i])
+            ref_p[i] = ref_p[i].to(dts[i]).float()
+        for i, p in enumerate(params):
+            st = opt.state[p]
+            assert st.get('step', 0) == ref_step[i], (s, i)
+            tol = 1e-5 if dts[i] == torch.float32 else 1e-2
+            assert rel_err(p.detach().float(), ref_p[i]) < tol, (s, i)
+            if ref_step[i]:
+                assert rel_err(st['exp_avg'], ref_m[i]) < 2e-5 and rel_err(st['exp_avg_sq'], ref_v[i]) < 2e-5, (s, i)
+
+
 def test_mixed_dtypes_and_wrong_sizes_are_refused_on_the_host(F):
     """the kernels trust the element type and sizes they are told: an fp32 LayerNorm weight next to bf16 activations,
     int32 token ids or 16-bit optimizer moments would be read with the wrong stride or past their end — refused before

@@ -625,6 +625,39 @@ def test_sequence_longer_than_the_positional_table_is_rejected_like_the_referenc
         model(**batch)
 
 
+def test_activation_dropout_keeps_the_residual_branch_gradient(monkeypatch):
+    """activation_dropout > 0 in a post-norm model (transformer.py:1005-1008): the FFN runs module by module, and the
+    gradient of the residual branch, which the fused block end parks on a ResidualLink, must still reach the layer
+    input.  Same seeds -> same masks, so the step with the links switched off (plain autograd accumulation) is the
+    exact reference; fp32, every gradient."""
+    from pasero_amd import rng
+    from pasero_amd.transformer import _LayerBase
+    g = load_golden('tiny_encdec_post')
+    cfg, model = build_model(g, torch.float32, 'cuda')
+    for layer in list(model.encoder.layers) + list(model.decoder.layers):
+        layer.activation_dropout.p = 0.25
+    model.train()
+    batch = text_batch(g, 'cuda')
+
+    def step():
+        rng.manual_seed(11)
+        model.zero_grad(set_to_none=True)
+        loss, _ = model(**batch)
+        loss.backward()
+        return loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    loss_a, grads_a = step()
+    monkeypatch.setattr(_LayerBase, '_linked', lambda self, *a, **k: None)
+    loss_b, grads_b = step()
+    assert loss_a == loss_b and grads_a.keys() == grads_b.keys()
+    for k in grads_a:
+        assert rel(grads_a[k], grads_b[k]) < 2e-5, k
+    # and the dropped activations do change the step
+    for layer in list(model.encoder.layers) + list(model.decoder.layers):
+        layer.activation_dropout.p = 0.0
+    assert step()[0] != loss_a
+
+
 def test_attention_dropout_training_step():
     """attention_dropout 0.1 (the IWSLT2023 recipes): the step runs through the dropout instantiations of the attention
     kernels, is reproducible from the seed, differs from the dropout-free step and from another seed, and in eval mode
