@@ -608,6 +608,44 @@ def gen_logmel():
          transformers_version=np.array(transformers.__version__))
 
 
+
+def gen_features_file():
+    """the speech feature file format and its collate.  The REAL `NumpyFile.build` writes a file of
+    ragged fp16 rows (pasero/files.py:122-159, as examples/Whisper/extract-features.py:164 uses it), the real
+    `NumpyFile.__next__` / `seek` read it back (files.py:164-192), the real `utils.tokens_as_tensor` collates batches
+    of its rows (utils.py:709-736).  Stored: the file's bytes (data the reference wrote), every row as the reference
+    reads it, and the collated batches in fp32 / bf16 (bf16 as its 16-bit pattern)."""
+    import tempfile
+    from pasero.files import NumpyFile
+    from pasero import utils
+    rs = np.random.RandomState(31)
+    lens = [37, 1, 12, 0, 25, 40, 3]  # a zero-length clip sits in the middle (same file position as its successor)
+    D = 16
+    feats = [(rs.standard_normal((n, D)) * 2.5).astype(np.float32) for n in lens]
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'feats.bin')
+        # num_feats larger than the number of arrays: trailing empty positions, skipped at load (files.py:113-116)
+        f = NumpyFile.build(path, feats, dtype='float16', num_feats=len(feats) + 2)
+        out['file_bytes'] = np.frombuffer(open(path, 'rb').read(), dtype=np.uint8)
+        idx, lengths = f.get_positions()
+        out['indices'], out['lengths'] = idx, lengths
+        rows = [next(f) for _ in range(len(idx))]
+        for i, r in enumerate(rows):
+            out[f'row{i}'] = r
+        f.seek(4)
+        out['seek4_tell'] = np.array(f.tell())
+        out['seek4_row'] = next(f)
+        f.close()
+        batches = [[0, 2, 4], [5, 1], [6, 3, 0, 5]]
+        out['batches'] = np.array([','.join(map(str, b)) for b in batches])
+        for bi, b in enumerate(batches):
+            for name, dt in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+                tokens, ln = utils.tokens_as_tensor([rows[i] for i in b], padding_idx=1, dtype=dt)
+                out[f'batch{bi}_{name}'] = (tokens.view(torch.int16).numpy() if dt == torch.bfloat16 else tokens.numpy())
+                out[f'batch{bi}_len'] = ln.numpy()
+    save('features_file', **out)
+
 GENERATORS = {
     'tiny_encdec_post': gen_tiny_post,
     'tiny_encdec_pre': gen_tiny_pre,
@@ -631,6 +669,7 @@ GENERATORS = {
     'return_layers': gen_return_layers,
     'adam_step': gen_optim,
     'logmel': gen_logmel,
+    'features_file': gen_features_file,
 }
 
 if __name__ == '__main__':

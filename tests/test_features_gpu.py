@@ -30,6 +30,31 @@ def test_collate_features_matches_reference(src, dtype, lens, D):
     assert torch.equal(got.cpu(), want) and torch.equal(got_len, want_len)
 
 
+@pytest.mark.parametrize('in_memory', [True, False])
+def test_collate_from_feature_file_matches_the_reference(in_memory, tmp_path):
+    """file written by the real NumpyFile.build -> rows -> the real utils.tokens_as_tensor (golden: features_file):
+    bit-exact in fp32 and bf16, lengths included, for three batches (one of them re-reads rows and holds an empty clip)"""
+    from conftest import load_golden
+    from pasero_amd.features import NumpyFile, collate_from_file
+    g = load_golden('features_file')
+    data = g['file_bytes'].tobytes()
+    if in_memory:
+        f = NumpyFile(data)
+    else:
+        (tmp_path / 'f.bin').write_bytes(data)
+        f = NumpyFile(str(tmp_path / 'f.bin'))
+    for bi, spec in enumerate(g['batches']):
+        b = [int(x) for x in str(spec).split(',')]
+        for name, dt in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+            got, lens = collate_from_file(f, b, dt, 'cuda')
+            want = torch.from_numpy(g[f'batch{bi}_{name}'])
+            if dt == torch.bfloat16:
+                want = want.view(torch.bfloat16)
+            assert got.dtype == dt and got.shape == want.shape, (bi, name)
+            assert torch.equal(got.cpu(), want), (bi, name)
+            assert lens.dtype == torch.int64 and torch.equal(lens, torch.from_numpy(g[f'batch{bi}_len']))
+
+
 def test_wav_to_log_mel_matches_oracle():
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
