@@ -1,0 +1,152 @@
+"""BASELINE.json configs C3, C4 and C5 at THEIR OWN size (reference presets pasero/config.py:
+2182-2240,2543-2550), one bf16 forward + backward of the real preset each:
+  C3  `transformer_big` 6+6, d=1024, f=4096, 16 heads, V=70 376, batch (256, 128, 128)
+  C4  `whisper_base` 6+6: 16 clips of 30 s -> log-mel on the device (K8) -> conv subsampler (K7) -> enc-dec, T=64
+  C5  `nllb_1b3` 24+24, d=1024, f=8192, pre-norm, V=256 206, batch (64, 128, 128)
+The CPU oracle would need many minutes per step at these sizes, so the checks are the size-independent properties of
+tests/test_fullsize_gpu.py (the loss is a sum over target tokens: a batch equals the sum of its halves, and so do its
+gradients; finite everywhere; `num_tokens` = non-pad targets), plus ONE full-width layer pair (d=1024, f=8192, 16 heads —
+the C5 layer) in fp32 against the oracle itself: loss within 1e-4 relative, every gradient."""
+import numpy as np
+import pytest
+import torch
+
+import paramgen
+from model_utils import rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    yield
+    torch.cuda.empty_cache()
+
+
+def _build(cfg_name, vocab, seed=3, **overrides):
+    """the preset with random-init weights drawn on the device (N(0, 0.02), LayerNorm weights 1): a CPU init of 1.4 G
+    parameters would take longer than the test"""
+    from pasero_amd import config as C, modules
+    from pasero_amd.transformer import Transformer
+    cfg = getattr(C, cfg_name)(dropout=0.0, **overrides)
+    with modules.fast_init(torch.device('cuda'), torch.bfloat16):
+        model = Transformer(cfg, C.DistributedConfig(), C.SyntheticTask(vocab))
+    model = model.to(torch.bfloat16).cuda()
+    gen = torch.Generator(device='cuda').manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and ('norm' in n and n.endswith('weight')):
+                p.fill_(1.0)
+            elif p.dim() == 1:
+                p.zero_()
+            else:
+                p.copy_(torch.randn(p.shape, generator=gen, device='cuda', dtype=torch.float32) * 0.02)
+    return cfg, model.train()
+
+
+def _halves_property(model, batch, watch, B, loss_tol=2e-5, grad_tol=3e-2):
+    def step(rows):
+        model.zero_grad(set_to_none=True)
+        loss, logs = model(**{k: v[rows].contiguous() for k, v in batch.items()})
+        loss.backward()
+        params = dict(model.named_parameters())
+        for n, p in params.items():
+            assert p.grad is None or torch.isfinite(p.grad).all(), n
+        assert all(params[n].grad is not None for n in watch)
+        return loss.item(), logs, {n: params[n].grad.float().clone() for n in watch}
+
+    full, logs, g = step(slice(None))
+    assert np.isfinite(full) and full > 0
+    h1, l1, g1 = step(slice(0, B // 2))
+    h2, l2, g2 = step(slice(B // 2, B))
+    assert logs['num_tokens'] == l1['num_tokens'] + l2['num_tokens']
+    assert abs(full - (h1 + h2)) <= loss_tol * abs(full)
+    for n in watch:  # bf16 gradients, summed in a different order and rounded per half
+        assert (g[n] - (g1[n] + g2[n])).abs().max().item() <= grad_tol * g[n].abs().max().item(), n
+    return full, logs
+
+
+def test_c3_transformer_big_full_size():
+    V, B, S, T = 70376, 256, 128, 128
+    cfg, model = _build('TransformerBigConfig', V)
+    assert (cfg.encoder_layers, cfg.decoder_layers, cfg.embed_dim, cfg.encoder_ffn_dim) == (6, 6, 1024, 4096)
+    assert model.encoder.embed_tokens.weight.shape == (V, 1024)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(9, B, S, T, V).items()}
+    full, logs = _halves_property(model, batch, ['encoder.embed_tokens.weight', 'decoder.layers.5.fc1.weight',
+                                                 'encoder.layers.0.self_attn.q_proj.weight',
+                                                 'decoder.layers.2.encoder_attn_layer_norm.weight'], B)
+    # a random-init model predicts ~uniformly: nll per token ~ ln V (in bits in the logs, transformer.py:375-376)
+    assert abs(logs['nll_loss'] / logs['num_tokens'] - np.log2(V)) < 0.15 * np.log2(V)
+
+
+def test_c5_nllb_1b3_full_size():
+    V, B, S, T = 256206, 64, 128, 128
+    cfg, model = _build('NLLB1B3Config', V)
+    assert (cfg.encoder_layers, cfg.decoder_layers, cfg.embed_dim, cfg.decoder_ffn_dim) == (24, 24, 1024, 8192)
+    assert cfg.encoder_prenorm and cfg.decoder_prenorm
+    nparams = sum(p.numel() for p in model.parameters())
+    assert abs(nparams - 1.37e9) < 0.02e9, nparams  # 1.37 G parameters
+    batch = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(10, B, S, T, V).items()}
+    full, logs = _halves_property(model, batch, ['encoder.embed_tokens.weight', 'decoder.layers.23.fc2.weight',
+                                                 'encoder.layers.11.self_attn.v_proj.weight',
+                                                 'decoder.layers.0.final_layer_norm.weight'], B)
+    assert abs(logs['nll_loss'] / logs['num_tokens'] - np.log2(V)) < 0.15 * np.log2(V)
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_c4_whisper_base_full_size():
+    """16 clips x 30 s of N(0, 0.1^2) noise -> pk_logmel -> (16, 3000, 80) -> conv k3 s1 + conv k3 s2 -> 1500 positions
+    -> 6+6 pre-norm GELU enc-dec (config.py:2543-2550), T = 64"""
+    from pasero_amd import functional as PF
+    from oracle import ref_cpu as O
+    V, B, T = 51865, 16, 64
+    cfg, model = _build('WhisperConfig', V)
+    assert (cfg.encoder_layers, cfg.decoder_layers, cfg.activation_fn, cfg.encoder_max_len) == (6, 6, 'gelu', 3000)
+    wav = 0.1 * torch.randn(B, 480000, generator=torch.Generator().manual_seed(0))
+    feats = PF.log_mel(wav.cuda())
+    assert feats.shape == (B, 3000, 80) and torch.isfinite(feats).all()
+    # the full-length clip against the oracle's restatement of the feature extractor (K8 tolerance of the kernel tests)
+    assert np.abs(feats[3].cpu().numpy() - O.log_mel(wav[3].numpy())).max() < 5e-4
+    tb = paramgen.make_text_batch(11, B, 4, T, V)
+    batch = {'encoder_input': feats.to(torch.bfloat16),
+             'encoder_input_length': torch.full((B,), 3000, dtype=torch.int64, device='cuda'),
+             'decoder_input': torch.from_numpy(tb['decoder_input']).cuda(),
+             'prompt_mask': torch.from_numpy(tb['prompt_mask']).cuda()}
+    with torch.no_grad():
+        enc_out, enc_mask, _ = model.encoder(batch['encoder_input'], batch['encoder_input_length'])
+    assert enc_out.shape == (B, 1500, 512) and not enc_mask.any()
+    _halves_property(model, batch, ['encoder.layers.0.fc1.weight', 'encoder.subsample.conv_layers.0.weight',
+                                    'decoder.layers.5.encoder_attn.k_proj.weight', 'decoder.embed_tokens.weight'], B)
+
+
+def test_full_width_layer_pair_fp32_against_the_oracle():
+    """one encoder + one decoder layer at the C5 widths (d=1024, f=8192, 16 heads of 64, pre-norm, S = T = 128) in fp32
+    against the CPU oracle on the same weights and batch: loss 1e-4 relative (north_star), every gradient"""
+    from oracle import ref_cpu as O
+    from pasero_amd import config as C
+    from pasero_amd.transformer import Transformer
+    from model_utils import load_paramgen
+    V, B, S, T = 1000, 4, 128, 128
+    cfg = C.NLLB1B3Config(encoder_layers=1, decoder_layers=1, dropout=0.0)
+    model = Transformer(cfg, C.DistributedConfig(), C.SyntheticTask(V))
+    load_paramgen(model, 41)
+    names_shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    P = O.to_torch_state(paramgen.make_state_dict(41, names_shapes))
+    if cfg.shared_embeddings:
+        P['decoder.embed_tokens.weight'] = P['encoder.embed_tokens.weight']
+    for v in P.values():
+        v.requires_grad_()
+    b = paramgen.make_text_batch(42, B, S, T, V)
+    tb = {k: torch.from_numpy(v) for k, v in b.items()}
+    ref_loss, ref_logs = O.transformer_forward(P, cfg, **tb)
+    ref_loss.backward()
+    model = model.float().cuda().train()
+    loss, logs = model(**{k: v.cuda() for k, v in tb.items()})
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * abs(ref_loss.item())
+    assert logs['num_tokens'] == ref_logs['num_tokens']
+    for n, p in model.named_parameters():
+        assert rel(p.grad, P[n].grad) < 3e-4 or P[n].grad.abs().max() < 1e-5, n
