@@ -115,6 +115,8 @@ class GemmTimer:
     def kernel_name(kernel, a_col, b_col, dtype):
         tf = {0: 'false', 1: 'true'}
         t = {0: 'float', 1: '__hip_bfloat16', 2: '_Float16'}[dtype]
+        if kernel == 8:
+            return 'gemm8p_kernel<%s, %s, %s>' % (t, tf[a_col], tf[b_col])
         if kernel == 256:
             return 'gemm256_kernel<%s, %s, %s, 8>' % (t, tf[a_col], tf[b_col])
         return 'gemm_kernel<%s, %s, %s>' % (t, tf[a_col], tf[b_col])

@@ -58,6 +58,9 @@ int pk_gemm(const void* A, const void* B, void* C, const void* bias, const void*
  * sample i and returns the kernel that ran (128 = gemm_kernel 128x128 tiles, 256 = gemm256_kernel), its operand
  * layouts, split-K factor, dtype, 2*M*N*K and the elapsed milliseconds. */
 int pk_gemm_timing_start(int max_samples, int stride);
+/* diagnostic: 1 / 0 routes the 256-tile GEMMs to the phase-interleaved kernel (gemm8p.hip, default) / to gemm256.hip;
+ * a negative argument only queries.  Returns the previous setting (env PK_GEMM_8P sets the initial one). */
+int pk_gemm_use_8p(int on);
 int pk_gemm_timing_stop(void);
 int pk_gemm_timing_read(int i, int* kernel, int* a_col, int* b_col, int* splitk, int* dtype, double* flops, float* ms);
 

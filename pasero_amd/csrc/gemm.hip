@@ -33,6 +33,11 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 extern "C" int pk_gemm256_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
                                  long long M, long long N, long long K, long long lda, long long ldb, int a_col,
                                  int b_col, int kchunk, int splitk, EpiParams ep, int dtype, void* stream);
+extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
+                                long long M, long long N, long long K, long long lda, long long ldb, int a_col,
+                                int b_col, int kchunk, int splitk, EpiParams ep, int dtype, void* stream);
+extern "C" int pk_gemm8p_eligible(long long M, long long N, long long K, long long lda, long long ldb, int a_col,
+                                  int b_col, int want_asum);
 extern "C" int pk_gemm_skinny_launch(const void* A, const void* B, void* C, long long M, long long N, long long K,
                                      long long lda, long long ldb, EpiParams ep, int dtype, void* stream);
 
@@ -697,6 +702,9 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict
     }
 }
 
+// PK_GEMM_8P=0 / pk_gemm_use_8p(0): keep the 256-tile GEMMs on gemm256.hip (A/B of the two K loops inside one process)
+int g_use_8p = [] { const char* e = getenv("PK_GEMM_8P"); return (!e || atoi(e) != 0) ? 1 : 0; }();
+
 // ---- optional launch timing (bench.py's roofline leg): HIP events around exactly the main GEMM kernel, on its stream ----
 struct GemmSample {
     hipEvent_t start, stop;
@@ -782,9 +790,12 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
             if (sk > 0 && (tile_pref == 256 || fills)) {
                 float* w2 = sk > 1 ? (float*)workspace : nullptr;
                 float* asw = (sk > 1 && asum_out) ? w2 + (size_t)sk * M * N : nullptr;
-                GemmSample* sm = timing_begin(256, a_col, b_col, std::max(sk, 1), dtype16, M, N, K, stream);
-                int rc = pk_gemm256_launch(A, B, C, w2, asw, asum_out, M, N, K, lda, ldb, a_col, b_col, (int)per,
-                                           std::max(sk, 1), ep, dtype16, stream);
+                // the phase-interleaved kernel (gemm8p.hip) takes what it can; gemm256.hip the rest (fused bias gradient,
+                // operands beyond 4 GiB).  PK_GEMM_8P=0 switches it off (A/B inside one process: tools/gemm_bench.py)
+                const bool e8 = g_use_8p && pk_gemm8p_eligible(M, N, K, lda, ldb, a_col, b_col, asum_out != nullptr);
+                GemmSample* sm = timing_begin(e8 ? 8 : 256, a_col, b_col, std::max(sk, 1), dtype16, M, N, K, stream);
+                int rc = (e8 ? pk_gemm8p_launch : pk_gemm256_launch)(A, B, C, w2, asw, asum_out, M, N, K, lda, ldb, a_col,
+                                                                    b_col, (int)per, std::max(sk, 1), ep, dtype16, stream);
                 timing_end(sm, stream);
                 if (rc != 1) return rc;
                 if (w2) {
@@ -863,6 +874,12 @@ extern "C" int pk_gemm(const void* A, const void* B, void* C, const void* bias, 
     if (dtype == PK_F16)
         return launch_gemm<f16>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
     return launch_gemm<float>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
+}
+
+extern "C" int pk_gemm_use_8p(int on) {
+    const int old = g_use_8p;
+    if (on >= 0) g_use_8p = on ? 1 : 0;
+    return old;
 }
 
 // ---- launch timing API (see include/pasero_hip.h) ----

@@ -1,0 +1,426 @@
+// 256x256-tile bf16 / fp16 MFMA GEMM with a phase-interleaved ("ping-pong") K loop — the main GEMM of the training step.
+// Same contract as gemm256.hip (C[m,n] = epi(alpha * sum_k A(m,k) B(n,k)), operands in row (k-contiguous) or col
+// (m/n-contiguous) form, fused bias / activation / residual / act' epilogues, split-K slabs, fused bias gradient); what
+// changes is how the K loop keeps the matrix cores fed.
+//
+// gemm256.hip runs all eight waves through "one barrier per K-tile": between two barriers every wave reads its
+// fragments, issues the next tile's LDS-DMA and runs its 32 MFMAs, so the two waves of a SIMD contend for the same
+// phases and every wave waits out the DMA's vmcnt(0).  Here (MI355X guide, "256^2 8-phase template"):
+//   * 8 waves = 2 (M) x 4 (N); wave (wr, wc) owns rows {128h + 64wr + [0,64)} and cols {128h + 32wc + [0,32)}, h = 0, 1
+//     of the tile: four 64x32 QUADRANTS (mh, nh), 128 fp32 accumulators per lane, v_mfma_f32_16x16x32 (the shape that
+//     holds the higher clock under load);
+//   * a K-tile (BK = 64) is FOUR half-tile images in LDS — A0, A1 (rows 0..127 / 128..255) and B0, B1, 16 KiB each,
+//     two stages (even / odd K-tiles) = 128 KiB — and FOUR phases, one quadrant each: 16 MFMAs per wave per phase.
+//     A phase = [load section: this phase's fragment reads + ONE half-tile of LDS-DMA for a later K-tile] s_barrier
+//     [MFMA section] s_barrier.  Waves 4..7 run ONE barrier behind waves 0..3, so on every SIMD one wave is in its
+//     MFMA section while its partner is in its load section: LDS reads, DMA issue and address arithmetic hide behind
+//     the partner's MFMAs instead of competing with the wave's own;
+//   * the DMA runs 5-6 phases (1.25-1.5 K-tiles) ahead and is retired by COUNTED waits — `s_waitcnt vmcnt(6)`: all but
+//     the three youngest half-tiles have landed — never vmcnt(0) inside the loop; raw s_barrier only.
+// Schedule of one iteration (two K-tiles t, t+1 in stages E, O); quadrant order (A0,B0) (A0,B1) (A1,B1) (A1,B0):
+//   phase   fragment reads         MFMA quadrant   DMA issued (after the wait)   last read of the slot it overwrites
+//   1       A0(E) B0(E)  [12]      (0,0)           B1(O) <- tile t+1             phase 6 of the previous iteration
+//   2       B1(E)        [4]       (0,1)           A1(O) <- t+1                  phase 7 of the previous iteration
+//   3       A1(E)        [8]       (1,1)           A0(E) <- t+2                  phase 1
+//   4       (B0 kept)    [0]       (1,0)           B0(E) <- t+2                  phase 1
+//   5       A0(O) B0(O)  [12]      (0,0)           B1(E) <- t+2                  phase 2
+//   6       B1(O)        [4]       (0,1)           A1(E) <- t+2                  phase 3
+//   7       A1(O)        [8]       (1,1)           A0(O) <- t+3                  phase 5
+//   8       (B0 kept)    [0]       (1,0)           B0(O) <- t+3                  phase 5
+// Hazards.  RAW: a half-tile is read one phase (or more) after the wait that retires it — the wait sits in front of a
+// barrier every wave passes before any wave's read.  WAR: a slot is overwritten >= 2 phases after its last read (the
+// staggered half issues its reads one barrier late; their lgkmcnt(0) follows the next barrier).
+// Tails: past the last K-tile the same DMA instructions are issued against an EMPTY descriptor (every lane out of
+// range, nothing fetched) into slots that are already dead, so one loop body with one wait count serves every K; an
+// odd number of K-tiles leaves the loop after phase 4.
+// Operand staging: `buffer_load_dwordx4 ... lds` (one SRD per operand, per-lane 32-bit offsets, the K offset in an
+// SGPR); rows / columns past the edge of the matrix re-read a valid one.  The LDS image is lane-linear, so the bank
+// swizzle sits on the per-lane SOURCE offset and is undone on the read (row images: ds_read_b128, chunk ^ (row>>1)&7;
+// col images: ds_read_b64_tr_b16, chunk ^ 2*((k&3) | ((k>>3)&1)<<2)).
+#include <algorithm>
+#include <type_traits>
+#include "common.h"
+#include "gemm_epi.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF = 16384, STAGE = 4 * HALF, SMEM = 2 * STAGE;  // slots of a stage: A0 A1 B0 B1
+constexpr int SLOT_A0 = 0, SLOT_A1 = 1, SLOT_B0 = 2, SLOT_B1 = 3;
+constexpr int CP = BN + 4;  // floats, epilogue staging pitch
+
+template <typename T> struct M16;
+template <> struct M16<bf16> {
+    typedef __attribute__((ext_vector_type(8))) __bf16 vec;
+    static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct M16<f16> {
+    typedef __attribute__((ext_vector_type(8))) _Float16 vec;
+    static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// one half-tile image: row form [128 rows][64 k] (128-B rows), col form [64 k][128 m] (256-B rows)
+template <bool COL> struct HT {
+    static constexpr int ROWB = COL ? 256 : 128;
+    __device__ static __forceinline__ int swz(int row) {
+        return COL ? (((row & 3) | (((row >> 3) & 1) << 2)) << 1) : ((row >> 1) & 7);
+    }
+    __device__ static __forceinline__ int offset(int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); }
+};
+
+// per-lane byte offset (into the operand's buffer, K offset excluded) of the 16 bytes this lane's DMA piece `piece`
+// (0..15, 1 KiB each) of half-tile `h` brings in; `ld` in elements
+// Past the edge of the matrix (`lim` rows of a row-form operand, `lim` columns of a col-form one) a VALID row / column
+// is re-read instead: it feeds only outputs that are never stored, and no access leaves the buffer whatever the
+// descriptor's range check covers.
+template <bool COL>
+__device__ __forceinline__ unsigned src_offset(int piece, int lane, long long ld, long long r0, long long lim) {
+    if constexpr (!COL) {  // 8 rows x 128 B per piece
+        const int row = piece * 8 + (lane >> 3), chunk = (lane & 7) ^ HT<false>::swz(row);
+        const long long gr = min(r0 + row, lim - 1);
+        return (unsigned)((gr * ld + chunk * 8) * 2);
+    } else {  // 4 k-rows x 256 B per piece
+        const int krow = piece * 4 + (lane >> 4), chunk = (lane & 15) ^ HT<true>::swz(krow);
+        long long gc = r0 + chunk * 8;
+        if (gc + 8 > lim) gc = 0;
+        return (unsigned)((krow * ld + gc) * 2);
+    }
+}
+
+// fragment of the 16 rows (tile) starting at local row / column `r0` of a half-tile image, k-step kk (32 deep):
+// lane l holds X[r0 + (l & 15)][32 kk + 8 (l >> 4) + j], j = 0..7 — the A and B operand layout of v_mfma_16x16x32
+template <typename T, bool COL>
+__device__ __forceinline__ typename M16<T>::vec frag(const char* img, int r0, int kk, int lane) {
+    static_assert(HT<true>::ROWB * 4 == 1024, "offset of the k + 4 rows in the asm below");
+    typedef typename M16<T>::vec V;
+    if constexpr (!COL) {
+        const int row = r0 + (lane & 15);
+        return *reinterpret_cast<const V*>(img + HT<false>::offset(row, kk * 4 + (lane >> 4)));
+    } else {
+        const int q = (lane & 15) >> 2, p = lane & 3;
+        const int krow = kk * 32 + 8 * (lane >> 4) + q, col = r0 + 4 * p;
+        const char* a = img + HT<true>::offset(krow, col >> 3) + (col & 7) * 2;
+        // inline asm, not the builtin: behind an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in front of the
+        // builtin's transposed reads (it cannot tell which LDS bytes they touch), which would drain the prefetch every
+        // phase.  The compiler does not wait for asm loads either: the phase's own `s_waitcnt lgkmcnt(0)` +
+        // sched_barrier stands between these reads and the MFMAs (tools/check_asm_loads.py audits the .s for any
+        // other use of the destination registers before that wait).
+        typedef __attribute__((address_space(3))) char lds_char;
+        const unsigned la = (unsigned)(unsigned long)(lds_char*)a;
+        s16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(la));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(la));  // k + 4: same swizzle
+        s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(V, f);
+    }
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    int q = n >> 3, r = n & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// one 64-row pass of the epilogue: thread t owns 16-byte chunk t % 32 of rows t / 32 + 16*it   (as in gemm256.hip)
+template <typename T, int ACT, int MODE>
+__device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, T* __restrict__ C, const EpiParams& ep,
+                                              long long mh, long long n0, long long M, long long N, int tid) {
+    const int col = (tid & 31) * 8, r0 = tid >> 5;
+    const long long gn = n0 + col;
+    if (gn + 8 > N) return;
+    float b[8];
+    if (MODE != 2 && ep.bias) {
+        Vec16<T> bv = load16<T>(reinterpret_cast<const T*>(ep.bias) + gn);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = bv.get(e);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = 0.f;
+    }
+    const float alpha = ep.alpha;
+    Vec16<T> av[4];
+    if (MODE != 0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const long long gm = mh + r0 + 16 * it;
+            if (gm < M) av[it] = load16<T>(reinterpret_cast<const T*>(ep.aux) + gm * ep.ldaux + gn);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const long long gm = mh + r0 + 16 * it;
+        if (gm >= M) continue;
+        const float* src = cs + (r0 + 16 * it) * CP + col;
+        const float4 a4 = *reinterpret_cast<const float4*>(src), b4 = *reinterpret_cast<const float4*>(src + 4);
+        float x[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = x[e] * alpha;
+            if (MODE == 2) {
+                if (ACT == PK_ACT_RELU) y = av[it].get(e) > 0.f ? y : 0.f;
+            } else {
+                y += b[e];
+                if (ACT == PK_ACT_RELU) y = fmaxf(y, 0.f);
+                if (MODE == 1) y += av[it].get(e);
+            }
+            x[e] = y;
+        }
+        typedef __attribute__((ext_vector_type(8))) float f32x8;
+        f32x8 f = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
+        Vec16<T> o;
+        o.raw = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename H16<T>::vec));
+        store16_nt<T>(C + gm * ep.ldc + gn, o);
+    }
+}
+
+template <typename T, bool A_COL, bool B_COL>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A, const T* __restrict__ B,
+                                                       T* __restrict__ C, float* __restrict__ ws,
+                                                       float* __restrict__ asum_ws, T* __restrict__ asum_out,
+                                                       long long M, long long N, long long K, long long lda,
+                                                       long long ldb, int kchunk, unsigned a_bytes, unsigned b_bytes,
+                                                       EpiParams ep) {
+    typedef typename M16<T>::vec V;
+    typedef __attribute__((address_space(3))) void lds_void;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nt_m = (int)((M + BM - 1) / BM), nt_n = (int)((N + BN - 1) / BN);
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);  // slab-major (K-slab, tile) walk: an XCD owns whole K-slabs
+    const int kslab = lin / (nt_m * nt_n);
+    int t = lin % (nt_m * nt_n);
+    const int GROUP_M = nt_n <= 2 ? 8 : 4;
+    int group_size = GROUP_M * nt_n, gid = t / group_size, first_m = gid * GROUP_M;
+    int gsz = min(nt_m - first_m, GROUP_M);
+    int tile_m = first_m + (t % group_size) % gsz, tile_n = (t % group_size) / gsz;
+    const long long m0 = (long long)tile_m * BM, n0 = (long long)tile_n * BN;
+    const long long kbeg = (long long)kslab * kchunk;
+    const long long kend = min(K, kbeg + (long long)kchunk);
+    const int nk = (int)((kend - kbeg) / BK);  // the launcher guarantees full K-tiles
+
+    // ---- operand streams: one buffer descriptor each, per-lane offsets of this wave's two DMA pieces per half-tile ----
+    unsigned offa[2][2], offb[2][2];  // [half][piece of this wave]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // (col form with M % 8 != 0: the host only sends it here when the rows are padded, lda >= M rounded up to 8)
+            offa[h][i] = src_offset<A_COL>(wave * 2 + i, lane, lda, m0 + 128 * h, A_COL ? ((M + 7) & ~7LL) : M);
+            offb[h][i] = src_offset<B_COL>(wave * 2 + i, lane, ldb, n0 + 128 * h, N);
+        }
+    // byte step of one K-tile, and the K offset of tile 0 (an SGPR operand of the DMA)
+    const unsigned kstep_a = A_COL ? (unsigned)(BK * lda * 2) : (unsigned)(BK * 2);
+    const unsigned kstep_b = B_COL ? (unsigned)(BK * ldb * 2) : (unsigned)(BK * 2);
+    const unsigned kbase_a = A_COL ? (unsigned)(kbeg * lda * 2) : (unsigned)(kbeg * 2);
+    const unsigned kbase_b = B_COL ? (unsigned)(kbeg * ldb * 2) : (unsigned)(kbeg * 2);
+
+    // half-tile `slot` of K-tile kt -> stage kt & 1.  Past the last K-tile the SAME two instructions are issued against
+    // an empty descriptor (every lane out of range: nothing is fetched), so the counted waits of the tail are those of
+    // the steady state; their destination is a slot whose last reader has passed (the schedule's WAR distance).
+    auto dma = [&](int kt, int slot) {
+        char* dst = smem + (kt & 1) * STAGE + slot * HALF + wave * 2048;
+        const bool live = kt < nk;
+        if (slot < 2) {
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, live ? (int)a_bytes : 0, 0x00020000);
+            const unsigned so = kbase_a + (unsigned)kt * kstep_a;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, offa[slot][0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, offa[slot][1], so, 0, 0);
+        } else {
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, live ? (int)b_bytes : 0, 0x00020000);
+            const unsigned so = kbase_b + (unsigned)kt * kstep_b;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, offb[slot - 2][0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, offb[slot - 2][1], so, 0, 0);
+        }
+    };
+
+    f32x4 acc[2][4][2][2];  // [mh][m-tile][nh][n-tile]: D'[n][m] of the swapped product — lane: m = l & 15, n = 4 (l >> 4) + r
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    V fa[4][2], fb[2][2][2];  // A fragments of the current row half [m-tile][kk]; B fragments [nh][n-tile][kk]
+
+    // One phase.  P = 0..3 (quadrant), `st` the K-tile's stage base, (dma_kt, dma_slot) the half-tile staged here.
+#define PK_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+    auto load_a = [&](const char* img) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = frag<T, A_COL>(img, wr * 64 + 16 * i, kk, lane);
+    };
+    auto load_b = [&](const char* img, int nh) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fb[nh][j][kk] = frag<T, B_COL>(img, wc * 32 + 16 * j, kk, lane);
+    };
+    auto mma = [&](int mh, int nh) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mh][i][nh][j] = M16<T>::mfma(fb[nh][j][kk], fa[i][kk], acc[mh][i][nh][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto phase = [&](auto p_c, const char* st, int dma_kt, int dma_slot) {
+        constexpr int P = decltype(p_c)::value;
+        if constexpr (P == 0) { load_b(st + SLOT_B0 * HALF, 0); load_a(st + SLOT_A0 * HALF); }
+        if constexpr (P == 1) load_b(st + SLOT_B1 * HALF, 1);
+        if constexpr (P == 2) load_a(st + SLOT_A1 * HALF);
+        PK_WAIT(6);  // all but the three youngest half-tiles have landed (what the NEXT phase reads is among them)
+        dma(dma_kt, dma_slot);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P == 0) mma(0, 0);
+        if constexpr (P == 1) mma(0, 1);
+        if constexpr (P == 2) mma(1, 1);
+        if constexpr (P == 3) mma(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    const char* const stE = smem;
+    const char* const stO = smem + STAGE;
+
+    if (nk > 0) {
+        // ---- prologue: K-tile 0 whole, K-tile 1's A0 B0 ----
+        dma(0, SLOT_A0); dma(0, SLOT_B0); dma(0, SLOT_B1); dma(0, SLOT_A1);
+        dma(1, SLOT_A0); dma(1, SLOT_B0);
+        PK_WAIT(8);  // A0, B0 of tile 0
+        asm volatile("; PK8P_LOOP_BEGIN" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave of every SIMD runs one barrier behind the first
+        for (int kt = 0; kt < nk; kt += 2) {
+            phase(I0{}, stE, kt + 1, SLOT_B1);
+            phase(I1{}, stE, kt + 1, SLOT_A1);
+            phase(I2{}, stE, kt + 2, SLOT_A0);
+            phase(I3{}, stE, kt + 2, SLOT_B0);
+            if (kt + 1 >= nk) break;  // odd number of K-tiles
+            phase(I0{}, stO, kt + 2, SLOT_B1);
+            phase(I1{}, stO, kt + 2, SLOT_A1);
+            phase(I2{}, stO, kt + 3, SLOT_A0);
+            phase(I3{}, stO, kt + 3, SLOT_B0);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();  // the first half catches the barrier count up
+        asm volatile("; PK8P_LOOP_END" ::: "memory");
+        PK_WAIT(0);  // (trailing DMAs of the tail are empty, but they still target LDS: retire them before it is reused)
+    }
+#undef PK_WAIT
+    __syncthreads();
+
+    // ---- epilogue: four 64-row passes of the accumulators through the fp32 staging buffer (all stages are free) ----
+    float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (wr == (p & 1)) {  // tile rows [64p, 64p + 64) = row half p >> 1 of the waves with wr == p & 1
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 v = acc[p >> 1][i][nh][j];
+                        float* d = cs + (16 * i + (lane & 15)) * CP + 128 * nh + 32 * wc + 16 * j + 4 * (lane >> 4);
+                        *reinterpret_cast<float4*>(d) = float4{v[0], v[1], v[2], v[3]};
+                    }
+        }
+        __syncthreads();
+        const long long mh = m0 + p * 64;
+        if (ws) {  // split-K partial: raw fp32 slab [splitk][M][N]
+            float* slab = ws + (long long)kslab * M * N;
+            const int col = (tid & 31) * 8, r0 = tid >> 5;
+            const long long gn = n0 + col;
+            if (gn + 8 <= N) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const long long gm = mh + r0 + 16 * it;
+                    if (gm >= M) continue;
+                    const float* src = cs + (r0 + 16 * it) * CP + col;
+                    float* dst = slab + gm * N + gn;
+                    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+                    *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(src + 4);
+                }
+            }
+        } else if (ep.mode == 0) {
+            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 0>(cs, C, ep, mh, n0, M, N, tid);
+            else epilogue_pass<T, PK_ACT_NONE, 0>(cs, C, ep, mh, n0, M, N, tid);
+        } else if (ep.mode == 1) {
+            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 1>(cs, C, ep, mh, n0, M, N, tid);
+            else epilogue_pass<T, PK_ACT_NONE, 1>(cs, C, ep, mh, n0, M, N, tid);
+        } else {
+            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 2>(cs, C, ep, mh, n0, M, N, tid);
+            else epilogue_pass<T, PK_ACT_NONE, 2>(cs, C, ep, mh, n0, M, N, tid);
+        }
+        if (p < 3) __syncthreads();
+    }
+}
+
+}  // namespace
+
+namespace {
+// extent of each operand in bytes (last row: only its valid part; col form with padded rows: the pad is readable)
+void operand_bytes(long long M, long long N, long long K, long long lda, long long ldb, int a_col, int b_col,
+                   long long* a_bytes, long long* b_bytes) {
+    const long long a_rows = a_col ? K : M, a_cols = a_col ? std::min(lda, (M + 7) & ~7LL) : K;
+    const long long b_rows = b_col ? K : N, b_cols = b_col ? N : K;
+    *a_bytes = ((a_rows - 1) * lda + a_cols) * 2;
+    *b_bytes = ((b_rows - 1) * ldb + b_cols) * 2;
+}
+}  // namespace
+
+// What this kernel takes beyond gemm256.hip's own conditions (checked by the dispatcher in gemm.hip): operands
+// addressable with 32-bit byte offsets (per-lane offsets and the K offset of the buffer loads), no fused bias gradient.
+extern "C" int pk_gemm8p_eligible(long long M, long long N, long long K, long long lda, long long ldb, int a_col,
+                                  int b_col, int want_asum) {
+    if (want_asum || K < BK || K % BK) return 0;
+    long long a_bytes, b_bytes;
+    operand_bytes(M, N, K, lda, ldb, a_col, b_col, &a_bytes, &b_bytes);
+    const long long lim = 0xFFFFFFFFLL - 4096;
+    return a_bytes <= lim && b_bytes <= lim;
+}
+
+// Returns 1 if the GEMM was launched, 0 if it is not eligible, or a hip error code.
+extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
+                                long long M, long long N, long long K, long long lda, long long ldb, int a_col,
+                                int b_col, int kchunk, int splitk, EpiParams ep, int dtype, void* stream) {
+    if (!pk_gemm8p_eligible(M, N, K, lda, ldb, a_col, b_col, asum_ws || asum_out)) return 0;
+    long long a_bytes, b_bytes;
+    operand_bytes(M, N, K, lda, ldb, a_col, b_col, &a_bytes, &b_bytes);
+    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN) * splitk)), block(512);
+    hipStream_t s = (hipStream_t)stream;
+#define PK_K(TT, AC, BC)                                                                                          \
+    hipLaunchKernelGGL((gemm8p_kernel<TT, AC, BC>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, ws,     \
+                       asum_ws, (TT*)asum_out, M, N, K, lda, ldb, kchunk, (unsigned)a_bytes, (unsigned)b_bytes, ep)
+#define PK_L(AC, BC)                                          \
+    do {                                                      \
+        if (dtype == PK_F16) PK_K(f16, AC, BC);               \
+        else PK_K(bf16, AC, BC);                              \
+    } while (0)
+    if (!a_col && !b_col) PK_L(false, false);
+    else if (!a_col && b_col) PK_L(false, true);
+    else if (a_col && !b_col) PK_L(true, false);
+    else PK_L(true, true);
+#undef PK_L
+#undef PK_K
+    PK_LAUNCH_CHECK();
+    return 1;
+}

@@ -119,7 +119,7 @@ def test_c4_whisper_base_full_size():
         enc_out, enc_mask, _ = model.encoder(batch['encoder_input'], batch['encoder_input_length'])
     assert enc_out.shape == (B, 1500, 512) and not enc_mask.any()
     _halves_property(model, batch, ['encoder.layers.0.fc1.weight', 'encoder.subsample.conv_layers.0.weight',
-                                    'decoder.layers.5.encoder_attn.k_proj.weight', 'decoder.embed_tokens.weight'], B)
+                                    'decoder.layers.5.encoder_attn.k_proj.weight', 'encoder.embed_tokens.weight'], B)
 
 
 def test_full_width_layer_pair_fp32_against_the_oracle():

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Audit of the gemm8p kernels' assembly (pasero_amd/csrc/gemm8p.hip), run by __graft_entry__.build() and the CPU tests:
+
+  1. between the PK8P_LOOP_BEGIN / PK8P_LOOP_END markers no `s_waitcnt` may drain the vector-memory counter below the
+     hand-placed counted waits (hipcc adds `vmcnt(0)` in front of LDS accesses it cannot disambiguate from an LDS-DMA
+     in flight: that would serialise the prefetch, silently);
+  2. the transposed LDS reads are inline asm, so the compiler neither waits for them nor knows when their destination
+     registers become valid: from each `ds_read_b64_tr_b16` to the next `s_waitcnt lgkmcnt(0)` nothing else may read or
+     write those registers (a compiler copy there would move stale data);
+  3. no scratch (spill) traffic anywhere in these kernels.
+
+Usage: check_asm_loads.py <file.s>     (exit code 1 and a report if a rule is broken)"""
+import re
+import sys
+
+
+def regs(tok: str):
+    m = re.fullmatch(r'v\[(\d+):(\d+)\]', tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r'v(\d+)', tok)
+    return {int(m.group(1))} if m else set()
+
+
+def operands(line: str):
+    body = line.split(';')[0].strip()
+    parts = body.split(None, 1)
+    if len(parts) < 2:
+        return parts[0] if parts else '', []
+    return parts[0], [t.strip() for t in re.split(r',\s*', parts[1])]
+
+
+def audit(path: str):
+    lines = open(path).read().splitlines()
+    problems, kernels = [], 0
+    i = 0
+    while i < len(lines):
+        m = re.match(r'^(_ZN[^:]*gemm8p_kernel[^:]*):', lines[i])
+        if not m:
+            i += 1
+            continue
+        name = m.group(1)
+        kernels += 1
+        j = i
+        while j < len(lines) and 's_endpgm' not in lines[j]:
+            j += 1
+        body = lines[i:j]
+        i = j
+        if any('scratch_' in ln for ln in body):
+            problems.append(f'{name}: scratch (spill) instructions')
+        try:
+            b = next(k for k, ln in enumerate(body) if 'PK8P_LOOP_BEGIN' in ln)
+            e = next(k for k, ln in enumerate(body) if 'PK8P_LOOP_END' in ln)
+        except StopIteration:
+            problems.append(f'{name}: loop markers not found')
+            continue
+        pending = {}  # register -> line of the asm tr read that wrote it
+        for k in range(b, e):
+            ln = body[k]
+            op, ops = operands(ln)
+            if op == 's_waitcnt':
+                mm = re.search(r'vmcnt\((\d+)\)', ln)
+                if mm and int(mm.group(1)) < 6:
+                    problems.append(f'{name}: line {k}: `{ln.strip()}` inside the K loop drains the LDS-DMA prefetch')
+                if 'lgkmcnt(0)' in ln:
+                    pending.clear()
+                continue
+            if op == 'ds_read_b64_tr_b16':
+                for r in regs(ops[0]):
+                    pending[r] = k
+                touched = set().union(*[regs(t) for t in ops[1:]]) if len(ops) > 1 else set()
+            else:
+                touched = set().union(*[regs(t) for t in ops]) if ops else set()
+                if op.startswith('ds_read') and ops:  # another LDS read may reuse... its destination only
+                    touched = set().union(*[regs(t) for t in ops[1:]]) | (regs(ops[0]) & set(pending))
+            bad = touched & set(pending)
+            if bad and op != 'ds_read_b64_tr_b16':
+                problems.append(f'{name}: line {k}: `{ln.strip()}` touches v{sorted(bad)} before the lgkmcnt(0) that '
+                                f'covers the asm read at line {pending[sorted(bad)[0]]}')
+    if kernels == 0:
+        problems.append('no gemm8p kernels found in ' + path)
+    return kernels, problems
+
+
+if __name__ == '__main__':
+    n, probs = audit(sys.argv[1])
+    for p in probs:
+        print('PROBLEM:', p)
+    print(f'{n} kernels audited, {len(probs)} problems')
+    sys.exit(1 if probs else 0)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of pk_gemm on the hot-path shapes (random bf16 data), next to torch.matmul (hipBLASLt) on the same
-data as the known-good reference.  usage: tools/gemm_bench.py [--only NAME] [--iters N] [--no-torch]"""
+"""Micro-benchmark of pk_gemm on the hot-path shapes (random bf16 data): the phase-interleaved kernel (gemm8p.hip) and
+the one-barrier-per-K-tile kernel (gemm256.hip) in alternating rounds inside ONE process, next to torch.matmul
+(hipBLASLt) on the same data as the known-good reference; every result is also checked against an fp32 product.
+usage: tools/gemm_bench.py [--only NAME ...] [--iters N] [--rounds R] [--no-torch] [--cold]"""
 import argparse
 import os
 import sys
@@ -91,12 +93,15 @@ def bench(fn, iters):
 
 
 def main():
+    from pasero_amd import lib
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', nargs='*')
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--rounds', type=int, default=3, help='interleaved rounds per variant (median reported)')
     ap.add_argument('--no-torch', action='store_true')
     ap.add_argument('--cold', action='store_true', help='evict caches between launches')
     args = ap.parse_args()
+    L = lib.load()
     for name, (M, N, K, a_col, b_col, splitk) in SHAPES.items():
         if args.only and name not in args.only:
             continue
@@ -107,18 +112,35 @@ def main():
         sk = F.choose_splitk(M, N, K) if splitk == 0 else splitk
         out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
         timer = bench_cold if args.cold else bench
-        us = timer(lambda: F.gemm(a, b, a_col=a_col, b_col=b_col, splitk=sk, out=out), args.iters)
-        tf = 2.0 * M * N * K / us / 1e6
-        line = f'{name:10s} M={M:6d} N={N:5d} K={K:6d} {"col" if a_col else "row"},{"col" if b_col else "row"} sk={sk:2d}  ours {us:8.1f} us {tf:7.1f} TF'
+        run = lambda: F.gemm(a, b, a_col=a_col, b_col=b_col, splitk=sk, out=out)  # noqa: E731
+        # correctness of both kernels on a row / column sample against fp32
+        rows = torch.arange(0, M, max(1, M // 257), device='cuda')
+        ref = A[rows].float() @ B.float().t()
+        errs = {}
+        for mode in (1, 0):
+            L.pk_gemm_use_8p(mode)
+            out.zero_()
+            run()
+            errs[mode] = ((out[rows].float() - ref).abs().max() / ref.abs().max()).item()
+        times = {1: [], 0: []}
+        for _ in range(args.rounds):
+            for mode in (1, 0):
+                L.pk_gemm_use_8p(mode)
+                times[mode].append(timer(run, args.iters))
+        L.pk_gemm_use_8p(1)
+        med = {m: sorted(v)[len(v) // 2] for m, v in times.items()}
+        tf = {m: 2.0 * M * N * K / med[m] / 1e6 for m in med}
+        line = (f'{name:14s} M={M:6d} N={N:5d} K={K:6d} {"col" if a_col else "row"},{"col" if b_col else "row"} sk={sk:2d}  '
+                f'8p {med[1]:7.1f} us {tf[1]:7.1f} TF (err {errs[1]:.1e}) | 256 {med[0]:7.1f} us {tf[0]:7.1f} TF (err {errs[0]:.1e})')
         if not args.no_torch:
             if a_col and b_col:
-                ref = lambda: torch.matmul(a.t(), b)  # noqa: E731
+                tref = lambda: torch.matmul(a.t(), b)  # noqa: E731
             elif b_col:
-                ref = lambda: torch.matmul(a, b)  # noqa: E731
+                tref = lambda: torch.matmul(a, b)  # noqa: E731
             else:
-                ref = lambda: torch.matmul(a, b.t())  # noqa: E731
-            us2 = bench(ref, args.iters)
-            line += f' | torch {us2:8.1f} us {2.0 * M * N * K / us2 / 1e6:7.1f} TF'
+                tref = lambda: torch.matmul(a, b.t())  # noqa: E731
+            us2 = timer(tref, args.iters)
+            line += f' | torch {us2:7.1f} us {2.0 * M * N * K / us2 / 1e6:7.1f} TF'
         print(line, flush=True)
 
 
