@@ -59,6 +59,7 @@ int pk_gemm(const void* A, const void* B, void* C, const void* bias, const void*
  * layouts, split-K factor, dtype, 2*M*N*K and the elapsed milliseconds. */
 int pk_gemm_timing_start(int max_samples, int stride);
 /* diagnostic: 1 / 0 routes the 256-tile GEMMs to the phase-interleaved kernel (gemm8p.hip, default) / to gemm256.hip;
+ * 2 additionally sends every eligible GEMM with M, N >= 256 there, whether or not its tiles fill the chip (tests);
  * a negative argument only queries.  Returns the previous setting (env PK_GEMM_8P sets the initial one). */
 int pk_gemm_use_8p(int on);
 int pk_gemm_timing_stop(void);

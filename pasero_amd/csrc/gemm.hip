@@ -763,9 +763,13 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
                             (!ep.bias || ((uintptr_t)ep.bias % 16) == 0) && (ep.mode == 0 || (flags & 8)) && ep.mode < 3;
         const bool addr_ok = (flags & 1) && (flags & 2) && (!a_col || M % 8 == 0 || lda >= ((M + 7) & ~7LL)) &&
                              (!b_col || N % 8 == 0) &&
-                             N % 8 == 0 && K % 64 == 0 && K > 0;
+                             N % 8 == 0 && K > 0;
+        // gemm8p.hip zero-fills a partial last K-tile (K % 8 == 0: the vocabulary dX GEMMs, K = V); gemm256.hip needs
+        // whole 64-deep tiles
+        const bool e8 = g_use_8p && pk_gemm8p_eligible(M, N, K, lda, ldb, a_col, b_col, asum_out != nullptr);
+        const bool k_ok = e8 || K % 64 == 0;
         const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        if (simple && addr_ok && tile_pref != 128 && M >= 256 && N >= 256) {
+        if (simple && addr_ok && k_ok && tile_pref != 128 && M >= 256 && N >= 256) {
             int sk = 1;
             long long per = K;
             // split-K (weight-gradient) GEMMs: the 256 kernel re-derives its own split factor (~1 workgroup per CU).
@@ -787,12 +791,11 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
                 if ((size_t)sk * M * (N + (asum_out ? 1 : 0)) * sizeof(float) > ws_bytes) sk = 0;  // does not fit
             }
             const bool fills = t256 * std::max(sk, 1) >= 160;
-            if (sk > 0 && (tile_pref == 256 || fills)) {
+            if (sk > 0 && (tile_pref == 256 || fills || (g_use_8p == 2 && e8))) {
                 float* w2 = sk > 1 ? (float*)workspace : nullptr;
                 float* asw = (sk > 1 && asum_out) ? w2 + (size_t)sk * M * N : nullptr;
                 // the phase-interleaved kernel (gemm8p.hip) takes what it can; gemm256.hip the rest (fused bias gradient,
                 // operands beyond 4 GiB).  PK_GEMM_8P=0 switches it off (A/B inside one process: tools/gemm_bench.py)
-                const bool e8 = g_use_8p && pk_gemm8p_eligible(M, N, K, lda, ldb, a_col, b_col, asum_out != nullptr);
                 GemmSample* sm = timing_begin(e8 ? 8 : 256, a_col, b_col, std::max(sk, 1), dtype16, M, N, K, stream);
                 int rc = (e8 ? pk_gemm8p_launch : pk_gemm256_launch)(A, B, C, w2, asw, asum_out, M, N, K, lda, ldb, a_col,
                                                                     b_col, (int)per, std::max(sk, 1), ep, dtype16, stream);
@@ -878,7 +881,7 @@ extern "C" int pk_gemm(const void* A, const void* B, void* C, const void* bias, 
 
 extern "C" int pk_gemm_use_8p(int on) {
     const int old = g_use_8p;
-    if (on >= 0) g_use_8p = on ? 1 : 0;
+    if (on >= 0) g_use_8p = on > 2 ? 2 : on;
     return old;
 }
 

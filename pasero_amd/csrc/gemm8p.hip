@@ -94,32 +94,16 @@ __device__ __forceinline__ unsigned src_offset(int piece, int lane, long long ld
     }
 }
 
-// fragment of the 16 rows (tile) starting at local row / column `r0` of a half-tile image, k-step kk (32 deep):
-// lane l holds X[r0 + (l & 15)][32 kk + 8 (l >> 4) + j], j = 0..7 — the A and B operand layout of v_mfma_16x16x32
+// row-form fragment of the 16 rows starting at local row `r0` of a half-tile image, k-step kk (32 deep): lane l holds
+// X[r0 + (l & 15)][32 kk + 8 (l >> 4) + j], j = 0..7 — the A and B operand layout of v_mfma_16x16x32.  (Col-form images
+// are read with ds_read_b64_tr_b16 inside the kernel: two 4-row x 16-column blocks per lane group, rows
+// 32 kk + 8 (l >> 4) + {0..3} and + {4..7}.)
 template <typename T, bool COL>
 __device__ __forceinline__ typename M16<T>::vec frag(const char* img, int r0, int kk, int lane) {
-    static_assert(HT<true>::ROWB * 4 == 1024, "offset of the k + 4 rows in the asm below");
+    static_assert(!COL, "col-form fragments: col_frag in the kernel");
     typedef typename M16<T>::vec V;
-    if constexpr (!COL) {
-        const int row = r0 + (lane & 15);
-        return *reinterpret_cast<const V*>(img + HT<false>::offset(row, kk * 4 + (lane >> 4)));
-    } else {
-        const int q = (lane & 15) >> 2, p = lane & 3;
-        const int krow = kk * 32 + 8 * (lane >> 4) + q, col = r0 + 4 * p;
-        const char* a = img + HT<true>::offset(krow, col >> 3) + (col & 7) * 2;
-        // inline asm, not the builtin: behind an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in front of the
-        // builtin's transposed reads (it cannot tell which LDS bytes they touch), which would drain the prefetch every
-        // phase.  The compiler does not wait for asm loads either: the phase's own `s_waitcnt lgkmcnt(0)` +
-        // sched_barrier stands between these reads and the MFMAs (tools/check_asm_loads.py audits the .s for any
-        // other use of the destination registers before that wait).
-        typedef __attribute__((address_space(3))) char lds_char;
-        const unsigned la = (unsigned)(unsigned long)(lds_char*)a;
-        s16x4 lo, hi;
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(la));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(la));  // k + 4: same swizzle
-        s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(V, f);
-    }
+    const int row = r0 + (lane & 15);
+    return *reinterpret_cast<const V*>(img + HT<false>::offset(row, kk * 4 + (lane >> 4)));
 }
 
 __device__ __forceinline__ int xcd_remap(int bid, int n) {
@@ -204,7 +188,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
     const long long m0 = (long long)tile_m * BM, n0 = (long long)tile_n * BN;
     const long long kbeg = (long long)kslab * kchunk;
     const long long kend = min(K, kbeg + (long long)kchunk);
-    const int nk = (int)((kend - kbeg) / BK);  // the launcher guarantees full K-tiles
+    // K-tiles of this slab; the last one may be partial (K % 8 == 0): col-form rows k >= K lie past the end of their
+    // buffer and read as zeros, row-form chunks k >= K are masked per lane (below)
+    const int nk = (int)((kend - kbeg + BK - 1) / BK);
+    const int kvalid = (int)(kend - kbeg) - (nk - 1) * BK;  // depth of the last K-tile, 8..64
 
     // ---- operand streams: one buffer descriptor each, per-lane offsets of this wave's two DMA pieces per half-tile ----
     unsigned offa[2][2], offb[2][2];  // [half][piece of this wave]
@@ -216,6 +203,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
             offa[h][i] = src_offset<A_COL>(wave * 2 + i, lane, lda, m0 + 128 * h, A_COL ? ((M + 7) & ~7LL) : M);
             offb[h][i] = src_offset<B_COL>(wave * 2 + i, lane, ldb, n0 + 128 * h, N);
         }
+    // row form, last K-tile: this lane's 16 bytes of piece i are columns k = 8 * chunk ... (the same chunk in both
+    // halves and both operands: rows 8 * (2 wave + i) + (lane >> 3), swizzle (row >> 1) & 7)
+    bool tail_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) tail_ok[i] = (((lane & 7) ^ ((4 * i + (lane >> 4)) & 7)) * 8) < kvalid;
+    constexpr unsigned DEAD_OFF = 0x80000000u;  // beyond every eligible operand (< 2 GiB), no 32-bit wrap with the K offset
     // byte step of one K-tile, and the K offset of tile 0 (an SGPR operand of the DMA)
     const unsigned kstep_a = A_COL ? (unsigned)(BK * lda * 2) : (unsigned)(BK * 2);
     const unsigned kstep_b = B_COL ? (unsigned)(BK * ldb * 2) : (unsigned)(BK * 2);
@@ -223,21 +216,27 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
     const unsigned kbase_b = B_COL ? (unsigned)(kbeg * ldb * 2) : (unsigned)(kbeg * 2);
 
     // half-tile `slot` of K-tile kt -> stage kt & 1.  Past the last K-tile the SAME two instructions are issued against
-    // an empty descriptor (every lane out of range: nothing is fetched), so the counted waits of the tail are those of
-    // the steady state; their destination is a slot whose last reader has passed (the schedule's WAR distance).
+    // an empty descriptor (every lane out of range: nothing is fetched, zeros land), so the counted waits of the tail
+    // are those of the steady state; their destination is a slot whose last reader has passed (the schedule's WAR
+    // distance).
     auto dma = [&](int kt, int slot) {
         char* dst = smem + (kt & 1) * STAGE + slot * HALF + wave * 2048;
         const bool live = kt < nk;
+        const bool tail = kt == nk - 1 && kvalid < BK;
         if (slot < 2) {
             __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, live ? (int)a_bytes : 0, 0x00020000);
             const unsigned so = kbase_a + (unsigned)kt * kstep_a;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, offa[slot][0], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, offa[slot][1], so, 0, 0);
+            unsigned v0 = offa[slot][0], v1 = offa[slot][1];
+            if (!A_COL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, v0, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, v1, so, 0, 0);
         } else {
             __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, live ? (int)b_bytes : 0, 0x00020000);
             const unsigned so = kbase_b + (unsigned)kt * kstep_b;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, offb[slot - 2][0], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, offb[slot - 2][1], so, 0, 0);
+            unsigned v0 = offb[slot - 2][0], v1 = offb[slot - 2][1];
+            if (!B_COL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, v0, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, v1, so, 0, 0);
         }
     };
 
@@ -253,19 +252,104 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
 
     V fa[4][2], fb[2][2][2];  // A fragments of the current row half [m-tile][kk]; B fragments [nh][n-tile][kk]
 
-    // One phase.  P = 0..3 (quadrant), `st` the K-tile's stage base, (dma_kt, dma_slot) the half-tile staged here.
-#define PK_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-    auto load_a = [&](const char* img) {
+    // col-form fragments: per-lane LDS byte address of tile i (A) / j (B) at k-step 0, slot 0, one set per stage; slot,
+    // k-step and the k + 4 rows are instruction immediates (16-bit: the stage does not fit)
+    unsigned ca[2][4], cb[2][2];
+    {
+        typedef __attribute__((address_space(3))) char lds_char;
+        const unsigned base = (unsigned)(unsigned long)(lds_char*)smem;
+        const int q = (lane & 15) >> 2, p = lane & 3, krow = 8 * (lane >> 4) + q;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int st = 0; st < 2; ++st) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = frag<T, A_COL>(img, wr * 64 + 16 * i, kk, lane);
+            for (int i = 0; i < 4; ++i) {
+                const int col = wr * 64 + 16 * i + 4 * p;
+                ca[st][i] = base + st * STAGE + HT<true>::offset(krow, col >> 3) + (col & 7) * 2;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = wc * 32 + 16 * j + 4 * p;
+                cb[st][j] = base + st * STAGE + HT<true>::offset(krow, col >> 3) + (col & 7) * 2;
+            }
+        }
+    }
+    // inline asm, not the builtin: behind an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in front of the builtin's
+    // transposed reads (it cannot tell which LDS bytes they touch), which would drain the prefetch every phase.  The
+    // compiler does not wait for asm loads either: the phase's own `s_waitcnt lgkmcnt(0)` + sched_barrier stands
+    // between these reads and the MFMAs (tools/check_asm_loads.py audits the .s for any other use of the destination
+    // registers before that wait).
+#define PK_TR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
+    auto col_frag = [&](unsigned addr, auto off_c) -> V {
+        constexpr int OFF = decltype(off_c)::value;
+        static_assert(OFF >= 0 && OFF + 4 * HT<true>::ROWB < 65536, "ds offset field");
+        s16x4 lo, hi;
+        PK_TR(lo, addr, OFF);
+        PK_TR(hi, addr, OFF + 4 * HT<true>::ROWB);  // rows k + 4: same swizzle
+        s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(V, f);
     };
-    auto load_b = [&](const char* img, int nh) {
+
+    // Fused bias gradient (col-form A = dY: the sum over k of every column), by the tile_n == 0 workgroups.  All of it
+    // sits in the load section of phase 4 / 8, which reads no fragments: threads 0..255 sum the A1 image of the phase's
+    // own K-tile (last read in the phase before, overwritten two phases later), threads 256..511 the A0 image of the
+    // NEXT K-tile (landed one phase earlier; past the end an empty DMA left zeros there); the first K-tile's A0 image
+    // is summed once behind the prologue.  Thread t: 16-byte chunk t & 15 of rows (t & 255) >> 4 + 16 it, it = 0..3.
+    // Inline-asm reads with their own wait (the compiler would put vmcnt(0) in front of plain loads of these images).
+    const bool do_asum = A_COL && (asum_ws || asum_out) && tile_n == 0;
+    float asum[8];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+    for (int e = 0; e < 8; ++e) asum[e] = 0.f;
+    unsigned asum_base = 0;  // LDS address for an even (stage 0) phase; ^ STAGE for an odd one
+    if constexpr (A_COL) {
+        typedef __attribute__((address_space(3))) char lds_char;
+        asum_base = (unsigned)(unsigned long)(lds_char*)smem + (tid < 256 ? SLOT_A1 * HALF : STAGE + SLOT_A0 * HALF) +
+                    HT<true>::offset((tid & 255) >> 4, tid & 15);
+    }
+    auto asum_step = [&](unsigned addr) {
+        static_assert(16 * HT<true>::ROWB == 4096, "row step of the immediates below");
+        uint4 r0, r1;
+        Vec16<T> v0, v1;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1) : "v"(addr));
+        v0.raw = r0; v1.raw = r1;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fb[nh][j][kk] = frag<T, B_COL>(img, wc * 32 + 16 * j, kk, lane);
+        for (int e = 0; e < 8; ++e) asum[e] += v0.get(e) + v1.get(e);
+        asm volatile("ds_read_b128 %0, %2 offset:8192\n\tds_read_b128 %1, %2 offset:12288\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1) : "v"(addr));
+        v0.raw = r0; v1.raw = r1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) asum[e] += v0.get(e) + v1.get(e);
+    };
+
+    // One phase.  P = 0..3 (quadrant), S = 0 / 1 the K-tile's stage, (dma_kt, dma_slot) the half-tile staged here.
+#define PK_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+    auto load_a = [&](auto s_c, auto slot_c) {
+        constexpr int S = decltype(s_c)::value, SLOT = decltype(slot_c)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (A_COL) {
+                fa[i][0] = col_frag(ca[S][i], std::integral_constant<int, SLOT * HALF>{});
+                fa[i][1] = col_frag(ca[S][i], std::integral_constant<int, SLOT * HALF + 32 * HT<true>::ROWB>{});
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    fa[i][kk] = frag<T, false>(smem + S * STAGE + SLOT * HALF, wr * 64 + 16 * i, kk, lane);
+            }
+        }
+    };
+    auto load_b = [&](auto s_c, auto slot_c, int nh) {
+        constexpr int S = decltype(s_c)::value, SLOT = decltype(slot_c)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (B_COL) {
+                fb[nh][j][0] = col_frag(cb[S][j], std::integral_constant<int, SLOT * HALF>{});
+                fb[nh][j][1] = col_frag(cb[S][j], std::integral_constant<int, SLOT * HALF + 32 * HT<true>::ROWB>{});
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    fb[nh][j][kk] = frag<T, false>(smem + S * STAGE + SLOT * HALF, wc * 32 + 16 * j, kk, lane);
+            }
+        }
     };
     auto mma = [&](int mh, int nh) {
         __builtin_amdgcn_s_setprio(1);
@@ -278,11 +362,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
                     acc[mh][i][nh][j] = M16<T>::mfma(fb[nh][j][kk], fa[i][kk], acc[mh][i][nh][j]);
         __builtin_amdgcn_s_setprio(0);
     };
-    auto phase = [&](auto p_c, const char* st, int dma_kt, int dma_slot) {
-        constexpr int P = decltype(p_c)::value;
-        if constexpr (P == 0) { load_b(st + SLOT_B0 * HALF, 0); load_a(st + SLOT_A0 * HALF); }
-        if constexpr (P == 1) load_b(st + SLOT_B1 * HALF, 1);
-        if constexpr (P == 2) load_a(st + SLOT_A1 * HALF);
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    auto phase = [&](auto p_c, auto s_c, int dma_kt, int dma_slot) {
+        constexpr int P = decltype(p_c)::value, S = decltype(s_c)::value;
+        if constexpr (P == 0) {
+            load_b(s_c, I2{}, 0);  // SLOT_B0
+            load_a(s_c, I0{});     // SLOT_A0
+        }
+        if constexpr (P == 1) load_b(s_c, I3{}, 1);  // SLOT_B1
+        if constexpr (P == 2) load_a(s_c, I1{});     // SLOT_A1
+        if constexpr (P == 3 && A_COL) {
+            if (do_asum) asum_step(S == 0 ? asum_base : asum_base ^ (unsigned)STAGE);
+        }
         PK_WAIT(6);  // all but the three youngest half-tiles have landed (what the NEXT phase reads is among them)
         dma(dma_kt, dma_slot);
         __builtin_amdgcn_sched_barrier(0);
@@ -296,10 +388,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    const char* const stE = smem;
-    const char* const stO = smem + STAGE;
+    static_assert(SLOT_A0 == 0 && SLOT_A1 == 1 && SLOT_B0 == 2 && SLOT_B1 == 3, "slot constants used above");
 
     if (nk > 0) {
         // ---- prologue: K-tile 0 whole, K-tile 1's A0 B0 ----
@@ -308,24 +397,46 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
         PK_WAIT(8);  // A0, B0 of tile 0
         asm volatile("; PK8P_LOOP_BEGIN" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if constexpr (A_COL) {
+            if (do_asum && wr == 1) asum_step(asum_base ^ (unsigned)STAGE);  // A0 image of K-tile 0 (stage 0)
+        }
         if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave of every SIMD runs one barrier behind the first
         for (int kt = 0; kt < nk; kt += 2) {
-            phase(I0{}, stE, kt + 1, SLOT_B1);
-            phase(I1{}, stE, kt + 1, SLOT_A1);
-            phase(I2{}, stE, kt + 2, SLOT_A0);
-            phase(I3{}, stE, kt + 2, SLOT_B0);
+            phase(I0{}, I0{}, kt + 1, SLOT_B1);
+            phase(I1{}, I0{}, kt + 1, SLOT_A1);
+            phase(I2{}, I0{}, kt + 2, SLOT_A0);
+            phase(I3{}, I0{}, kt + 2, SLOT_B0);
             if (kt + 1 >= nk) break;  // odd number of K-tiles
-            phase(I0{}, stO, kt + 2, SLOT_B1);
-            phase(I1{}, stO, kt + 2, SLOT_A1);
-            phase(I2{}, stO, kt + 3, SLOT_A0);
-            phase(I3{}, stO, kt + 3, SLOT_B0);
+            phase(I0{}, I1{}, kt + 2, SLOT_B1);
+            phase(I1{}, I1{}, kt + 2, SLOT_A1);
+            phase(I2{}, I1{}, kt + 3, SLOT_A0);
+            phase(I3{}, I1{}, kt + 3, SLOT_B0);
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();  // the first half catches the barrier count up
         asm volatile("; PK8P_LOOP_END" ::: "memory");
         PK_WAIT(0);  // (trailing DMAs of the tail are empty, but they still target LDS: retire them before it is reused)
     }
 #undef PK_WAIT
+#undef PK_TR
     __syncthreads();
+
+    if constexpr (A_COL) {
+        if (do_asum) {  // 16 row groups -> one sum per column of the tile
+            float* red = reinterpret_cast<float*>(smem);  // [16][256]
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                red[((tid & 255) >> 4) * BM + (tid < 256 ? 128 : 0) + (tid & 15) * 8 + e] = asum[e];
+            __syncthreads();
+            if (tid < BM && m0 + tid < M) {
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += red[r * BM + tid];
+                if (asum_ws) asum_ws[(long long)kslab * M + m0 + tid] = sum;
+                else asum_out[m0 + tid] = from_f32<T>(sum);
+            }
+            __syncthreads();
+        }
+    }
 
     // ---- epilogue: four 64-row passes of the accumulators through the fp32 staging buffer (all stages are free) ----
     float* cs = reinterpret_cast<float*>(smem);
@@ -387,14 +498,15 @@ void operand_bytes(long long M, long long N, long long K, long long lda, long lo
 }
 }  // namespace
 
-// What this kernel takes beyond gemm256.hip's own conditions (checked by the dispatcher in gemm.hip): operands
-// addressable with 32-bit byte offsets (per-lane offsets and the K offset of the buffer loads), no fused bias gradient.
+// What this kernel takes on top of the dispatcher's conditions (gemm.hip): K a multiple of 8 (partial last K-tile) and
+// operands below 2 GiB (32-bit per-lane offsets + K offset of the buffer loads).
 extern "C" int pk_gemm8p_eligible(long long M, long long N, long long K, long long lda, long long ldb, int a_col,
                                   int b_col, int want_asum) {
-    if (want_asum || K < BK || K % BK) return 0;
+    (void)want_asum;
+    if (K < 8 || K % 8) return 0;
     long long a_bytes, b_bytes;
     operand_bytes(M, N, K, lda, ldb, a_col, b_col, &a_bytes, &b_bytes);
-    const long long lim = 0xFFFFFFFFLL - 4096;
+    const long long lim = 0x7FFFFFFFLL - 65536;  // (2 GiB: an offset of 2^31 must be out of range without wrapping)
     return a_bytes <= lim && b_bytes <= lim;
 }
 

@@ -58,3 +58,72 @@ def test_gemm_dispatch_fuzz(F, seed):
         scale = max(1.0, float(np.sqrt(K)))  # entries are sums of K unit-variance products
         err = (got.double().cpu() - ref).abs().max().item()
         assert err <= tol * scale * 4, (what, err)
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_gemm8p_fuzz(F, seed):
+    """the phase-interleaved 256-tile kernel (csrc/gemm8p.hip) on every path it has: all four operand layouts, one /
+    odd / even numbers of K-tiles, a partial last K-tile (K % 8 == 0: zero-filled through the buffer range check for
+    col-form operands, masked per lane for row-form ones), split-K slabs, the fused bias gradient (col-form A), edge
+    tiles in M and N, padded leading dimensions with NaN in the pad, every fused epilogue — against fp64"""
+    from pasero_amd import lib
+    L = lib.load()
+    old = L.pk_gemm_use_8p(2)  # every eligible GEMM with M, N >= 256
+    try:
+        rs = np.random.RandomState(5000 + seed)
+        sizes_m = [256, 264, 500, 512, 776, 1024, 1288]
+        sizes_k = [64, 72, 128, 136, 192, 200, 320, 448, 512, 584, 1000, 1024, 2056]
+        for case in range(24):
+            dtype = [torch.bfloat16, torch.float16][rs.randint(2)]
+            M, N, K = int(rs.choice(sizes_m)), int(rs.choice(sizes_m)), int(rs.choice(sizes_k))
+            a_col, b_col = bool(rs.randint(2)), bool(rs.randint(2))
+            pad_a, pad_b = int(rs.choice([0, 8, 16])), int(rs.choice([0, 8]))
+            if a_col and M % 8:
+                pad_a = 8  # (col form needs 16-byte addressable rows)
+            a, a64 = _operand(rs, *((K, M) if a_col else (M, K)), pad_a, dtype)
+            b, b64 = _operand(rs, *((K, N) if b_col else (N, K)), pad_b, dtype)
+            splitk = int(rs.choice([1, 1, 2, 3])) if K >= 512 else 1
+            mode = int(rs.choice([0, 0, 1, 2])) if splitk == 1 else int(rs.choice([0, 1]))
+            act = ['none', 'relu'][rs.randint(2)]
+            bias = (torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(dtype)
+                    if (rs.randint(2) and mode != 2) else None)
+            aux = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32)).to(dtype) if mode else None
+            want_asum = a_col and bool(rs.randint(2))
+            asum = torch.full((M,), float('nan'), dtype=dtype, device='cuda') if want_asum else None
+            ref = (a64.t() if a_col else a64) @ (b64 if b_col else b64.t())
+            if mode == 2:
+                ref = ref * (aux.double() > 0) if act == 'relu' else ref
+            else:
+                if bias is not None:
+                    ref = ref + bias.double()
+                if act == 'relu':
+                    ref = ref.clamp(min=0)
+                if aux is not None:
+                    ref = ref + aux.double()
+            got = F.gemm(a, b, a_col=a_col, b_col=b_col, bias=None if bias is None else bias.cuda(), act=act,
+                         aux=None if aux is None else aux.cuda(), mode=mode, splitk=splitk, asum_out=asum)
+            what = (seed, case, str(dtype), M, N, K, a_col, b_col, pad_a, pad_b, splitk, mode, act, bias is not None,
+                    want_asum)
+            assert torch.isfinite(got.float()).all(), what
+            scale = max(1.0, float(np.sqrt(K)))
+            err = (got.double().cpu() - ref).abs().max().item()
+            assert err <= 8e-3 * scale * 4, (what, err)
+            if want_asum:
+                ref_sum = a64.sum(0)
+                err = (asum.double().cpu() - ref_sum).abs().max().item()
+                assert err <= 8e-3 * scale * 4, (what, 'asum', err)
+    finally:
+        L.pk_gemm_use_8p(old)
+
+
+def test_gemm8p_takes_the_vocabulary_dx_shapes(F):
+    """dX = dlogits . E with K = V = 8032 (not a multiple of 64) and V = 70376, row-form A, col-form B: on the
+    phase-interleaved kernel, exact against fp32 on a row sample"""
+    for M, N, K in [(8192, 512, 8032), (2048, 1024, 70376)]:
+        g = torch.Generator(device='cuda').manual_seed(K)
+        a = (torch.randn(M, K, device='cuda', generator=g) * 0.05).bfloat16()
+        e = torch.randn(K, N, device='cuda', generator=g).bfloat16()
+        got = F.gemm(a, e, b_col=True)
+        rows = torch.arange(0, M, 97, device='cuda')
+        ref = a[rows].float() @ e.float()
+        assert ((got[rows].float() - ref).abs().max() / ref.abs().max()).item() < 6e-3
