@@ -159,7 +159,11 @@ __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, T* _
         f32x8 f = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
         Vec16<T> o;
         o.raw = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename H16<T>::vec));
+#ifdef PK8P_PLAIN_STORES
+        store16<T>(C + gm * ep.ldc + gn, o);
+#else
         store16_nt<T>(C + gm * ep.ldc + gn, o);
+#endif
     }
 }
 
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
                                                        float* __restrict__ asum_ws, T* __restrict__ asum_out,
                                                        long long M, long long N, long long K, long long lda,
                                                        long long ldb, int kchunk, unsigned a_bytes, unsigned b_bytes,
-                                                       EpiParams ep) {
+                                                       int total, EpiParams ep) {
     typedef typename M16<T>::vec V;
     typedef __attribute__((address_space(3))) void lds_void;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -178,7 +182,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
     const int wr = wave >> 2, wc = wave & 3;
 
     const int nt_m = (int)((M + BM - 1) / BM), nt_n = (int)((N + BN - 1) / BN);
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);  // slab-major (K-slab, tile) walk: an XCD owns whole K-slabs
+    // persistent walk: workgroup b takes the virtual blocks b, b + G, b + 2G ... of the `total` (K-slab, tile) items
+    // (G = gridDim.x, a multiple of 8 or == total: blocks b and b + G then carry the same XCD label)
+    for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+    const int lin = xcd_remap(vb, total);  // slab-major (K-slab, tile) walk: an XCD owns whole K-slabs
     const int kslab = lin / (nt_m * nt_n);
     int t = lin % (nt_m * nt_n);
     const int GROUP_M = nt_n <= 2 ? 8 : 4;
@@ -481,8 +488,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
             if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 2>(cs, C, ep, mh, n0, M, N, tid);
             else epilogue_pass<T, PK_ACT_NONE, 2>(cs, C, ep, mh, n0, M, N, tid);
         }
-        if (p < 3) __syncthreads();
+        __syncthreads();  // (also in front of the next tile's DMA: the staging buffer overlays the stages)
     }
+    }  // persistent walk
 }
 
 }  // namespace
@@ -517,11 +525,14 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
     if (!pk_gemm8p_eligible(M, N, K, lda, ldb, a_col, b_col, asum_ws || asum_out)) return 0;
     long long a_bytes, b_bytes;
     operand_bytes(M, N, K, lda, ldb, a_col, b_col, &a_bytes, &b_bytes);
-    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN) * splitk)), block(512);
+    const int total = (int)(((M + BM - 1) / BM) * ((N + BN - 1) / BN) * splitk);
+    // PK8P_GRID (diagnostic): workgroups of the persistent walk; 0 = one per (K-slab, tile) item
+    static const int grid_cap = [] { const char* e = getenv("PK8P_GRID"); return e ? atoi(e) : 0; }();
+    dim3 grid((unsigned)((grid_cap > 0 && total > grid_cap) ? grid_cap : total)), block(512);
     hipStream_t s = (hipStream_t)stream;
 #define PK_K(TT, AC, BC)                                                                                          \
     hipLaunchKernelGGL((gemm8p_kernel<TT, AC, BC>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, ws,     \
-                       asum_ws, (TT*)asum_out, M, N, K, lda, ldb, kchunk, (unsigned)a_bytes, (unsigned)b_bytes, ep)
+                       asum_ws, (TT*)asum_out, M, N, K, lda, ldb, kchunk, (unsigned)a_bytes, (unsigned)b_bytes, total, ep)
 #define PK_L(AC, BC)                                          \
     do {                                                      \
         if (dtype == PK_F16) PK_K(f16, AC, BC);               \

@@ -115,8 +115,9 @@ _workspaces = {}
 
 
 def workspace(nbytes: int, device, tag: str = 'default') -> torch.Tensor:
-    """Grow-only per-(device, tag) scratch buffer; kernels on one stream use it in order, so sharing is safe."""
-    key = (str(device), tag)
+    """Grow-only per-(device, stream, tag) scratch buffer; kernels on one stream use it in order, so sharing is safe
+    (the weight-gradient GEMMs that run on a second stream get their own)."""
+    key = (str(device), tag, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

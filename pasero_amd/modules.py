@@ -14,6 +14,7 @@ import torch.nn as nn
 from torch import Tensor, LongTensor, BoolTensor
 
 from . import functional as F
+from .profiling import region as _bench_region
 from .autograd import (LinearFn, PackedLinearFn, AttentionFn, ResidualLayerNormFn, DropoutFn, EmbeddingFn,
                        ActivationFn, GLUFn, RotaryFn, ResidualLink)
 
@@ -150,62 +151,67 @@ def get_activation_fn(activation_fn: str = 'relu'):
     return Activation('relu')
 
 
+# adapter activation names (the reference builds nn.ReLU / nn.GELU(approximate='tanh') / Identity, modules.py:276-283)
+_ADAPTER_ACTS = {None: 'none', 'none': 'none', 'relu': 'relu', 'gelu': 'gelu_tanh'}
+
+
 class AdapterLayer(nn.Module):
-    """Bottleneck adapter (Bapna et al., 2019) / LoRA branch (modules.py:248-370), same constructor, parameter names
-    (`down`, `up`, `layer_norm`), initialisation, enable/disable and checkpoint-loading behaviour; the forward pass is
-    one fused autograd function (AdapterFn): LayerNorm -> down + activation -> up · scaling + residual."""
+    """Bottleneck adapter (Bapna et al., 2019) and, without LayerNorm / biases / activation / residual, a LoRA branch —
+    the checkpoint and fine-tuning contract of pasero/models/modules.py:248-370: sub-modules `layer_norm`, `down`,
+    `up` (parameter names), near-zero or LoRA-style initialisation, `enable()` / `disable()`, and at inference an
+    adapter missing from the checkpoint switches itself off for good while a different bottleneck size is adopted.
+    The forward pass is ONE fused autograd function (AdapterFn): LayerNorm -> down + activation -> up·scaling + residual."""
 
     def __init__(self, input_dim: int, projection_dim: int, output_dim: Optional[int] = None, zero_init: bool = False,
                  layer_norm: bool = True, bias: bool = True, residual: bool = True, activation_fn: str = 'relu',
                  scaling: float = 1.0):
         super().__init__()
-        self.input_dim = input_dim
-        self.output_dim = output_dim or input_dim
-        self.projection_dim = projection_dim
-        self.zero_init = zero_init
-        self.has_layer_norm = layer_norm
-        self.bias = bias
-        self.residual = residual
-        assert not self.residual or self.output_dim == self.input_dim
-        if activation_fn is None or activation_fn == 'none':
-            self.act_name = 'none'
-        elif activation_fn == 'relu':
-            self.act_name = 'relu'
-        elif activation_fn == 'gelu':
-            self.act_name = 'gelu_tanh'  # the reference uses nn.GELU(approximate='tanh') here
-        else:
-            raise NotImplementedError
-        self.down = None
-        self.scaling = scaling
-        self._init()
+        if activation_fn not in _ADAPTER_ACTS:
+            raise NotImplementedError(f'adapter activation {activation_fn!r}')
+        out_dim = output_dim or input_dim
+        if residual and out_dim != input_dim:
+            raise AssertionError('a residual adapter keeps the width of its input')
+        self.input_dim, self.projection_dim, self.output_dim = input_dim, projection_dim, out_dim
+        self.zero_init, self.has_layer_norm, self.bias, self.residual = zero_init, layer_norm, bias, residual
+        self.act_name, self.scaling = _ADAPTER_ACTS[activation_fn], scaling
+        self.disabled = False
+        self.layer_norm = self.down = self.up = None
+        self._build(device=None, dtype=None)
 
     @classmethod
     def LoRA(cls, input_dim: int, projection_dim: int, output_dim: int, lora_alpha: int) -> 'AdapterLayer':
-        return cls(input_dim, projection_dim, output_dim, layer_norm=False, bias=False, residual=False,
-                   activation_fn=None, zero_init=True, scaling=lora_alpha / projection_dim)
+        """the low-rank branch of `Linear` (modules.py:288-301): x -> up(down(x)) * alpha / rank, starts at zero"""
+        return cls(input_dim, projection_dim, output_dim, zero_init=True, layer_norm=False, bias=False,
+                   residual=False, activation_fn=None, scaling=lora_alpha / projection_dim)
 
-    def _init(self) -> None:
-        self.disabled = False
-        device = None if self.down is None else self.down.weight.device
-        dtype = None if self.down is None else self.down.weight.dtype
-        self.down = nn.Linear(self.input_dim, self.projection_dim, bias=self.bias, device=device, dtype=dtype)
-        self.up = nn.Linear(self.projection_dim, self.output_dim, bias=self.bias, device=device, dtype=dtype)
-        self.layer_norm = (nn.LayerNorm(self.input_dim, device=device, dtype=dtype) if self.has_layer_norm
-                           else Identity())
+    def _build(self, device, dtype) -> None:
+        """(re)create the three sub-modules for the current bottleneck size and draw their initial values"""
+        kw = dict(device=device, dtype=dtype)
+        self.down = nn.Linear(self.input_dim, self.projection_dim, bias=self.bias, **kw)
+        self.up = nn.Linear(self.projection_dim, self.output_dim, bias=self.bias, **kw)
+        self.layer_norm = nn.LayerNorm(self.input_dim, **kw) if self.has_layer_norm else Identity()
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self) -> None:
+        """zero_init: LoRA's start (down ~ kaiming-uniform, up = 0: the branch is exactly zero); otherwise both
+        projections within 1e-6 of zero, so a fresh adapter is (almost) the identity; biases zero (modules.py:310-325)"""
         if self.zero_init:
             nn.init.kaiming_uniform_(self.down.weight, a=math.sqrt(5))
-            nn.init.zeros_(self.up.weight)
+            self.up.weight.zero_()
         else:
-            delta = 1e-6
-            nn.init.uniform_(self.down.weight, -delta, delta)
-            nn.init.uniform_(self.up.weight, -delta, delta)
+            for lin in (self.down, self.up):
+                lin.weight.uniform_(-1e-6, 1e-6)
         if self.bias:
-            nn.init.zeros_(self.down.bias)
-            nn.init.zeros_(self.up.bias)
+            self.down.bias.zero_()
+            self.up.bias.zero_()
+
+    @property
+    def permanently_disabled(self) -> bool:
+        return self.down is None
 
     def enable(self) -> None:
-        if self.down is not None:  # not permanently disabled
-            self.disabled = False
+        self.disabled = self.permanently_disabled
 
     def disable(self) -> None:
         self.disabled = True
@@ -215,22 +221,25 @@ class AdapterLayer(nn.Module):
         if self.disabled:
             return x if residual is None else residual
         from .autograd import AdapterFn
-        ln = self.layer_norm if self.has_layer_norm else None
-        res = residual if residual is not None else (x if self.residual else None)
-        return AdapterFn.apply(x, res, None if ln is None else ln.weight, None if ln is None else ln.bias,
-                               1e-5 if ln is None else ln.eps, self.down.weight, self.down.bias, self.up.weight,
+        norm = self.layer_norm if self.has_layer_norm else None
+        if residual is None and self.residual:
+            residual = x
+        return AdapterFn.apply(x, residual, getattr(norm, 'weight', None), getattr(norm, 'bias', None),
+                               getattr(norm, 'eps', 1e-5), self.down.weight, self.down.bias, self.up.weight,
                                self.up.bias, self.act_name, float(self.scaling))
 
     def _load_from_state_dict(self, state_dict, prefix: str, *args, **kwargs) -> None:
-        # inference: adapters missing from the checkpoint are disabled, bottleneck sizes follow the checkpoint
-        if not self.training and prefix + 'down.weight' not in state_dict:
-            self.disable()
-            self.up = self.down = self.layer_norm = None
-        elif not self.training:
-            projection_dim = state_dict[prefix + 'down.weight'].size(0)
-            if projection_dim != self.projection_dim:
-                self.projection_dim = projection_dim
-                self._init()
+        """inference-time conveniences of the reference loader (modules.py:349-370); training loads strictly"""
+        if not self.training:
+            saved = state_dict.get(prefix + 'down.weight')
+            if saved is None:  # the checkpoint has no such adapter: it stays off
+                self.disabled = True
+                self.layer_norm = self.down = self.up = None
+            elif saved.size(0) != self.projection_dim:  # another bottleneck size: follow the checkpoint
+                like = self.down.weight
+                self.projection_dim = saved.size(0)
+                self._build(device=like.device, dtype=like.dtype)
+                self.disabled = False
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
 
@@ -523,6 +532,7 @@ class MultiheadAttention(nn.Module):
             self._pack()
         return self._w_flat, self._b_flat
 
+    @_bench_region('attention')
     def forward(self, query: Tensor, key: Tensor, value: Tensor, attn_mask: Optional[BoolTensor] = None,
                 state: Optional[dict] = None, return_attn: bool = False):
         """

@@ -20,6 +20,7 @@ import torch.nn as nn
 from torch import Tensor, LongTensor, BoolTensor
 
 from . import modules
+from .profiling import block as _bench_block, region as _bench_region
 from .modules import Embedding, Identity
 from .autograd import (FFNFn, GatedFFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn,
                        AddPositionsFn, LinearFn, ResidualLink)
@@ -183,13 +184,16 @@ class Transformer(EncoderDecoder):
         loss, nll, ntok = sums.tolist()  # the ONE host sync of the step (reference: 3x .item(), :375-377)
         return {'loss': loss / LN2, 'nll_loss': nll / LN2, 'num_tokens': int(ntok), 'num_lines': batch_size}
 
+    @_bench_region('loss')
     def compute_loss_fused(self, features: Tensor, target: LongTensor):
-        """tied projection + label-smoothed CE without materialising the logits (:324-380 + modules.py:935-947)"""
+        """tied projection + label-smoothed CE without materialising the logits (:324-380 + modules.py:935-947); in the
+        `--benchmark` log the reference's 'output_projection' and 'loss' entries are both inside this one 'loss'"""
         dec = self.decoder
         weight = dec.embed_tokens.weight if dec.output_projection is None else dec.output_projection.weight
         sums = VocabCrossEntropyFn.apply(features, weight, target, self.padding_idx, self.cfg.label_smoothing or 0.0)
         return sums[0], self._logs(sums.detach(), target.size(0))
 
+    @_bench_region('loss')
     def compute_loss(self, logits: Tensor, target: LongTensor, layer_outputs: dict, *args, **kwargs):
         """:324-380 on materialised logits (API-compatible entry point; subclasses may override it)"""
         sums = CrossEntropyFn.apply(logits, target, self.padding_idx, self.cfg.label_smoothing or 0.0)
@@ -339,6 +343,7 @@ class TransformerEncoder(Encoder):
         layer = TransformerEncoderLayer(self.cfg, self.dist_cfg, layer_id)
         return modules.checkpoint_wrapper(layer, activate=self.cfg.checkpoint_activations)
 
+    @_bench_region('encoder')
     def forward(self, encoder_input: Tensor, encoder_input_length: LongTensor, return_layers=[], meta: dict = {},
                 **kwargs):
         """:698-752 -> (encoder_out (B,S,D), padding_mask (B,S) bool, layer_outputs)"""
@@ -403,6 +408,7 @@ class TransformerDecoder(Decoder):
         layer = TransformerDecoderLayer(self.cfg, self.dist_cfg, layer_id)
         return modules.checkpoint_wrapper(layer, activate=self.cfg.checkpoint_activations)
 
+    @_bench_region('decoder')
     def forward(self, encoder_out: Tensor, encoder_mask: BoolTensor, decoder_input: LongTensor,
                 prompt_mask: Optional[Tensor] = None, state: Optional[dict] = None, return_layers=[],
                 meta: dict = {}, project: bool = True, **kwargs):
@@ -434,10 +440,11 @@ class TransformerDecoder(Decoder):
         x = self.layer_norm(x)
         if not project:
             return x, layer_outputs
-        if self.output_projection is None:
-            x = self.embed_tokens.projection(x)
-        else:
-            x = self.output_projection(x)
+        with _bench_block('output_projection'):
+            if self.output_projection is None:
+                x = self.embed_tokens.projection(x)
+            else:
+                x = self.output_projection(x)
         return x, layer_outputs
 
 

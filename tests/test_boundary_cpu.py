@@ -63,3 +63,37 @@ def test_class_surface():
         assert hasattr(T.TransformerDecoderLayer, hook)
     with pytest.raises(NotImplementedError):
         M.set_tp_group(object())
+
+
+def test_benchmark_names_of_the_reference_are_kept():
+    """`pasero-train --benchmark` (cli/train.py:109-110) logs <name>_wall / _mem for the blocks the reference wraps in
+    `utils.benchmark(name)`: 'attention' (modules.py:578), 'loss' (transformer.py:323), 'encoder' / 'decoder'
+    (transformer.py:697,830), 'output_projection' (transformer.py:892).  The mirror classes carry the same names on the
+    same methods; stand-alone, the object has the reference's surface and metric names."""
+    import inspect
+    from pasero_amd import modules, profiling, transformer
+    wrapped = {'attention': modules.MultiheadAttention.forward, 'encoder': transformer.TransformerEncoder.forward,
+               'decoder': transformer.TransformerDecoder.forward, 'loss': transformer.Transformer.compute_loss}
+    for name, fn in wrapped.items():
+        assert hasattr(fn, '__wrapped__'), name
+        src = inspect.getsource(fn)
+        assert f"_bench_region('{name}')" in src, name
+    assert "_bench_block('output_projection')" in inspect.getsource(transformer.TransformerDecoder.forward)
+    b = profiling.Benchmark(use_cuda=False, enabled=True)
+    with b('forward'):
+        with b('forward'):  # a nested block of the same name counts once
+            pass
+    with b.pause():
+        with b('skipped'):
+            pass
+    m = b.metrics
+    assert set(m) == {'forward_wall'} and m['forward_wall'] >= 0
+    for attr in ('enable', 'disable', 'pause', 'reset', 'cpu', 'metrics'):
+        assert hasattr(profiling.benchmark, attr)
+    calls = []
+
+    @profiling.region('x')
+    def f(a):
+        calls.append(a)
+        return a + 1
+    assert f(1) == 2 and calls == [1]  # disabled: a plain call
