@@ -118,8 +118,11 @@ int pk_attn_probs(const void* q, const void* k, void* probs, const unsigned char
 int pk_embed_fwd(const long long* ids, const void* E, const void* pos, void* out, long long ntok, int Tlen, int d,
                  long long V, float scale, int pos_start, float drop_p, unsigned long long seed,
                  unsigned long long offset, int dtype, void* stream);
-/*   dE[V,d] = scatter-add over tokens of dout * keep/(1-p) * scale, row pad_idx excluded (nn.Embedding padding_idx);
- *   bf16: accumulated in fp32 in `workspace` (>= V*d*4 bytes) and rounded once */
+/*   dE[V,d] = sum over tokens of dout * keep/(1-p) * scale into row ids[tok]; row pad_idx (nn.Embedding padding_idx) and
+ *   rows without tokens are zero.  Deterministic: the token positions are radix-sorted by id (stable) and every row is
+ *   summed in that fixed order in fp32, rounded once — no float atomics.  `workspace`: pk_embed_bwd_workspace(ntok, V)
+ *   bytes.  d % 8 == 0, d <= 4096. */
+size_t pk_embed_bwd_workspace(long long ntok, long long V);
 int pk_embed_bwd(const long long* ids, const void* dout, void* dE, void* workspace, size_t ws_bytes, long long ntok,
                  int d, long long V, long long pad_idx, float scale, float drop_p, unsigned long long seed,
                  unsigned long long offset, int dtype, void* stream);

@@ -49,37 +49,6 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
     }
 }
 
-// dE32[id] += dout * keep * drop_scale * scale  (fp32 atomics: one 256-byte wave-instruction per 64 floats of a row)
-template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ ids, const T* __restrict__ dout,
-                                                        float* __restrict__ dE32, long long ntok, int d, long long V,
-                                                        long long pad_idx, float scale, unsigned thr,
-                                                        float drop_scale, unsigned long long seed,
-                                                        unsigned long long offset) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (long long tok = (long long)blockIdx.x * 4 + wave; tok < ntok; tok += (long long)gridDim.x * 4) {
-        long long id = ids[tok];
-        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-        if (id == pad_idx) continue;  // nn.Embedding(padding_idx): that row never receives gradient
-        float* grow = dE32 + id * d;
-        for (int c = lane; c < d; c += 64) {
-            long long off = tok * d + c;
-            float g = to_f32<T>(dout[off]) * scale;
-            if (thr) {
-                Philox4 r = philox4x32_10(seed, offset, (unsigned long long)off >> 2);
-                unsigned rv = (off & 3) == 0 ? r.x : (off & 3) == 1 ? r.y : (off & 3) == 2 ? r.z : r.w;
-                g = rv >= thr ? g * drop_scale : 0.f;
-            }
-            atomicAdd(grow + c, g);
-        }
-    }
-}
-
-template <typename T> __global__ void f32_to_T_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        dst[i] = from_f32<T>(src[i]);
-}
-
 // ------------------------------------------------------------------------------------------------------
 // label-smoothed cross entropy: one workgroup per row
 // ------------------------------------------------------------------------------------------------------
@@ -338,40 +307,7 @@ extern "C" int pk_embed_fwd(const long long* ids, const void* E, const void* pos
     return 0;
 }
 
-// dE (dtype) = scatter-add of dout rows; `workspace` >= V*d*4 bytes (fp32 accumulation buffer, zeroed here)
-extern "C" int pk_embed_bwd(const long long* ids, const void* dout, void* dE, void* workspace, size_t ws_bytes,
-                            long long ntok, int d, long long V, long long pad_idx, float scale, float drop_p,
-                            unsigned long long seed, unsigned long long offset, int dtype, void* stream) {
-    PK_CHECK_ARG(ids && dout && dE, "pk_embed_bwd: null tensor");
-    hipStream_t s = (hipStream_t)stream;
-    unsigned thr = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
-    float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    float* acc;
-    if (dtype == PK_F32) {
-        acc = (float*)dE;
-    } else {
-        PK_CHECK_ARG(workspace && ws_bytes >= (size_t)V * d * 4, "pk_embed_bwd: workspace too small");
-        acc = (float*)workspace;
-    }
-    hipError_t e = hipMemsetAsync(acc, 0, (size_t)V * d * 4, s);
-    if (e != hipSuccess) { pk_set_error("pk_embed_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
-    if (ntok > 0) {
-        PK_DTYPE_SWITCH(dtype, "pk_embed_bwd", {
-            hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3(grid_for(ntok, 4)), dim3(256), 0, s, ids, (const T*)dout,
-                               acc, ntok, d, V, pad_idx, scale, thr, ds, seed, offset);
-        })
-        PK_LAUNCH_CHECK();
-    }
-    if (dtype == PK_BF16) {
-        hipLaunchKernelGGL((f32_to_T_kernel<bf16>), dim3(grid_for(V * d, 1024)), dim3(256), 0, s, acc, (bf16*)dE,
-                           V * d);
-        PK_LAUNCH_CHECK();
-    } else if (dtype == PK_F16) {
-        hipLaunchKernelGGL((f32_to_T_kernel<f16>), dim3(grid_for(V * d, 1024)), dim3(256), 0, s, acc, (f16*)dE, V * d);
-        PK_LAUNCH_CHECK();
-    }
-    return 0;
-}
+// (pk_embed_bwd: embed_bwd.hip)
 
 // Label-smoothed CE of `rows` logit rows.  row_loss/row_nll [rows] fp32 outputs (0 for pad rows); row_lse optional;
 // dlogits optional (may alias logits): d(loss_sum)/dlogits.

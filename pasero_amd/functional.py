@@ -244,10 +244,8 @@ def embed_bwd(ids: Tensor, dout: Tensor, V: int, pad_idx: int, scale: float, dro
     assert dout.is_contiguous() and ids.is_contiguous() and ids.dtype == torch.int64
     assert dout.numel() == ids.numel() * d
     dE = torch.empty(V, d, dtype=dout.dtype, device=dout.device)
-    ws, ws_bytes = None, 0
-    if dout.dtype != torch.float32:
-        ws_bytes = V * d * 4
-        ws = lib.workspace(ws_bytes, dout.device, 'embed')
+    ws_bytes = lib.load().pk_embed_bwd_workspace(ids.numel(), V)
+    ws = lib.workspace(ws_bytes, dout.device, 'embed')
     L = lib.load()
     check(L.pk_embed_bwd(ptr(ids), ptr(dout), ptr(dE), ptr(ws), ws_bytes, ids.numel(), d, V, int(pad_idx),
                          float(scale), float(drop_p), int(seed), int(offset), dtype_code(dout), stream_ptr()),

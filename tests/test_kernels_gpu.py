@@ -471,6 +471,35 @@ def test_embedding_fwd_bwd(F, dtype):
         assert torch.equal((dE_u[:B * T] != 0) & nz, fw_kept & nz)
 
 
+@pytest.mark.parametrize('dtype,V,d,ntok', [(torch.bfloat16, 8032, 512, 32768), (torch.float32, 1000, 1024, 3000),
+                                            (torch.bfloat16, 70376, 2048, 5000), (torch.float16, 300, 136, 777)])
+def test_embedding_backward_is_deterministic_and_exact(F, dtype, V, d, ntok):
+    """the gradient of the lookup is a fixed-order sum per vocabulary row (stable sort of the token positions by id, no
+    float atomics): two runs are bitwise equal, heavy rows (one id on a quarter of the tokens, like EOS / a language
+    tag) and a pad id included, and the values match an fp32 index_add; widths of 1, 2 and 4 column blocks"""
+    g = torch.Generator().manual_seed(V + d)
+    ids = torch.randint(0, V, (ntok,), generator=g)
+    ids[torch.rand(ntok, generator=g) < 0.25] = 2      # a heavy hitter
+    ids[torch.rand(ntok, generator=g) < 0.05] = 1      # padding positions
+    ids[:3] = torch.tensor([-5, V + 7, V - 1])         # out-of-range ids clamp like the forward kernel
+    dout = (torch.randn(ntok, d, generator=g) * 0.5).to(dtype)
+    runs = [F.embed_bwd(ids.cuda(), dout.cuda(), V, 1, 1.5, drop_p=0.1, seed=3, offset=9) for _ in range(3)]
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    dE = F.embed_bwd(ids.cuda(), dout.cuda(), V, 1, 1.5)
+    ref = torch.zeros(V, d, dtype=torch.float64)
+    keep = ids != 1
+    ref.index_add_(0, ids.clamp(0, V - 1)[keep], dout.double()[keep] * 1.5)
+    ref[1] = 0
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    assert rel_err(dE, ref.float()) < tol
+    assert dE[1].abs().max().item() == 0
+    untouched = torch.ones(V, dtype=torch.bool)
+    untouched[ids.clamp(0, V - 1)] = False
+    assert dE[untouched.cuda()].abs().max().item() == 0 if untouched.any() else True
+    empty = F.embed_bwd(ids[:0].cuda(), dout[:0].cuda(), V, 1, 1.0)
+    assert empty.shape == (V, d) and empty.abs().max().item() == 0
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('eps', [0.0, 0.1])
 @pytest.mark.parametrize('V', [8032, 101, 70376])
