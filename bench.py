@@ -256,7 +256,7 @@ def rehearse_cpu(args, rank: int, world: int):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     if rank == 0:
-        print(json.dumps({'metric': 'target tokens/sec (fwd+bwd), Transformer-base d=512', 'value': tokens / elapsed,
+        _JSON_LINE.append(json.dumps({'metric': 'target tokens/sec (fwd+bwd), Transformer-base d=512', 'value': tokens / elapsed,
                           'unit': 'target tokens/s', 'n_gpus': world, 'rccl_ranks': world, 'steps': args.steps,
                           'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
                           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -268,12 +268,31 @@ def rehearse_cpu(args, rank: int, world: int):
         dist.destroy_process_group()
 
 
+_JSON_LINE = []
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args))  # (before the redirect below: the children inherit the real stdout)
+    # rank 0's stdout carries ONE line, the JSON: whatever native libraries print there while the run is set up (RCCL's
+    # version banner at communicator creation, for one) goes to stderr instead; the descriptor is restored for the line
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        run(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        os.close(json_fd)
+        if _JSON_LINE:
+            print(_JSON_LINE[0], flush=True)
+
+
+def run(args):
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        raise SystemExit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
@@ -372,6 +391,8 @@ def main():
             'config': {'workload': f'{args.workload}: {cfg_name} V={V}, per-GPU batch (B,S,T)=({B},{S},{T}), '
                                    f'dropout {cfg.dropout}, label smoothing {cfg.label_smoothing}, full-length rows',
                        'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}',
+                       'gradient_all_reduce': (getattr(getattr(ddp, '_native', None), 'report', None)
+                                               or ('torch.distributed' if world > 1 else None)),
                        'step': 'forward + backward' + (' + bucketed RCCL all-reduce + fused logs all-reduce' if world > 1 else ''),
                        'algorithmic_tflop_per_step_per_gpu': step_flops / 1e12,
                        'model_tflops_per_gpu': step_flops * args.steps / elapsed / 1e12,
@@ -391,7 +412,7 @@ def main():
                                                         'sampled_launches': v['launches']} for k, v in summ.items()}}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
-        print(json.dumps(out))
+        _JSON_LINE.append(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -202,6 +202,22 @@ int pk_mt_adam(const long long* table, int ntensors, const int* chunk_tensor, co
 int pk_mt_copy(const long long* table, int ntensors, const int* chunk_tensor, const long long* chunk_start, int nchunks,
                int dtype, void* stream);
 
+/* ---- Data-parallel gradient all-reduce over RCCL's C API (replaces the collective inside torch DDP's
+ * reducer, pasero/training.py:243-250).  The RCCL symbols come from the library the process already loaded
+ * (pk_comm_open: dlopen of PyTorch-ROCm's librccl), one communicator per process:
+ *   pk_comm_unique_id   rank 0 draws the id (128 bytes) and the host side broadcasts it;
+ *   pk_comm_init        every rank, collectively, on its current device;
+ *   pk_comm_all_reduce_mean  buf <- mean over ranks, in place, on `stream`; schedule 0 = ncclAllReduce(avg),
+ *                       1 = ncclReduceScatter(avg) + ncclAllGather, 2 = direct: grouped send/recv of the shards over all
+ *                       xGMI links at once, a fixed-order fp32 sum of the n copies, grouped send/recv of the result
+ *                       (needs `scratch` of `count` elements).  Schedules 1, 2: count % (8 * nranks) == 0. */
+int pk_comm_open(const char* librccl_path);
+int pk_comm_unique_id(void* out, int nbytes);
+int pk_comm_init(const void* id_bytes, int nranks, int rank);
+int pk_comm_destroy(void);
+int pk_comm_size(void);
+int pk_comm_all_reduce_mean(void* buf, long long count, int dtype, int schedule, void* scratch, void* stream);
+
 /* gated activation backward (SwiGLU / GEGLU FFN, transformer.py:1013-1016): h = act(z) * u
  *   dz = dh * u * act'(z)      du = dh * act(z) */
 int pk_gated_act_bwd(const void* dh, const void* z, const void* u, void* dz, void* du, long long n, int act, int dtype,

@@ -24,7 +24,11 @@ Design for 8 x MI355X over xGMI (RCCL):
   * `no_sync()` skips the reduction for gradient accumulation (training.py:392-408): only the last micro-batch reduces.
 Semantics follow torch DDP: gradients are AVERAGED over ranks, so `Trainer.train_step`'s `grad *= dp_size/num_tokens`
 normalisation (training.py:455-477) stays unchanged.
-Works with any torch.distributed backend ('nccl' = RCCL on ROCm; 'gloo' on CPU for the tests).
+Works with any torch.distributed backend ('nccl' = RCCL on ROCm; 'gloo' on CPU for the tests).  On the GPU with the
+'nccl' backend the bucket collectives do not go through torch.distributed at all: `RcclComm` below drives RCCL's C API
+from the library's own native entry points (csrc/comm.hip) on the communication stream, with the schedule — RCCL's
+all-reduce, reduce-scatter + all-gather, or the direct grouped send/recv exchange over all xGMI links — that it
+measured fastest on the actual set of GPUs at construction, after checking each against torch.distributed's result.
 """
 import contextlib
 import os
@@ -36,10 +40,104 @@ import torch.nn as nn
 from torch.autograd import Variable
 
 
+class RcclComm:
+    """One RCCL communicator per process, created through the C ABI (pk_comm_*): rank 0 draws the unique id, the default
+    torch.distributed group carries it to the other ranks (the only use of torch.distributed on this path), every rank
+    joins.  `choose_schedule` then runs every schedule of `pk_comm_all_reduce_mean` on random data, requires each to
+    agree with `dist.all_reduce(AVG)`, times it, and all ranks adopt the fastest correct one (None: stay on
+    torch.distributed).  PASERO_DDP_RCCL=0 disables the native path, PASERO_DDP_SCHEDULE=0|1|2 pins a schedule."""
+    SCHEDULES = {0: 'ncclAllReduce', 1: 'ncclReduceScatter + ncclAllGather', 2: 'direct grouped send/recv'}
+    _instance = None
+
+    @classmethod
+    def get(cls, group, device):
+        if cls._instance is None:
+            cls._instance = cls(group, device)
+        return cls._instance if cls._instance.schedule is not None else None
+
+    def __init__(self, group, device):
+        import ctypes
+        from . import lib
+        self.lib, self.check = lib.load(), lib.check
+        self.device, self.group = device, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.schedule, self.report = None, {}
+        self._scratch = None
+        try:
+            path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+            self.check(self.lib.pk_comm_open(path.encode()), 'pk_comm_open')
+            if self.lib.pk_comm_size() == 0:
+                buf = ctypes.create_string_buffer(128)
+                if self.rank == 0:
+                    self.check(self.lib.pk_comm_unique_id(buf, 128), 'pk_comm_unique_id')
+                t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=device)
+                dist.broadcast(t, dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                ident = bytes(t.cpu().tolist())
+                with torch.cuda.device(device):
+                    self.check(self.lib.pk_comm_init(ident, self.world, self.rank), 'pk_comm_init')
+            self.choose_schedule()
+        except Exception as e:  # any failure: the reducer keeps using torch.distributed
+            self.schedule = None
+            self.report['error'] = repr(e)
+
+    def all_reduce_mean(self, flat: torch.Tensor, schedule: Optional[int] = None) -> None:
+        """flat <- mean over ranks, in place, on the current stream"""
+        from .lib import dtype_code, ptr, stream_ptr
+        sched = self.schedule if schedule is None else schedule
+        scratch = None
+        if sched == 2 and self.world > 1:
+            nbytes = flat.numel() * flat.element_size()
+            if self._scratch is None or self._scratch.numel() < nbytes:
+                self._scratch = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
+            scratch = self._scratch
+        self.check(self.lib.pk_comm_all_reduce_mean(ptr(flat), flat.numel(), dtype_code(flat), int(sched), ptr(scratch),
+                                                    stream_ptr()), 'pk_comm_all_reduce_mean')
+
+    def choose_schedule(self, numel: int = 1 << 22) -> None:
+        pinned = os.environ.get('PASERO_DDP_SCHEDULE')
+        numel = (numel // (8 * self.world)) * 8 * self.world
+        g = torch.Generator(device=self.device).manual_seed(1234 + self.rank)
+        x = torch.randn(numel, generator=g, device=self.device).to(torch.bfloat16)
+        ref = x.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.AVG, group=self.group)
+        tol = 2.0 ** -6 * ref.float().abs().max().item()
+        ok, ms = [], []
+        for sched in (0, 1, 2):
+            try:
+                y = x.clone()
+                self.all_reduce_mean(y, sched)
+                good = bool(((y.float() - ref.float()).abs().max() <= tol).item())
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                for _ in range(3):
+                    self.all_reduce_mean(y, sched)
+                ev1.record()
+                ev1.synchronize()
+                ok.append(1.0 if good else 0.0)
+                ms.append(ev0.elapsed_time(ev1) / 3)
+            except Exception:
+                ok.append(0.0)
+                ms.append(float('inf'))
+        stats = torch.tensor(ok + [-m if m != float('inf') else -1e9 for m in ms], dtype=torch.float64, device=self.device)
+        dist.all_reduce(stats, op=dist.ReduceOp.MIN, group=self.group)  # valid on EVERY rank; slowest rank's time
+        ok = stats[:3].tolist()
+        ms = [-v for v in stats[3:].tolist()]
+        self.report.update({'ms_per_all_reduce_of_%d_MiB' % (numel * 2 >> 20): dict(zip(self.SCHEDULES.values(), ms)),
+                            'correct': dict(zip(self.SCHEDULES.values(), [bool(v) for v in ok]))})
+        valid = [i for i in (0, 1, 2) if ok[i] > 0]
+        if pinned is not None and int(pinned) in valid:
+            self.schedule = int(pinned)
+        elif valid:
+            self.schedule = min(valid, key=lambda i: ms[i])
+        else:
+            self.schedule = None
+        self.report['schedule'] = None if self.schedule is None else self.SCHEDULES[self.schedule]
+
+
 class _Bucket:
     __slots__ = ('params', 'offsets', 'flat', 'pending', 'ready', 'launched', 'work', 'dtype', 'numel', 'plan')
 
-    def __init__(self, params: List[nn.Parameter]):
+    def __init__(self, params: List[nn.Parameter], multiple: int = 8):
         self.params = params
         self.dtype = params[0].dtype
         self.offsets = []
@@ -47,6 +145,7 @@ class _Bucket:
         for p in params:
             self.offsets.append(n)
             n += (p.numel() + 7) // 8 * 8  # keep every slice 16-byte aligned for the kernels that read the grads
+        n = (n + multiple - 1) // multiple * multiple  # whole 16-byte chunks per rank shard (reduce-scatter schedules)
         self.numel = n
         self.flat = torch.zeros(n, dtype=self.dtype, device=params[0].device)
         self.pending = 0
@@ -81,6 +180,10 @@ class DistributedDataParallel(nn.Module):
         self._comm_stream = torch.cuda.Stream() if self._is_cuda else None
         self._buckets: List[_Bucket] = []
         self._where = {}
+        self._native: Optional[RcclComm] = None
+        if (self._reduce_enabled and self._is_cuda and dist.get_backend(process_group) == 'nccl'
+                and os.environ.get('PASERO_DDP_RCCL', '1') != '0'):
+            self._native = RcclComm.get(process_group, self._params[0].device)
         self._build_buckets(int(bucket_cap_mb * (1 << 20)))
         self._callback_queued = False
         self._next = 0  # first bucket not launched yet
@@ -94,12 +197,12 @@ class DistributedDataParallel(nn.Module):
         for p in reversed(self._params):
             nbytes = p.numel() * p.element_size()
             if cur and (cur_bytes + nbytes > cap_bytes or p.dtype != cur[0].dtype):
-                self._buckets.append(_Bucket(cur))
+                self._buckets.append(_Bucket(cur, 8 * self.world_size))
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
         if cur:
-            self._buckets.append(_Bucket(cur))
+            self._buckets.append(_Bucket(cur, 8 * self.world_size))
         for bi, b in enumerate(self._buckets):
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
@@ -205,6 +308,10 @@ class DistributedDataParallel(nn.Module):
             self._all_reduce_avg(b)
 
     def _all_reduce_avg(self, b: _Bucket) -> None:
+        if self._native is not None:  # RCCL's C API on the communication stream; stream order is the completion handle
+            self._native.all_reduce_mean(b.flat)
+            b.work = None
+            return
         backend = dist.get_backend(self.process_group)
         if backend == 'nccl':  # RCCL averages in the collective: no extra pass over the bucket
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.process_group, async_op=True)

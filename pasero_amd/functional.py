@@ -421,27 +421,36 @@ def argmax_rows(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
 
 
 def mt_copy_plan(numels, device):
-    """chunk list (device tensors) of a multi-tensor copy over tensors of `numels` elements (pk_mt_copy)"""
+    """chunk list (device tensors) of a multi-tensor copy over tensors of `numels` elements (pk_mt_copy), plus the
+    pointer table's home: a device tensor and two pinned host buffers that alternate between calls (the upload is an
+    asynchronous copy on the launch stream; no allocation and no host synchronisation per call)"""
     chunk = lib.load().pk_mt_chunk_size()
     ct, cs = [], []
     for i, n in enumerate(numels):
         for start in range(0, n, chunk):
             ct.append(i)
             cs.append(start)
-    return (torch.tensor(ct, dtype=torch.int32, device=device), torch.tensor(cs, dtype=torch.int64, device=device),
-            list(numels))
+    n = len(numels)
+    table = torch.empty(3 * n, dtype=torch.int64, device=device)
+    pinned = [torch.empty(3 * n, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+    for buf in pinned:
+        buf[2 * n:] = torch.tensor(list(numels), dtype=torch.int64)
+    return {'ct': torch.tensor(ct, dtype=torch.int32, device=device), 'cs': torch.tensor(cs, dtype=torch.int64, device=device),
+            'numels': list(numels), 'table': table, 'pinned': pinned, 'turn': 0}
 
 
 def mt_copy(srcs, dsts, plan) -> None:
     """dsts[i] <- srcs[i] for every pair, in one launch (the gradient pack of a data-parallel bucket, ddp.py)"""
-    ct, cs, numels = plan
     if not srcs:
         return
     require_gpu(*srcs, *dsts)
-    for s, d, n in zip(srcs, dsts, numels):
-        assert s.dtype == dsts[0].dtype and d.dtype == dsts[0].dtype and s.numel() == n and d.numel() == n
+    numels, n = plan['numels'], len(srcs)
+    for s, d, k in zip(srcs, dsts, numels):
+        assert s.dtype == dsts[0].dtype and d.dtype == dsts[0].dtype and s.numel() == k and d.numel() == k
         assert s.is_contiguous() and d.is_contiguous()
-    table = torch.tensor([s.data_ptr() for s in srcs] + [d.data_ptr() for d in dsts] + numels,
-                         dtype=torch.int64).to(dsts[0].device, non_blocking=True)
-    check(lib.load().pk_mt_copy(ptr(table), len(srcs), ptr(ct), ptr(cs), ct.numel(), dtype_code(dsts[0]),
-                                stream_ptr()), 'pk_mt_copy')
+    plan['turn'] ^= 1
+    host = plan['pinned'][plan['turn']]
+    host.numpy()[:2 * n] = [s.data_ptr() for s in srcs] + [d.data_ptr() for d in dsts]
+    plan['table'].copy_(host, non_blocking=True)
+    check(lib.load().pk_mt_copy(ptr(plan['table']), n, ptr(plan['ct']), ptr(plan['cs']), plan['ct'].numel(),
+                                dtype_code(dsts[0]), stream_ptr()), 'pk_mt_copy')

@@ -56,6 +56,12 @@ SIGNATURES = {
     'pk_mt_sqnorm': (I, [P, I, P, P, I, F, P, P, I, P, I, P]),
     'pk_mt_adam': (I, [P, I, P, P, I, P, F, F, F, F, F, F, F, I, P, I, P]),
     'pk_mt_copy': (I, [P, I, P, P, I, I, P]),
+    'pk_comm_open': (I, [c_char_p]),
+    'pk_comm_unique_id': (I, [P, I]),
+    'pk_comm_init': (I, [P, I, I]),
+    'pk_comm_destroy': (I, []),
+    'pk_comm_size': (I, []),
+    'pk_comm_all_reduce_mean': (I, [P, LL, I, I, P, P]),
     'pk_logmel_workspace': (SZ, [I]),
     'pk_logmel': (I, [P, P, LL, P, P, SZ, I, P]),
 }

@@ -1,7 +1,8 @@
-"""The gradient reducer on the GPU through RCCL ('nccl' backend).  A GPU box has one card, so the process group has one
+"""The gradient reducer on the GPU through RCCL (the native pk_comm_* path over RCCL's C API; 'nccl' backend for the
+communicator's bootstrap).  A GPU box has one card, so the process group has one
 rank and PASERO_DDP_FORCE_REDUCE keeps the bucket -> all-reduce(AVG) -> communication-stream -> re-pointed `.grad`
-path live; with one rank the reduced gradients must equal the plain ones (up to the order of the fp32 atomics in the
-embedding / LayerNorm-parameter gradients).  (The world_size-2 semantics are
+path live; with one rank the reduced gradients must equal the plain ones (every reduction of the step is a fixed-order
+sum: bitwise).  (The world_size-2 semantics are
 covered on CPU with gloo in test_ddp_cpu.py.)"""
 import os
 import socket
@@ -45,6 +46,11 @@ def test_rccl_bucketed_all_reduce_single_rank(monkeypatch, dtype):
             p.grad = None
         ddp = DistributedDataParallel(model, bucket_cap_mb=0.05)
         assert len(ddp._buckets) > 1
+        # the collectives run through RCCL's C API (csrc/comm.hip), not torch.distributed: the communicator came up,
+        # every schedule reproduced dist.all_reduce on random data, one was adopted
+        assert ddp._native is not None, getattr(__import__('pasero_amd.ddp').ddp.RcclComm._instance, 'report', None)
+        rep = ddp._native.report
+        assert all(rep['correct'].values()) and rep['schedule'] in ddp._native.SCHEDULES.values(), rep
         rng.manual_seed(5)
         loss2, _ = ddp(**batch)
         loss2.backward()
@@ -139,3 +145,29 @@ def test_two_ranks_average_the_gradients_of_the_hip_model():
         assert out['buckets'] > 1
         assert out['worst'] <= 2e-4, (r, out['name'], out['worst'])
         assert abs(out['loss_sum'] - out['ref_loss']) <= 1e-5 * abs(out['ref_loss'])
+
+
+@pytest.mark.timeout(300)
+def test_native_comm_schedules_single_rank(monkeypatch):
+    """pk_comm_all_reduce_mean with one rank: all three schedules (all-reduce, reduce-scatter + all-gather, the direct
+    exchange with its fixed-order shard mean) leave the buffer unchanged, for every dtype and for sizes that are not a
+    multiple of the chunk the kernels use; the multi-rank equivalence with dist.all_reduce is what `RcclComm` itself
+    checks at construction on whatever set of GPUs it runs on."""
+    from pasero_amd.ddp import RcclComm
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', str(_free_port()))
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        comm = RcclComm.get(None, dev)
+        assert comm is not None, RcclComm._instance.report
+        for dtype in (torch.float32, torch.bfloat16, torch.float16):
+            for n in (8, 4096 + 8, 1 << 20):
+                x = torch.randn(n, device=dev).to(dtype)
+                for sched in (0, 1, 2):
+                    y = x.clone()
+                    comm.all_reduce_mean(y, sched)
+                    torch.cuda.synchronize()
+                    assert torch.equal(x, y), (dtype, n, sched)
+    finally:
+        dist.destroy_process_group()
