@@ -759,8 +759,10 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         // 256x256-tile kernel (gemm256.hip): LDS-DMA only, so it needs 16-byte addressable operands, K in whole 64-tiles
         // and one of the lean epilogues; it pays when its (4x fewer) tiles still fill the chip.
         static const int tile_pref = [] { const char* e = getenv("PK_GEMM_TILE"); return e ? atoi(e) : 0; }();
-        const bool simple = !ep.preact && (ep.act == PK_ACT_NONE || ep.act == PK_ACT_RELU) && (flags & 4) &&
-                            (!ep.bias || ((uintptr_t)ep.bias % 16) == 0) && (ep.mode == 0 || (flags & 8)) && ep.mode < 3;
+        // epilogues of the 256-tile kernels: everything 16-byte addressable; gemm256.hip only knows none / ReLU without
+        // a pre-activation output, gemm8p.hip every activation, `preact` and the gate product (mode 3)
+        const bool epi_ok = (flags & 4) && (!ep.bias || ((uintptr_t)ep.bias % 16) == 0) && (ep.mode == 0 || (flags & 8));
+        const bool lean_epi = !ep.preact && (ep.act == PK_ACT_NONE || ep.act == PK_ACT_RELU) && ep.mode < 3;
         const bool addr_ok = (flags & 1) && (flags & 2) && (!a_col || M % 8 == 0 || lda >= ((M + 7) & ~7LL)) &&
                              (!b_col || N % 8 == 0) &&
                              N % 8 == 0 && K > 0;
@@ -768,6 +770,7 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         // whole 64-deep tiles
         const bool e8 = g_use_8p && pk_gemm8p_eligible(M, N, K, lda, ldb, a_col, b_col, asum_out != nullptr);
         const bool k_ok = e8 || K % 64 == 0;
+        const bool simple = epi_ok && (lean_epi || (e8 && splitk <= 1));  // (the split-K reduce kernel has its own epilogue)
         const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
         if (simple && addr_ok && k_ok && tile_pref != 128 && M >= 256 && N >= 256) {
             int sk = 1;

@@ -167,13 +167,68 @@ __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, T* _
     }
 }
 
-template <typename T, bool A_COL, bool B_COL>
+// The same 64-row pass for every other epilogue of pk_gemm (include/pasero_hip.h): any activation (GELU erf / tanh, SiLU:
+// the Whisper / BLOOM / Llama feed-forward layers, pasero/models/modules.py:220-228), the pre-activation as a second output
+// (`preact`: what act' needs in backward), mode 3 = act(v + bias) * aux (the SwiGLU / GEGLU gate, transformer.py:1011-1018)
+// and mode 2 with a general act'.  Activation chosen at run time: these layers spend their time in erf / tanh anyway.
+// (NOT inlined: erf / tanh / exp need registers the K loop cannot spare — inlined, this pass made hipcc spill inside the
+// loop of every instantiation; as a call, its cost stays inside the call)
+template <typename T>
+__device__ __noinline__ void epilogue_pass_any(const float* __restrict__ cs, T* __restrict__ C, const EpiParams& ep,
+                                                  long long mh, long long n0, long long M, long long N, int tid) {
+    const int col = (tid & 31) * 8, r0 = tid >> 5;
+    const long long gn = n0 + col;
+    if (gn + 8 > N) return;
+    float b[8];
+    if (ep.mode != 2 && ep.bias) {
+        Vec16<T> bv = load16<T>(reinterpret_cast<const T*>(ep.bias) + gn);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = bv.get(e);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = 0.f;
+    }
+    const float alpha = ep.alpha;
+    const int act = ep.act, mode = ep.mode;
+    for (int it = 0; it < 4; ++it) {
+        const long long gm = mh + r0 + 16 * it;
+        if (gm >= M) continue;
+        Vec16<T> av;
+        if (mode != 0) av = load16<T>(reinterpret_cast<const T*>(ep.aux) + gm * ep.ldaux + gn);
+        const float* src = cs + (r0 + 16 * it) * CP + col;
+        const float4 a4 = *reinterpret_cast<const float4*>(src), b4 = *reinterpret_cast<const float4*>(src + 4);
+        float x[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+        Vec16<T> pre, o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = x[e] * alpha;
+            if (mode == 2) {
+                y *= act_bwd(act, av.get(e));
+            } else {
+                y += b[e];
+                pre.set(e, y);
+                y = act_fwd(act, y);
+                if (mode == 1) y += av.get(e);
+                else if (mode == 3) y *= av.get(e);
+            }
+            o.set(e, y);
+        }
+        store16_nt<T>(C + gm * ep.ldc + gn, o);
+        if (ep.preact && mode != 2) store16_nt<T>(reinterpret_cast<T*>(ep.preact) + gm * ep.ldpre + gn, pre);
+    }
+}
+
+// ANY: the instantiation for the general epilogues (epilogue_pass_any); the lean one never calls a function, so it needs no
+// scratch memory (a kernel with a call gets a stack, and the waves of a 1024-workgroup launch then start measurably slower)
+// TAIL: the instantiation whose last K-tile may be partial (K % 64 != 0: the vocabulary dX GEMMs); the common one carries no
+// per-lane masking in its DMA issue (VALU work in a load section is taken out of the partner wave's MFMA issue slots)
+template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A, const T* __restrict__ B,
                                                        T* __restrict__ C, float* __restrict__ ws,
                                                        float* __restrict__ asum_ws, T* __restrict__ asum_out,
                                                        long long M, long long N, long long K, long long lda,
                                                        long long ldb, int kchunk, unsigned a_bytes, unsigned b_bytes,
-                                                       int total, EpiParams ep) {
+                                                       int total, unsigned long long* stamps, EpiParams ep) {
     typedef typename M16<T>::vec V;
     typedef __attribute__((address_space(3))) void lds_void;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -182,10 +237,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
     const int wr = wave >> 2, wc = wave & 3;
 
     const int nt_m = (int)((M + BM - 1) / BM), nt_n = (int)((N + BN - 1) / BN);
-    // persistent walk: workgroup b takes the virtual blocks b, b + G, b + 2G ... of the `total` (K-slab, tile) items
-    // (G = gridDim.x, a multiple of 8 or == total: blocks b and b + G then carry the same XCD label)
-    for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
-    const int lin = xcd_remap(vb, total);  // slab-major (K-slab, tile) walk: an XCD owns whole K-slabs
+    // diagnostic build (-DPK8P_STAMPS, tools/gemm_phase_stamps.py): s_memrealtime at the seams of the tile, into a buffer
+    // of their own (never into an output); the shipped build has no stamp
+#ifdef PK8P_STAMPS
+    int stamp_i = 0;
+#define PK_STAMP() do { if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 64 + (stamp_i++ & 63)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PK_STAMP() do { } while (0)
+#endif
+    PK_STAMP();  // tile start
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);  // slab-major (K-slab, tile) walk: an XCD owns whole K-slabs
     const int kslab = lin / (nt_m * nt_n);
     int t = lin % (nt_m * nt_n);
     const int GROUP_M = nt_n <= 2 ? 8 : 4;
@@ -228,20 +289,24 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
     // distance).
     auto dma = [&](int kt, int slot) {
         char* dst = smem + (kt & 1) * STAGE + slot * HALF + wave * 2048;
+#ifdef PK8P_ABL_NODMA
+        const bool live = kt < 0;  // ablation build: every DMA empty (the MFMAs chew on whatever LDS holds)
+#else
         const bool live = kt < nk;
-        const bool tail = kt == nk - 1 && kvalid < BK;
+#endif
+        const bool tail = TAIL && kt == nk - 1 && kvalid < BK;
         if (slot < 2) {
             __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, live ? (int)a_bytes : 0, 0x00020000);
             const unsigned so = kbase_a + (unsigned)kt * kstep_a;
             unsigned v0 = offa[slot][0], v1 = offa[slot][1];
-            if (!A_COL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
+            if (TAIL && !A_COL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, v0, so, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, v1, so, 0, 0);
         } else {
             __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, live ? (int)b_bytes : 0, 0x00020000);
             const unsigned so = kbase_b + (unsigned)kt * kstep_b;
             unsigned v0 = offb[slot - 2][0], v1 = offb[slot - 2][1];
-            if (!B_COL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
+            if (TAIL && !B_COL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, v0, so, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, v1, so, 0, 0);
         }
@@ -366,7 +431,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
+#ifdef PK8P_ABL_NOMFMA
+                    asm volatile("" :: "v"(fb[nh][j][kk]), "v"(fa[i][kk]));  // ablation build: fragments stay live, no MFMA
+#else
                     acc[mh][i][nh][j] = M16<T>::mfma(fb[nh][j][kk], fa[i][kk], acc[mh][i][nh][j]);
+#endif
         __builtin_amdgcn_s_setprio(0);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -402,6 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
         dma(0, SLOT_A0); dma(0, SLOT_B0); dma(0, SLOT_B1); dma(0, SLOT_A1);
         dma(1, SLOT_A0); dma(1, SLOT_B0);
         PK_WAIT(8);  // A0, B0 of tile 0
+        PK_STAMP();  // first K-tile landed
         asm volatile("; PK8P_LOOP_BEGIN" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if constexpr (A_COL) {
@@ -426,6 +496,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
 #undef PK_WAIT
 #undef PK_TR
     __syncthreads();
+    PK_STAMP();  // K loop done
 
     if constexpr (A_COL) {
         if (do_asum) {  // 16 row groups -> one sum per column of the tile
@@ -478,6 +549,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
                     *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(src + 4);
                 }
             }
+        } else if constexpr (ANY) {
+            epilogue_pass_any<T>(cs, C, ep, mh, n0, M, N, tid);
         } else if (ep.mode == 0) {
             if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 0>(cs, C, ep, mh, n0, M, N, tid);
             else epilogue_pass<T, PK_ACT_NONE, 0>(cs, C, ep, mh, n0, M, N, tid);
@@ -488,9 +561,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
             if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 2>(cs, C, ep, mh, n0, M, N, tid);
             else epilogue_pass<T, PK_ACT_NONE, 2>(cs, C, ep, mh, n0, M, N, tid);
         }
-        __syncthreads();  // (also in front of the next tile's DMA: the staging buffer overlays the stages)
+        if (p < 3) __syncthreads();
     }
-    }  // persistent walk
+#ifdef PK8P_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PK_STAMP();  // epilogue stores acknowledged
+#endif
+#undef PK_STAMP
 }
 
 }  // namespace
@@ -526,23 +603,34 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
     long long a_bytes, b_bytes;
     operand_bytes(M, N, K, lda, ldb, a_col, b_col, &a_bytes, &b_bytes);
     const int total = (int)(((M + BM - 1) / BM) * ((N + BN - 1) / BN) * splitk);
-    // PK8P_GRID (diagnostic): workgroups of the persistent walk; 0 = one per (K-slab, tile) item
-    static const int grid_cap = [] { const char* e = getenv("PK8P_GRID"); return e ? atoi(e) : 0; }();
-    dim3 grid((unsigned)((grid_cap > 0 && total > grid_cap) ? grid_cap : total)), block(512);
+    unsigned long long* stamps = nullptr;  // PK8P_STAMP_PTR: device buffer of the diagnostic build's time stamps
+    if (const char* e = getenv("PK8P_STAMP_PTR")) stamps = (unsigned long long*)strtoull(e, nullptr, 0);
+    dim3 grid((unsigned)total), block(512);
     hipStream_t s = (hipStream_t)stream;
-#define PK_K(TT, AC, BC)                                                                                          \
-    hipLaunchKernelGGL((gemm8p_kernel<TT, AC, BC>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, ws,     \
-                       asum_ws, (TT*)asum_out, M, N, K, lda, ldb, kchunk, (unsigned)a_bytes, (unsigned)b_bytes, total, ep)
-#define PK_L(AC, BC)                                          \
-    do {                                                      \
-        if (dtype == PK_F16) PK_K(f16, AC, BC);               \
-        else PK_K(bf16, AC, BC);                              \
+    const bool any = ep.preact || ep.mode == 3 || (ep.act != PK_ACT_NONE && ep.act != PK_ACT_RELU);
+    const bool tail = (K % BK) != 0;
+#define PK_K(TT, AC, BC, ANYV, TAILV)                                                                                  \
+    hipLaunchKernelGGL((gemm8p_kernel<TT, AC, BC, ANYV, TAILV>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, \
+                       ws, asum_ws, (TT*)asum_out, M, N, K, lda, ldb, kchunk, (unsigned)a_bytes, (unsigned)b_bytes,    \
+                       total, stamps, ep)
+#define PK_D(TT, AC, BC)                                                       \
+    do {                                                                       \
+        if (any && tail) PK_K(TT, AC, BC, true, true);                         \
+        else if (any) PK_K(TT, AC, BC, true, false);                           \
+        else if (tail) PK_K(TT, AC, BC, false, true);                          \
+        else PK_K(TT, AC, BC, false, false);                                   \
+    } while (0)
+#define PK_L(AC, BC)                                   \
+    do {                                               \
+        if (dtype == PK_F16) PK_D(f16, AC, BC);        \
+        else PK_D(bf16, AC, BC);                       \
     } while (0)
     if (!a_col && !b_col) PK_L(false, false);
     else if (!a_col && b_col) PK_L(false, true);
     else if (a_col && !b_col) PK_L(true, false);
     else PK_L(true, true);
 #undef PK_L
+#undef PK_D
 #undef PK_K
     PK_LAUNCH_CHECK();
     return 1;

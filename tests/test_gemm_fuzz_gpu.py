@@ -116,6 +116,37 @@ def test_gemm8p_fuzz(F, seed):
         L.pk_gemm_use_8p(old)
 
 
+@pytest.mark.parametrize('act', ['gelu', 'gelu_tanh', 'swiglu'])
+def test_gemm8p_activation_preact_and_gate_epilogues(F, act):
+    """the feed-forward epilogues beyond ReLU on the phase-interleaved kernel: GELU (erf: whisper_base, config.py:2550),
+    tanh-GELU, SiLU — with the pre-activation as a second output (what the backward's act' reads), the act' product of
+    the dH GEMM (mode 2) and the gate product act(x W1) * (x W3) of SwiGLU / GEGLU (mode 3) — against fp64"""
+    from pasero_amd import lib
+    L = lib.load()
+    old = L.pk_gemm_use_8p(2)
+    try:
+        fn = {'gelu': lambda t: torch.nn.functional.gelu(t), 'gelu_tanh': lambda t: torch.nn.functional.gelu(t, approximate='tanh'),
+              'swiglu': lambda t: torch.nn.functional.silu(t)}[act]
+        rs = np.random.RandomState(77)
+        M, N, K = 520, 776, 320
+        a, a64 = _operand(rs, M, K, 8, torch.bfloat16)
+        b, b64 = _operand(rs, N, K, 0, torch.bfloat16)
+        bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).bfloat16()
+        aux = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32)).bfloat16()
+        z = (a64 @ b64.t()) * 0.05 + bias.double()
+        pre = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+        y = F.gemm(a, b, bias=bias.cuda(), act=act, preact=pre, alpha=0.05)
+        assert (pre.double().cpu() - z).abs().max().item() < 4e-2 and (y.double().cpu() - fn(z)).abs().max().item() < 4e-2
+        y3 = F.gemm(a, b, bias=bias.cuda(), act=act, aux=aux.cuda(), mode=3, alpha=0.05)
+        assert (y3.double().cpu() - fn(z) * aux.double()).abs().max().item() < 8e-2
+        zz = aux.double().clone().requires_grad_()
+        fn(zz).sum().backward()
+        y2 = F.gemm(a, b, act=act, aux=aux.cuda(), mode=2, alpha=0.05)
+        assert (y2.double().cpu() - (a64 @ b64.t()) * 0.05 * zz.grad).abs().max().item() < 8e-2
+    finally:
+        L.pk_gemm_use_8p(old)
+
+
 def test_gemm8p_takes_the_vocabulary_dx_shapes(F):
     """dX = dlogits . E with K = V = 8032 (not a multiple of 64) and V = 70376, row-form A, col-form B: on the
     phase-interleaved kernel, exact against fp32 on a row sample"""

@@ -7,11 +7,13 @@
   2. the transposed LDS reads are inline asm, so the compiler neither waits for them nor knows when their destination
      registers become valid: from each `ds_read_b64_tr_b16` to the next `s_waitcnt lgkmcnt(0)` nothing else may read or
      write those registers (a compiler copy there would move stale data);
-  3. no scratch (spill) traffic anywhere in these kernels.
+  3. no scratch (spill) traffic inside the K loop (spills in the prologue / epilogue are reported, not refused).
 
 Usage: check_asm_loads.py <file.s>     (exit code 1 and a report if a rule is broken)"""
 import re
 import sys
+
+notes = []
 
 
 def regs(tok: str):
@@ -33,6 +35,8 @@ def operands(line: str):
 def audit(path: str):
     lines = open(path).read().splitlines()
     problems, kernels = [], 0
+    global notes
+    notes = []
     i = 0
     while i < len(lines):
         m = re.match(r'^(_ZN[^:]*gemm8p_kernel[^:]*):', lines[i])
@@ -46,17 +50,21 @@ def audit(path: str):
             j += 1
         body = lines[i:j]
         i = j
-        if any('scratch_' in ln for ln in body):
-            problems.append(f'{name}: scratch (spill) instructions')
+        n_scratch = sum('scratch_' in ln for ln in body)
         try:
             b = next(k for k, ln in enumerate(body) if 'PK8P_LOOP_BEGIN' in ln)
             e = next(k for k, ln in enumerate(body) if 'PK8P_LOOP_END' in ln)
         except StopIteration:
             problems.append(f'{name}: loop markers not found')
             continue
+        if n_scratch:
+            notes.append(f'{name}: {n_scratch} scratch instructions outside the K loop')
         pending = {}  # register -> line of the asm tr read that wrote it
         for k in range(b, e):
             ln = body[k]
+            if 'scratch_' in ln:
+                problems.append(f'{name}: line {k}: spill traffic inside the K loop: `{ln.strip()}`')
+                n_scratch -= 1
             op, ops = operands(ln)
             if op == 's_waitcnt':
                 mm = re.search(r'vmcnt\((\d+)\)', ln)
@@ -86,5 +94,7 @@ if __name__ == '__main__':
     n, probs = audit(sys.argv[1])
     for p in probs:
         print('PROBLEM:', p)
+    for t in notes:
+        print('note:', t)
     print(f'{n} kernels audited, {len(probs)} problems')
     sys.exit(1 if probs else 0)
