@@ -115,8 +115,8 @@ class GemmTimer:
     def kernel_name(kernel, a_col, b_col, dtype):
         tf = {0: 'false', 1: 'true'}
         t = {0: 'float', 1: '__hip_bfloat16', 2: '_Float16'}[dtype]
-        if kernel == 8:
-            return 'gemm8p_kernel<%s, %s, %s>' % (t, tf[a_col], tf[b_col])
+        if kernel & 0xF == 8 and kernel < 256:  # gemm8p instantiation: <T, A_COL, B_COL, ANY epilogue, TAIL K-tile>
+            return 'gemm8p_kernel<%s, %s, %s, %s, %s>' % (t, tf[a_col], tf[b_col], tf[(kernel >> 4) & 1], tf[(kernel >> 5) & 1])
         if kernel == 256:
             return 'gemm256_kernel<%s, %s, %s, 8>' % (t, tf[a_col], tf[b_col])
         return 'gemm_kernel<%s, %s, %s>' % (t, tf[a_col], tf[b_col])

@@ -799,7 +799,10 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
                 float* asw = (sk > 1 && asum_out) ? w2 + (size_t)sk * M * N : nullptr;
                 // the phase-interleaved kernel (gemm8p.hip) takes what it can; gemm256.hip the rest (fused bias gradient,
                 // operands beyond 4 GiB).  PK_GEMM_8P=0 switches it off (A/B inside one process: tools/gemm_bench.py)
-                GemmSample* sm = timing_begin(e8 ? 8 : 256, a_col, b_col, std::max(sk, 1), dtype16, M, N, K, stream);
+                // (sample tag of the gemm8p instantiation: 8 | 0x10 general epilogue | 0x20 partial last K-tile)
+                const bool any_epi = ep.preact || ep.mode == 3 || (ep.act != PK_ACT_NONE && ep.act != PK_ACT_RELU);
+                const int tag8 = 8 | (any_epi ? 0x10 : 0) | (K % 64 ? 0x20 : 0);
+                GemmSample* sm = timing_begin(e8 ? tag8 : 256, a_col, b_col, std::max(sk, 1), dtype16, M, N, K, stream);
                 int rc = (e8 ? pk_gemm8p_launch : pk_gemm256_launch)(A, B, C, w2, asw, asum_out, M, N, K, lda, ldb, a_col,
                                                                     b_col, (int)per, std::max(sk, 1), ep, dtype16, stream);
                 timing_end(sm, stream);

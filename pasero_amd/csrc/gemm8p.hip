@@ -18,15 +18,17 @@
 //   * the DMA runs 5-6 phases (1.25-1.5 K-tiles) ahead and is retired by COUNTED waits — `s_waitcnt vmcnt(6)`: all but
 //     the three youngest half-tiles have landed — never vmcnt(0) inside the loop; raw s_barrier only.
 // Schedule of one iteration (two K-tiles t, t+1 in stages E, O); quadrant order (A0,B0) (A0,B1) (A1,B1) (A1,B0):
-//   phase   fragment reads         MFMA quadrant   DMA issued (after the wait)   last read of the slot it overwrites
-//   1       A0(E) B0(E)  [12]      (0,0)           B1(O) <- tile t+1             phase 6 of the previous iteration
-//   2       B1(E)        [4]       (0,1)           A1(O) <- t+1                  phase 7 of the previous iteration
-//   3       A1(E)        [8]       (1,1)           A0(E) <- t+2                  phase 1
-//   4       (B0 kept)    [0]       (1,0)           B0(E) <- t+2                  phase 1
-//   5       A0(O) B0(O)  [12]      (0,0)           B1(E) <- t+2                  phase 2
-//   6       B1(O)        [4]       (0,1)           A1(E) <- t+2                  phase 3
-//   7       A1(O)        [8]       (1,1)           A0(O) <- t+3                  phase 5
-//   8       (B0 kept)    [0]       (1,0)           B0(O) <- t+3                  phase 5
+//   phase   fragment reads            MFMA quadrant   DMA issued (after the wait)   last read of the slot it overwrites
+//   1       A0(E)           [8]       (0,0)           B1(O) <- tile t+1             phase 6 of the previous iteration
+//   2       B1(E)           [4]       (0,1)           A1(O) <- t+1                  phase 7 of the previous iteration
+//   3       A1(E)           [8]       (1,1)           B0(E) <- t+2                  phase 8 of the previous iteration
+//   4       B0(O) of t+1    [4]       (1,0)           A0(E) <- t+2                  phase 1
+//   5       A0(O)           [8]       (0,0)           B1(E) <- t+2                  phase 2
+//   6       B1(O)           [4]       (0,1)           A1(E) <- t+2                  phase 3
+//   7       A1(O)           [8]       (1,1)           B0(O) <- t+3                  phase 4
+//   8       B0(E) of t+2    [4]       (1,0)           A0(O) <- t+3                  phase 5
+// (the B0 fragments of a K-tile are read one phase EARLY, into their own register set, in the otherwise read-free load
+// section of the previous K-tile's last phase: 8 / 4 / 8 / 4 reads per phase instead of 12 / 4 / 8 / 0)
 // Hazards.  RAW: a half-tile is read one phase (or more) after the wait that retires it — the wait sits in front of a
 // barrier every wave passes before any wave's read.  WAR: a slot is overwritten >= 2 phases after its last read (the
 // staggered half issues its reads one barrier late; their lgkmcnt(0) follows the next barrier).
@@ -322,7 +324,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    V fa[4][2], fb[2][2][2];  // A fragments of the current row half [m-tile][kk]; B fragments [nh][n-tile][kk]
+    // A fragments of the current row half [m-tile][kk]; B fragments: B1 of the current K-tile, and B0 in TWO sets — the set
+    // of stage S is filled one phase early, in the read-free load section of the previous K-tile's last phase, so the
+    // fragment reads per phase are 8 / 4 / 8 / 4 instead of 12 / 4 / 8 / 0 (the 12-read section was the longest)
+    V fa[4][2], fb0[2][2][2], fb1[2][2];  // fb0[stage][n-tile][kk], fb1[n-tile][kk]
 
     // col-form fragments: per-lane LDS byte address of tile i (A) / j (B) at k-step 0, slot 0, one set per stage; slot,
     // k-step and the k + 4 rows are instruction immediates (16-bit: the stage does not fit)
@@ -361,20 +366,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
         return __builtin_bit_cast(V, f);
     };
 
-    // Fused bias gradient (col-form A = dY: the sum over k of every column), by the tile_n == 0 workgroups.  All of it
-    // sits in the load section of phase 4 / 8, which reads no fragments: threads 0..255 sum the A1 image of the phase's
-    // own K-tile (last read in the phase before, overwritten two phases later), threads 256..511 the A0 image of the
-    // NEXT K-tile (landed one phase earlier; past the end an empty DMA left zeros there); the first K-tile's A0 image
-    // is summed once behind the prologue.  Thread t: 16-byte chunk t & 15 of rows (t & 255) >> 4 + 16 it, it = 0..3.
-    // Inline-asm reads with their own wait (the compiler would put vmcnt(0) in front of plain loads of these images).
+    // Fused bias gradient (col-form A = dY: the sum over k of every column), by the tile_n == 0 workgroups, in the two
+    // light load sections of a K-tile: threads 256..511 sum its A0 image in phase 2 (next to the four B1 fragment reads;
+    // the slot is overwritten two phases later), threads 0..255 its A1 image in phase 4.  Thread t: 16-byte chunk t & 15
+    // of rows (t & 255) >> 4 + 16 it, it = 0..3.  Inline-asm reads with their own wait (the compiler would put vmcnt(0)
+    // in front of plain loads of these images).
     const bool do_asum = A_COL && (asum_ws || asum_out) && tile_n == 0;
     float asum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) asum[e] = 0.f;
-    unsigned asum_base = 0;  // LDS address for an even (stage 0) phase; ^ STAGE for an odd one
+    unsigned asum_base = 0;  // LDS address of this thread's first chunk in stage 0 (+ STAGE for stage 1)
     if constexpr (A_COL) {
         typedef __attribute__((address_space(3))) char lds_char;
-        asum_base = (unsigned)(unsigned long)(lds_char*)smem + (tid < 256 ? SLOT_A1 * HALF : STAGE + SLOT_A0 * HALF) +
+        asum_base = (unsigned)(unsigned long)(lds_char*)smem + (tid < 256 ? SLOT_A1 : SLOT_A0) * HALF +
                     HT<true>::offset((tid & 255) >> 4, tid & 15);
     }
     auto asum_step = [&](unsigned addr) {
@@ -409,21 +413,21 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
             }
         }
     };
-    auto load_b = [&](auto s_c, auto slot_c, int nh) {
+    auto load_b = [&](auto s_c, auto slot_c, V (&dst)[2][2]) {
         constexpr int S = decltype(s_c)::value, SLOT = decltype(slot_c)::value;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if constexpr (B_COL) {
-                fb[nh][j][0] = col_frag(cb[S][j], std::integral_constant<int, SLOT * HALF>{});
-                fb[nh][j][1] = col_frag(cb[S][j], std::integral_constant<int, SLOT * HALF + 32 * HT<true>::ROWB>{});
+                dst[j][0] = col_frag(cb[S][j], std::integral_constant<int, SLOT * HALF>{});
+                dst[j][1] = col_frag(cb[S][j], std::integral_constant<int, SLOT * HALF + 32 * HT<true>::ROWB>{});
             } else {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
-                    fb[nh][j][kk] = frag<T, false>(smem + S * STAGE + SLOT * HALF, wc * 32 + 16 * j, kk, lane);
+                    dst[j][kk] = frag<T, false>(smem + S * STAGE + SLOT * HALF, wc * 32 + 16 * j, kk, lane);
             }
         }
     };
-    auto mma = [&](int mh, int nh) {
+    auto mma = [&](int mh, int nh, V (&b)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -432,9 +436,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #ifdef PK8P_ABL_NOMFMA
-                    asm volatile("" :: "v"(fb[nh][j][kk]), "v"(fa[i][kk]));  // ablation build: fragments stay live, no MFMA
+                    asm volatile("" :: "v"(b[j][kk]), "v"(fa[i][kk]));  // ablation build: fragments stay live, no MFMA
 #else
-                    acc[mh][i][nh][j] = M16<T>::mfma(fb[nh][j][kk], fa[i][kk], acc[mh][i][nh][j]);
+                    acc[mh][i][nh][j] = M16<T>::mfma(b[j][kk], fa[i][kk], acc[mh][i][nh][j]);
 #endif
         __builtin_amdgcn_s_setprio(0);
     };
@@ -442,14 +446,20 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     auto phase = [&](auto p_c, auto s_c, int dma_kt, int dma_slot) {
         constexpr int P = decltype(p_c)::value, S = decltype(s_c)::value;
-        if constexpr (P == 0) {
-            load_b(s_c, I2{}, 0);  // SLOT_B0
-            load_a(s_c, I0{});     // SLOT_A0
+        using SN = std::integral_constant<int, S ^ 1>;
+        if constexpr (P == 0) load_a(s_c, I0{});                  // A0 of this K-tile
+        if constexpr (P == 1) {
+            load_b(s_c, I3{}, fb1);                               // B1
+            if constexpr (A_COL) {
+                if (do_asum && wr == 1) asum_step(asum_base + S * STAGE);
+            }
         }
-        if constexpr (P == 1) load_b(s_c, I3{}, 1);  // SLOT_B1
-        if constexpr (P == 2) load_a(s_c, I1{});     // SLOT_A1
-        if constexpr (P == 3 && A_COL) {
-            if (do_asum) asum_step(S == 0 ? asum_base : asum_base ^ (unsigned)STAGE);
+        if constexpr (P == 2) load_a(s_c, I1{});                  // A1
+        if constexpr (P == 3) {
+            load_b(SN{}, I2{}, fb0[S ^ 1]);                       // B0 of the NEXT K-tile (other stage)
+            if constexpr (A_COL) {
+                if (do_asum && wr == 0) asum_step(asum_base + S * STAGE);
+            }
         }
         PK_WAIT(6);  // all but the three youngest half-tiles have landed (what the NEXT phase reads is among them)
         dma(dma_kt, dma_slot);
@@ -457,10 +467,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (P == 0) mma(0, 0);
-        if constexpr (P == 1) mma(0, 1);
-        if constexpr (P == 2) mma(1, 1);
-        if constexpr (P == 3) mma(1, 0);
+        if constexpr (P == 0) mma(0, 0, fb0[S]);
+        if constexpr (P == 1) mma(0, 1, fb1);
+        if constexpr (P == 2) mma(1, 1, fb1);
+        if constexpr (P == 3) mma(1, 0, fb0[S]);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
@@ -468,26 +478,24 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
 
     if (nk > 0) {
         // ---- prologue: K-tile 0 whole, K-tile 1's A0 B0 ----
-        dma(0, SLOT_A0); dma(0, SLOT_B0); dma(0, SLOT_B1); dma(0, SLOT_A1);
-        dma(1, SLOT_A0); dma(1, SLOT_B0);
-        PK_WAIT(8);  // A0, B0 of tile 0
+        dma(0, SLOT_B0); dma(0, SLOT_A0); dma(0, SLOT_B1); dma(0, SLOT_A1);
+        dma(1, SLOT_B0); dma(1, SLOT_A0);
+        PK_WAIT(8);  // B0, A0 of tile 0
         PK_STAMP();  // first K-tile landed
         asm volatile("; PK8P_LOOP_BEGIN" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if constexpr (A_COL) {
-            if (do_asum && wr == 1) asum_step(asum_base ^ (unsigned)STAGE);  // A0 image of K-tile 0 (stage 0)
-        }
+        load_b(I0{}, I2{}, fb0[0]);  // B0 of K-tile 0 (every later one is read a phase ahead, inside the loop)
         if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave of every SIMD runs one barrier behind the first
         for (int kt = 0; kt < nk; kt += 2) {
             phase(I0{}, I0{}, kt + 1, SLOT_B1);
             phase(I1{}, I0{}, kt + 1, SLOT_A1);
-            phase(I2{}, I0{}, kt + 2, SLOT_A0);
-            phase(I3{}, I0{}, kt + 2, SLOT_B0);
+            phase(I2{}, I0{}, kt + 2, SLOT_B0);
+            phase(I3{}, I0{}, kt + 2, SLOT_A0);
             if (kt + 1 >= nk) break;  // odd number of K-tiles
             phase(I0{}, I1{}, kt + 2, SLOT_B1);
             phase(I1{}, I1{}, kt + 2, SLOT_A1);
-            phase(I2{}, I1{}, kt + 3, SLOT_A0);
-            phase(I3{}, I1{}, kt + 3, SLOT_B0);
+            phase(I2{}, I1{}, kt + 3, SLOT_B0);
+            phase(I3{}, I1{}, kt + 3, SLOT_A0);
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();  // the first half catches the barrier count up
         asm volatile("; PK8P_LOOP_END" ::: "memory");
@@ -588,6 +596,7 @@ void operand_bytes(long long M, long long N, long long K, long long lda, long lo
 extern "C" int pk_gemm8p_eligible(long long M, long long N, long long K, long long lda, long long ldb, int a_col,
                                   int b_col, int want_asum) {
     (void)want_asum;
+    if (a_col && !b_col) return 0;  // (no caller on the path; its instantiation would need more than 256 registers)
     if (K < 8 || K % 8) return 0;
     long long a_bytes, b_bytes;
     operand_bytes(M, N, K, lda, ldb, a_col, b_col, &a_bytes, &b_bytes);
@@ -627,7 +636,6 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
     } while (0)
     if (!a_col && !b_col) PK_L(false, false);
     else if (!a_col && b_col) PK_L(false, true);
-    else if (a_col && !b_col) PK_L(true, false);
     else PK_L(true, true);
 #undef PK_L
 #undef PK_D

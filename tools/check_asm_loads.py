@@ -66,6 +66,9 @@ def audit(path: str):
                 problems.append(f'{name}: line {k}: spill traffic inside the K loop: `{ln.strip()}`')
                 n_scratch -= 1
             op, ops = operands(ln)
+            if op in ('s_branch', 's_endpgm', 's_setpc_b64'):
+                pending.clear()  # what follows is only reached by a jump: not in program order behind these reads
+                continue
             if op == 's_waitcnt':
                 mm = re.search(r'vmcnt\((\d+)\)', ln)
                 if mm and int(mm.group(1)) < 6:

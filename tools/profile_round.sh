@@ -6,17 +6,20 @@
 #   3. two separate PMC passes (FETCH_SIZE, WRITE_SIZE) -> hbm_traffic_pmc.json
 set -euo pipefail
 R=${1:-r01}
+W=${2:-c2_base_bf16}      # bench.py --workload (second argument; the default bench line is C2)
+ST=${3:-100}              # timed steps
 OUT=gpurun_out/profile_$R
+[ "$W" != c2_base_bf16 ] && OUT=gpurun_out/profile_${R}_$W
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 400 python3 bench.py > $OUT/bench.log 2>&1
+timeout -k 10 400 python3 bench.py --workload $W --steps $ST > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log > $OUT/bench.json
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --workload $W --steps $ST --no-cpu-baseline > $OUT/trace.log 2>&1
 cp $(find $OUT/trace -name '*_kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
-python3 tools/rocprof_summary.py $OUT/trace 25 > $OUT/kernel_summary.txt
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
-python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over 'bench.py --steps 3 --warmup 1' ($R); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); L2<->fabric traffic, Infinity-Cache hits included" > $OUT/hbm_traffic_pmc.json
+python3 tools/rocprof_summary.py $OUT/trace $((ST + 10)) > $OUT/kernel_summary.txt
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --workload $W --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --workload $W --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
+python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over 'bench.py --workload $W --steps 3 --warmup 1' ($R); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); L2<->fabric traffic, Infinity-Cache hits included" > $OUT/hbm_traffic_pmc.json
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
 cat $OUT/bench.json
 head -14 $OUT/kernel_summary.txt
