@@ -8,6 +8,7 @@
 // [2][d] fp32 slab, then a column-parallel reduction kernel over the slabs (no atomics).
 // RMSNorm (pasero/models/modules.py:192-202: y = x * rsqrt(mean(x^2) + eps) * weight, computed in fp32) is the same
 // kernels with the mean fixed at 0: the C ABI selects it with mean == NULL (then beta must be NULL too).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -377,7 +378,8 @@ inline int ln_bwd_max_blocks(int d) {
 
 inline int ln_grid(long long rows) {
     long long blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+    static const long long cap = [] { const char* e = getenv("PK_LN_GRID_CAP"); return e ? atoll(e) : 2048LL; }();
+    return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
 template <typename T>

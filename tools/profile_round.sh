@@ -12,8 +12,7 @@ OUT=gpurun_out/profile_$R
 [ "$W" != c2_base_bf16 ] && OUT=gpurun_out/profile_${R}_$W
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 400 python3 bench.py --workload $W --steps $ST > $OUT/bench.log 2>&1
-tail -1 $OUT/bench.log > $OUT/bench.json
+timeout -k 10 400 python3 bench.py --workload $W --steps $ST > $OUT/bench.json 2> $OUT/bench.err
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --workload $W --steps $ST --no-cpu-baseline > $OUT/trace.log 2>&1
 cp $(find $OUT/trace -name '*_kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 python3 tools/rocprof_summary.py $OUT/trace $((ST + 10)) > $OUT/kernel_summary.txt
