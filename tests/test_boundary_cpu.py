@@ -97,3 +97,18 @@ def test_benchmark_names_of_the_reference_are_kept():
         calls.append(a)
         return a + 1
     assert f(1) == 2 and calls == [1]  # disabled: a plain call
+
+
+def test_gemm8p_assembly_audit_is_part_of_the_build():
+    """csrc/gemm8p.hip keeps an LDS-DMA prefetch in flight behind hand-counted `s_waitcnt vmcnt(6)` and reads col-form
+    operands with inline-asm `ds_read_b64_tr_b16`: the build audits its assembly (tools/check_asm_loads.py) and this
+    test checks the audit ran on the current source and found every instantiation clean"""
+    import os
+    import subprocess
+    from conftest import ROOT
+    csrc = os.path.join(ROOT, 'pasero_amd', 'csrc')
+    subprocess.check_call(['make', '-C', csrc, 'gemm8p.audit'], stdout=subprocess.DEVNULL)
+    report = open(os.path.join(csrc, 'gemm8p.audit')).read()
+    last = report.strip().splitlines()[-1]
+    assert last.endswith(', 0 problems') and int(last.split()[0]) >= 24, last
+    assert 'PROBLEM' not in report
