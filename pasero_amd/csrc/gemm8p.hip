@@ -53,6 +53,13 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF = 16384, STAGE = 4 * HALF, SMEM = 2 * STAGE;  // slots of a stage: A0 A1 B0 B1
 constexpr int SLOT_A0 = 0, SLOT_A1 = 1, SLOT_B0 = 2, SLOT_B1 = 3;
 constexpr int CP = BN + 4;  // floats, epilogue staging pitch
+// cache policy bits of the operand DMA (buffer_load aux: 0 default, 1 sc0, 2 nt, 16 sc1): experiment switches
+#ifndef PK8P_AUX_A
+#define PK8P_AUX_A 0
+#endif
+#ifndef PK8P_AUX_B
+#define PK8P_AUX_B 0
+#endif
 
 template <typename T> struct M16;
 template <> struct M16<bf16> {
@@ -302,15 +309,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
             const unsigned so = kbase_a + (unsigned)kt * kstep_a;
             unsigned v0 = offa[slot][0], v1 = offa[slot][1];
             if (TAIL && !A_COL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, v0, so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, v1, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, v0, so, 0, PK8P_AUX_A);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, v1, so, 0, PK8P_AUX_A);
         } else {
             __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, live ? (int)b_bytes : 0, 0x00020000);
             const unsigned so = kbase_b + (unsigned)kt * kstep_b;
             unsigned v0 = offb[slot - 2][0], v1 = offb[slot - 2][1];
             if (TAIL && !B_COL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, v0, so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, v1, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, v0, so, 0, PK8P_AUX_B);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, v1, so, 0, PK8P_AUX_B);
         }
     };
 
