@@ -158,3 +158,40 @@ def test_gemm8p_takes_the_vocabulary_dx_shapes(F):
         rows = torch.arange(0, M, 97, device='cuda')
         ref = a[rows].float() @ e.float()
         assert ((got[rows].float() - ref).abs().max() / ref.abs().max()).item() < 6e-3
+
+
+@pytest.mark.parametrize('a_col,b_col', [(False, False), (False, True), (True, True)])
+def test_gemm8p_is_bitwise_reproducible_under_load(F, a_col, b_col):
+    """race screen of the phase-interleaved K loop: its LDS images are refilled by DMA 5-6 phases ahead and guarded only by
+    counted waits and barriers, so a misplaced read shows as rare wrong tiles that come and go with timing.  The same
+    GEMM (short K = one iteration + tail paths, K = 512, an odd number of K-tiles, a partial last K-tile, split-K)
+    runs 60 times while a second stream keeps the memory system busy; every result must equal the first bit for bit
+    and the fp64 product within bf16 rounding."""
+    from pasero_amd import lib
+    L = lib.load()
+    old = L.pk_gemm_use_8p(2)
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device='cuda')
+    try:
+        for M, N, K, splitk in [(2048, 1024, 128, 1), (4096, 2048, 512, 1), (1024, 1024, 1088, 1), (2048, 512, 968, 1),
+                                (1024, 512, 4096, 4)]:
+            g = torch.Generator(device='cuda').manual_seed(M + K)
+            A = torch.randn(M, K, device='cuda', generator=g).bfloat16()
+            B = torch.randn(N, K, device='cuda', generator=g).bfloat16()
+            a = A.t().contiguous() if a_col else A
+            b = B.t().contiguous() if b_col else B
+            ref = None
+            for it in range(60):
+                if it % 3 == 0:
+                    with torch.cuda.stream(side):
+                        junk.fill_(it & 255)  # uneven background traffic
+                out = F.gemm(a, b, a_col=a_col, b_col=b_col, splitk=splitk)
+                if ref is None:
+                    ref = out.clone()
+                    exact = A.double() @ B.double().t()
+                    assert (ref.double() - exact).abs().max().item() <= 8e-3 * 4 * float(np.sqrt(K))
+                else:
+                    assert torch.equal(out, ref), (M, N, K, splitk, it)
+            torch.cuda.synchronize()
+    finally:
+        L.pk_gemm_use_8p(old)
