@@ -250,7 +250,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
     // of their own (never into an output); the shipped build has no stamp
 #ifdef PK8P_STAMPS
     int stamp_i = 0;
-#define PK_STAMP() do { if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 64 + (stamp_i++ & 63)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PK_STAMP() do { if (stamps && tid == 0) { stamps[(size_t)blockIdx.x * 64 + (stamp_i & 31)] = __builtin_amdgcn_s_memrealtime(); \
+        stamps[(size_t)blockIdx.x * 64 + 32 + (stamp_i & 31)] = __builtin_amdgcn_s_memtime(); ++stamp_i; } } while (0)
 #else
 #define PK_STAMP() do { } while (0)
 #endif
