@@ -65,6 +65,30 @@ int pk_gemm_use_8p(int on);
 int pk_gemm_timing_stop(void);
 int pk_gemm_timing_read(int i, int* kernel, int* a_col, int* b_col, int* splitk, int* dtype, double* flops, float* ms);
 
+/* ---- The weight gradients of one layer in ONE launch: replaces the per-nn.Linear `grad_weight = grad_output^T @ input`
+ * (+ `grad_bias = grad_output.sum(0)`) that autograd issues one by one during the backward of a layer,
+ * pasero/models/transformer.py:1056-1099 (encoder layer), :1341-1417 (decoder layer), modules.py:92-96.
+ *   problem p:  C_p[M,N] = A_p^T B_p   with A_p = dY [K][lda] and B_p = X [K][ldb] (both as pk_gemm's col form),
+ *               asum_out_p[m] = sum_k A_p(k,m)  (optional: the bias gradient), C_p in the operands' 16-bit type.
+ * Each of those GEMMs has a small output (4..16 tiles of 256 x 256 at d = 512) and a contraction over all B*T rows: alone
+ * it needs 16..64 K-slices to fill the chip, i.e. that many fp32 partial outputs and a reduction launch per GEMM.  Up to
+ * PK_WGRAD_MAX problems launched together share the 256 CUs with 4-5 slices each: one GEMM launch (every workgroup a
+ * K-chunk of the same length) + one reduction launch (fixed slab order: deterministic).
+ *   pk_gemm_wgrad_group_eligible: 1 if a problem can ride (16-bit dtype, M, N >= 256, 16-byte addressable operands and
+ *     output, operands below 2 GiB); anything else goes through pk_gemm.  pk_gemm_wgrad_group refuses ineligible problems.
+ *   pk_gemm_wgrad_group_workspace: bytes of fp32 scratch the group needs (0 if no problem is split). */
+#define PK_WGRAD_MAX 8
+typedef struct PkWgradProblem {
+    const void* A;
+    const void* B;
+    void* C;
+    void* asum_out; /* [M] or NULL */
+    long long M, N, K, lda, ldb, ldc;
+} PkWgradProblem;
+int pk_gemm_wgrad_group_eligible(const PkWgradProblem* problem, int dtype);
+size_t pk_gemm_wgrad_group_workspace(const PkWgradProblem* problems, int n);
+int pk_gemm_wgrad_group(const PkWgradProblem* problems, int n, int dtype, void* workspace, size_t ws_bytes, void* stream);
+
 /* ---- Residual + dropout + LayerNorm (K4): replaces `residual + dropout(x)` followed by nn.LayerNorm,
  * pasero/models/transformer.py:1043-1054,1073-1086 (encoder), :1322-1339,1389-1407 (decoder), :941-947 (Norm).
  *   z = (residual ? residual : 0) + dropout(x)          -> z_out (optional)

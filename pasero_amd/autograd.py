@@ -107,12 +107,99 @@ def _wgrad(dy2d: Tensor, x2d: Tensor, want_w: bool, want_b: bool):
     return None, (F.colsum(dy2d) if want_b else None)
 
 
+class WGradGroup:
+    """The weight-gradient GEMMs of ONE layer, collected during its backward and launched together.
+
+    Each dW = dYᵀ·X of a layer has a small output (d x d ... f x d) and a contraction over all B·T rows: launched one by
+    one, every GEMM needs 16-64 K-slices of its own to fill the chip, that many fp32 partial outputs and a reduction
+    launch.  Launched together (`F.wgrad_group` -> pk_gemm_wgrad_group) they fill the 256 CUs with 4-5 slices each.
+    Mechanics: `WGradSinkFn` is the first autograd node of the layer and takes the layer's weights as extra inputs; the
+    GEMM functions of the layer (LinearFn, FFNFn, PackedLinearFn) hand their (dY, X) pairs to the group instead of
+    returning dW, and the sink — whose backward runs last in the layer, when the gradient of the layer input arrives —
+    launches the group and returns the gradients to autograd, so `.grad` accumulation and the DDP hooks see nothing new.
+    Every deferred op was created after the sink (higher sequence number: the engine runs it first when both are ready)
+    and is ready no later than a node on the sink's own dependency chain; an `add` after the sink has run would lose a
+    gradient and raises instead."""
+    __slots__ = ('slots', 'entries', 'closed', 'nparams')
+
+    def __init__(self):
+        self.slots = {}
+        self.entries = []
+        self.closed = False
+        self.nparams = 0
+
+    def bind(self, params):
+        self.nparams = len(params)
+        self.slots = {(p.data_ptr(), p.numel()): i for i, p in enumerate(params)}
+
+    def slot(self, p):
+        """position of parameter `p` among the sink's inputs (None: not taken — frozen, cast by autocast, LoRA...)"""
+        return None if p is None else self.slots.get((p.data_ptr(), p.numel()))
+
+    def add(self, dy2: Tensor, x2: Tensor, w_targets, b_targets) -> None:
+        """dW = dy2ᵀ·x2; `w_targets` / `b_targets`: [(slot, row0, row1)] — which rows of dW / db are whose gradient"""
+        if self.closed:
+            raise RuntimeError('pasero_amd: a weight gradient was handed to a layer\'s WGradGroup after the group had '
+                               'been launched; it would be lost (set PASERO_NO_WGRAD_GROUP=1 and report the model)')
+        want_b = bool(b_targets)
+        if F.wgrad_group_eligible(dy2, x2):
+            self.entries.append((dy2, x2, want_b, w_targets, b_targets, None))
+        else:  # small / unaligned / fp32 problems: the ordinary GEMM, now
+            r = weight_grad(dy2, x2, want_b)
+            self.entries.append((None, None, want_b, w_targets, b_targets, r if want_b else (r, None)))
+
+    def flush(self):
+        self.closed = True
+        entries, self.entries = self.entries, []
+        todo = [e for e in entries if e[5] is None]
+        done = F.wgrad_group([(e[0], e[1], e[2]) for e in todo]) if todo else []
+        it = iter(done)
+        grads = [None] * self.nparams
+        for dy2, x2, want_b, w_t, b_t, res in entries:
+            dw, db = res if res is not None else next(it)
+            for tensor, targets in ((dw, w_t), (db, b_t)):
+                for slot, r0, r1 in targets or ():
+                    g = tensor if (r0 == 0 and r1 == tensor.size(0)) else tensor[r0:r1]
+                    grads[slot] = g if grads[slot] is None else grads[slot] + g
+        return grads
+
+
+class WGradSinkFn(Function):
+    """identity on x at the entry of a layer; its backward launches the layer's grouped weight-gradient GEMM (WGradGroup)
+    and returns the gradients of `params` (the layer's Linear weights and biases)"""
+
+    @staticmethod
+    def forward(ctx, x, group, *params):
+        group.bind(params)
+        ctx.group = group
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dx):
+        grads = ctx.group.flush()
+        return (dx, None, *[g if need else None for g, need in zip(grads, ctx.needs_input_grad[2:])])
+
+
+def _defer(group, dy2, x2, weight, bias, want_w: bool, want_b: bool) -> bool:
+    """hand dW (and db) of one nn.Linear to the layer's group; False: the caller computes them itself"""
+    if group is None or not want_w:
+        return False
+    ws = group.slot(weight)
+    bs = group.slot(bias) if want_b else None
+    if ws is None or (want_b and bs is None):
+        return False
+    N = weight.size(0)
+    group.add(dy2, x2, [(ws, 0, N)], [(bs, 0, N)] if want_b else None)
+    return True
+
+
 class LinearFn(Function):
     """y = act(x Wᵀ + b)   (pasero/models/modules.py:92-96 + the activation that follows fc1)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act: str = 'none', link=None):
+    def forward(ctx, x, weight, bias, act: str = 'none', link=None, group=None):
         ctx.link = link.attach() if (link is not None and ctx.needs_input_grad[0]) else None
+        ctx.group, ctx.bias = group, (bias if group is not None else None)
         x2 = _2d(_contig(x))
         need_pre = act not in ('none', 'relu') and any(wants_grad(ctx))
         pre = torch.empty(x2.size(0), weight.size(0), dtype=x.dtype, device=x.device) if need_pre else None
@@ -132,13 +219,15 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = _dx_gemm(dy2, weight, ctx.link).view(*dy.shape[:-1], weight.size(1))
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        if _defer(ctx.group, dy2, x2, weight, ctx.bias, ctx.needs_input_grad[1], want_b):
+            pass  # (the layer's WGradSinkFn returns both gradients)
+        elif ctx.needs_input_grad[1]:
             dw = weight_grad(dy2, x2, want_b)
             if want_b:
                 dw, db = dw
         elif want_b:
             db = F.colsum(dy2)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class FFNFn(Function):
@@ -146,8 +235,9 @@ class FFNFn(Function):
     Backward fuses act'(.) into the epilogue of the dH = dY·W2 GEMM."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act: str, link=None):
+    def forward(ctx, x, w1, b1, w2, b2, act: str, link=None, group=None):
         ctx.link = link.attach() if (link is not None and ctx.needs_input_grad[0]) else None
+        ctx.group, ctx.biases = group, ((b1, b2) if group is not None else (None, None))
         x2 = _2d(_contig(x))
         grad = any(wants_grad(ctx))
         need_pre = grad and act not in ('none', 'relu')
@@ -168,10 +258,14 @@ class FFNFn(Function):
             dh = F.gemm(dy2, w2, b_col=True)
         else:
             dh = F.gemm(dy2, w2, b_col=True, act=ctx.act, aux=aux, mode=2)
-        dw2, db2 = _wgrad(dy2, h, ctx.needs_input_grad[3], ctx.has_b2 and ctx.needs_input_grad[4])
-        dx = _dx_gemm(dh, w1, ctx.link).view(*dy.shape[:-1], w1.size(1)) if ctx.needs_input_grad[0] else None
-        dw1, db1 = _wgrad(dh, x2, ctx.needs_input_grad[1], ctx.has_b1 and ctx.needs_input_grad[2])
-        return dx, dw1, db1, dw2, db2, None, None
+        ng = ctx.needs_input_grad
+        dw1 = db1 = dw2 = db2 = None
+        if not _defer(ctx.group, dy2, h, w2, ctx.biases[1], ng[3], ctx.has_b2 and ng[4]):
+            dw2, db2 = _wgrad(dy2, h, ng[3], ctx.has_b2 and ng[4])
+        dx = _dx_gemm(dh, w1, ctx.link).view(*dy.shape[:-1], w1.size(1)) if ng[0] else None
+        if not _defer(ctx.group, dh, x2, w1, ctx.biases[0], ng[1], ctx.has_b1 and ng[2]):
+            dw1, db1 = _wgrad(dh, x2, ng[1], ctx.has_b1 and ng[2])
+        return dx, dw1, db1, dw2, db2, None, None, None
 
 
 class GatedFFNFn(Function):
@@ -215,7 +309,11 @@ class PackedLinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, w_flat, b_flat, n: int, link, *params):
+        group = None
+        if params and isinstance(params[-1], WGradGroup):
+            group, params = params[-1], params[:-1]
         ctx.link = link.attach() if (link is not None and ctx.needs_input_grad[0]) else None
+        ctx.group, ctx.params = group, (params if group is not None else None)
         x2 = _2d(_contig(x))
         y = F.gemm(x2, w_flat, bias=b_flat)
         ctx.n = n
@@ -232,9 +330,18 @@ class PackedLinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = _dx_gemm(dy2, w_flat, ctx.link).view(*dy.shape[:-1], w_flat.size(1))
         D = w_flat.size(0) // n
-        grads = [None] * (2 * n)
+        grads = [None] * (2 * n + (1 if ctx.group is not None else 0))
         want_w = any(ctx.needs_input_grad[5:5 + n])
         want_b = any(ctx.has_bias[i] and ctx.needs_input_grad[5 + n + i] for i in range(n))
+        if ctx.group is not None and want_w:
+            # every wanted slice must be one of the sink's parameters, or the whole GEMM stays here
+            g, ps = ctx.group, ctx.params
+            w_t = [(g.slot(ps[i]), i * D, (i + 1) * D) for i in range(n) if ctx.needs_input_grad[5 + i]]
+            b_t = [(g.slot(ps[n + i]), i * D, (i + 1) * D) for i in range(n)
+                   if ctx.has_bias[i] and ctx.needs_input_grad[5 + n + i]]
+            if all(t[0] is not None for t in w_t + b_t):
+                g.add(dy2, x2, w_t, b_t)
+                return (dx, None, None, None, None, *grads)
         dw, db = _wgrad(dy2, x2, want_w, want_b)
         for i in range(n):
             if want_w and ctx.needs_input_grad[5 + i]:

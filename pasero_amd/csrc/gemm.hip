@@ -38,6 +38,10 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
                                 int b_col, int kchunk, int splitk, EpiParams ep, int dtype, void* stream);
 extern "C" int pk_gemm8p_eligible(long long M, long long N, long long K, long long lda, long long ldb, int a_col,
                                   int b_col, int want_asum);
+extern "C" int pk_gemm8p_group_eligible(const PkWgradProblem* q);
+extern "C" int pk_gemm8p_group_plan(const PkWgradProblem* p, int n, size_t* ws_bytes, int* workgroups, int* slabs);
+extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream);
+extern "C" int pk_gemm8p_group_reduce(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream);
 extern "C" int pk_gemm_skinny_launch(const void* A, const void* B, void* C, long long M, long long N, long long K,
                                      long long lda, long long ldb, EpiParams ep, int dtype, void* stream);
 
@@ -883,6 +887,45 @@ extern "C" int pk_gemm(const void* A, const void* B, void* C, const void* bias, 
     if (dtype == PK_F16)
         return launch_gemm<f16>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
     return launch_gemm<float>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
+}
+
+// ---- grouped weight gradients (see include/pasero_hip.h) ----
+extern "C" int pk_gemm_wgrad_group_eligible(const PkWgradProblem* q, int dtype) {
+    if (!q || (dtype != PK_BF16 && dtype != PK_F16) || !g_use_8p) return 0;
+    return pk_gemm8p_group_eligible(q);
+}
+
+extern "C" size_t pk_gemm_wgrad_group_workspace(const PkWgradProblem* p, int n) {
+    size_t b = 0;
+    if (!p || pk_gemm8p_group_plan(p, n, &b, nullptr, nullptr) != 0) return 0;
+    return b;
+}
+
+extern "C" int pk_gemm_wgrad_group(const PkWgradProblem* p, int n, int dtype, void* workspace, size_t ws_bytes,
+                                   void* stream) {
+    if (n == 0) return 0;
+    PK_CHECK_ARG(p && n > 0 && n <= PK_WGRAD_MAX, "pk_gemm_wgrad_group: 1..%d problems per launch, got %d", PK_WGRAD_MAX, n);
+    PK_CHECK_ARG(dtype == PK_BF16 || dtype == PK_F16, "pk_gemm_wgrad_group: 16-bit operands only (dtype %d)", dtype);
+    for (int i = 0; i < n; ++i)
+        PK_CHECK_ARG(pk_gemm_wgrad_group_eligible(&p[i], dtype),
+                     "pk_gemm_wgrad_group: problem %d (M=%lld N=%lld K=%lld) is not eligible; ask "
+                     "pk_gemm_wgrad_group_eligible first and send it through pk_gemm", i, p[i].M, p[i].N, p[i].K);
+    size_t need = 0;
+    int wgs = 0;
+    PK_CHECK_ARG(pk_gemm8p_group_plan(p, n, &need, &wgs, nullptr) == 0, "pk_gemm_wgrad_group: plan failed");
+    PK_CHECK_ARG(need == 0 || (workspace && ws_bytes >= need && ((uintptr_t)workspace % 16) == 0),
+                 "pk_gemm_wgrad_group: workspace too small or misaligned (%zu < %zu)", ws_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    double flops = 0;
+    for (int i = 0; i < n; ++i) flops += 2.0 * (double)p[i].M * (double)p[i].N * (double)p[i].K;
+    // (sample tag 8 | 0x40: the grouped instantiation of the phase-interleaved kernel; flops = the sum over the group)
+    GemmSample* sm = timing_begin(8 | 0x40, 1, 1, n, dtype, 1, 1, 1, s);
+    if (sm) sm->flops = flops;
+    int rc = pk_gemm8p_group_launch(p, n, dtype, (float*)workspace, stream);
+    timing_end(sm, s);
+    if (rc != 1) return rc;
+    rc = pk_gemm8p_group_reduce(p, n, dtype, (float*)workspace, stream);
+    return rc == 1 ? 0 : rc;
 }
 
 extern "C" int pk_gemm_use_8p(int on) {

@@ -231,13 +231,15 @@ __device__ __noinline__ void epilogue_pass_any(const float* __restrict__ cs, T* 
 // scratch memory (a kernel with a call gets a stack, and the waves of a 1024-workgroup launch then start measurably slower)
 // TAIL: the instantiation whose last K-tile may be partial (K % 64 != 0: the vocabulary dX GEMMs); the common one carries no
 // per-lane masking in its DMA issue (VALU work in a load section is taken out of the partner wave's MFMA issue slots)
+// `lin`: this workgroup's position in the slab-major (K-slab, tile) walk of ONE problem (the kernels below derive it from
+// blockIdx through the XCD-contiguous remap; the grouped kernel subtracts the first workgroup of the problem)
 template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL>
-__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A, const T* __restrict__ B,
-                                                       T* __restrict__ C, float* __restrict__ ws,
-                                                       float* __restrict__ asum_ws, T* __restrict__ asum_out,
-                                                       long long M, long long N, long long K, long long lda,
-                                                       long long ldb, int kchunk, unsigned a_bytes, unsigned b_bytes,
-                                                       int total, unsigned long long* stamps, EpiParams ep) {
+__device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
+                                            float* __restrict__ ws, float* __restrict__ asum_ws,
+                                            T* __restrict__ asum_out, long long M, long long N, long long K,
+                                            long long lda, long long ldb, int kchunk, unsigned a_bytes,
+                                            unsigned b_bytes, int lin, unsigned long long* stamps,
+                                            const EpiParams& ep) {
     typedef typename M16<T>::vec V;
     typedef __attribute__((address_space(3))) void lds_void;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -256,7 +258,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
 #define PK_STAMP() do { } while (0)
 #endif
     PK_STAMP();  // tile start
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);  // slab-major (K-slab, tile) walk: an XCD owns whole K-slabs
     const int kslab = lin / (nt_m * nt_n);
     int t = lin % (nt_m * nt_n);
     const int GROUP_M = nt_n <= 2 ? 8 : 4;
@@ -586,6 +587,98 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
 #undef PK_STAMP
 }
 
+template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A, const T* __restrict__ B,
+                                                       T* __restrict__ C, float* __restrict__ ws,
+                                                       float* __restrict__ asum_ws, T* __restrict__ asum_out,
+                                                       long long M, long long N, long long K, long long lda,
+                                                       long long ldb, int kchunk, unsigned a_bytes, unsigned b_bytes,
+                                                       int total, unsigned long long* stamps, EpiParams ep) {
+    // slab-major (K-slab, tile) walk over the XCD-contiguous remap: an XCD owns whole K-slabs
+    gemm8p_tile<T, A_COL, B_COL, ANY, TAIL>(A, B, C, ws, asum_ws, asum_out, M, N, K, lda, ldb, kchunk, a_bytes, b_bytes,
+                                            xcd_remap(blockIdx.x, gridDim.x), stamps, ep);
+}
+
+// ---- grouped weight gradients: up to PK_WGRAD_MAX (col,col) problems C_p = A_p^T B_p in ONE launch ----
+// The weight-gradient GEMMs of a layer (q|k|v, out-proj, fc1, fc2, ...: outputs of 4..16 tiles, contraction over all
+// B*T rows) each need split-K to fill 256 CUs on their own — 16..64 fp32 slabs per output and a reduction launch per
+// GEMM.  Launched together they fill the chip with 4-5 slabs per output: the table below travels by value in the
+// kernel arguments (scalar selects, no indexed access: an indexed by-value array would be copied to scratch).
+struct GroupProb {
+    const void* A; const void* B; void* C; float* ws; float* asum_ws; void* asum_out;
+    long long M, N, K, lda, ldb, ldc;
+    int kchunk, wg_begin, blk_begin, nslab;
+    unsigned a_bytes, b_bytes;
+};
+struct GroupArgs {
+    GroupProb p[PK_WGRAD_MAX];
+    int n;
+};
+
+__device__ __forceinline__ GroupProb group_select(const GroupArgs& g, int first_field_of, int pos) {
+    // the LAST problem whose first workgroup (first_field_of = 0) / first reduction block (= 1) is <= pos
+    GroupProb q = g.p[0];
+#pragma unroll
+    for (int i = 1; i < PK_WGRAD_MAX; ++i) {
+        const int b = first_field_of ? g.p[i].blk_begin : g.p[i].wg_begin;
+        if (i < g.n && pos >= b) q = g.p[i];
+    }
+    return q;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm8p_group_kernel(GroupArgs g, unsigned long long* stamps) {
+    const int pos = xcd_remap(blockIdx.x, gridDim.x);
+    const GroupProb q = group_select(g, 0, pos);
+    EpiParams ep;
+    ep.bias = nullptr; ep.aux = nullptr; ep.preact = nullptr;
+    ep.ldaux = 0; ep.ldc = q.ldc; ep.ldpre = 0;
+    ep.act = PK_ACT_NONE; ep.mode = 0; ep.alpha = 1.f;
+    gemm8p_tile<T, true, true, false, false>((const T*)q.A, (const T*)q.B, (T*)q.C, q.ws, q.asum_ws, (T*)q.asum_out, q.M,
+                                             q.N, q.K, q.lda, q.ldb, q.kchunk, q.a_bytes, q.b_bytes, pos - q.wg_begin,
+                                             stamps, ep);
+}
+
+// C_p = sum over the K-slabs of problem p (fixed order: deterministic), 16-byte chunks; + the fused bias-gradient sums
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(GroupArgs g, int total_blocks) {
+    const GroupProb q = group_select(g, 1, (int)blockIdx.x);
+    int next = total_blocks;
+#pragma unroll
+    for (int i = PK_WGRAD_MAX - 1; i >= 1; --i)
+        if (i < g.n && g.p[i].blk_begin > q.blk_begin) next = g.p[i].blk_begin;
+    const int nblk = next - q.blk_begin, blk = (int)blockIdx.x - q.blk_begin;
+    if (q.nslab <= 1) return;  // (written by the GEMM itself; such a problem owns no blocks anyway)
+    const long long M = q.M, N = q.N, slab = M * N;
+    if (q.asum_ws) {
+        for (long long m = (long long)blk * 256 + threadIdx.x; m < M; m += (long long)nblk * 256) {
+            float t = 0.f;
+            for (int z = 0; z < q.nslab; ++z) t += q.asum_ws[(long long)z * M + m];
+            reinterpret_cast<T*>(q.asum_out)[m] = from_f32<T>(t);
+        }
+    }
+    const long long nchunks_row = N / 8, total = M * nchunks_row;
+    T* C = reinterpret_cast<T*>(q.C);
+    for (long long c = (long long)blk * 256 + threadIdx.x; c < total; c += (long long)nblk * 256) {
+        const long long gm = c / nchunks_row, gn = (c % nchunks_row) * 8;
+        const float* p = q.ws + gm * N + gn;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll 4
+        for (int z = 0; z < q.nslab; ++z) {
+            const float4 a4 = *reinterpret_cast<const float4*>(p + (long long)z * slab);
+            const float4 b4 = *reinterpret_cast<const float4*>(p + (long long)z * slab + 4);
+            v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
+            v[4] += b4.x; v[5] += b4.y; v[6] += b4.z; v[7] += b4.w;
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, v[e]);
+        store16_nt<T>(C + gm * q.ldc + gn, o);
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -648,6 +741,145 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
 #undef PK_L
 #undef PK_D
 #undef PK_K
+    PK_LAUNCH_CHECK();
+    return 1;
+}
+
+// ---- grouped weight gradients (host side) ----
+namespace {
+struct GroupPlan {
+    int nslab[PK_WGRAD_MAX], kchunk[PK_WGRAD_MAX], wg_begin[PK_WGRAD_MAX], blk_begin[PK_WGRAD_MAX];
+    size_t ws_off[PK_WGRAD_MAX], asum_off[PK_WGRAD_MAX];  // in floats
+    int total_wgs, total_blks;
+    size_t ws_floats;
+};
+
+inline long long tiles256(const PkWgradProblem& q) { return ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN); }
+
+// One K-chunk length L for every problem of the group (workgroups of equal duration), problem p cut into
+// ceil(K_p / L) slabs.  L minimises  rounds x (time of a workgroup) + the slab traffic:  rounds = ceil(workgroups / 256),
+// a workgroup = L / 64 K-tiles of ~1.45 us + ~6.5 us of prologue / epilogue (tools/gemm_phase_stamps.py), 512 KiB of
+// fp32 slab written and read back per split workgroup at ~5 TB/s.
+void plan_group(const PkWgradProblem* p, int n, GroupPlan* pl) {
+    long long kmax = 0;
+    for (int i = 0; i < n; ++i) kmax = std::max(kmax, p[i].K);
+    double best = 1e30;
+    long long bestL = (kmax + BK - 1) / BK * BK, prevL = -1;
+    for (int s = 1; s <= 64; ++s) {
+        const long long L = ((kmax + s - 1) / s + BK - 1) / BK * BK;
+        if (L == prevL) continue;
+        prevL = L;
+        long long wgs = 0, split_wgs = 0;
+        for (int i = 0; i < n; ++i) {
+            const long long sp = (p[i].K + L - 1) / L;
+            wgs += tiles256(p[i]) * sp;
+            if (sp > 1) split_wgs += tiles256(p[i]) * sp;
+        }
+        const double rounds = (double)((wgs + 255) / 256);
+        const double cost = rounds * ((double)L / BK * 1.45 + 6.5) + (double)split_wgs * 0.105 + (split_wgs ? 4.0 : 0.0);
+        if (cost < best) { best = cost; bestL = L; }
+        if (L <= 512) break;
+    }
+    int wg = 0, blk = 0;
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        const int sp = (int)((p[i].K + bestL - 1) / bestL);
+        pl->nslab[i] = sp;
+        pl->kchunk[i] = (int)bestL;
+        pl->wg_begin[i] = wg;
+        wg += (int)tiles256(p[i]) * sp;
+        pl->blk_begin[i] = blk;
+        pl->ws_off[i] = pl->asum_off[i] = 0;
+        if (sp > 1) {
+            const long long chunks = p[i].M * (p[i].N / 8);
+            blk += (int)std::min(2048LL, (chunks + 255) / 256);
+            pl->ws_off[i] = off;
+            off += ((size_t)sp * p[i].M * p[i].N + 3) & ~(size_t)3;
+            if (p[i].asum_out) {
+                pl->asum_off[i] = off;
+                off += ((size_t)sp * p[i].M + 3) & ~(size_t)3;
+            }
+        }
+    }
+    pl->total_wgs = wg;
+    pl->total_blks = blk;
+    pl->ws_floats = off;
+}
+}  // namespace
+
+// 1 if the problem can ride in a grouped launch: what the dispatcher asks of a 256-tile (col,col) GEMM (gemm.hip)
+extern "C" int pk_gemm8p_group_eligible(const PkWgradProblem* q) {
+    auto al = [](const void* p, long long ld) { return ((uintptr_t)p % 16) == 0 && (ld % 8) == 0; };
+    if (!q->A || !q->B || !q->C) return 0;
+    if (q->M < 256 || q->N < 256 || q->K < 64 || q->N % 8) return 0;
+    if (!al(q->A, q->lda) || !al(q->B, q->ldb) || !al(q->C, q->ldc)) return 0;
+    if (q->M % 8 && q->lda < ((q->M + 7) & ~7LL)) return 0;
+    if (tiles256(*q) > 4096) return 0;
+    return pk_gemm8p_eligible(q->M, q->N, q->K, q->lda, q->ldb, 1, 1, q->asum_out != nullptr);
+}
+
+extern "C" int pk_gemm8p_group_plan(const PkWgradProblem* p, int n, size_t* ws_bytes, int* workgroups, int* slabs) {
+    if (n < 1 || n > PK_WGRAD_MAX) return -1;
+    GroupPlan pl;
+    plan_group(p, n, &pl);
+    if (ws_bytes) *ws_bytes = pl.ws_floats * sizeof(float);
+    if (workgroups) *workgroups = pl.total_wgs;
+    if (slabs) for (int i = 0; i < n; ++i) slabs[i] = pl.nslab[i];
+    return 0;
+}
+
+// Returns 1 if launched, a hip error code otherwise.  The caller (gemm.hip: pk_gemm_wgrad_group) has checked eligibility
+// and the workspace size.
+extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream) {
+    GroupPlan pl;
+    plan_group(p, n, &pl);
+    GroupArgs g;
+    g = GroupArgs{};
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        GroupProb& q = g.p[i];
+        long long a_bytes, b_bytes;
+        operand_bytes(p[i].M, p[i].N, p[i].K, p[i].lda, p[i].ldb, 1, 1, &a_bytes, &b_bytes);
+        q.A = p[i].A; q.B = p[i].B; q.C = p[i].C; q.asum_out = p[i].asum_out;
+        q.M = p[i].M; q.N = p[i].N; q.K = p[i].K; q.lda = p[i].lda; q.ldb = p[i].ldb; q.ldc = p[i].ldc;
+        q.kchunk = pl.kchunk[i]; q.wg_begin = pl.wg_begin[i]; q.blk_begin = pl.blk_begin[i]; q.nslab = pl.nslab[i];
+        q.a_bytes = (unsigned)a_bytes; q.b_bytes = (unsigned)b_bytes;
+        q.ws = pl.nslab[i] > 1 ? workspace + pl.ws_off[i] : nullptr;
+        q.asum_ws = (pl.nslab[i] > 1 && p[i].asum_out) ? workspace + pl.asum_off[i] : nullptr;
+    }
+    for (int i = n; i < PK_WGRAD_MAX; ++i) { g.p[i].wg_begin = 0x7fffffff; g.p[i].blk_begin = 0x7fffffff; }
+    unsigned long long* stamps = nullptr;
+    if (const char* e = getenv("PK8P_STAMP_PTR")) stamps = (unsigned long long*)strtoull(e, nullptr, 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PK_F16) hipLaunchKernelGGL((gemm8p_group_kernel<f16>), dim3(pl.total_wgs), dim3(512), 0, s, g, stamps);
+    else hipLaunchKernelGGL((gemm8p_group_kernel<bf16>), dim3(pl.total_wgs), dim3(512), 0, s, g, stamps);
+    PK_LAUNCH_CHECK();
+    return 1;
+}
+
+extern "C" int pk_gemm8p_group_reduce(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream) {
+    GroupPlan pl;
+    plan_group(p, n, &pl);
+    if (pl.total_blks == 0) return 1;
+    GroupArgs g;
+    g = GroupArgs{};
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        GroupProb& q = g.p[i];
+        q.C = p[i].C; q.asum_out = p[i].asum_out; q.M = p[i].M; q.N = p[i].N; q.ldc = p[i].ldc;
+        q.nslab = pl.nslab[i];
+        // a problem without slabs owns no blocks: its first block is that of the next split problem (never selected:
+        // group_select takes the LAST problem whose first block is <= the block index)
+        q.blk_begin = pl.blk_begin[i];
+        q.ws = pl.nslab[i] > 1 ? workspace + pl.ws_off[i] : nullptr;
+        q.asum_ws = (pl.nslab[i] > 1 && p[i].asum_out) ? workspace + pl.asum_off[i] : nullptr;
+    }
+    for (int i = n; i < PK_WGRAD_MAX; ++i) { g.p[i].wg_begin = 0x7fffffff; g.p[i].blk_begin = 0x7fffffff; }
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PK_F16)
+        hipLaunchKernelGGL((wgrad_group_reduce_kernel<f16>), dim3(pl.total_blks), dim3(256), 0, s, g, pl.total_blks);
+    else
+        hipLaunchKernelGGL((wgrad_group_reduce_kernel<bf16>), dim3(pl.total_blks), dim3(256), 0, s, g, pl.total_blks);
     PK_LAUNCH_CHECK();
     return 1;
 }

@@ -9,3 +9,14 @@ struct EpiParams {
     int mode;           // 0: act(v+bias)   1: act(v+bias) + aux   2: v * act'(aux)
     float alpha;
 };
+
+// One weight-gradient problem of a grouped launch (include/pasero_hip.h: PkWgradProblem): C[M,N] = A^T B, both operands
+// in col form (A = dY [K][lda], B = X [K][ldb]), asum_out[m] = sum_k A(m,k) (optional bias gradient)
+#define PK_WGRAD_MAX 8
+struct PkWgradProblem {
+    const void* A;
+    const void* B;
+    void* C;
+    void* asum_out;
+    long long M, N, K, lda, ldb, ldc;
+};

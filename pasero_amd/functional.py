@@ -1,6 +1,7 @@
 """Thin, non-differentiable wrappers over the C ABI (one Python function per kernel entry point).
 They only do argument checking, output allocation and the ctypes call; autograd lives in `pasero_amd.autograd`.
 """
+import ctypes
 from typing import Optional
 
 import torch
@@ -56,6 +57,49 @@ def gemm(a: Tensor, b: Tensor, *, a_col: bool = False, b_col: bool = False, bias
                     _ld(aux) if aux is not None else 0, _ld(preact) if preact is not None else 0,
                     int(a_col), int(b_col), ACT[act], mode, float(alpha), dtype_code(a), int(splitk),
                     ptr(ws), ws_bytes, ptr(asum_out), stream_ptr()), 'pk_gemm')
+    return out
+
+
+def _wgrad_problem(dy: Tensor, x: Tensor, dw: Optional[Tensor], db: Optional[Tensor]) -> 'lib.PkWgradProblem':
+    return lib.PkWgradProblem(ptr(dy), ptr(x), ptr(dw), ptr(db), dy.size(1), x.size(1), dy.size(0), _ld(dy), _ld(x),
+                              _ld(dw) if dw is not None else x.size(1))
+
+
+def wgrad_group_eligible(dy: Tensor, x: Tensor) -> bool:
+    """Can dW = dyᵀ·x (dy [rows, N_out], x [rows, K_in]) ride in a grouped launch (pk_gemm_wgrad_group)?  The output is a
+    fresh contiguous tensor, so only the operands decide."""
+    if not (dy.is_cuda and x.is_cuda) or dy.dtype != x.dtype or dy.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    if dy.dim() != 2 or x.dim() != 2 or dy.size(0) != x.size(0) or dy.stride(1) != 1 or x.stride(1) != 1:
+        return False
+    q = _wgrad_problem(dy, x, None, None)
+    q.C = 16  # (placeholder: any 16-byte aligned non-null address; the real output is allocated at launch time)
+    return bool(lib.load().pk_gemm_wgrad_group_eligible(ctypes.byref(q), dtype_code(dy)))
+
+
+def wgrad_group(entries):
+    """entries: [(dy [rows, N_out], x [rows, K_in], want_bias)], every one `wgrad_group_eligible` and of one dtype.
+    Returns [(dW [N_out, K_in], db [N_out] or None)]: all weight gradients in ONE GEMM launch + one reduction launch per
+    PK_WGRAD_MAX problems (include/pasero_hip.h:pk_gemm_wgrad_group)."""
+    L = lib.load()
+    out = []
+    for i in range(0, len(entries), lib.PK_WGRAD_MAX):
+        part = entries[i:i + lib.PK_WGRAD_MAX]
+        ref = part[0][0]
+        require_gpu(*[t for e in part for t in e[:2]])
+        _same(ref, *[t for e in part for t in e[:2]], what='wgrad_group')
+        res = []
+        for dy, x, want_b in part:
+            dw = torch.empty(dy.size(1), x.size(1), dtype=dy.dtype, device=dy.device)
+            db = torch.empty(dy.size(1), dtype=dy.dtype, device=dy.device) if want_b else None
+            res.append((dw, db))
+        arr = (lib.PkWgradProblem * len(part))(*[_wgrad_problem(dy, x, dw, db)
+                                                 for (dy, x, _), (dw, db) in zip(part, res)])
+        ws_bytes = L.pk_gemm_wgrad_group_workspace(arr, len(part))
+        ws = lib.workspace(ws_bytes, ref.device, 'splitk') if ws_bytes else None
+        check(L.pk_gemm_wgrad_group(arr, len(part), dtype_code(ref), ptr(ws), ws_bytes, stream_ptr()),
+              'pk_gemm_wgrad_group')
+        out.extend(res)
     return out
 
 

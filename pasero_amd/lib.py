@@ -26,6 +26,9 @@ SIGNATURES = {
     'pk_gemm_timing_start': (I, [I, I]),
     'pk_gemm_timing_stop': (I, []),
     'pk_gemm_timing_read': (I, [I, P, P, P, P, P, P, P]),
+    'pk_gemm_wgrad_group_eligible': (I, [P, I]),
+    'pk_gemm_wgrad_group_workspace': (SZ, [P, I]),
+    'pk_gemm_wgrad_group': (I, [P, I, I, P, SZ, P]),
     'pk_decoder_step_scratch': (SZ, [P, I]),
     'pk_decoder_step': (I, [P, P, I, I, I, P, P, LL, P, P, I, P, SZ, P, LL, P]),
     'pk_argmax_rows': (I, [P, LL, LL, LL, P, LL, I, P]),
@@ -65,6 +68,15 @@ SIGNATURES = {
     'pk_logmel_workspace': (SZ, [I]),
     'pk_logmel': (I, [P, P, LL, P, P, SZ, I, P]),
 }
+
+PK_WGRAD_MAX = 8
+
+
+class PkWgradProblem(ctypes.Structure):
+    """include/pasero_hip.h: one weight-gradient problem of a grouped launch"""
+    _fields_ = [('A', P), ('B', P), ('C', P), ('asum_out', P),
+                ('M', LL), ('N', LL), ('K', LL), ('lda', LL), ('ldb', LL), ('ldc', LL)]
+
 
 _lib = None
 

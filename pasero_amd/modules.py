@@ -73,8 +73,8 @@ class Linear(nn.Linear):
         self.lora_rank, self.lora_alpha = lora_rank, lora_alpha
         self.lora = AdapterLayer.LoRA(in_features, lora_rank, out_features, lora_alpha) if lora_rank else None
 
-    def forward(self, input: Tensor, link=None) -> Tensor:
-        output = LinearFn.apply(input, self.weight, self.bias, 'none', link)
+    def forward(self, input: Tensor, link=None, group=None) -> Tensor:
+        output = LinearFn.apply(input, self.weight, self.bias, 'none', link, group)
         if self.lora is not None:
             output = self.lora(input, residual=output)
         return output
@@ -490,6 +490,7 @@ class MultiheadAttention(nn.Module):
         self.causal = causal
         self._w_flat = self._b_flat = None
         self._residual_link = None  # set by the owning layer for one call (see transformer._LayerBase._linked)
+        self._wgroup = None         # likewise: the layer's grouped weight-gradient launch (autograd.WGradGroup)
 
     def reset_parameters(self) -> None:
         # xavier-uniform with gain 1/sqrt(2) for q, k, v (modules.py:565-576)
@@ -551,6 +552,8 @@ class MultiheadAttention(nn.Module):
             attn_mask = attn_mask if attn_mask.is_contiguous() else attn_mask.contiguous()
         w, b = self._flat()
         link, self._residual_link = self._residual_link, None  # gradient of the residual branch rides on the dX GEMM
+        group, self._wgroup = self._wgroup, None  # weight gradients ride in the layer's grouped launch
+        gp = () if group is None else (group,)
         q_w, k_w, v_w = self.q_proj.weight, self.k_proj.weight, self.v_proj.weight
         q_b, k_b, v_b = self.q_proj.bias, self.k_proj.bias, self.v_proj.bias
 
@@ -605,18 +608,18 @@ class MultiheadAttention(nn.Module):
             S = k.size(1)
             attn = AttentionFn.apply(q, k.view(B, S, D), v.view(B, S, D), attn_mask, H, self.causal and T > 1, scale)
         elif key is query and value is query:
-            qkv = rope(PackedLinearFn.apply(query, w, b, 3, link, q_w, k_w, v_w, q_b, k_b, v_b), 0)
+            qkv = rope(PackedLinearFn.apply(query, w, b, 3, link, q_w, k_w, v_w, q_b, k_b, v_b, *gp), 0)
             attn = AttentionFn.apply(qkv, None, None, attn_mask, H, self.causal and T > 1, scale, drop)
         elif key is value:
-            q = LinearFn.apply(query, q_w, q_b, 'none', link)
-            kv = PackedLinearFn.apply(key, w[D:], None if b is None else b[D:], 2, None, k_w, v_w, k_b, v_b)
+            q = LinearFn.apply(query, q_w, q_b, 'none', link, group)
+            kv = PackedLinearFn.apply(key, w[D:], None if b is None else b[D:], 2, None, k_w, v_w, k_b, v_b, *gp)
             attn = AttentionFn.apply(q, kv, None, attn_mask, H, self.causal and T > 1, scale, drop)
         else:
-            q = LinearFn.apply(query, q_w, q_b, 'none', link)
-            k = LinearFn.apply(key, k_w, k_b, 'none')
-            v = LinearFn.apply(value, v_w, v_b, 'none')
+            q = LinearFn.apply(query, q_w, q_b, 'none', link, group)
+            k = LinearFn.apply(key, k_w, k_b, 'none', None, group)
+            v = LinearFn.apply(value, v_w, v_b, 'none', None, group)
             attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale, drop)
-        attn = self.out_proj(attn)
+        attn = self.out_proj(attn, group=group) if group is not None else self.out_proj(attn)
         return attn, weights
 
 

@@ -13,6 +13,7 @@ File:line citations are into /root/reference/pasero/models/transformer.py unless
 """
 import logging
 import math
+import os
 from typing import Optional, Union
 
 import torch
@@ -23,11 +24,13 @@ from . import modules
 from .profiling import block as _bench_block, region as _bench_region
 from .modules import Embedding, Identity
 from .autograd import (FFNFn, GatedFFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn,
-                       AddPositionsFn, LinearFn, ResidualLink)
+                       AddPositionsFn, LinearFn, ResidualLink, WGradGroup, WGradSinkFn)
 
 from .config import register_model  # also enters the reference's registry when `pasero` is importable
 
 logger = logging.getLogger('models')
+# diagnostic: every weight-gradient GEMM launched on its own, as in round 1 (A/B of the grouped launch)
+_NO_WGRAD_GROUP = bool(int(os.environ.get('PASERO_NO_WGRAD_GROUP', '0') or 0))
 LN2 = math.log(2)
 
 
@@ -473,11 +476,41 @@ class _LayerBase(nn.Module):
         if self.fc3 is not None:
             return GatedFFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc3.weight, self.fc3.bias,
                                     self.fc2.weight, self.fc2.bias, self.activation_fn.name, link)
+        group, self._ffn_group = getattr(self, '_ffn_group', None), None
         if not (self.training and self.activation_dropout.p > 0):
             return FFNFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
-                               self.activation_fn.name, link)
-        y = self.activation_dropout(self.activation_fn(self.fc1(x, link=link)))
-        return self.fc2(y)
+                               self.activation_fn.name, link, group)
+        y = self.activation_dropout(self.activation_fn(self.fc1(x, link=link, group=group)))
+        return self.fc2(y, group=group)
+
+    def _wgrad_open(self, x: Tensor, attns) -> Tensor:
+        """Entry of a layer: collect this layer's weight-gradient GEMMs into one grouped launch (autograd.WGradGroup).
+        The sink node goes on `x`; the attention modules and the feed-forward pick the group up for this one call."""
+        self._wgrad_close(attns)
+        if (_NO_WGRAD_GROUP or not torch.is_grad_enabled() or not x.is_cuda or not x.requires_grad
+                or x.dtype not in (torch.bfloat16, torch.float16) or torch.is_autocast_enabled('cuda')
+                or self.cfg.checkpoint_activations or self.fc3 is not None):
+            return x
+        linears = [self.fc1, self.fc2]
+        for a in attns:
+            linears += [a.q_proj, a.k_proj, a.v_proj, a.out_proj]
+        if any(m.lora is not None for m in linears):
+            return x
+        params = [p for m in linears for p in (m.weight, m.bias) if p is not None and p.requires_grad
+                  and p.dtype == x.dtype]
+        if not params:
+            return x
+        group = WGradGroup()
+        for a in attns:
+            a._wgroup = group
+        self._ffn_group = group
+        return WGradSinkFn.apply(x, group, *params)
+
+    def _wgrad_close(self, attns) -> None:
+        """(a hook that skipped its sub-block must not leave the group behind for a later call)"""
+        for a in attns:
+            a._wgroup = None
+        self._ffn_group = None
 
     def _residual(self, x: Tensor, residual: Tensor) -> Tensor:
         return ResidualDropoutFn.apply(x, residual, self.dropout.p if self.training else 0.0)
@@ -565,6 +598,7 @@ class TransformerEncoderLayer(_LayerBase):
         if self.cfg.check_inf:
             raise NotImplementedError('pasero_amd: --check-inf clamping (fp16 T5) is not implemented')
         self.return_layers = return_layers
+        x = self._wgrad_open(x, (self.self_attn,))
         residual = x
         link = self._linked(('self_attention', 'self_attn_prenorm'), 'self_attn_residual', 'self_attn_postnorm',
                             self.self_attn_layer_norm, self.self_attn, '_residual_link')
@@ -577,6 +611,7 @@ class TransformerEncoderLayer(_LayerBase):
         x = self.ffn_prenorm(x)
         x = self.ffn(x, residual, padding_mask)
         x = self._block_end(x, residual, self.final_layer_norm, 'ffn_residual', 'ffn_postnorm', link)
+        self._wgrad_close((self.self_attn,))
         layer_outputs = self.layer_outputs
         self.layer_outputs = {}
         self.return_layers = []
@@ -668,6 +703,8 @@ class TransformerDecoderLayer(_LayerBase):
         if self.cfg.check_inf:
             raise NotImplementedError('pasero_amd: --check-inf clamping (fp16 T5) is not implemented')
         self.return_layers = return_layers
+        if state is None:
+            x = self._wgrad_open(x, (self.self_attn, self.encoder_attn))
         residual = x
         link = None
         if state is None:
@@ -689,6 +726,7 @@ class TransformerDecoderLayer(_LayerBase):
         x = self.ffn_prenorm(x)
         x = self.ffn(x, residual, padding_mask)
         x = self._block_end(x, residual, self.final_layer_norm, 'ffn_residual', 'ffn_postnorm', link)
+        self._wgrad_close((self.self_attn, self.encoder_attn))
         layer_outputs = self.layer_outputs
         self.layer_outputs = {}
         if self.name in return_layers:

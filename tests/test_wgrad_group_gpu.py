@@ -1,0 +1,164 @@
+"""The grouped weight-gradient launch (include/pasero_hip.h: pk_gemm_wgrad_group; autograd.WGradGroup): every dW = dYᵀ·X
+of a layer in one GEMM launch + one reduction launch.  Checked against an fp64 contraction and against the one-by-one
+pk_gemm path it replaces (pasero/models/modules.py:92-96: what autograd does for nn.Linear), at the kernel level on
+shapes around every edge of the plan (ragged M / N / K, problems of different K, unsplit problems, more problems than one
+launch holds) and at the model level (every gradient of a base-width model with and without the group)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+
+
+def _problem(rows, n_out, k_in, dtype, seed, pad_out=0):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    dy = (torch.randn(rows, n_out + pad_out, device='cuda', generator=g) * 0.5).to(dtype)[:, :n_out]
+    x = torch.randn(rows, k_in, device='cuda', generator=g).to(dtype)
+    return dy, x
+
+
+def _check(entries, dtype):
+    from pasero_amd import functional as F
+    res = F.wgrad_group(entries)
+    assert len(res) == len(entries)
+    tol = 2 ** -8  # one unit of bf16 storage (fp16: 2^-11; the looser one covers both)
+    for (dy, x, want_b), (dw, db) in zip(entries, res):
+        ref = dy.double().t() @ x.double()
+        scale = ref.abs().max().item()
+        assert dw.shape == ref.shape and dw.dtype == dtype
+        assert (dw.double() - ref).abs().max().item() <= tol * scale, (dy.shape, x.shape)
+        one = F.gemm(dy, x, a_col=True, b_col=True, splitk=F.choose_splitk(dy.size(1), x.size(1), dy.size(0)))
+        # both are fp32 sums rounded once: they differ by at most one rounding step of the output type
+        assert (dw.double() - one.double()).abs().max().item() <= tol * scale
+        if want_b:
+            bref = dy.double().sum(0)
+            assert (db.double() - bref).abs().max().item() <= tol * max(bref.abs().max().item(), 1.0) * 2
+        else:
+            assert db is None
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_group_of_one_layer(dtype):
+    rows, d, f = 4096, 512, 2048
+    entries = [(*_problem(rows, 3 * d, d, dtype, 1), True), (*_problem(rows, d, d, dtype, 2), True),
+               (*_problem(rows, f, d, dtype, 3), True), (*_problem(rows, d, f, dtype, 4), False)]
+    _check(entries, dtype)
+
+
+def test_ragged_shapes_and_mixed_contractions():
+    from pasero_amd import functional as F
+    dt = torch.bfloat16
+    entries = [
+        (*_problem(1000, 264, 520, dt, 5), True),             # M, N, K all off the tile grid (K % 8 == 0)
+        (*_problem(4096 + 64, 512, 256, dt, 6), False),       # another K in the same group
+        (*_problem(520, 1032, 768, dt, 7), True),
+        (*_problem(3000, 300, 512, dt, 8, pad_out=4), True),  # M % 8 != 0 with padded rows (the vocabulary layout)
+        (*_problem(72, 512, 512, dt, 9), True),               # K of barely more than one K-tile
+    ]
+    for dy, x, _ in entries:
+        assert F.wgrad_group_eligible(dy, x), (dy.shape, x.shape)
+    _check(entries, dt)
+
+
+def test_unsplit_problems_and_more_than_one_launch():
+    dt = torch.bfloat16
+    # 4096 x 4096 outputs: 256 tiles each -> no K split for them; eleven problems -> two launches
+    entries = [(*_problem(512, 4096, 4096, dt, 20), True)]
+    entries += [(*_problem(2048, 512, 512, dt, 21 + i), bool(i & 1)) for i in range(10)]
+    _check(entries, dt)
+
+
+def test_ineligible_problems_are_refused_by_the_c_entry_and_routed_by_the_group():
+    from pasero_amd import functional as F
+    from pasero_amd.autograd import WGradGroup
+    dy, x = _problem(2048, 64, 512, torch.bfloat16, 30)        # 64 output rows: below the 256-tile kernel's floor
+    assert not F.wgrad_group_eligible(dy, x)
+    with pytest.raises(RuntimeError, match='not eligible'):
+        F.wgrad_group([(dy, x, False)])
+    dyf, xf = _problem(2048, 512, 512, torch.float32, 31)      # fp32: the exact-fp32 128-tile kernel, one by one
+    assert not F.wgrad_group_eligible(dyf, xf)
+    w = torch.nn.Parameter(torch.empty(64, 512, device='cuda', dtype=torch.bfloat16))
+    w2 = torch.nn.Parameter(torch.empty(512, 512, device='cuda', dtype=torch.bfloat16))
+    g = WGradGroup()
+    g.bind([w, w2])
+    g.add(dy, x, [(g.slot(w), 0, 64)], None)                   # computed on the spot by pk_gemm
+    dy2, x2 = _problem(2048, 512, 512, torch.bfloat16, 32)
+    g.add(dy2, x2, [(g.slot(w2), 0, 512)], None)               # waits for the launch
+    grads = g.flush()
+    assert torch.equal(grads[0], F.gemm(dy, x, a_col=True, b_col=True, splitk=F.choose_splitk(64, 512, 2048)))
+    ref = dy2.double().t() @ x2.double()
+    assert (grads[1].double() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item()
+    with pytest.raises(RuntimeError, match='after the group had been launched'):
+        g.add(dy2, x2, [(1, 0, 512)], None)
+
+
+def _model(V=2000, layers=2, dropout=0.1):
+    from pasero_amd.config import TransformerConfig, DistributedConfig, SyntheticTask
+    from pasero_amd.transformer import Transformer
+    from model_utils import load_paramgen
+    cfg = TransformerConfig(dropout=dropout, encoder_layers=layers, decoder_layers=layers)
+    model = Transformer(cfg, DistributedConfig(), SyntheticTask(V))
+    load_paramgen(model, 3)
+    return model.to(torch.bfloat16).cuda().train()
+
+
+def _grads(model, batch, grouped, monkeypatch):
+    from pasero_amd import transformer, rng
+    monkeypatch.setattr(transformer, '_NO_WGRAD_GROUP', not grouped)
+    rng.manual_seed(1234)
+    model.zero_grad(set_to_none=True)
+    loss, _ = model(**batch)
+    loss.backward()
+    return loss.item(), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def test_model_gradients_with_and_without_the_group(monkeypatch):
+    """base-width model (d = 512: every layer GEMM is eligible), dropout on, ragged batch: same loss bit for bit (the
+    forward pass is untouched), every gradient within bf16 rounding of the one-by-one path, the group really ran"""
+    import paramgen
+    from pasero_amd import functional as F
+    V = 2000
+    model = _model(V)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(5, 32, 64, 64, V, ragged=True).items()}
+    calls = []
+    real = F.wgrad_group
+    monkeypatch.setattr(F, 'wgrad_group', lambda e: (calls.append(len(e)), real(e))[1])
+    l0, g0 = _grads(model, batch, False, monkeypatch)
+    assert calls == []
+    l1, g1 = _grads(model, batch, True, monkeypatch)
+    # encoder layer: q|k|v, out, fc1, fc2; decoder layer: + cross q, k|v, out
+    assert calls == [7, 7, 4, 4], calls
+    assert l0 == l1
+    assert set(g0) == set(g1)
+    for n in g0:
+        ref = g0[n]
+        err = (g1[n] - ref).norm().item() / max(ref.norm().item(), 1e-20)
+        assert err < 4e-3, (n, err)  # two bf16 roundings of (almost) the same fp32 sums
+    # run to run the grouped path is bitwise reproducible (fixed slab order)
+    l2, g2 = _grads(model, batch, True, monkeypatch)
+    assert l2 == l1 and all(torch.equal(g1[n], g2[n]) for n in g1)
+
+
+def test_frozen_and_partially_frozen_layers(monkeypatch):
+    """frozen weights get no gradient and are no input of the sink; a q|k|v arena with one frozen projection still rides in
+    the group (the frozen slice of the flat gradient is simply not handed out)"""
+    import paramgen
+    V = 2000
+    model = _model(V, layers=1, dropout=0.0)
+    for n, p in model.named_parameters():
+        if 'encoder.layers.0.fc1' in n or n.endswith('decoder.layers.0.self_attn.k_proj.weight'):
+            p.requires_grad_(False)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(6, 16, 64, 64, V).items()}
+    l0, g0 = _grads(model, batch, False, monkeypatch)
+    l1, g1 = _grads(model, batch, True, monkeypatch)
+    assert l0 == l1 and set(g0) == set(g1)
+    assert not any('encoder.layers.0.fc1' in n for n in g1)
+    assert 'decoder.layers.0.self_attn.q_proj.weight' in g1 and 'decoder.layers.0.self_attn.k_proj.weight' not in g1
+    for n in g0:
+        err = (g1[n] - g0[n]).norm().item() / max(g0[n].norm().item(), 1e-20)
+        assert err < 4e-3, (n, err)
