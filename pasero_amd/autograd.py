@@ -120,21 +120,24 @@ class WGradGroup:
     Every deferred op was created after the sink (higher sequence number: the engine runs it first when both are ready)
     and is ready no later than a node on the sink's own dependency chain; an `add` after the sink has run would lose a
     gradient and raises instead."""
-    __slots__ = ('slots', 'entries', 'closed', 'nparams')
+    __slots__ = ('slots', 'entries', 'closed', 'params')
 
     def __init__(self):
         self.slots = {}
         self.entries = []
         self.closed = False
-        self.nparams = 0
+        self.params = ()
 
     def bind(self, params):
-        self.nparams = len(params)
-        self.slots = {(p.data_ptr(), p.numel()): i for i, p in enumerate(params)}
+        # by object identity (the group keeps the parameters alive): a parameter's storage may move between the layer
+        # entry and its use — MultiheadAttention packs q|k|v into one arena at its first call — the object does not;
+        # the 16-bit copies autocast makes of fp32 parameters are other objects and stay on the one-by-one path
+        self.params = tuple(params)
+        self.slots = {id(p): i for i, p in enumerate(self.params)}
 
     def slot(self, p):
         """position of parameter `p` among the sink's inputs (None: not taken — frozen, cast by autocast, LoRA...)"""
-        return None if p is None else self.slots.get((p.data_ptr(), p.numel()))
+        return None if p is None else self.slots.get(id(p))
 
     def add(self, dy2: Tensor, x2: Tensor, w_targets, b_targets) -> None:
         """dW = dy2ᵀ·x2; `w_targets` / `b_targets`: [(slot, row0, row1)] — which rows of dW / db are whose gradient"""
@@ -154,7 +157,7 @@ class WGradGroup:
         todo = [e for e in entries if e[5] is None]
         done = F.wgrad_group([(e[0], e[1], e[2]) for e in todo]) if todo else []
         it = iter(done)
-        grads = [None] * self.nparams
+        grads = [None] * len(self.params)
         for dy2, x2, want_b, w_t, b_t, res in entries:
             dw, db = res if res is not None else next(it)
             for tensor, targets in ((dw, w_t), (db, b_t)):

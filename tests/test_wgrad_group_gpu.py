@@ -128,9 +128,15 @@ def test_model_gradients_with_and_without_the_group(monkeypatch):
     calls = []
     real = F.wgrad_group
     monkeypatch.setattr(F, 'wgrad_group', lambda e: (calls.append(len(e)), real(e))[1])
+    # the grouped step FIRST: the q|k|v arenas are packed inside this very forward pass (the parameters' storage moves
+    # after the layer's sink was built; the group must still recognise them)
+    l1, g1 = _grads(model, batch, True, monkeypatch)
+    assert calls == [7, 7, 4, 4], calls
+    del calls[:]
     l0, g0 = _grads(model, batch, False, monkeypatch)
     assert calls == []
-    l1, g1 = _grads(model, batch, True, monkeypatch)
+    l1b, g1b = _grads(model, batch, True, monkeypatch)
+    assert l1b == l1 and all(torch.equal(g1[n], g1b[n]) for n in g1)
     # encoder layer: q|k|v, out, fc1, fc2; decoder layer: + cross q, k|v, out
     assert calls == [7, 7, 4, 4], calls
     assert l0 == l1
