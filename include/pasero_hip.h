@@ -89,6 +89,21 @@ int pk_gemm_wgrad_group_eligible(const PkWgradProblem* problem, int dtype);
 size_t pk_gemm_wgrad_group_workspace(const PkWgradProblem* problems, int n);
 int pk_gemm_wgrad_group(const PkWgradProblem* problems, int n, int dtype, void* workspace, size_t ws_bytes, void* stream);
 
+/* ---- Linear + residual + dropout + LayerNorm in one kernel (K4 fused into K2/K5): replaces the tail of a post-norm
+ * sub-block, `x = self.out_proj(x)` / `x = self.fc2(x)` followed by `x = residual + dropout(x); x = LayerNorm(x)`,
+ * pasero/models/modules.py:739, pasero/models/transformer.py:1018,1043-1048,1076-1086 and :1322-1339,1389-1407.
+ *   v = A Wᵀ + bias;  z = (residual ? residual : 0) + dropout(v) -> z_out (optional);  y = LN(z) * gamma + beta -> y_out
+ *   A [M][lda], W [N][ldb] (nn.Linear layout), residual [M][ldr], z_out / y_out [M][N] contiguous, mean / rstd [M] fp32
+ *   (mean == NULL: RMSNorm, beta must be NULL).  Dropout mask and statistics exactly as pk_residual_ln_fwd takes them
+ *   (same Philox function of (seed, offset, element): pk_residual_ln_bwd regenerates the mask), so the stand-alone
+ *   backward serves both.  LayerNorm needs whole rows in one tile: N must be 512 (pk_gemm_ln_eligible; K % 64 == 0,
+ *   16-bit operands, 16-byte addressable); other shapes take pk_gemm + pk_residual_ln_fwd. */
+int pk_gemm_ln_eligible(long long M, long long N, long long K, long long lda, long long ldb, int dtype);
+int pk_gemm_ln_fwd(const void* A, const void* W, const void* bias, const void* residual, const void* gamma,
+                   const void* beta, void* z_out, void* y_out, float* mean, float* rstd, long long M, long long N,
+                   long long K, long long lda, long long ldb, long long ldr, float eps, float drop_p,
+                   unsigned long long seed, unsigned long long offset, int dtype, void* stream);
+
 /* ---- Residual + dropout + LayerNorm (K4): replaces `residual + dropout(x)` followed by nn.LayerNorm,
  * pasero/models/transformer.py:1043-1054,1073-1086 (encoder), :1322-1339,1389-1407 (decoder), :941-947 (Norm).
  *   z = (residual ? residual : 0) + dropout(x)          -> z_out (optional)

@@ -435,6 +435,121 @@ class ResidualLayerNormFn(Function):
                 dbeta if ctx.has_beta else None, None, None, None, None)
 
 
+class BlockTail:
+    """What the LAST GEMM of a post-norm sub-block needs to finish the block itself (LinearResidualLnFn): handed by the
+    layer to the module that runs that GEMM (MultiheadAttention.out_proj) for one call; `done` tells the layer that the
+    output it got back is already  LayerNorm(residual + dropout(.))."""
+    __slots__ = ('residual', 'gamma', 'beta', 'eps', 'p', 'done')
+
+    def __init__(self, residual, gamma, beta, eps: float, p: float):
+        self.residual, self.gamma, self.beta, self.eps, self.p = residual, gamma, beta, eps, p
+        self.done = False
+
+
+def block_tail_eligible(rows: int, weight: Tensor, residual: Tensor, gamma: Tensor) -> bool:
+    """can `LayerNorm(residual + dropout(x Wᵀ + b))` over `rows` rows run as one kernel (pk_gemm_ln_fwd)?  d = 512, whole
+    K-tiles, 16-bit tensors of one type, and no autocast (its 16-bit copies of fp32 parameters take the general path)"""
+    if torch.is_autocast_enabled('cuda') or not residual.is_cuda or rows == 0:
+        return False
+    if not (weight.dtype == residual.dtype == gamma.dtype) or residual.size(-1) != weight.size(0):
+        return False
+    return F.gemm_ln_eligible_shape(rows, weight)
+
+
+def _ln_tail_backward(ctx, dy, z, gamma, mean, rstd):
+    """LayerNorm + dropout backward of a fused block end -> (dres, dsub, dgamma, dbeta): the gradient of the residual
+    branch, the (masked, scaled) gradient of the GEMM output, the parameter gradients"""
+    want_pg = ctx.need_gamma or ctx.need_beta
+    dres, dsub, dgamma, dbeta = F.residual_ln_bwd(
+        _contig(dy), None, z, gamma, mean, rstd, want_dres=True, want_dx=ctx.p > 0, want_param_grads=want_pg,
+        has_beta=ctx.has_beta, drop_p=ctx.p, seed=ctx.seed, offset=ctx.offset)
+    if ctx.p == 0:
+        dsub = dres
+    return dres, dsub, (dgamma if ctx.need_gamma else None), (dbeta if ctx.need_beta else None)
+
+
+class LinearResidualLnFn(Function):
+    """y = LayerNorm(residual + dropout(x Wᵀ + b)) in ONE kernel (pk_gemm_ln_fwd): the output projection of an attention
+    block together with the post-norm block end (pasero/models/modules.py:739 + transformer.py:1043-1048,1076-1086).
+    Backward: the stand-alone LayerNorm backward kernel, then the dX GEMM; dW rides in the layer's grouped launch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, gamma, beta, eps: float, p: float, link=None, group=None):
+        x2 = _2d(_contig(x))
+        res2 = _2d(_contig(residual))
+        seed, offset = rng.next_offset() if p > 0 else (0, 0)
+        grad = any(wants_grad(ctx))
+        y, z, mean, rstd = F.gemm_ln_fwd(x2, weight, bias, res2, gamma, beta, eps, p, seed, offset, want_z=grad)
+        # (a link no GEMM picked up — a sub-block path that does not forward it — must not swallow the gradient)
+        ctx.link = link if (link is not None and link.attached and residual.requires_grad) else None
+        ctx.group, ctx.bias = group, (bias if group is not None else None)
+        ctx.p, ctx.seed, ctx.offset = p, seed, offset
+        ctx.has_bias, ctx.has_beta = bias is not None, beta is not None
+        ctx.x_shape = x.shape
+        ctx.save_for_backward(x2, weight, z, gamma, mean, rstd)
+        return y.view(residual.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, z, gamma, mean, rstd = ctx.saved_tensors
+        ng = ctx.needs_input_grad  # x, weight, bias, residual, gamma, beta
+        ctx.need_gamma, ctx.need_beta = ng[4], ctx.has_beta and ng[5]
+        dres, dsub, dgamma, dbeta = _ln_tail_backward(ctx, dy, z, gamma, mean, rstd)
+        dsub2 = _2d(dsub)
+        dx = _dx_gemm(dsub2, weight, None).view(ctx.x_shape) if ng[0] else None
+        dw = db = None
+        want_b = ctx.has_bias and ng[2]
+        if not _defer(ctx.group, dsub2, x2, weight, ctx.bias, ng[1], want_b):
+            dw, db = _wgrad(dsub2, x2, ng[1], want_b)
+        if ctx.link is not None:  # the residual-branch gradient rides on the sub-block's first dX GEMM
+            ctx.link.dres = dres
+            dres = None
+        return dx, dw, db, (dres.view(dy.shape) if (dres is not None and ng[3]) else None), dgamma, dbeta, None, None, None, None
+
+
+class FFNResidualLnFn(Function):
+    """y = LayerNorm(x + dropout(fc2(act(fc1 x)))): a whole post-norm feed-forward sub-block (pasero/models/transformer.py:
+    999-1019 + 1043-1054) as two launches — fc1 with the activation in its epilogue, fc2 with bias, dropout, the residual
+    and LayerNorm in its epilogue.  Backward: LayerNorm backward, dH = (dZ·W2) ⊙ act′, dX = dH·W1 + (residual-branch
+    gradient, in the epilogue); both weight gradients ride in the layer's grouped launch."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act: str, gamma, beta, eps: float, p: float, group=None):
+        x2 = _2d(_contig(x))
+        grad = any(wants_grad(ctx))
+        need_pre = grad and act not in ('none', 'relu')
+        pre = torch.empty(x2.size(0), w1.size(0), dtype=x.dtype, device=x.device) if need_pre else None
+        h = F.gemm(x2, w1, bias=b1, act=act, preact=pre)
+        seed, offset = rng.next_offset() if p > 0 else (0, 0)
+        y, z, mean, rstd = F.gemm_ln_fwd(h, w2, b2, x2, gamma, beta, eps, p, seed, offset, want_z=grad)
+        ctx.group, ctx.biases = group, ((b1, b2) if group is not None else (None, None))
+        ctx.act, ctx.p, ctx.seed, ctx.offset = act, p, seed, offset
+        ctx.has_b1, ctx.has_b2, ctx.has_beta = b1 is not None, b2 is not None, beta is not None
+        ctx.save_for_backward(x2, w1, w2, h, pre, z, gamma, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, h, pre, z, gamma, mean, rstd = ctx.saved_tensors
+        ng = ctx.needs_input_grad  # x, w1, b1, w2, b2, act, gamma, beta
+        ctx.need_gamma, ctx.need_beta = ng[6], ctx.has_beta and ng[7]
+        dres, dsub, dgamma, dbeta = _ln_tail_backward(ctx, dy, z, gamma, mean, rstd)
+        dy2 = _2d(dsub)
+        if ctx.act == 'none':
+            dh = F.gemm(dy2, w2, b_col=True)
+        else:
+            dh = F.gemm(dy2, w2, b_col=True, act=ctx.act, aux=h if pre is None else pre, mode=2)
+        dw1 = db1 = dw2 = db2 = None
+        if not _defer(ctx.group, dy2, h, w2, ctx.biases[1], ng[3], ctx.has_b2 and ng[4]):
+            dw2, db2 = _wgrad(dy2, h, ng[3], ctx.has_b2 and ng[4])
+        dx = None
+        if ng[0]:  # the residual is x itself: its gradient is the aux operand of the dX GEMM
+            dx = F.gemm(dh, w1, b_col=True, aux=_2d(dres), mode=1).view(dy.shape)
+        if not _defer(ctx.group, dh, x2, w1, ctx.biases[0], ng[1], ctx.has_b1 and ng[2]):
+            dw1, db1 = _wgrad(dh, x2, ng[1], ctx.has_b1 and ng[2])
+        return dx, dw1, db1, dw2, db2, None, dgamma, dbeta, None, None, None
+
+
 class AdapterFn(Function):
     """y = res + s · up(act(down(LN(x))))   — the bottleneck adapter of Bapna et al. and, without LayerNorm / biases /
     activation and with `res` = the frozen layer's output, LoRA (pasero/models/modules.py:248-370 AdapterLayer.forward,

@@ -143,6 +143,50 @@ def residual_ln_fwd(x: Tensor, residual: Optional[Tensor], gamma: Optional[Tenso
     return y, z, mean, rstd
 
 
+def gemm_ln_eligible(x: Tensor, weight: Tensor) -> bool:
+    """can `LN(residual + dropout(x Wᵀ + b))` run as ONE kernel (pk_gemm_ln_fwd)?  x [M, K], weight [512, K], 16-bit"""
+    if not (x.is_cuda and weight.is_cuda) or x.dtype != weight.dtype or x.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    if x.dim() != 2 or weight.dim() != 2 or x.size(1) != weight.size(1) or x.stride(1) != 1 or weight.stride(1) != 1:
+        return False
+    if x.data_ptr() % 16 or weight.data_ptr() % 16 or x.size(0) == 0:
+        return False
+    return bool(lib.load().pk_gemm_ln_eligible(x.size(0), weight.size(0), x.size(1), _ld(x), _ld(weight), dtype_code(x)))
+
+
+def gemm_ln_eligible_shape(rows: int, weight: Tensor) -> bool:
+    """the same question for a contiguous [rows, K] input that does not exist yet"""
+    if not weight.is_cuda or weight.dtype not in (torch.bfloat16, torch.float16) or weight.dim() != 2:
+        return False
+    if weight.stride(1) != 1 or weight.data_ptr() % 16 or rows == 0:
+        return False
+    return bool(lib.load().pk_gemm_ln_eligible(rows, weight.size(0), weight.size(1), weight.size(1), _ld(weight),
+                                               dtype_code(weight)))
+
+
+def gemm_ln_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Optional[Tensor], gamma: Tensor,
+                beta: Optional[Tensor], eps: float, drop_p: float = 0.0, seed: int = 0, offset: int = 0,
+                want_z: bool = True, rms: bool = False):
+    """z = residual + dropout(x Wᵀ + bias); y = LN(z) (RMSNorm with `rms`) in one kernel.  x [M, K], weight [N, K],
+    residual [M, N].  Returns (y, z or None, mean or None, rstd) like residual_ln_fwd."""
+    require_gpu(x, weight, bias, residual, gamma, beta)
+    _same(x, weight, bias, residual, gamma, beta, what='gemm_ln_fwd')
+    M, K = x.shape
+    N = weight.size(0)
+    assert weight.size(1) == K and (residual is None or (residual.shape == (M, N) and residual.stride(1) == 1))
+    assert all(t is None or (t.numel() == N and t.is_contiguous()) for t in (bias, gamma, beta))
+    assert not (rms and beta is not None)
+    y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    z = torch.empty(M, N, dtype=x.dtype, device=x.device) if want_z else None
+    mean = None if rms else torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(lib.load().pk_gemm_ln_fwd(ptr(x), ptr(weight), ptr(bias), ptr(residual), ptr(gamma), ptr(beta), ptr(z), ptr(y),
+                                    ptr(mean), ptr(rstd), M, N, K, _ld(x), _ld(weight),
+                                    _ld(residual) if residual is not None else 0, float(eps), float(drop_p), int(seed),
+                                    int(offset), dtype_code(x), stream_ptr()), 'pk_gemm_ln_fwd')
+    return y, z, mean, rstd
+
+
 def residual_ln_bwd(dy: Optional[Tensor], dz_extra: Optional[Tensor], z: Optional[Tensor], gamma: Optional[Tensor],
                     mean: Optional[Tensor], rstd: Optional[Tensor], *, want_dres: bool, want_dx: bool,
                     want_param_grads: bool, has_beta: bool = True, drop_p: float = 0.0, seed: int = 0,

@@ -29,6 +29,8 @@ SIGNATURES = {
     'pk_gemm_wgrad_group_eligible': (I, [P, I]),
     'pk_gemm_wgrad_group_workspace': (SZ, [P, I]),
     'pk_gemm_wgrad_group': (I, [P, I, I, P, SZ, P]),
+    'pk_gemm_ln_eligible': (I, [LL, LL, LL, LL, LL, I]),
+    'pk_gemm_ln_fwd': (I, [P] * 10 + [LL] * 6 + [F, F, ULL, ULL, I, P]),
     'pk_decoder_step_scratch': (SZ, [P, I]),
     'pk_decoder_step': (I, [P, P, I, I, I, P, P, LL, P, P, I, P, SZ, P, LL, P]),
     'pk_argmax_rows': (I, [P, LL, LL, LL, P, LL, I, P]),

@@ -16,6 +16,7 @@ from torch import Tensor, LongTensor, BoolTensor
 from . import functional as F
 from .profiling import region as _bench_region
 from .autograd import (LinearFn, PackedLinearFn, AttentionFn, ResidualLayerNormFn, DropoutFn, EmbeddingFn,
+                       LinearResidualLnFn, block_tail_eligible,
                        ActivationFn, GLUFn, RotaryFn, ResidualLink)
 
 
@@ -491,6 +492,7 @@ class MultiheadAttention(nn.Module):
         self._w_flat = self._b_flat = None
         self._residual_link = None  # set by the owning layer for one call (see transformer._LayerBase._linked)
         self._wgroup = None         # likewise: the layer's grouped weight-gradient launch (autograd.WGradGroup)
+        self._tail = None           # likewise: the post-norm block end, to be fused into out_proj (autograd.BlockTail)
 
     def reset_parameters(self) -> None:
         # xavier-uniform with gain 1/sqrt(2) for q, k, v (modules.py:565-576)
@@ -554,6 +556,7 @@ class MultiheadAttention(nn.Module):
         link, self._residual_link = self._residual_link, None  # gradient of the residual branch rides on the dX GEMM
         group, self._wgroup = self._wgroup, None  # weight gradients ride in the layer's grouped launch
         gp = () if group is None else (group,)
+        tail, self._tail = self._tail, None  # residual + dropout + LayerNorm of the block end ride on the out_proj GEMM
         q_w, k_w, v_w = self.q_proj.weight, self.k_proj.weight, self.v_proj.weight
         q_b, k_b, v_b = self.q_proj.bias, self.k_proj.bias, self.v_proj.bias
 
@@ -619,7 +622,13 @@ class MultiheadAttention(nn.Module):
             k = LinearFn.apply(key, k_w, k_b, 'none', None, group)
             v = LinearFn.apply(value, v_w, v_b, 'none', None, group)
             attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale, drop)
-        attn = self.out_proj(attn, group=group) if group is not None else self.out_proj(attn)
+        if (tail is not None and state is None and self.out_proj.lora is None
+                and block_tail_eligible(B * T, self.out_proj.weight, tail.residual, tail.gamma)):
+            attn = LinearResidualLnFn.apply(attn, self.out_proj.weight, self.out_proj.bias, tail.residual, tail.gamma,
+                                            tail.beta, tail.eps, tail.p, link, group)
+            tail.done = True
+        else:
+            attn = self.out_proj(attn, group=group) if group is not None else self.out_proj(attn)
         return attn, weights
 
 

@@ -24,13 +24,16 @@ from . import modules
 from .profiling import block as _bench_block, region as _bench_region
 from .modules import Embedding, Identity
 from .autograd import (FFNFn, GatedFFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn,
-                       AddPositionsFn, LinearFn, ResidualLink, WGradGroup, WGradSinkFn)
+                       AddPositionsFn, LinearFn, ResidualLink, WGradGroup, WGradSinkFn, BlockTail, FFNResidualLnFn,
+                       block_tail_eligible)
 
 from .config import register_model  # also enters the reference's registry when `pasero` is importable
 
 logger = logging.getLogger('models')
 # diagnostic: every weight-gradient GEMM launched on its own, as in round 1 (A/B of the grouped launch)
 _NO_WGRAD_GROUP = bool(int(os.environ.get('PASERO_NO_WGRAD_GROUP', '0') or 0))
+# diagnostic: the post-norm block ends as stand-alone LayerNorm launches (A/B of the fused GEMM + LayerNorm kernel)
+_NO_FUSED_TAIL = bool(int(os.environ.get('PASERO_NO_FUSED_TAIL', '0') or 0))
 LN2 = math.log(2)
 
 
@@ -523,21 +526,57 @@ class _LayerBase(nn.Module):
         cls = TransformerDecoderLayer if isinstance(self, TransformerDecoderLayer) else TransformerEncoderLayer
         return all(getattr(type(self), n) is getattr(cls, n) for n in names)
 
+    def _stock_postnorm(self, branch_hooks, residual_hook: str, postnorm_hook: str, norm) -> bool:
+        """a post-norm sub-block whose hooks are all the stock ones and whose norm is a LayerNorm module"""
+        return (not self.prenorm and isinstance(self._norm_module(norm), modules.LayerNorm)
+                and self._hooks_are_base(residual_hook, postnorm_hook, *branch_hooks))
+
     def _linked(self, branch_hooks, residual_hook: str, postnorm_hook: str, norm, target, attr: str):
         """For a post-norm sub-block whose hooks are all the stock ones: hand a ResidualLink to the module that runs the
         sub-block's first GEMM (`target.attr`), to be passed on to the fused block end.  None otherwise."""
-        norm = self._norm_module(norm)
-        if (self.prenorm or not torch.is_grad_enabled() or not isinstance(norm, modules.LayerNorm)
-                or not self._hooks_are_base(residual_hook, postnorm_hook, *branch_hooks)):
+        if not torch.is_grad_enabled() or not self._stock_postnorm(branch_hooks, residual_hook, postnorm_hook, norm):
             return None
         link = ResidualLink()
         setattr(target, attr, link)
         return link
 
+    def _tail_for(self, attn, branch_hooks, residual_hook: str, postnorm_hook: str, norm, residual: Tensor):
+        """For a stock post-norm attention block: let `attn` (the MultiheadAttention that runs the block's last GEMM)
+        finish the block inside its out_proj kernel — residual + dropout + LayerNorm in the GEMM epilogue
+        (autograd.LinearResidualLnFn).  The module may decline (shape, dtype, LoRA, incremental state): `tail.done`."""
+        attn._tail = None
+        if _NO_FUSED_TAIL or not self._stock_postnorm(branch_hooks, residual_hook, postnorm_hook, norm):
+            return None
+        norm = self._norm_module(norm)
+        tail = BlockTail(residual, norm.weight, norm.bias, norm.eps, self.dropout.p if self.training else 0.0)
+        attn._tail = tail
+        return tail
+
+    def _ffn_block(self, x: Tensor, residual: Tensor, padding_mask, link) -> Tensor:
+        """`x = ffn_prenorm(x); x = ffn(x, ...); x = ffn_residual(x, residual); x = ffn_postnorm(x)` — for a stock
+        post-norm block of base width: fc1 (+ activation) and fc2 + bias + dropout + residual + LayerNorm as two launches
+        (autograd.FFNResidualLnFn); the reference's hook sequence otherwise"""
+        norm = self._norm_module(self.final_layer_norm)
+        if (not _NO_FUSED_TAIL and x is residual and self.fc3 is None and self.fc1.lora is None
+                and not (self.training and self.activation_dropout.p > 0)
+                and self._stock_postnorm(('ffn', 'ffn_prenorm'), 'ffn_residual', 'ffn_postnorm', self.final_layer_norm)
+                and block_tail_eligible(x.numel() // x.size(-1), self.fc2.weight, x, norm.weight)):
+            self._ffn_link = None
+            group, self._ffn_group = getattr(self, '_ffn_group', None), None
+            return FFNResidualLnFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+                                         self.activation_fn.name, norm.weight, norm.bias, norm.eps,
+                                         self.dropout.p if self.training else 0.0, group)
+        x = self.ffn_prenorm(x)
+        x = self.ffn(x, residual, padding_mask)
+        return self._block_end(x, residual, self.final_layer_norm, 'ffn_residual', 'ffn_postnorm', link)
+
     def _block_end(self, x: Tensor, residual: Tensor, norm, residual_hook: str, postnorm_hook: str,
-                   link=None) -> Tensor:
+                   link=None, tail=None) -> Tensor:
         """`x = *_residual(x, residual); x = *_postnorm(x)` — one fused kernel for post-norm layers whose hooks are not
-        overridden by a subclass, the reference's two hook calls otherwise"""
+        overridden by a subclass, the reference's two hook calls otherwise; nothing at all if the sub-block's last GEMM
+        has already done it (`tail.done`)"""
+        if tail is not None and tail.done:
+            return x
         norm = self._norm_module(norm)
         if self._hooks_are_base(residual_hook, postnorm_hook) and not self.prenorm and isinstance(norm, modules.LayerNorm):
             return ResidualLayerNormFn.apply(x, residual, norm.weight, norm.bias, norm.eps,
@@ -602,15 +641,17 @@ class TransformerEncoderLayer(_LayerBase):
         residual = x
         link = self._linked(('self_attention', 'self_attn_prenorm'), 'self_attn_residual', 'self_attn_postnorm',
                             self.self_attn_layer_norm, self.self_attn, '_residual_link')
+        tail = self._tail_for(self.self_attn, ('self_attention', 'self_attn_prenorm'), 'self_attn_residual',
+                              'self_attn_postnorm', self.self_attn_layer_norm, residual)
         x = self.self_attn_prenorm(x)
         x = self.self_attention(x, residual, padding_mask)
-        x = self._block_end(x, residual, self.self_attn_layer_norm, 'self_attn_residual', 'self_attn_postnorm', link)
+        self.self_attn._tail = None
+        x = self._block_end(x, residual, self.self_attn_layer_norm, 'self_attn_residual', 'self_attn_postnorm', link,
+                            tail)
         residual = x
         link = self._linked(('ffn', 'ffn_prenorm'), 'ffn_residual', 'ffn_postnorm', self.final_layer_norm, self,
                             '_ffn_link')
-        x = self.ffn_prenorm(x)
-        x = self.ffn(x, residual, padding_mask)
-        x = self._block_end(x, residual, self.final_layer_norm, 'ffn_residual', 'ffn_postnorm', link)
+        x = self._ffn_block(x, residual, padding_mask, link)
         self._wgrad_close((self.self_attn,))
         layer_outputs = self.layer_outputs
         self.layer_outputs = {}
@@ -710,22 +751,29 @@ class TransformerDecoderLayer(_LayerBase):
         if state is None:
             link = self._linked(('self_attention', 'self_attn_prenorm'), 'self_attn_residual', 'self_attn_postnorm',
                                 self.self_attn_layer_norm, self.self_attn, '_residual_link')
+        tail = None
+        if state is None:
+            tail = self._tail_for(self.self_attn, ('self_attention', 'self_attn_prenorm'), 'self_attn_residual',
+                                  'self_attn_postnorm', self.self_attn_layer_norm, residual)
         x = self.self_attn_prenorm(x)
         x = self.self_attention(x, residual, padding_mask, self_attn_mask=self_attn_mask, state=state)
-        x = self._block_end(x, residual, self.self_attn_layer_norm, 'self_attn_residual', 'self_attn_postnorm', link)
+        self.self_attn._tail = None
+        x = self._block_end(x, residual, self.self_attn_layer_norm, 'self_attn_residual', 'self_attn_postnorm', link,
+                            tail)
         residual = x
         link = self._linked(('cross_attention', 'cross_attn_prenorm'), 'cross_attn_residual', 'cross_attn_postnorm',
                             self.encoder_attn_layer_norm, self.encoder_attn, '_residual_link')
+        tail = self._tail_for(self.encoder_attn, ('cross_attention', 'cross_attn_prenorm'), 'cross_attn_residual',
+                              'cross_attn_postnorm', self.encoder_attn_layer_norm, residual)
         x = self.cross_attn_prenorm(x)
         x = self.cross_attention(x, residual, encoder_out, encoder_mask)
+        self.encoder_attn._tail = None
         x = self._block_end(x, residual, self.encoder_attn_layer_norm, 'cross_attn_residual', 'cross_attn_postnorm',
-                            link)
+                            link, tail)
         residual = x
         link = self._linked(('ffn', 'ffn_prenorm'), 'ffn_residual', 'ffn_postnorm', self.final_layer_norm, self,
                             '_ffn_link')
-        x = self.ffn_prenorm(x)
-        x = self.ffn(x, residual, padding_mask)
-        x = self._block_end(x, residual, self.final_layer_norm, 'ffn_residual', 'ffn_postnorm', link)
+        x = self._ffn_block(x, residual, padding_mask, link)
         self._wgrad_close((self.self_attn, self.encoder_attn))
         layer_outputs = self.layer_outputs
         self.layer_outputs = {}
