@@ -15,7 +15,9 @@
  *   - returns 0 on success, -1 on an argument error, or a hipError_t; pk_last_error() gives the message
  *     (thread-local).
  *   - dropout masks are a pure function of (seed, offset, element index) [Philox4x32-10]: the backward call takes
- *     the same (seed, offset) as the forward call and regenerates the mask, nothing is stored.
+ *     the same (seed, offset) as the forward call and regenerates the mask, nothing is stored.  Element i is kept iff
+ *     the 16-bit draw number (i & 7) of philox(seed, offset, i >> 3) is >= floor(p * 65536): one evaluation serves the
+ *     eight elements of a 16-byte chunk (p is quantised to 1/65536; the kept values are scaled by 1 / (1 - p)).
  */
 #ifndef PASERO_HIP_H
 #define PASERO_HIP_H

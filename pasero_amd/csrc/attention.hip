@@ -55,9 +55,7 @@ struct AttnParams {
 
 __device__ __forceinline__ bool drop_keep1(const AttnParams& p, long long row, int s) {
     const unsigned long long idx = (unsigned long long)row * 8ull * p.mask_pitch + s;
-    Philox4 r = philox4x32_10(p.seed, p.offset, idx >> 2);
-    const unsigned w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
-    return w >= p.drop_thr;
+    return dropout_keep1(p.seed, p.offset, idx, p.drop_thr);
 }
 __device__ __forceinline__ bool drop_bit(const AttnParams& p, long long row, int s) {
     return (p.drop_mask[row * p.mask_pitch + (s >> 3)] >> (s & 7)) & 1;

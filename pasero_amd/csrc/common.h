@@ -211,9 +211,36 @@ __host__ __device__ __forceinline__ unsigned dropout_threshold(float p) {
     double t = (double)p * 4294967296.0;
     return t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
 }
-// 4 keep flags for elements [4*q, 4*q+4) of a flat tensor
+// The mask: element i of a flat tensor is kept iff  u16[i & 7] >= thr >> 16,  where u16[0..7] are the eight 16-bit halves
+// (low half first) of the four words of philox4x32_10(seed, offset, i >> 3).  One Philox evaluation serves eight elements
+// = one 16-byte chunk of a 16-bit tensor (the evaluation is ~60 VALU instructions: with a 32-bit draw per element it
+// was the largest single cost of the LayerNorm epilogues); the drop probability is quantised to 1 / 65536.
+__device__ __forceinline__ void dropout_keep8(unsigned long long seed, unsigned long long offset,
+                                              unsigned long long q8, unsigned thr, bool keep[8]) {
+    const Philox4 r = philox4x32_10(seed, offset, q8);
+    const unsigned t = thr >> 16;
+    keep[0] = (r.x & 0xffffu) >= t; keep[1] = (r.x >> 16) >= t; keep[2] = (r.y & 0xffffu) >= t; keep[3] = (r.y >> 16) >= t;
+    keep[4] = (r.z & 0xffffu) >= t; keep[5] = (r.z >> 16) >= t; keep[6] = (r.w & 0xffffu) >= t; keep[7] = (r.w >> 16) >= t;
+}
+// 4 keep flags for elements [4*q, 4*q+4) of a flat tensor (one half of dropout_keep8's draw)
 __device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned long long offset,
                                               unsigned long long q, unsigned thr, bool keep[4]) {
-    Philox4 r = philox4x32_10(seed, offset, q);
-    keep[0] = r.x >= thr; keep[1] = r.y >= thr; keep[2] = r.z >= thr; keep[3] = r.w >= thr;
+    const Philox4 r = philox4x32_10(seed, offset, q >> 1);
+    const unsigned a = (q & 1) ? r.z : r.x, b = (q & 1) ? r.w : r.y, t = thr >> 16;
+    keep[0] = (a & 0xffffu) >= t; keep[1] = (a >> 16) >= t; keep[2] = (b & 0xffffu) >= t; keep[3] = (b >> 16) >= t;
+}
+// one element
+__device__ __forceinline__ bool dropout_keep1(unsigned long long seed, unsigned long long offset,
+                                              unsigned long long i, unsigned thr) {
+    const Philox4 r = philox4x32_10(seed, offset, i >> 3);
+    const unsigned j = (unsigned)(i & 7), w = (j >> 1) == 0 ? r.x : (j >> 1) == 1 ? r.y : (j >> 1) == 2 ? r.z : r.w;
+    return ((j & 1) ? (w >> 16) : (w & 0xffffu)) >= (thr >> 16);
+}
+// the EPV (4 or 8) elements of the 16-byte chunk that starts at element `elem0` (a multiple of EPV)
+template <int EPV>
+__device__ __forceinline__ void dropout_keep_chunk(unsigned long long seed, unsigned long long offset,
+                                                   unsigned long long elem0, unsigned thr, bool* keep) {
+    static_assert(EPV == 4 || EPV == 8, "16-byte chunks of 4- or 2-byte elements");
+    if constexpr (EPV == 8) dropout_keep8(seed, offset, elem0 >> 3, thr, keep);
+    else dropout_keep4(seed, offset, elem0 >> 2, thr, keep);
 }

@@ -46,14 +46,11 @@ __device__ __forceinline__ void add_row_chunk(float (&a)[8], const T* __restrict
         const float4 lo = *reinterpret_cast<const float4*>(dout + off), hi = *reinterpret_cast<const float4*>(dout + off + 4);
         g[0] = lo.x; g[1] = lo.y; g[2] = lo.z; g[3] = lo.w; g[4] = hi.x; g[5] = hi.y; g[6] = hi.z; g[7] = hi.w;
     }
-    if (thr) {  // element e of the flat tensor draws component e & 3 of philox(seed, offset, e >> 2)  (embed_fwd_kernel)
+    if (thr) {  // the mask embed_fwd_kernel drew (common.h: dropout_keep8 — `off` is a multiple of 8)
+        bool keep[8];
+        dropout_keep8(seed, offset, (unsigned long long)off >> 3, thr, keep);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            Philox4 r = philox4x32_10(seed, offset, (unsigned long long)(off >> 2) + h);
-            const unsigned rv[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[4 * h + e] = rv[e] >= thr ? g[4 * h + e] * drop_scale : 0.f;
-        }
+        for (int e = 0; e < 8; ++e) g[e] = keep[e] ? g[e] * drop_scale : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[e] += g[e] * scale;

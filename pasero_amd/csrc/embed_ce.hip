@@ -34,8 +34,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
             long long off = tok * d + (long long)ch * EPV;
             bool keep[EPV];
             if (thr) {
-#pragma unroll
-                for (int e = 0; e < EPV; e += 4) dropout_keep4(seed, offset, (unsigned long long)(off + e) >> 2, thr, keep + e);
+                dropout_keep_chunk<EPV>(seed, offset, (unsigned long long)off, thr, keep);
             }
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
@@ -246,17 +245,14 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
     for (long long ch = (long long)blockIdx.x * 256 + threadIdx.x; ch < nvec; ch += (long long)gridDim.x * 256) {
         Vec16<T> v = load16<T>(x + ch * EPV), o;
         bool keep[EPV];
-#pragma unroll
-        for (int e = 0; e < EPV; e += 4) dropout_keep4(seed, offset, (unsigned long long)(ch * EPV + e) >> 2, thr, keep + e);
+        dropout_keep_chunk<EPV>(seed, offset, (unsigned long long)(ch * EPV), thr, keep);
 #pragma unroll
         for (int e = 0; e < EPV; ++e) o.set(e, keep[e] ? v.get(e) * drop_scale : 0.f);
         store16<T>(out + ch * EPV, o);
     }
     if (blockIdx.x == 0) {
         for (long long i = nvec * EPV + threadIdx.x; i < n; i += 256) {
-            Philox4 r = philox4x32_10(seed, offset, (unsigned long long)i >> 2);
-            unsigned rv = (i & 3) == 0 ? r.x : (i & 3) == 1 ? r.y : (i & 3) == 2 ? r.z : r.w;
-            out[i] = from_f32<T>(rv >= thr ? to_f32<T>(x[i]) * drop_scale : 0.f);
+            out[i] = from_f32<T>(dropout_keep1(seed, offset, (unsigned long long)i, thr) ? to_f32<T>(x[i]) * drop_scale : 0.f);
         }
     }
 }

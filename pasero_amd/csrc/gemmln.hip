@@ -209,6 +209,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_ln_kernel(const T* __restrict__
     T* yo = reinterpret_cast<T*>(ln.y_out);
     const bool rms = ln.mean_out == nullptr;
     constexpr int RPW = EROWS / 8;  // rows per wave per pass
+    // Every residual row this wave will need is requested NOW, before the first store: vmcnt retires loads and stores in
+    // one in-order queue, so a load issued behind the z / y stores of an earlier row would not return before those
+    // stores are acknowledged — with every CU of the chip writing at once that is microseconds per row.
+    Vec16<T> rv[LBM / 8];
+    if (res) {
+#pragma unroll
+        for (int p = 0; p < LBM / EROWS; ++p)
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const long long gm = min(m0 + p * EROWS + wave * RPW + rr, M - 1);
+                rv[p * RPW + rr] = load16<T>(res + gm * ln.ldr + col);
+            }
+    }
 #pragma unroll
     for (int p = 0; p < LBM / EROWS; ++p) {
         constexpr int PPH = 64 / EROWS, MT = EROWS / 16;  // passes per row half, m-tiles per pass
@@ -234,18 +247,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p_ln_kernel(const T* __restrict__
             const float4 a4 = *reinterpret_cast<const float4*>(src), b4 = *reinterpret_cast<const float4*>(src + 4);
             float x[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
             const long long off = gm * LBN + col;
-            Vec16<T> rv;
-            if (res) rv = load16<T>(res + gm * ln.ldr + col);
             bool keep[8];
             if (ln.thr) {
-                dropout_keep4(ln.seed, ln.offset, (unsigned long long)off >> 2, ln.thr, keep);
-                dropout_keep4(ln.seed, ln.offset, ((unsigned long long)off >> 2) + 1, ln.thr, keep + 4);
+                dropout_keep8(ln.seed, ln.offset, (unsigned long long)off >> 3, ln.thr, keep);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float a = x[e] + bia[e];
                 if (ln.thr) a = keep[e] ? a * ln.drop_scale : 0.f;
-                if (res) a += rv.get(e);
+                if (res) a += rv[p * RPW + rr].get(e);
                 x[e] = a;
             }
             // z is a tensor of the storage type in the reference (and what the backward pass re-reads): statistics on

@@ -37,8 +37,7 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
                 Vec16<T> xv = load16<T>(x + off);
                 bool keep[EPV];
                 if (thr) {
-#pragma unroll
-                    for (int e = 0; e < EPV; e += 4) dropout_keep4(seed, offset, (unsigned long long)(off + e) >> 2, thr, keep + e);
+                    dropout_keep_chunk<EPV>(seed, offset, (unsigned long long)off, thr, keep);
                 }
                 Vec16<T> rv;
                 if (residual) rv = load16<T>(residual + off);
@@ -207,9 +206,7 @@ __global__ __launch_bounds__(256, NCH == 4 ? 3 : NCH == 8 ? 2 : 1) void residual
                     if (dx_out) {
                         bool keep[EPV];
                         if (thr) {
-#pragma unroll
-                            for (int e = 0; e < EPV; e += 4)
-                                dropout_keep4(seed, offset, (unsigned long long)(off + e) >> 2, thr, keep + e);
+                            dropout_keep_chunk<EPV>(seed, offset, (unsigned long long)off, thr, keep);
                         }
                         Vec16<T> o;
 #pragma unroll
@@ -302,9 +299,7 @@ __global__ __launch_bounds__(256, NCH == 4 ? 3 : NCH == 8 ? 2 : 1) void residual
                 if (dx_out) {
                     bool keep[EPV];
                     if (thr) {
-#pragma unroll
-                        for (int e = 0; e < EPV; e += 4)
-                            dropout_keep4(seed, offset, (unsigned long long)(off + e) >> 2, thr, keep + e);
+                        dropout_keep_chunk<EPV>(seed, offset, (unsigned long long)off, thr, keep);
                     }
                     Vec16<T> o;
 #pragma unroll
