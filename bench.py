@@ -117,6 +117,10 @@ class GemmTimer:
     def kernel_name(kernel, a_col, b_col, dtype):
         tf = {0: 'false', 1: 'true'}
         t = {0: 'float', 1: '__hip_bfloat16', 2: '_Float16'}[dtype]
+        if kernel == (8 | 0x40):  # the grouped weight-gradient launch (pk_gemm_wgrad_group): flops = sum over the group
+            return 'gemm8p_group_kernel<%s>' % t
+        if kernel == (8 | 0x80):  # Linear + residual + dropout + LayerNorm (pk_gemm_ln_fwd)
+            return 'gemm8p_ln_kernel<%s>' % t
         if kernel & 0xF == 8 and kernel < 256:  # gemm8p instantiation: <T, A_COL, B_COL, ANY epilogue, TAIL K-tile>
             return 'gemm8p_kernel<%s, %s, %s, %s, %s>' % (t, tf[a_col], tf[b_col], tf[(kernel >> 4) & 1], tf[(kernel >> 5) & 1])
         if kernel == 256:

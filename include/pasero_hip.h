@@ -57,8 +57,10 @@ int pk_gemm(const void* A, const void* B, void* C, const void* bias, const void*
  * nn.Linear calls in torch.cuda.Event pairs).  After pk_gemm_timing_start(max_samples, stride) every `stride`-th pk_gemm
  * call records a HIP event pair around exactly its main GEMM kernel (not the split-K reduce), on the launching stream.
  * pk_gemm_timing_stop() ends sampling and returns the number of samples; pk_gemm_timing_read(i, ...) synchronises on
- * sample i and returns the kernel that ran (128 = gemm_kernel 128x128 tiles, 256 = gemm256_kernel), its operand
- * layouts, split-K factor, dtype, 2*M*N*K and the elapsed milliseconds. */
+ * sample i and returns the kernel that ran (128 = gemm_kernel 128x128 tiles, 256 = gemm256_kernel, 8 | flags = a
+ * gemm8p instantiation: 0x10 general epilogue, 0x20 partial last K-tile, 0x40 the grouped weight-gradient launch of
+ * pk_gemm_wgrad_group [flops = the sum over the group, splitk = the number of problems], 0x80 pk_gemm_ln_fwd), its
+ * operand layouts, split-K factor, dtype, 2*M*N*K and the elapsed milliseconds. */
 int pk_gemm_timing_start(int max_samples, int stride);
 /* diagnostic: 1 / 0 routes the 256-tile GEMMs to the phase-interleaved kernel (gemm8p.hip, default) / to gemm256.hip;
  * 2 additionally sends every eligible GEMM with M, N >= 256 there, whether or not its tiles fill the chip (tests);

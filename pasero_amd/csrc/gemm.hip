@@ -42,6 +42,11 @@ extern "C" int pk_gemm8p_group_eligible(const PkWgradProblem* q);
 extern "C" int pk_gemm8p_group_plan(const PkWgradProblem* p, int n, size_t* ws_bytes, int* workgroups, int* slabs);
 extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream);
 extern "C" int pk_gemm8p_group_reduce(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream);
+extern "C" int pk_gemmln_launch(const void* A, const void* W, const void* bias, const void* residual, const void* gamma,
+                                const void* beta, void* z_out, void* y_out, float* mean, float* rstd, long long M,
+                                long long N, long long K, long long lda, long long ldb, long long ldr, float eps,
+                                float drop_p, unsigned long long seed, unsigned long long offset, int dtype,
+                                void* stream);
 extern "C" int pk_gemm_skinny_launch(const void* A, const void* B, void* C, long long M, long long N, long long K,
                                      long long lda, long long ldb, EpiParams ep, int dtype, void* stream);
 
@@ -926,6 +931,22 @@ extern "C" int pk_gemm_wgrad_group(const PkWgradProblem* p, int n, int dtype, vo
     if (rc != 1) return rc;
     rc = pk_gemm8p_group_reduce(p, n, dtype, (float*)workspace, stream);
     return rc == 1 ? 0 : rc;
+}
+
+// ---- Linear + residual + dropout + LayerNorm in one kernel (gemmln.hip; see include/pasero_hip.h) ----
+extern "C" int pk_gemm_ln_fwd(const void* A, const void* W, const void* bias, const void* residual, const void* gamma,
+                              const void* beta, void* z_out, void* y_out, float* mean, float* rstd, long long M,
+                              long long N, long long K, long long lda, long long ldb, long long ldr, float eps,
+                              float drop_p, unsigned long long seed, unsigned long long offset, int dtype,
+                              void* stream) {
+    if (M == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    // (sample tag 8 | 0x80: the 128 x 512-tile instantiation with the LayerNorm epilogue)
+    GemmSample* sm = timing_begin(8 | 0x80, 0, 0, 1, dtype, M, N, K, s);
+    const int rc = pk_gemmln_launch(A, W, bias, residual, gamma, beta, z_out, y_out, mean, rstd, M, N, K, lda, ldb, ldr,
+                                    eps, drop_p, seed, offset, dtype, stream);
+    timing_end(sm, s);
+    return rc;
 }
 
 extern "C" int pk_gemm_use_8p(int on) {

@@ -307,11 +307,12 @@ extern "C" int pk_gemm_ln_eligible(long long M, long long N, long long K, long l
     return ((M - 1) * lda + K) * 2 <= lim && ((N - 1) * ldb + K) * 2 <= lim;
 }
 
-extern "C" int pk_gemm_ln_fwd(const void* A, const void* W, const void* bias, const void* residual, const void* gamma,
-                              const void* beta, void* z_out, void* y_out, float* mean, float* rstd, long long M,
-                              long long N, long long K, long long lda, long long ldb, long long ldr, float eps,
-                              float drop_p, unsigned long long seed, unsigned long long offset, int dtype,
-                              void* stream) {
+// (the public entry pk_gemm_ln_fwd lives in gemm.hip, next to the launch-timing hooks of bench.py's roofline leg)
+extern "C" int pk_gemmln_launch(const void* A, const void* W, const void* bias, const void* residual, const void* gamma,
+                                const void* beta, void* z_out, void* y_out, float* mean, float* rstd, long long M,
+                                long long N, long long K, long long lda, long long ldb, long long ldr, float eps,
+                                float drop_p, unsigned long long seed, unsigned long long offset, int dtype,
+                                void* stream) {
     if (M == 0) return 0;
     PK_CHECK_ARG(A && W && gamma && y_out && rstd, "pk_gemm_ln_fwd: null operand");
     PK_CHECK_ARG(pk_gemm_ln_eligible(M, N, K, lda, ldb, dtype),
