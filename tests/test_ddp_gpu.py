@@ -23,8 +23,23 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _base_width_model(dtype):
+    """two base-width layers (d = 512): the layers whose weight gradients ride in a grouped launch returned by the
+    layer's sink node and whose block ends run inside their GEMMs"""
+    import paramgen
+    from model_utils import load_paramgen
+    from pasero_amd.config import TransformerConfig, DistributedConfig, SyntheticTask
+    from pasero_amd.transformer import Transformer
+    V = 2000
+    model = Transformer(TransformerConfig(dropout=0.1, encoder_layers=2, decoder_layers=2), DistributedConfig(),
+                        SyntheticTask(V))
+    load_paramgen(model, 3)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(5, 16, 64, 64, V, ragged=True).items()}
+    return model.to(dtype).cuda(), batch
+
+
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, 'base_width_bf16'])
 def test_rccl_bucketed_all_reduce_single_rank(monkeypatch, dtype):
     from pasero_amd import rng
     from pasero_amd.ddp import DistributedDataParallel
@@ -34,10 +49,19 @@ def test_rccl_bucketed_all_reduce_single_rank(monkeypatch, dtype):
     dev = torch.device('cuda', 0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     try:
-        g = load_golden('tiny_encdec_post')
-        cfg, model = build_model(g, dtype, 'cuda')
+        if dtype == 'base_width_bf16':
+            dtype = torch.bfloat16
+            model, batch = _base_width_model(dtype)
+            from pasero_amd import functional as F
+            launches = []
+            real = F.wgrad_group
+            monkeypatch.setattr(F, 'wgrad_group', lambda e: (launches.append(len(e)), real(e))[1])
+        else:
+            launches = None
+            g = load_golden('tiny_encdec_post')
+            cfg, model = build_model(g, dtype, 'cuda')
+            batch = text_batch(g, 'cuda')
         model.train()
-        batch = text_batch(g, 'cuda')
         rng.manual_seed(5)
         loss, _ = model(**batch)
         loss.backward()
@@ -56,6 +80,8 @@ def test_rccl_bucketed_all_reduce_single_rank(monkeypatch, dtype):
         loss2.backward()
         torch.cuda.synchronize()
         assert loss2.item() == loss.item()
+        if launches is not None:  # both steps launched their weight gradients per layer, under the reducer's hooks too
+            assert launches == [7, 7, 4, 4] * 2, launches
         rtol = 1e-5 if dtype == torch.float32 else 2e-2
         for n, p in model.named_parameters():
             if n in plain:
