@@ -107,8 +107,11 @@ def test_gemm8p_assembly_audit_is_part_of_the_build():
     import subprocess
     from conftest import ROOT
     csrc = os.path.join(ROOT, 'pasero_amd', 'csrc')
-    subprocess.check_call(['make', '-C', csrc, 'gemm8p.audit'], stdout=subprocess.DEVNULL)
-    report = open(os.path.join(csrc, 'gemm8p.audit')).read()
-    last = report.strip().splitlines()[-1]
-    assert last.endswith(', 0 problems') and int(last.split()[0]) >= 24, last
-    assert 'PROBLEM' not in report
+    # gemm8p.hip: 3 operand layouts x 2 dtypes x {lean, general epilogue} x {whole, partial last K-tile} + the grouped
+    # weight-gradient kernel per dtype; gemmln.hip (the same K-loop discipline on a 128 x 512 tile): one kernel per dtype
+    for name, at_least in (('gemm8p', 26), ('gemmln', 2)):
+        subprocess.check_call(['make', '-C', csrc, f'{name}.audit'], stdout=subprocess.DEVNULL)
+        report = open(os.path.join(csrc, f'{name}.audit')).read()
+        last = report.strip().splitlines()[-1]
+        assert last.endswith(', 0 problems') and int(last.split()[0]) >= at_least, (name, last)
+        assert 'PROBLEM' not in report

@@ -1,0 +1,98 @@
+"""Host logic of the grouped weight-gradient launch (pasero_amd.autograd.WGradGroup / WGradSinkFn) without a GPU: which
+gradient lands in which sink slot, row slices of a packed q|k|v gradient, accumulation when a slot is hit twice, the
+refusal after the launch, and the autograd ordering the mechanism rests on (the sink's backward runs after the backward
+of every op of its layer, including ops whose INPUT does not descend from the sink — the cross-attention key / value
+projection).  The GEMMs themselves are stood in for by torch.matmul here; the kernels are checked in
+tests/test_wgrad_group_gpu.py."""
+import pytest
+import torch
+
+from pasero_amd import autograd as A
+from pasero_amd import functional as F
+
+
+@pytest.fixture()
+def cpu_gemms(monkeypatch):
+    monkeypatch.setattr(F, 'wgrad_group_eligible', lambda dy, x: dy.size(1) >= 8)  # "small" problems: the fallback path
+    monkeypatch.setattr(F, 'wgrad_group', lambda entries: [(dy.t() @ x, dy.sum(0) if b else None) for dy, x, b in entries])
+    monkeypatch.setattr(A, 'weight_grad', lambda dy, x, want_bias=False: ((dy.t() @ x, dy.sum(0)) if want_bias
+                                                                           else dy.t() @ x))
+
+
+def test_slots_slices_accumulation_and_refusal(cpu_gemms):
+    torch.manual_seed(0)
+    w1, b1 = torch.nn.Parameter(torch.randn(8, 5)), torch.nn.Parameter(torch.randn(8))
+    wq, wk = torch.nn.Parameter(torch.randn(4, 5)), torch.nn.Parameter(torch.randn(4, 5))
+    small = torch.nn.Parameter(torch.randn(3, 5))
+    g = A.WGradGroup()
+    g.bind([w1, b1, wq, wk, small])
+    assert g.slot(w1) == 0 and g.slot(wk) == 3 and g.slot(torch.nn.Parameter(w1.detach().clone())) is None
+    dy, x = torch.randn(7, 8), torch.randn(7, 5)
+    g.add(dy, x, [(0, 0, 8)], [(1, 0, 8)])                       # a Linear with bias
+    g.add(dy, x, [(0, 0, 8)], None)                              # the same weight used twice: gradients add up
+    dyp = torch.randn(7, 8)
+    g.add(dyp, x, [(2, 0, 4), (3, 4, 8)], None)                  # packed projection: rows 0..3 -> wq, 4..7 -> wk
+    dys = torch.randn(7, 3)
+    g.add(dys, x, [(4, 0, 3)], None)                             # not eligible: computed on the spot
+    grads = g.flush()
+    assert torch.allclose(grads[0], 2 * dy.t() @ x) and torch.allclose(grads[1], dy.sum(0))
+    assert torch.allclose(grads[2], (dyp.t() @ x)[:4]) and torch.allclose(grads[3], (dyp.t() @ x)[4:])
+    assert torch.allclose(grads[4], dys.t() @ x)
+    with pytest.raises(RuntimeError, match='after the group had been launched'):
+        g.add(dy, x, [(0, 0, 8)], None)
+
+
+class _Lin(torch.autograd.Function):
+    """y = x Wᵀ whose weight gradient is handed to the group (what LinearFn does on the GPU)"""
+
+    @staticmethod
+    def forward(ctx, x, w, group, log, tag):
+        ctx.save_for_backward(x, w)
+        ctx.group, ctx.log, ctx.tag = group, log, tag
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        ctx.log.append(ctx.tag)
+        ctx.group.add(dy, x, [(ctx.group.slot(w), 0, w.size(0))], None)
+        return dy @ w, None, None, None, None
+
+
+def test_sink_runs_last_in_its_layer_and_returns_the_gradients(cpu_gemms):
+    """a layer shaped like the decoder's: q from the layer input, k|v from ANOTHER tensor (the encoder output), both
+    feeding one op; two such layers in sequence.  Each sink must run after both projections of its own layer."""
+    torch.manual_seed(1)
+    enc = torch.randn(6, 8, requires_grad=True)
+    x = torch.randn(6, 8, requires_grad=True)
+    ws = [torch.nn.Parameter(torch.randn(8, 8) * 0.3) for _ in range(4)]
+    log = []
+
+    def layer(x, wq, wkv, name):
+        class Logged(A.WGradGroup):
+            def flush(self):
+                log.append(name + ':sink')
+                return super().flush()
+
+        g = Logged()
+        x = A.WGradSinkFn.apply(x, g, wq, wkv)
+        q = _Lin.apply(x, wq, g, log, name + ':q')
+        kv = _Lin.apply(enc, wkv, g, log, name + ':kv')
+        return torch.tanh(q * kv) + x
+
+    y = layer(layer(x, ws[0], ws[1], 'L0'), ws[2], ws[3], 'L1')
+    y.sum().backward()
+    assert log.index('L1:sink') > max(log.index('L1:q'), log.index('L1:kv'))
+    assert log.index('L0:sink') > max(log.index('L0:q'), log.index('L0:kv'))
+    assert log.index('L1:sink') < log.index('L0:sink')
+    # the same graph with ordinary autograd
+    ref = [w.detach().clone().requires_grad_() for w in ws]
+    x2, enc2 = x.detach().clone().requires_grad_(), enc.detach().clone().requires_grad_()
+
+    def plain(x, wq, wkv):
+        return torch.tanh((x @ wq.t()) * (enc2 @ wkv.t())) + x
+
+    plain(plain(x2, ref[0], ref[1]), ref[2], ref[3]).sum().backward()
+    for w, r in zip(ws, ref):
+        assert torch.allclose(w.grad, r.grad, atol=1e-5)
+    assert torch.allclose(x.grad, x2.grad, atol=1e-5) and torch.allclose(enc.grad, enc2.grad, atol=1e-5)
