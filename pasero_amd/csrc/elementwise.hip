@@ -15,13 +15,13 @@ __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ dy, cons
         Vec16<T> xv = load16<T>(x + ch * EPV), o, g;
         if (BWD) g = load16<T>(dy + ch * EPV);
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) o.set(e, BWD ? g.get(e) * act_bwd(act, xv.get(e)) : act_fwd(act, xv.get(e)));
+        for (int e = 0; e < EPV; ++e) o.set(e, BWD ? g.get(e) * act_bwd_t<T>(act, xv.get(e)) : act_fwd_t<T>(act, xv.get(e)));
         store16<T>(out + ch * EPV, o);
     }
     if (blockIdx.x == 0)
         for (long long i = nvec * EPV + threadIdx.x; i < n; i += 256) {
             float xv = to_f32<T>(x[i]);
-            out[i] = from_f32<T>(BWD ? to_f32<T>(dy[i]) * act_bwd(act, xv) : act_fwd(act, xv));
+            out[i] = from_f32<T>(BWD ? to_f32<T>(dy[i]) * act_bwd_t<T>(act, xv) : act_fwd_t<T>(act, xv));
         }
 }
 
@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256) void gated_act_bwd_kernel(const T* __restrict_
         Vec16<T> g = load16<T>(dh + ch * EPV), zv = load16<T>(z + ch * EPV), uv = load16<T>(u + ch * EPV), o1, o2;
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
-            o1.set(e, g.get(e) * uv.get(e) * act_bwd(act, zv.get(e)));
-            o2.set(e, g.get(e) * act_fwd(act, zv.get(e)));
+            o1.set(e, g.get(e) * uv.get(e) * act_bwd_t<T>(act, zv.get(e)));
+            o2.set(e, g.get(e) * act_fwd_t<T>(act, zv.get(e)));
         }
         store16<T>(dz + ch * EPV, o1);
         store16<T>(du + ch * EPV, o2);
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void gated_act_bwd_kernel(const T* __restrict_
     if (blockIdx.x == 0)
         for (long long i = nvec * EPV + threadIdx.x; i < n; i += 256) {
             float gi = to_f32<T>(dh[i]), zi = to_f32<T>(z[i]), ui = to_f32<T>(u[i]);
-            dz[i] = from_f32<T>(gi * ui * act_bwd(act, zi));
-            du[i] = from_f32<T>(gi * act_fwd(act, zi));
+            dz[i] = from_f32<T>(gi * ui * act_bwd_t<T>(act, zi));
+            du[i] = from_f32<T>(gi * act_fwd_t<T>(act, zi));
         }
 }
 

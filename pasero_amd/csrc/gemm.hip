@@ -232,11 +232,11 @@ __device__ __forceinline__ void epilogue_chunk(float (&v)[8], int n_valid, long 
     for (int e = 0; e < EPV; ++e) {
         float x = v[e] * ep.alpha;
         if (ep.mode == 2) {
-            x *= act_bwd(ep.act, a[e]);
+            x *= act_bwd_t<TO>(ep.act, a[e]);
         } else {
             if (ep.bias && e < n_valid) x += to_f32<TO>(reinterpret_cast<const TO*>(ep.bias)[gn + e]);
             pre.set(e, x);
-            x = act_fwd(ep.act, x);
+            x = act_fwd_t<TO>(ep.act, x);
             if (ep.mode == 1) x += a[e];
             else if (ep.mode == 3) x *= a[e];
         }

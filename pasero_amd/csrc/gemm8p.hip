@@ -152,11 +152,11 @@ __device__ __noinline__ void epilogue_pass_any(const float* __restrict__ cs, T* 
         for (int e = 0; e < 8; ++e) {
             float y = x[e] * alpha;
             if (mode == 2) {
-                y *= act_bwd(act, av.get(e));
+                y *= act_bwd_fast(act, av.get(e));
             } else {
                 y += b[e];
                 pre.set(e, y);
-                y = act_fwd(act, y);
+                y = act_fwd_fast(act, y);
                 if (mode == 1) y += av.get(e);
                 else if (mode == 3) y *= av.get(e);
             }
