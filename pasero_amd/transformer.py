@@ -34,6 +34,8 @@ logger = logging.getLogger('models')
 _NO_WGRAD_GROUP = bool(int(os.environ.get('PASERO_NO_WGRAD_GROUP', '0') or 0))
 # diagnostic: the post-norm block ends as stand-alone LayerNorm launches (A/B of the fused GEMM + LayerNorm kernel)
 _NO_FUSED_TAIL = bool(int(os.environ.get('PASERO_NO_FUSED_TAIL', '0') or 0))
+# diagnostic: read the step's sums at the end of the forward pass, as the reference does (A/B of the deferred read)
+_EAGER_LOGS = bool(int(os.environ.get('PASERO_EAGER_LOGS', '0') or 0))
 LN2 = math.log(2)
 
 
@@ -54,6 +56,95 @@ def _norm_cls(cfg, wrappable: bool = False):
     if cfg.norm_bias:
         return modules.WrappableLayerNorm if wrappable else modules.LayerNorm
     return modules.LayerNormWithoutBias
+
+
+class StepLogs(dict):
+    """`logs` of a training / validation step (pasero/models/transformer.py:375-380: 'loss', 'nll_loss' in bits,
+    'num_tokens', 'num_lines') whose numbers are still on their way from the device.  The reference reads them with three
+    `.item()` calls at the end of the forward pass, which makes the host wait for the whole forward before it can enqueue
+    the backward (the GPU then idles until the first backward kernel arrives).  Here the three sums are copied to pinned
+    memory asynchronously and the wait happens when a value is first READ — in `Trainer.train_step` that is after
+    `loss.backward()` has been enqueued (training.py:402-446).  It is a dict with the reference's keys from the start
+    (`in`, `len`, `keys()` need no wait); every way of reading a value goes through `_wait` first."""
+    __slots__ = ('_pending',)
+
+    def __init__(self, sums: Tensor, batch_size: int):
+        super().__init__(loss=None, nll_loss=None, num_tokens=None, num_lines=batch_size)
+        host = torch.empty(3, dtype=torch.float32, pin_memory=True)
+        host.copy_(sums, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        self._pending = (host, event)
+
+    def _wait(self) -> None:
+        if self._pending is not None:
+            (host, event), self._pending = self._pending, None
+            event.synchronize()
+            loss, nll, ntok = host.tolist()
+            super().__setitem__('loss', loss / LN2)
+            super().__setitem__('nll_loss', nll / LN2)
+            super().__setitem__('num_tokens', int(ntok))
+
+    def __getitem__(self, key):
+        self._wait()
+        return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        self._wait()
+        return super().get(key, default)
+
+    def __iter__(self):  # (overridden so that dict(logs) / {**logs} take the keys() + __getitem__ path, not a raw copy)
+        return super().__iter__()
+
+    def keys(self):
+        return super().keys()
+
+    def items(self):
+        self._wait()
+        return super().items()
+
+    def values(self):
+        self._wait()
+        return super().values()
+
+    def pop(self, *args):
+        self._wait()
+        return super().pop(*args)
+
+    def popitem(self):
+        self._wait()
+        return super().popitem()
+
+    def setdefault(self, key, default=None):
+        self._wait()
+        return super().setdefault(key, default)
+
+    def copy(self):
+        self._wait()
+        return dict(super().items())
+
+    def __eq__(self, other):
+        self._wait()
+        return super().__eq__(other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __or__(self, other):
+        self._wait()
+        return dict(super().items()) | other
+
+    def __ror__(self, other):
+        self._wait()
+        return other | dict(super().items())
+
+    def __repr__(self):
+        self._wait()
+        return super().__repr__()
+
+    def __reduce__(self):
+        self._wait()
+        return (dict, (dict(super().items()),))
 
 
 class BaseModel(nn.Module):
@@ -187,6 +278,8 @@ class Transformer(EncoderDecoder):
 
     @staticmethod
     def _logs(sums: Tensor, batch_size: int) -> dict:
+        if sums.is_cuda and not _EAGER_LOGS:
+            return StepLogs(sums, batch_size)  # no host sync here: the copy is waited for when a value is first read
         loss, nll, ntok = sums.tolist()  # the ONE host sync of the step (reference: 3x .item(), :375-377)
         return {'loss': loss / LN2, 'nll_loss': nll / LN2, 'num_tokens': int(ntok), 'num_lines': batch_size}
 

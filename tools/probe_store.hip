@@ -21,6 +21,13 @@ __global__ __launch_bounds__(512) void probe(unsigned* out, long long ld_bytes, 
             char* p;
             if (SHAPE == 0) p = base + (size_t)chunk * 16;
             else if (SHAPE == 1) p = base + (size_t)(chunk >> 5) * ld_bytes + (chunk & 31) * 16;  // 2 rows x 512 B per wave-instr
+            else if (SHAPE == 3) {  // register epilogue with a wave owning 64 CONTIGUOUS columns and the two row halves of a
+                // 16-row MFMA tile exchanging one chunk (DPP row_ror:8): instruction (mh, i, h2): 8 rows x 128 B (full lines)
+                const int lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3, mh = it >> 3, i = (it >> 1) & 3, h2 = it & 1;
+                const int r = lane & 15, g = lane >> 4;
+                const int row = 128 * mh + 64 * wr + 16 * i + 8 * h2 + (r & 7), col = 64 * wc + 32 * (r >> 3) + 8 * g;
+                p = base + (size_t)row * ld_bytes + col * 2;
+            }
             else {  // the register epilogue: wave (wr, wc), instruction (mh, i, nh): 16 rows x 64 B
                 const int lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3, mh = it >> 3, i = (it >> 1) & 3, nh = it & 1;
                 const int row = 128 * mh + 64 * wr + 16 * i + (lane & 15), col = 128 * nh + 32 * wc + 8 * (lane >> 4);
@@ -57,6 +64,8 @@ int main() {
         run<1, 1>("nt x4, tile rows 512 B", buf, t, nwg, ld, 4);
         run<0, 2>("plain x4, 16 rows x 64 B / instr", buf, t, nwg, ld, 4);
         run<1, 2>("nt x4, 16 rows x 64 B / instr", buf, t, nwg, ld, 4);
+        run<0, 3>("plain x4, 8 rows x 128 B / instr", buf, t, nwg, ld, 4);
+        run<1, 3>("nt x4, 8 rows x 128 B / instr", buf, t, nwg, ld, 4);
     }
     return 0;
 }
