@@ -445,7 +445,22 @@ def _contiguous(t: Tensor) -> Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-class MultiheadAttention(nn.Module):
+# attributes the layers set on a module for ONE call (hand-overs between a layer and the module that runs part of its
+# sub-block, per-call bookkeeping): plain Python values — nn.Module.__setattr__ would run its Parameter / Module / buffer
+# checks on every one of them, ~2.5 us each and ~280 of them per C2 step
+PER_CALL_ATTRS = frozenset({'_residual_link', '_wgroup', '_tail', '_ffn_link', '_ffn_group', 'return_layers',
+                            'layer_outputs'})
+
+
+class _PerCallAttrs:
+    def __setattr__(self, name, value):
+        if name in PER_CALL_ATTRS:
+            self.__dict__[name] = value
+        else:
+            super().__setattr__(name, value)
+
+
+class MultiheadAttention(_PerCallAttrs, nn.Module):
     """modules.py:487-771.  q/k/v projections live in one flat [3D, D] arena (the three nn.Parameters are views of
     it, names and shapes unchanged) so self-attention runs ONE projection GEMM that reads x once, and the attention
     kernels read q, k, v in place from the packed output."""

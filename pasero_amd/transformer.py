@@ -547,7 +547,7 @@ class TransformerDecoder(Decoder):
         return x, layer_outputs
 
 
-class _LayerBase(nn.Module):
+class _LayerBase(modules._PerCallAttrs, nn.Module):
     """pieces shared by the encoder and decoder layers"""
 
     def _build_ffn(self, cfg, ffn_dim: int):
