@@ -118,8 +118,9 @@ class WGradGroup:
     returning dW, and the sink — whose backward runs last in the layer, when the gradient of the layer input arrives —
     launches the group and returns the gradients to autograd, so `.grad` accumulation and the DDP hooks see nothing new.
     Every deferred op was created after the sink (higher sequence number: the engine runs it first when both are ready)
-    and is ready no later than a node on the sink's own dependency chain; an `add` after the sink has run would lose a
-    gradient and raises instead."""
+    and is ready no later than a node on the sink's own dependency chain.  Once the sink has run the group is closed: an
+    op that comes later (a second backward over a retained graph) computes and returns its gradient itself (`_defer`);
+    a direct `add` to a closed group would lose a gradient and raises."""
     __slots__ = ('slots', 'entries', 'closed', 'params')
 
     def __init__(self):
@@ -185,7 +186,9 @@ class WGradSinkFn(Function):
 
 def _defer(group, dy2, x2, weight, bias, want_w: bool, want_b: bool) -> bool:
     """hand dW (and db) of one nn.Linear to the layer's group; False: the caller computes them itself"""
-    if group is None or not want_w:
+    if group is None or not want_w or group.closed:
+        # (closed: a second backward over a retained graph, or an op the engine ran after the layer's sink — the op
+        # computes its gradient itself and returns it to autograd the ordinary way: nothing is lost, only not grouped)
         return False
     ws = group.slot(weight)
     bs = group.slot(bias) if want_b else None
@@ -336,7 +339,7 @@ class PackedLinearFn(Function):
         grads = [None] * (2 * n + (1 if ctx.group is not None else 0))
         want_w = any(ctx.needs_input_grad[5:5 + n])
         want_b = any(ctx.has_bias[i] and ctx.needs_input_grad[5 + n + i] for i in range(n))
-        if ctx.group is not None and want_w:
+        if ctx.group is not None and want_w and not ctx.group.closed:
             # every wanted slice must be one of the sink's parameters, or the whole GEMM stays here
             g, ps = ctx.group, ctx.params
             w_t = [(g.slot(ps[i]), i * D, (i + 1) * D) for i in range(n) if ctx.needs_input_grad[5 + i]]

@@ -22,7 +22,13 @@
 // none of them spills.  Measured (bf16, B = 256, H = 8, T = S = 128): forward 41.5 -> 33.6 us; Whisper encoder shape
 // (T = S = 1500): forward 181 -> 148 us, backward (dQ + dK/dV kernels) 546 -> 407 us.  The fused backward spills 27
 // registers at three waves and stays at two; the dQ kernel for heads of 128 spills at two and stays at one.
-constexpr int q_min_waves(int mode, int hd) { return mode == 0 ? (hd == 64 ? 3 : 2) : (hd == 64 ? 2 : 1); }
+#ifndef PK_ATTN_FWD_WAVES
+#define PK_ATTN_FWD_WAVES 3
+#endif
+#ifndef PK_ATTN_FUSED_WAVES
+#define PK_ATTN_FUSED_WAVES 2
+#endif
+constexpr int q_min_waves(int mode, int hd) { return mode == 0 ? (hd == 64 ? PK_ATTN_FWD_WAVES : 2) : (hd == 64 ? 2 : 1); }
 constexpr int dkv_min_waves(int hd) { return hd == 64 ? 2 : 1; }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -730,7 +736,7 @@ __device__ __forceinline__ bf16x8_t ds_tr_frag(const char* lds, int row0, int s,
 }
 
 template <typename T, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_fused128_kernel(
+__global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ o,
     const T* __restrict__ d_o, const float* __restrict__ lse, float* __restrict__ delta, T* __restrict__ dq,
     T* __restrict__ dk, T* __restrict__ dv, AttnParams p) {

@@ -168,3 +168,22 @@ def test_frozen_and_partially_frozen_layers(monkeypatch):
     for n in g0:
         err = (g1[n] - g0[n]).norm().item() / max(g0[n].norm().item(), 1e-20)
         assert err < 4e-3, (n, err)
+
+
+def test_second_backward_over_a_retained_graph(monkeypatch):
+    """the layer's group is launched once; a second backward over the same graph must still deliver every gradient (each
+    op then computes its own weight gradient and returns it to autograd): .grad doubles"""
+    import paramgen
+    V = 2000
+    model = _model(V, layers=1, dropout=0.0)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(6, 16, 64, 64, V).items()}
+    from pasero_amd import transformer
+    monkeypatch.setattr(transformer, '_NO_WGRAD_GROUP', False)
+    model.zero_grad(set_to_none=True)
+    loss, _ = model(**batch)
+    loss.backward(retain_graph=True)
+    once = {n: p.grad.float().clone() for n, p in model.named_parameters()}
+    loss.backward()
+    for n, p in model.named_parameters():
+        want = 2 * once[n]
+        assert (p.grad.float() - want).norm().item() <= 1e-2 * max(want.norm().item(), 1e-20), n
