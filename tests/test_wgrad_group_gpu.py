@@ -187,3 +187,19 @@ def test_second_backward_over_a_retained_graph(monkeypatch):
     for n, p in model.named_parameters():
         want = 2 * once[n]
         assert (p.grad.float() - want).norm().item() <= 1e-2 * max(want.norm().item(), 1e-20), n
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_groups(seed):
+    """random groups through the planner: 1..11 problems of unrelated sizes (outputs of 1..25 tiles, contractions of one
+    to a hundred K-tiles with ragged ends, with and without bias sums), every output against fp64 and against pk_gemm"""
+    import random
+    rnd = random.Random(1000 + seed)
+    n = rnd.randint(1, 11)
+    entries = []
+    for i in range(n):
+        rows = rnd.choice([64, 72, 200, 512, 1000, 1536, 2048, 4104, 6400])
+        n_out = 8 * rnd.randint(32, 160)
+        k_in = 8 * rnd.randint(32, 160)
+        entries.append((*_problem(rows, n_out, k_in, torch.bfloat16, 7 * seed + i), rnd.random() < 0.5))
+    _check(entries, torch.bfloat16)
