@@ -163,9 +163,9 @@ int pk_embed_fwd(const long long* ids, const void* E, const void* pos, void* out
                  unsigned long long offset, int dtype, void* stream);
 /*   dE[V,d] = sum over tokens of dout * keep/(1-p) * scale into row ids[tok]; row pad_idx (nn.Embedding padding_idx) and
  *   rows without tokens are zero.  Deterministic: the token positions are radix-sorted by id (stable) and every row is
- *   summed in that fixed order in fp32, rounded once — no float atomics.  `workspace`: pk_embed_bwd_workspace(ntok, V)
+ *   summed in that fixed order in fp32, rounded once — no float atomics.  `workspace`: pk_embed_bwd_workspace(ntok, V, d)
  *   bytes.  d % 8 == 0, d <= 4096. */
-size_t pk_embed_bwd_workspace(long long ntok, long long V);
+size_t pk_embed_bwd_workspace(long long ntok, long long V, int d);
 int pk_embed_bwd(const long long* ids, const void* dout, void* dE, void* workspace, size_t ws_bytes, long long ntok,
                  int d, long long V, long long pad_idx, float scale, float drop_p, unsigned long long seed,
                  unsigned long long offset, int dtype, void* stream);

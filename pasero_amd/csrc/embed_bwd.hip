@@ -57,38 +57,104 @@ __device__ __forceinline__ void add_row_chunk(float (&a)[8], const T* __restrict
 }
 
 // NB column blocks of 512 per lane (d <= 512 * NB); d % 8 == 0
+// One workgroup per POS_PER_WG = 64 sorted positions.  A RUN is a maximal sequence of equal ids, clipped to the range of
+// the workgroup: short runs (the common case: a vocabulary row seen a few times) are summed by ONE wave each, in position
+// order, without LDS or barriers (wave w takes the runs number w, w + 4, ... of the range); runs longer than SHORT_RUN are
+// summed by the four waves together (wave w takes positions w, w + 4, ...; partial sums combined through LDS in wave
+// order).  A run that ends inside the range it began in is written to its row, rounded once.  A run that crosses a range
+// boundary — a frequent token: BOS / EOS, punctuation, a language tag — leaves fp32 partial sums, one per workgroup it
+// touches, which embed_fixup_kernel adds in workgroup order.  So the time of the kernel does not depend on how the ids
+// are distributed (the first version gave a whole run to the workgroup of its head: a token seen 7 000 times in a batch of
+// 32 768 cost 1.4 ms), and every row is still a fixed-order sum.
+constexpr int SHORT_RUN = 16;
+constexpr int FLAG_BEGIN = 1, FLAG_END = 2, FLAG_SPAN = 4;  // partial of a run cut at the range start / end / both
+
 template <typename T, int NB>
 __global__ __launch_bounds__(256) void embed_segsum_kernel(const unsigned* __restrict__ keys,
                                                            const unsigned* __restrict__ toks,
                                                            const T* __restrict__ dout, T* __restrict__ dE,
+                                                           float* __restrict__ part, int* __restrict__ flags,
                                                            long long ntok, int d, long long pad_idx, float scale,
                                                            unsigned thr, float drop_scale, unsigned long long seed,
                                                            unsigned long long offset) {
     __shared__ float red[3][NB * 512];
+    __shared__ int wg_flags;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long p0 = (long long)blockIdx.x * POS_PER_WG;
-    const long long p1 = min(ntok, p0 + POS_PER_WG);
-    for (long long p = p0; p < p1; ++p) {
-        const unsigned id = keys[p];
-        if ((p > 0 && keys[p - 1] == id) || (long long)id == pad_idx) continue;  // not a segment head / nn.Embedding(padding_idx)
+    const int n_valid = (int)min((long long)POS_PER_WG, ntok - p0);
+    if (threadIdx.x == 0) wg_flags = 0;
+    const unsigned kv = lane < n_valid ? keys[p0 + lane] : 0xffffffffu;
+    const unsigned tv = lane < n_valid ? toks[p0 + lane] : 0u;
+    const unsigned kup = __shfl_up(kv, 1);
+    unsigned long long starts = __ballot(lane < n_valid && (lane == 0 || kv != kup));
+    const bool cut0 = p0 > 0 && keys[p0 - 1] == (unsigned)__builtin_amdgcn_readfirstlane(kv);
+    const unsigned klast = (unsigned)__builtin_amdgcn_readlane(kv, n_valid - 1);
+    const bool cut1 = p0 + n_valid < ntok && keys[p0 + n_valid] == klast;
+    __syncthreads();
+
+    auto finish = [&](float (&a)[NB][8], int s, int e, unsigned id) {  // (called by ONE wave per run)
+        const bool cb = s == 0 && cut0, ce = e == n_valid && cut1;
+        if (!cb && !ce) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int c0 = b * 512 + lane * 8;
+                if (c0 >= d) continue;
+                T* dst = dE + (long long)id * d + c0;
+                if constexpr (sizeof(T) == 2) {
+                    Vec16<T> o;
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) o.set(x, a[b][x]);
+                    store16<T>(dst, o);
+                } else {
+                    *reinterpret_cast<float4*>(dst) = float4{a[b][0], a[b][1], a[b][2], a[b][3]};
+                    *reinterpret_cast<float4*>(dst + 4) = float4{a[b][4], a[b][5], a[b][6], a[b][7]};
+                }
+            }
+            return;
+        }
+        float* dst = part + ((long long)blockIdx.x * 2 + (cb ? 0 : 1)) * d;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int c0 = b * 512 + lane * 8;
+            if (c0 >= d) continue;
+            *reinterpret_cast<float4*>(dst + c0) = float4{a[b][0], a[b][1], a[b][2], a[b][3]};
+            *reinterpret_cast<float4*>(dst + c0 + 4) = float4{a[b][4], a[b][5], a[b][6], a[b][7]};
+        }
+        if (lane == 0) atomicOr(&wg_flags, cb ? (ce ? FLAG_BEGIN | FLAG_SPAN : FLAG_BEGIN) : FLAG_END);
+    };
+
+    int r = 0;
+    while (starts) {  // (uniform over the workgroup: every wave walks the same list of runs)
+        const int s = __builtin_ctzll(starts);
+        starts &= starts - 1;
+        const int e = starts ? __builtin_ctzll(starts) : n_valid;
+        const unsigned id = (unsigned)__builtin_amdgcn_readlane(kv, s);
+        const bool is_long = e - s > SHORT_RUN;
+        const int mine = r++ & 3;
+        if ((long long)id == pad_idx) continue;  // nn.Embedding(padding_idx): its row stays zero
+        if (!is_long && mine != wave) continue;
         float a[NB][8];
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[b][e] = 0.f;
-        for (long long q = p + wave; q < ntok && keys[q] == id; q += 4) {
-            const long long tok = toks[q];
+            for (int x = 0; x < 8; ++x) a[b][x] = 0.f;
+        for (int q = is_long ? s + wave : s; q < e; q += is_long ? 4 : 1) {
+            const long long tok = (long long)(unsigned)__builtin_amdgcn_readlane(tv, q);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int c0 = b * 512 + lane * 8;
                 if (c0 < d) add_row_chunk<T>(a[b], dout, tok, d, c0, scale, thr, drop_scale, seed, offset);
             }
         }
+        if (!is_long) {
+            finish(a, s, e, id);
+            continue;
+        }
         if (wave > 0) {
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) red[wave - 1][b * 512 + lane * 8 + e] = a[b][e];
+                for (int x = 0; x < 8; ++x) red[wave - 1][b * 512 + lane * 8 + x] = a[b][x];
         }
         __syncthreads();
         if (wave == 0) {
@@ -99,20 +165,67 @@ __global__ __launch_bounds__(256) void embed_segsum_kernel(const unsigned* __res
 #pragma unroll
                 for (int w = 0; w < 3; ++w)  // fixed order: wave 0 + wave 1 + wave 2 + wave 3
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) a[b][e] += red[w][c0 + e];
-                T* dst = dE + (long long)id * d + c0;
-                if constexpr (sizeof(T) == 2) {
-                    Vec16<T> o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o.set(e, a[b][e]);
-                    store16<T>(dst, o);
-                } else {
-                    *reinterpret_cast<float4*>(dst) = float4{a[b][0], a[b][1], a[b][2], a[b][3]};
-                    *reinterpret_cast<float4*>(dst + 4) = float4{a[b][4], a[b][5], a[b][6], a[b][7]};
-                }
+                    for (int x = 0; x < 8; ++x) a[b][x] += red[w][c0 + x];
             }
+            finish(a, s, e, id);
         }
         __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) flags[blockIdx.x] = wg_flags;
+}
+
+// rows whose run crosses workgroup ranges: the workgroup in whose range the run BEGINS adds the partial sums of the
+// ranges it runs through, in range order, and writes the row (one wave per chain; lane = 8 columns per block of 512)
+template <typename T, int NB>
+__global__ __launch_bounds__(64) void embed_fixup_kernel(const unsigned* __restrict__ keys, const float* __restrict__ part,
+                                                        const int* __restrict__ flags, T* __restrict__ dE, int nwg,
+                                                        long long ntok, int d, long long pad_idx) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (!(flags[w] & FLAG_END)) return;  // no run that begins here and goes on
+    const long long last = min(ntok, (long long)(w + 1) * POS_PER_WG) - 1;
+    const unsigned id = keys[last];
+    float a[NB][8];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int c0 = b * 512 + lane * 8;
+        if (c0 < d) {
+            const float* src = part + ((long long)w * 2 + 1) * d + c0;
+            const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+            a[b][0] = lo.x; a[b][1] = lo.y; a[b][2] = lo.z; a[b][3] = lo.w;
+            a[b][4] = hi.x; a[b][5] = hi.y; a[b][6] = hi.z; a[b][7] = hi.w;
+        }
+    }
+    for (int j = w + 1; j < nwg; ++j) {
+        const int f = flags[j];
+        if (!(f & FLAG_BEGIN)) break;  // (cannot happen: the run was cut at the end of range j - 1)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int c0 = b * 512 + lane * 8;
+            if (c0 < d) {
+                const float* src = part + ((long long)j * 2) * d + c0;
+                const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+                a[b][0] += lo.x; a[b][1] += lo.y; a[b][2] += lo.z; a[b][3] += lo.w;
+                a[b][4] += hi.x; a[b][5] += hi.y; a[b][6] += hi.z; a[b][7] += hi.w;
+            }
+        }
+        if (!(f & FLAG_SPAN)) break;
+    }
+    if ((long long)id == pad_idx) return;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int c0 = b * 512 + lane * 8;
+        if (c0 >= d) continue;
+        T* dst = dE + (long long)id * d + c0;
+        if constexpr (sizeof(T) == 2) {
+            Vec16<T> o;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) o.set(x, a[b][x]);
+            store16<T>(dst, o);
+        } else {
+            *reinterpret_cast<float4*>(dst) = float4{a[b][0], a[b][1], a[b][2], a[b][3]};
+            *reinterpret_cast<float4*>(dst + 4) = float4{a[b][4], a[b][5], a[b][6], a[b][7]};
+        }
     }
 }
 
@@ -135,9 +248,11 @@ size_t sort_temp_bytes(long long ntok, long long V) {
 
 // bytes of `workspace` pk_embed_bwd needs for `ntok` tokens over a vocabulary of V rows (sort keys / values in and out +
 // the sort's own scratch)
-extern "C" size_t pk_embed_bwd_workspace(long long ntok, long long V) {
+extern "C" size_t pk_embed_bwd_workspace(long long ntok, long long V, int d) {
     if (ntok <= 0) return 256;
-    return 4 * align_up((size_t)ntok * 4) + align_up(sort_temp_bytes(ntok, V)) + 256;
+    const size_t nwg = (size_t)((ntok + POS_PER_WG - 1) / POS_PER_WG);
+    return 4 * align_up((size_t)ntok * 4) + align_up(sort_temp_bytes(ntok, V)) + align_up(nwg * 2 * (size_t)d * 4) +
+           align_up(nwg * 4) + 256;
 }
 
 // dE[V,d] = sum over tokens of dout[tok] * keep/(1-p) * scale into row ids[tok]; row pad_idx and rows without tokens 0.
@@ -153,12 +268,15 @@ extern "C" int pk_embed_bwd(const long long* ids, const void* dout, void* dE, vo
     hipError_t e = hipMemsetAsync(dE, 0, (size_t)V * d * esz, s);
     if (e != hipSuccess) { pk_set_error("pk_embed_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
     if (ntok == 0) return 0;
-    PK_CHECK_ARG(workspace && ws_bytes >= pk_embed_bwd_workspace(ntok, V), "pk_embed_bwd: workspace too small");
+    PK_CHECK_ARG(workspace && ws_bytes >= pk_embed_bwd_workspace(ntok, V, d), "pk_embed_bwd: workspace too small");
     const size_t seg = align_up((size_t)ntok * 4);
     char* w = (char*)workspace;
     unsigned *k_in = (unsigned*)w, *k_out = (unsigned*)(w + seg), *v_in = (unsigned*)(w + 2 * seg), *v_out = (unsigned*)(w + 3 * seg);
     void* temp = w + 4 * seg;
     size_t temp_bytes = sort_temp_bytes(ntok, V);
+    const int nwg = (int)((ntok + POS_PER_WG - 1) / POS_PER_WG);
+    float* part = (float*)(w + 4 * seg + align_up(temp_bytes));            // [nwg][2][d] partial sums of cut runs
+    int* flags = (int*)((char*)part + align_up((size_t)nwg * 2 * d * 4));  // [nwg]
     hipLaunchKernelGGL(embed_keys_kernel, dim3((unsigned)std::min<long long>(1024, (ntok + 255) / 256)), dim3(256), 0, s, ids,
                        k_in, v_in, ntok, V);
     PK_LAUNCH_CHECK();
@@ -166,11 +284,15 @@ extern "C" int pk_embed_bwd(const long long* ids, const void* dout, void* dE, vo
     if (e != hipSuccess) { pk_set_error("pk_embed_bwd: radix sort: %s", hipGetErrorString(e)); return (int)e; }
     const unsigned thr = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
     const float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    const dim3 grid((unsigned)((ntok + POS_PER_WG - 1) / POS_PER_WG));
+    const dim3 grid((unsigned)nwg);
     const int nb = (d + 511) / 512;
 #define PK_SEG(TT, NBV)                                                                                               \
-    hipLaunchKernelGGL((embed_segsum_kernel<TT, NBV>), grid, dim3(256), 0, s, k_out, v_out, (const TT*)dout, (TT*)dE, ntok, d, \
-                       pad_idx, scale, thr, ds, seed, offset)
+    do {                                                                                                              \
+        hipLaunchKernelGGL((embed_segsum_kernel<TT, NBV>), grid, dim3(256), 0, s, k_out, v_out, (const TT*)dout, (TT*)dE, \
+                           part, flags, ntok, d, pad_idx, scale, thr, ds, seed, offset);                             \
+        hipLaunchKernelGGL((embed_fixup_kernel<TT, NBV>), grid, dim3(64), 0, s, k_out, part, flags, (TT*)dE, nwg, ntok, d, \
+                           pad_idx);                                                                                  \
+    } while (0)
 #define PK_SEG_NB(TT)                                      \
     do {                                                   \
         if (nb <= 1) PK_SEG(TT, 1);                        \

@@ -332,7 +332,7 @@ def embed_bwd(ids: Tensor, dout: Tensor, V: int, pad_idx: int, scale: float, dro
     assert dout.is_contiguous() and ids.is_contiguous() and ids.dtype == torch.int64
     assert dout.numel() == ids.numel() * d
     dE = torch.empty(V, d, dtype=dout.dtype, device=dout.device)
-    ws_bytes = lib.load().pk_embed_bwd_workspace(ids.numel(), V)
+    ws_bytes = lib.load().pk_embed_bwd_workspace(ids.numel(), V, d)
     ws = lib.workspace(ws_bytes, dout.device, 'embed')
     L = lib.load()
     check(L.pk_embed_bwd(ptr(ids), ptr(dout), ptr(dE), ptr(ws), ws_bytes, ids.numel(), d, V, int(pad_idx),

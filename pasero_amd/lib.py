@@ -42,7 +42,7 @@ SIGNATURES = {
     'pk_attn_bwd': (I, [P] * 11 + [I, I, I, I, I] + [LL] * 16 + [I, F, F, P, I, P]),
     'pk_attn_probs': (I, [P, P, P, P, I, I, I, I, I, LL, LL, LL, LL, I, F, I, P]),
     'pk_embed_fwd': (I, [P, P, P, P, LL, I, I, LL, F, I, F, ULL, ULL, I, P]),
-    'pk_embed_bwd_workspace': (SZ, [LL, LL]),
+    'pk_embed_bwd_workspace': (SZ, [LL, LL, I]),
     'pk_embed_bwd': (I, [P, P, P, P, SZ, LL, I, LL, LL, F, F, ULL, ULL, I, P]),
     'pk_ce_rows': (I, [P, LL, P, P, LL, P, P, P, LL, LL, LL, F, I, P]),
     'pk_ce_finalize': (I, [P, P, P, LL, LL, P, P]),

@@ -500,6 +500,33 @@ def test_embedding_backward_is_deterministic_and_exact(F, dtype, V, d, ntok):
     assert empty.shape == (V, d) and empty.abs().max().item() == 0
 
 
+@pytest.mark.parametrize('counts', [
+    [640],                              # one id on every token: a run through ten workgroup ranges
+    [64, 64, 64],                       # runs that end exactly on the range boundaries
+    [63, 1, 64, 65, 1, 62],             # one off on either side of a boundary
+    [1] * 70 + [17, 16, 200, 3],        # short runs, the long-run threshold, a run over three ranges, a ragged tail
+    [5, 0, 130, 1],                     # an id without tokens in between
+    [100, 300],                         # the pad id (row 1 below) on a run that crosses ranges
+])
+def test_embedding_backward_runs_across_workgroup_ranges(F, counts):
+    """the sorted token positions are cut into ranges of 64 per workgroup and a vocabulary row seen more often than that is
+    summed in pieces (partials of the cut runs added in range order by a second kernel): run layouts around every edge
+    of that scheme, against an fp64 index_add, bitwise reproducible"""
+    V, d = len(counts) + 2, 256
+    ids = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)])
+    ids = ids[torch.randperm(ids.numel(), generator=torch.Generator().manual_seed(len(counts)))]
+    dout = torch.randn(ids.numel(), d, generator=torch.Generator().manual_seed(7)).bfloat16()
+    pad = 1 if counts == [100, 300] else V - 1
+    a = F.embed_bwd(ids.cuda(), dout.cuda(), V, pad, 0.5)
+    b = F.embed_bwd(ids.cuda(), dout.cuda(), V, pad, 0.5)
+    assert torch.equal(a, b)
+    ref = torch.zeros(V, d, dtype=torch.float64)
+    ref.index_add_(0, ids, dout.double() * 0.5)
+    ref[pad] = 0
+    assert rel_err(a, ref.float()) < 6e-3
+    assert a[pad].abs().max().item() == 0
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('eps', [0.0, 0.1])
 @pytest.mark.parametrize('V', [8032, 101, 70376])
