@@ -253,13 +253,17 @@ int pk_mt_copy(const long long* table, int ntensors, const int* chunk_tensor, co
  *   pk_comm_all_reduce_mean  buf <- mean over ranks, in place, on `stream`; schedule 0 = ncclAllReduce(avg),
  *                       1 = ncclReduceScatter(avg) + ncclAllGather, 2 = direct: grouped send/recv of the shards over all
  *                       xGMI links at once, a fixed-order fp32 sum of the n copies, grouped send/recv of the result
- *                       (needs `scratch` of `count` elements).  Schedules 1, 2: count % (8 * nranks) == 0. */
+ *                       (needs `scratch` of `count` elements).  Schedules 1, 2: count % (8 * nranks) == 0.
+ *   pk_comm_direct_plan the element offsets schedule 2 uses (shard length, own shard, per-peer send / receive offsets):
+ *                       host arithmetic only — no GPU, no communicator — so the layout can be replayed on any machine */
 int pk_comm_open(const char* librccl_path);
 int pk_comm_unique_id(void* out, int nbytes);
 int pk_comm_init(const void* id_bytes, int nranks, int rank);
 int pk_comm_destroy(void);
 int pk_comm_size(void);
 int pk_comm_all_reduce_mean(void* buf, long long count, int dtype, int schedule, void* scratch, void* stream);
+int pk_comm_direct_plan(long long count, int nranks, int rank, long long* shard, long long* own_off, long long* send_off,
+                        long long* recv_off);
 
 /* gated activation backward (SwiGLU / GEGLU FFN, transformer.py:1013-1016): h = act(z) * u
  *   dz = dh * u * act'(z)      du = dh * act(z) */

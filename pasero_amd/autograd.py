@@ -125,7 +125,10 @@ class WGradGroup:
 
     def __init__(self):
         self.slots = {}
-        self.entries = []
+        self.entries = {}  # (producing node, weight slots) -> entry: a node that adds twice (a partial backward through
+        # its part of a retained graph that never reached the sink, then the full one) REPLACES its entry instead of being
+        # summed twice; two nodes that share a weight both count.  (Entries keep dY and X of every Linear of the layer
+        # alive until the sink runs: the memory price of the single launch.)
         self.closed = False
         self.params = ()
 
@@ -140,21 +143,22 @@ class WGradGroup:
         """position of parameter `p` among the sink's inputs (None: not taken — frozen, cast by autocast, LoRA...)"""
         return None if p is None else self.slots.get(id(p))
 
-    def add(self, dy2: Tensor, x2: Tensor, w_targets, b_targets) -> None:
+    def add(self, dy2: Tensor, x2: Tensor, w_targets, b_targets, owner=None) -> None:
         """dW = dy2ᵀ·x2; `w_targets` / `b_targets`: [(slot, row0, row1)] — which rows of dW / db are whose gradient"""
         if self.closed:
             raise RuntimeError('pasero_amd: a weight gradient was handed to a layer\'s WGradGroup after the group had '
                                'been launched; it would be lost (set PASERO_NO_WGRAD_GROUP=1 and report the model)')
         want_b = bool(b_targets)
+        key = (owner if owner is not None else ('anon', len(self.entries)), tuple(t[0] for t in w_targets))
         if F.wgrad_group_eligible(dy2, x2):
-            self.entries.append((dy2, x2, want_b, w_targets, b_targets, None))
+            self.entries[key] = (dy2, x2, want_b, w_targets, b_targets, None)
         else:  # small / unaligned / fp32 problems: the ordinary GEMM, now
             r = weight_grad(dy2, x2, want_b)
-            self.entries.append((None, None, want_b, w_targets, b_targets, r if want_b else (r, None)))
+            self.entries[key] = (None, None, want_b, w_targets, b_targets, r if want_b else (r, None))
 
     def flush(self):
         self.closed = True
-        entries, self.entries = self.entries, []
+        entries, self.entries = list(self.entries.values()), {}
         todo = [e for e in entries if e[5] is None]
         done = F.wgrad_group([(e[0], e[1], e[2]) for e in todo]) if todo else []
         it = iter(done)
@@ -184,7 +188,7 @@ class WGradSinkFn(Function):
         return (dx, None, *[g if need else None for g, need in zip(grads, ctx.needs_input_grad[2:])])
 
 
-def _defer(group, dy2, x2, weight, bias, want_w: bool, want_b: bool) -> bool:
+def _defer(group, dy2, x2, weight, bias, want_w: bool, want_b: bool, owner=None) -> bool:
     """hand dW (and db) of one nn.Linear to the layer's group; False: the caller computes them itself"""
     if group is None or not want_w or group.closed:
         # (closed: a second backward over a retained graph, or an op the engine ran after the layer's sink — the op
@@ -195,7 +199,7 @@ def _defer(group, dy2, x2, weight, bias, want_w: bool, want_b: bool) -> bool:
     if ws is None or (want_b and bs is None):
         return False
     N = weight.size(0)
-    group.add(dy2, x2, [(ws, 0, N)], [(bs, 0, N)] if want_b else None)
+    group.add(dy2, x2, [(ws, 0, N)], [(bs, 0, N)] if want_b else None, owner)
     return True
 
 
@@ -225,7 +229,7 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = _dx_gemm(dy2, weight, ctx.link).view(*dy.shape[:-1], weight.size(1))
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if _defer(ctx.group, dy2, x2, weight, ctx.bias, ctx.needs_input_grad[1], want_b):
+        if _defer(ctx.group, dy2, x2, weight, ctx.bias, ctx.needs_input_grad[1], want_b, owner=id(ctx)):
             pass  # (the layer's WGradSinkFn returns both gradients)
         elif ctx.needs_input_grad[1]:
             dw = weight_grad(dy2, x2, want_b)
@@ -266,10 +270,10 @@ class FFNFn(Function):
             dh = F.gemm(dy2, w2, b_col=True, act=ctx.act, aux=aux, mode=2)
         ng = ctx.needs_input_grad
         dw1 = db1 = dw2 = db2 = None
-        if not _defer(ctx.group, dy2, h, w2, ctx.biases[1], ng[3], ctx.has_b2 and ng[4]):
+        if not _defer(ctx.group, dy2, h, w2, ctx.biases[1], ng[3], ctx.has_b2 and ng[4], owner=id(ctx)):
             dw2, db2 = _wgrad(dy2, h, ng[3], ctx.has_b2 and ng[4])
         dx = _dx_gemm(dh, w1, ctx.link).view(*dy.shape[:-1], w1.size(1)) if ng[0] else None
-        if not _defer(ctx.group, dh, x2, w1, ctx.biases[0], ng[1], ctx.has_b1 and ng[2]):
+        if not _defer(ctx.group, dh, x2, w1, ctx.biases[0], ng[1], ctx.has_b1 and ng[2], owner=id(ctx)):
             dw1, db1 = _wgrad(dh, x2, ng[1], ctx.has_b1 and ng[2])
         return dx, dw1, db1, dw2, db2, None, None, None
 
@@ -346,7 +350,7 @@ class PackedLinearFn(Function):
             b_t = [(g.slot(ps[n + i]), i * D, (i + 1) * D) for i in range(n)
                    if ctx.has_bias[i] and ctx.needs_input_grad[5 + n + i]]
             if all(t[0] is not None for t in w_t + b_t):
-                g.add(dy2, x2, w_t, b_t)
+                g.add(dy2, x2, w_t, b_t, id(ctx))
                 return (dx, None, None, None, None, *grads)
         dw, db = _wgrad(dy2, x2, want_w, want_b)
         for i in range(n):
@@ -502,7 +506,7 @@ class LinearResidualLnFn(Function):
         dx = _dx_gemm(dsub2, weight, None).view(ctx.x_shape) if ng[0] else None
         dw = db = None
         want_b = ctx.has_bias and ng[2]
-        if not _defer(ctx.group, dsub2, x2, weight, ctx.bias, ng[1], want_b):
+        if not _defer(ctx.group, dsub2, x2, weight, ctx.bias, ng[1], want_b, owner=id(ctx)):
             dw, db = _wgrad(dsub2, x2, ng[1], want_b)
         if ctx.link is not None:  # the residual-branch gradient rides on the sub-block's first dX GEMM
             ctx.link.dres = dres
@@ -543,12 +547,12 @@ class FFNResidualLnFn(Function):
         else:
             dh = F.gemm(dy2, w2, b_col=True, act=ctx.act, aux=h if pre is None else pre, mode=2)
         dw1 = db1 = dw2 = db2 = None
-        if not _defer(ctx.group, dy2, h, w2, ctx.biases[1], ng[3], ctx.has_b2 and ng[4]):
+        if not _defer(ctx.group, dy2, h, w2, ctx.biases[1], ng[3], ctx.has_b2 and ng[4], owner=id(ctx)):
             dw2, db2 = _wgrad(dy2, h, ng[3], ctx.has_b2 and ng[4])
         dx = None
         if ng[0]:  # the residual is x itself: its gradient is the aux operand of the dX GEMM
             dx = F.gemm(dh, w1, b_col=True, aux=_2d(dres), mode=1).view(dy.shape)
-        if not _defer(ctx.group, dh, x2, w1, ctx.biases[0], ng[1], ctx.has_b1 and ng[2]):
+        if not _defer(ctx.group, dh, x2, w1, ctx.biases[0], ng[1], ctx.has_b1 and ng[2], owner=id(ctx)):
             dw1, db1 = _wgrad(dh, x2, ng[1], ctx.has_b1 and ng[2])
         return dx, dw1, db1, dw2, db2, None, dgamma, dbeta, None, None, None
 

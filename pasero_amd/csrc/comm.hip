@@ -52,6 +52,17 @@ struct Rccl {
         }                                                                                            \
     } while (0)
 
+// inside ncclGroupStart .. ncclGroupEnd: close the group before reporting (an open group would swallow the next call)
+#define PK_NCCL_G(call, what)                                                                        \
+    do {                                                                                             \
+        int r_ = (call);                                                                             \
+        if (r_ != 0) {                                                                               \
+            pk_set_error("%s: %s", what, g.GetErrorString ? g.GetErrorString(r_) : "rccl error");    \
+            g.GroupEnd();                                                                            \
+            return r_ > 0 ? -r_ - 1000 : r_;                                                         \
+        }                                                                                            \
+    } while (0)
+
 int nccl_type(int dtype) { return dtype == PK_F32 ? NCCL_F32 : dtype == PK_BF16 ? NCCL_BF16 : NCCL_F16; }
 size_t elem_size(int dtype) { return dtype == PK_F32 ? 4 : 2; }
 
@@ -133,6 +144,25 @@ extern "C" int pk_comm_destroy(void) {
 
 extern "C" int pk_comm_size(void) { return g.comm ? g.nranks : 0; }
 
+// Where the direct schedule (2) of pk_comm_all_reduce_mean puts things, in ELEMENTS — pure host arithmetic, no GPU and no
+// communicator needed (tests/test_ddp_cpu.py replays it for 2, 4 and 8 ranks).  Exchange 1: this rank sends
+// buf[send_off[p], + shard) to every peer p and receives p's copy of its own shard into scratch[recv_off[p], + shard);
+// the reduction reads part r from scratch + recv_off[r] (r != rank) or from buf + own_off (r == rank), r = 0..n-1 in
+// order, and writes buf[own_off, + shard).  Exchange 2: sends that shard to every peer, receives p's reduced shard into
+// buf[send_off[p], + shard).
+extern "C" int pk_comm_direct_plan(long long count, int nranks, int rank, long long* shard, long long* own_off,
+                                   long long* send_off, long long* recv_off) {
+    PK_CHECK_ARG(nranks >= 1 && rank >= 0 && rank < nranks && count >= 0, "pk_comm_direct_plan: bad arguments");
+    PK_CHECK_ARG(count % ((long long)nranks * 8) == 0, "pk_comm_direct_plan: count %lld is not a multiple of %d", count,
+                 nranks * 8);
+    PK_CHECK_ARG(shard && own_off && send_off && recv_off, "pk_comm_direct_plan: null output");
+    const long long sh = count / nranks;
+    *shard = sh;
+    *own_off = (long long)rank * sh;
+    for (int p = 0; p < nranks; ++p) { send_off[p] = (long long)p * sh; recv_off[p] = (long long)p * sh; }
+    return 0;
+}
+
 // buf[0 .. count) <- mean over the ranks, in place, enqueued on `stream`.  schedules 1 and 2: count % (nranks * 8) == 0
 // (whole 16-byte chunks per shard); schedule 2: `scratch` of count elements.
 extern "C" int pk_comm_all_reduce_mean(void* buf, long long count, int dtype, int schedule, void* scratch, void* stream) {
@@ -146,10 +176,11 @@ extern "C" int pk_comm_all_reduce_mean(void* buf, long long count, int dtype, in
         PK_NCCL(g.AllReduce(buf, buf, (size_t)count, t, NCCL_AVG, g.comm, s), "ncclAllReduce");
         return 0;
     }
-    PK_CHECK_ARG(count % ((long long)n * 8) == 0, "pk_comm_all_reduce_mean: count %lld is not a multiple of %d", count, n * 8);
-    const long long shard = count / n;
+    PK_CHECK_ARG(n <= 64, "pk_comm_all_reduce_mean: %d ranks", n);
+    long long shard, own_off, send_off[64], recv_off[64];
+    if (int rc = pk_comm_direct_plan(count, n, g.rank, &shard, &own_off, send_off, recv_off)) return rc;
     const size_t esz = elem_size(dtype);
-    char* own = (char*)buf + (size_t)g.rank * shard * esz;
+    char* own = (char*)buf + (size_t)own_off * esz;
     if (schedule == 1) {
         PK_NCCL(g.ReduceScatter(buf, own, (size_t)shard, t, NCCL_AVG, g.comm, s), "ncclReduceScatter");
         PK_NCCL(g.AllGather(own, buf, (size_t)shard, t, g.comm, s), "ncclAllGather");
@@ -161,8 +192,8 @@ extern "C" int pk_comm_all_reduce_mean(void* buf, long long count, int dtype, in
         PK_NCCL(g.GroupStart(), "ncclGroupStart");
         for (int peer = 0; peer < n; ++peer) {
             if (peer == g.rank) continue;
-            PK_NCCL(g.Send((char*)buf + (size_t)peer * shard * esz, (size_t)shard, t, peer, g.comm, s), "ncclSend");
-            PK_NCCL(g.Recv((char*)scratch + (size_t)peer * shard * esz, (size_t)shard, t, peer, g.comm, s), "ncclRecv");
+            PK_NCCL_G(g.Send((char*)buf + (size_t)send_off[peer] * esz, (size_t)shard, t, peer, g.comm, s), "ncclSend");
+            PK_NCCL_G(g.Recv((char*)scratch + (size_t)recv_off[peer] * esz, (size_t)shard, t, peer, g.comm, s), "ncclRecv");
         }
         PK_NCCL(g.GroupEnd(), "ncclGroupEnd");
     }
@@ -178,8 +209,8 @@ extern "C" int pk_comm_all_reduce_mean(void* buf, long long count, int dtype, in
         PK_NCCL(g.GroupStart(), "ncclGroupStart");
         for (int peer = 0; peer < n; ++peer) {
             if (peer == g.rank) continue;
-            PK_NCCL(g.Send(own, (size_t)shard, t, peer, g.comm, s), "ncclSend");
-            PK_NCCL(g.Recv((char*)buf + (size_t)peer * shard * esz, (size_t)shard, t, peer, g.comm, s), "ncclRecv");
+            PK_NCCL_G(g.Send(own, (size_t)shard, t, peer, g.comm, s), "ncclSend");
+            PK_NCCL_G(g.Recv((char*)buf + (size_t)send_off[peer] * esz, (size_t)shard, t, peer, g.comm, s), "ncclRecv");
         }
         PK_NCCL(g.GroupEnd(), "ncclGroupEnd");
     }

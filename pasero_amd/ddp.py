@@ -31,6 +31,7 @@ all-reduce, reduce-scatter + all-gather, or the direct grouped send/recv exchang
 measured fastest on the actual set of GPUs at construction, after checking each against torch.distributed's result.
 """
 import contextlib
+import logging
 import os
 from typing import List, Optional, Sequence
 
@@ -38,6 +39,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 from torch.autograd import Variable
+
+logger = logging.getLogger('pasero_amd.ddp')
 
 
 class RcclComm:
@@ -51,9 +54,24 @@ class RcclComm:
 
     @classmethod
     def get(cls, group, device):
+        dev = torch.device(device)
         if cls._instance is None:
-            cls._instance = cls(group, device)
-        return cls._instance if cls._instance.schedule is not None else None
+            cls._instance = cls(group, dev)
+        inst = cls._instance
+        if inst.group is not group or inst.device != dev:
+            # the library holds ONE communicator per process: a second reducer over another group / device must not
+            # silently ride on the first one's ranks
+            logger.warning('pasero_amd.ddp: the native RCCL communicator belongs to another process group or device; '
+                           'this reducer uses torch.distributed')
+            return None
+        return inst if inst.schedule is not None else None
+
+    def _all_agree(self, ok: bool) -> bool:
+        """True iff `ok` on EVERY rank (one tiny all-reduce over torch.distributed): a rank must not enter a native
+        collective its peers have given up on — they would wait for it forever"""
+        t = torch.tensor([1.0 if ok else 0.0], device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item() > 0)
 
     def __init__(self, group, device):
         import ctypes
@@ -63,22 +81,43 @@ class RcclComm:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.schedule, self.report = None, {}
         self._scratch = None
+        # Every step below that can fail on ONE rank alone (library not found, out of memory, a RCCL error) is followed
+        # by `_all_agree`: either all ranks go on to the next native call or all fall back to torch.distributed.
+        err = None
         try:
             path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
             self.check(self.lib.pk_comm_open(path.encode()), 'pk_comm_open')
-            if self.lib.pk_comm_size() == 0:
-                buf = ctypes.create_string_buffer(128)
-                if self.rank == 0:
+        except Exception as e:
+            err = e
+        if self._all_agree(err is None):
+            buf = ctypes.create_string_buffer(128)
+            try:
+                if self.lib.pk_comm_size() == 0 and self.rank == 0:
                     self.check(self.lib.pk_comm_unique_id(buf, 128), 'pk_comm_unique_id')
-                t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=device)
-                dist.broadcast(t, dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-                ident = bytes(t.cpu().tolist())
-                with torch.cuda.device(device):
-                    self.check(self.lib.pk_comm_init(ident, self.world, self.rank), 'pk_comm_init')
-            self.choose_schedule()
-        except Exception as e:  # any failure: the reducer keeps using torch.distributed
+            except Exception as e:
+                err = e
+            fresh = self.lib.pk_comm_size() == 0
+            if self._all_agree(err is None):
+                if fresh:
+                    t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=device)
+                    dist.broadcast(t, dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                    ident = bytes(t.cpu().tolist())
+                    try:  # (ncclCommInitRank is itself collective: every rank is here)
+                        with torch.cuda.device(device):
+                            self.check(self.lib.pk_comm_init(ident, self.world, self.rank), 'pk_comm_init')
+                    except Exception as e:
+                        err = e
+                if self._all_agree(err is None):
+                    try:
+                        self.choose_schedule()
+                    except Exception as e:
+                        err, self.schedule = e, None
+        if err is not None or self.schedule is None:
             self.schedule = None
-            self.report['error'] = repr(e)
+            self.report['error'] = repr(err) if err is not None else 'no schedule passed its check on every rank'
+            # said ONCE, loudly: a training job would otherwise never know it is not on the native path
+            logger.warning('pasero_amd.ddp: RCCL C-API bring-up failed on rank %d (%s); gradient all-reduce falls back '
+                           'to torch.distributed', self.rank, self.report['error'])
 
     def all_reduce_mean(self, flat: torch.Tensor, schedule: Optional[int] = None) -> None:
         """flat <- mean over ranks, in place, on the current stream"""
@@ -105,6 +144,16 @@ class RcclComm:
         for sched in (0, 1, 2):
             try:
                 y = x.clone()
+                if sched == 2 and self.world > 1:  # the one allocation a trial makes: before the ranks commit to it
+                    self._scratch = torch.empty(numel * 2, dtype=torch.uint8, device=self.device)
+                ready = True
+            except Exception:
+                ready = False
+            if not self._all_agree(ready):
+                ok.append(0.0)
+                ms.append(float('inf'))
+                continue
+            try:
                 self.all_reduce_mean(y, sched)
                 good = bool(((y.float() - ref.float()).abs().max() <= tol).item())
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -135,7 +184,7 @@ class RcclComm:
 
 
 class _Bucket:
-    __slots__ = ('params', 'offsets', 'flat', 'pending', 'ready', 'launched', 'work', 'dtype', 'numel', 'plan')
+    __slots__ = ('params', 'offsets', 'flat', 'pending', 'ready', 'launched', 'work', 'dtype', 'numel', 'plan', 'packed')
 
     def __init__(self, params: List[nn.Parameter], multiple: int = 8):
         self.params = params
@@ -153,6 +202,8 @@ class _Bucket:
         self.launched = False
         self.work = None
         self.plan = None  # chunk list of the pack kernel (device tensors), built at the first pack
+        self.packed = [False] * len(params)  # had a gradient when the bucket was packed (this backward or an earlier,
+        # unsynchronised micro-batch): these get their reduced slice back
 
     def view(self, i: int) -> torch.Tensor:
         p = self.params[i]
@@ -250,6 +301,7 @@ class DistributedDataParallel(nn.Module):
         for b in self._buckets:
             b.pending = len(b.params)
             b.ready = [False] * len(b.params)
+            b.packed = [False] * len(b.params)
             b.launched = False
             if b.work is not None:  # a collective of the aborted step: every rank issued it, let it finish
                 b.work.wait()
@@ -279,7 +331,11 @@ class DistributedDataParallel(nn.Module):
 
     @torch.no_grad()
     def _pack(self, b: _Bucket) -> None:
-        idx = [i for i, p in enumerate(b.params) if p.grad is not None]
+        # every parameter that HAS a gradient is packed — also one whose hook did not fire in this backward: gradients
+        # accumulated under no_sync() by earlier micro-batches (update_freq > 1 with rank- or batch-dependent adapters,
+        # training.py:392-408) are reduced with the rest and must come back (`_finalize` keeps what was packed)
+        b.packed = [p.grad is not None for p in b.params]
+        idx = [i for i, had in enumerate(b.packed) if had]
         if len(idx) < len(b.params):
             b.flat.zero_()  # parameters without a gradient on this rank contribute zeros
         if not idx:
@@ -326,7 +382,9 @@ class DistributedDataParallel(nn.Module):
         self._callback_queued = False
         used_anywhere = None
         if self.find_unused_parameters:
-            used = torch.tensor([float(r) for b in self._buckets for r in b.ready], dtype=torch.float32,
+            # "used" = has a gradient to contribute: produced by this backward, or left by an unsynchronised one
+            used = torch.tensor([float(r or p.grad is not None) for b in self._buckets
+                                 for r, p in zip(b.ready, b.params)], dtype=torch.float32,
                                 device=self._buckets[0].flat.device)
             dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.process_group)
             used_anywhere = used.bool().tolist()
@@ -349,7 +407,8 @@ class DistributedDataParallel(nn.Module):
                 if used_anywhere is not None:
                     keep = used_anywhere[k]  # no rank produced a gradient: leave None, like torch DDP does
                 else:
-                    keep = b.ready[i]  # (without find_unused_parameters every rank uses the same parameters)
+                    keep = b.ready[i] or b.packed[i]  # (every rank uses the same parameters; `packed`: gradients of
+                    # earlier no_sync() micro-batches whose parameter the last micro-batch did not touch)
                 p.grad = b.view(i) if keep else None
                 k += 1
 

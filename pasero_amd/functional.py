@@ -524,7 +524,7 @@ def mt_copy_plan(numels, device):
     for buf in pinned:
         buf[2 * n:] = torch.tensor(list(numels), dtype=torch.int64)
     return {'ct': torch.tensor(ct, dtype=torch.int32, device=device), 'cs': torch.tensor(cs, dtype=torch.int64, device=device),
-            'numels': list(numels), 'table': table, 'pinned': pinned, 'turn': 0}
+            'numels': list(numels), 'table': table, 'pinned': pinned, 'turn': 0, 'uploaded': [None, None]}
 
 
 def mt_copy(srcs, dsts, plan) -> None:
@@ -537,8 +537,17 @@ def mt_copy(srcs, dsts, plan) -> None:
         assert s.dtype == dsts[0].dtype and d.dtype == dsts[0].dtype and s.numel() == k and d.numel() == k
         assert s.is_contiguous() and d.is_contiguous()
     plan['turn'] ^= 1
-    host = plan['pinned'][plan['turn']]
+    turn = plan['turn']
+    host = plan['pinned'][turn]
+    if plan['uploaded'][turn] is not None:
+        # the upload issued from this pinned buffer two calls ago must have been READ by the device before the host
+        # rewrites it (a host that runs steps ahead of the GPU — lazy logs, a bench loop — would otherwise hand the
+        # kernel another call's addresses); by now it almost always has: the wait is a query
+        plan['uploaded'][turn].synchronize()
     host.numpy()[:2 * n] = [s.data_ptr() for s in srcs] + [d.data_ptr() for d in dsts]
     plan['table'].copy_(host, non_blocking=True)
+    ev = plan['uploaded'][turn] or torch.cuda.Event()
+    ev.record()
+    plan['uploaded'][turn] = ev
     check(lib.load().pk_mt_copy(ptr(plan['table']), n, ptr(plan['ct']), ptr(plan['cs']), plan['ct'].numel(),
                                 dtype_code(dsts[0]), stream_ptr()), 'pk_mt_copy')

@@ -67,6 +67,7 @@ SIGNATURES = {
     'pk_comm_destroy': (I, []),
     'pk_comm_size': (I, []),
     'pk_comm_all_reduce_mean': (I, [P, LL, I, I, P, P]),
+    'pk_comm_direct_plan': (I, [LL, I, I, P, P, P, P]),
     'pk_logmel_workspace': (SZ, [I]),
     'pk_logmel': (I, [P, P, LL, P, P, SZ, I, P]),
 }

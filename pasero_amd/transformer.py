@@ -89,6 +89,28 @@ class StepLogs(dict):
         self._wait()
         return super().__getitem__(key)
 
+    def __setitem__(self, key, value):
+        if key in ('loss', 'nll_loss', 'num_tokens'):  # a write before the first read must not be overwritten when the
+            self._wait()                               # sums arrive; other keys (:300-321) need no wait
+        super().__setitem__(key, value)
+
+    def __delitem__(self, key):
+        self._wait()
+        super().__delitem__(key)
+
+    def update(self, *args, **kwargs):
+        self._wait()
+        super().update(*args, **kwargs)
+
+    def clear(self):
+        self._pending = None
+        super().clear()
+
+    def __ior__(self, other):
+        self._wait()
+        super().update(other)
+        return self
+
     def get(self, key, default=None):
         self._wait()
         return super().get(key, default)
@@ -641,6 +663,8 @@ class _LayerBase(modules._PerCallAttrs, nn.Module):
         if _NO_FUSED_TAIL or not self._stock_postnorm(branch_hooks, residual_hook, postnorm_hook, norm):
             return None
         norm = self._norm_module(norm)
+        if getattr(norm, 'weight', None) is None:  # LayerNorm(elementwise_affine=False): the stand-alone kernel
+            return None
         tail = BlockTail(residual, norm.weight, norm.bias, norm.eps, self.dropout.p if self.training else 0.0)
         attn._tail = tail
         return tail
@@ -653,6 +677,7 @@ class _LayerBase(modules._PerCallAttrs, nn.Module):
         if (not _NO_FUSED_TAIL and x is residual and self.fc3 is None and self.fc1.lora is None
                 and not (self.training and self.activation_dropout.p > 0)
                 and self._stock_postnorm(('ffn', 'ffn_prenorm'), 'ffn_residual', 'ffn_postnorm', self.final_layer_norm)
+                and getattr(norm, 'weight', None) is not None
                 and block_tail_eligible(x.numel() // x.size(-1), self.fc2.weight, x, norm.weight)):
             self._ffn_link = None
             group, self._ffn_group = getattr(self, '_ffn_group', None), None

@@ -20,6 +20,12 @@ def test_library_exports_every_header_symbol():
     for n in sorted(names):
         assert hasattr(L, n), f'{n} declared in include/pasero_hip.h but not exported'
     assert names == set(lib.SIGNATURES), 'pasero_amd/lib.py SIGNATURES out of sync with the header'
+    # ... and nothing else: the launchers the translation units call across files stay local (linker version script
+    # generated from the header, csrc/Makefile: exports.map)
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ' T ' in ln}
+    assert exported == names, f'exported but not declared: {sorted(exported - names)}'
     assert L.pk_version() >= 100
 
 

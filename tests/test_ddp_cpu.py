@@ -254,3 +254,90 @@ def test_ddp_rank_divergent_adapters_frozen_state_abort_and_logs():
 
 def test_ddp_collectives_are_issued_in_bucket_order():
     _run(_worker_order)
+
+
+def _worker_accum_skip(rank, world, port, ret):
+    """update_freq > 1 with adapters: micro-batch 1 (under no_sync) uses adapter 'de', micro-batch 2 (synchronised) does
+    not touch it — the accumulated gradient of 'de' is reduced with the rest and must still be there afterwards
+    (pasero/training.py:392-408; torch DDP keeps it)"""
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pasero_amd.ddp import DistributedDataParallel
+    out = {}
+    for find_unused in (False, True):
+        torch.manual_seed(5)
+        net = AdapterNet()
+        ddp = DistributedDataParallel(net, bucket_cap_mb=0.0002, find_unused_parameters=find_unused)
+        xs = [torch.randn(2, 8, generator=torch.Generator().manual_seed(10 * r + i)) for r in range(world) for i in (0, 1)]
+        x1, x2 = xs[2 * rank], xs[2 * rank + 1]
+        ref = AdapterNet()
+        ref.load_state_dict(net.state_dict())
+        sum(ref(xs[2 * r], 'de') + ref(xs[2 * r + 1], 'fr') for r in range(world)).backward()
+        with ddp.no_sync():
+            ddp(x1, 'de').backward()
+        ddp(x2, 'fr').backward()
+        tag = f'unused={find_unused}'
+        for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            if not p.requires_grad:
+                continue
+            if n.startswith('adapters.never'):
+                out[f'{tag}:{n}'] = p.grad is None or float(p.grad.abs().max()) == 0.0
+            else:
+                out[f'{tag}:{n}'] = p.grad is not None and torch.allclose(p.grad, q.grad / world, rtol=1e-5, atol=1e-6)
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_no_sync_gradient_survives_a_last_micro_batch_that_skips_its_parameter():
+    _run(_worker_accum_skip)
+
+
+@pytest.mark.parametrize('n', [2, 4, 8])
+def test_direct_all_reduce_layout_replayed_on_the_host(n):
+    """schedule 2 of pk_comm_all_reduce_mean (csrc/comm.hip) for n ranks, replayed with numpy from the offsets the
+    library itself computes (pk_comm_direct_plan: host arithmetic, no GPU): exchange 1 into scratch, the fixed-order
+    mean of shard_mean_kernel (part r from scratch + r * shard, the rank's own part from the bucket), exchange 2 —
+    every rank must end with the mean of the n buckets, and only multiples of 8 n elements are accepted"""
+    import ctypes
+    import numpy as np
+    from pasero_amd import lib
+    L = lib.load()
+    count = 8 * n * 5
+    rng = np.random.default_rng(n)
+    bufs = [rng.standard_normal(count).astype(np.float32) for _ in range(n)]
+    want = np.mean(np.stack(bufs), axis=0, dtype=np.float64)
+    plans = []
+    for r in range(n):
+        shard, own = ctypes.c_longlong(), ctypes.c_longlong()
+        send, recv = (ctypes.c_longlong * n)(), (ctypes.c_longlong * n)()
+        assert L.pk_comm_direct_plan(count, n, r, ctypes.byref(shard), ctypes.byref(own), send, recv) == 0
+        assert shard.value * n == count and shard.value % 8 == 0 and own.value == r * shard.value
+        plans.append((shard.value, own.value, list(send), list(recv)))
+    sh = plans[0][0]
+    scratch = [np.full(count, np.nan, np.float32) for _ in range(n)]
+    for r in range(n):      # exchange 1: r sends buf[send_off[p]] to p, which receives it at scratch[recv_off[r]]
+        for p in range(n):
+            if p != r:
+                so, ro = plans[r][2][p], plans[p][3][r]
+                scratch[p][ro: ro + sh] = bufs[r][so: so + sh]
+    for r in range(n):      # the reduction kernel's indexing
+        own = plans[r][1]
+        acc = np.zeros(sh, np.float32)
+        for part in range(n):
+            acc += bufs[r][own: own + sh] if part == r else scratch[r][part * sh: part * sh + sh]
+        bufs[r][own: own + sh] = acc * np.float32(1.0 / n)
+    for r in range(n):      # exchange 2: r's reduced shard lands at buf[send_off[r]] of every peer
+        own = plans[r][1]
+        for p in range(n):
+            if p != r:
+                dst = plans[p][2][r]
+                bufs[p][dst: dst + sh] = bufs[r][own: own + sh]
+    for r in range(n):
+        assert not np.isnan(bufs[r]).any() and np.allclose(bufs[r], want, rtol=1e-5, atol=1e-6), r
+    one = ctypes.c_longlong()
+    arr = (ctypes.c_longlong * n)()
+    assert L.pk_comm_direct_plan(count + 8, n, 0, ctypes.byref(one), ctypes.byref(one), arr, arr) != 0
+    assert b'multiple' in L.pk_last_error()

@@ -54,6 +54,19 @@ def test_updates_survive_the_wait_and_equality_compares_values():
     assert logs == {**WANT, 'prompt_nll_loss': 0.5} and logs != WANT
     logs = _pending()
     assert logs.pop('num_lines') == 4 and logs.setdefault('loss', 0.0) == WANT['loss']
+    # a value written over one of the pending entries BEFORE the first read is what a later read returns
+    logs = _pending()
+    logs['loss'] = 9.0
+    assert logs['loss'] == 9.0 and logs['num_tokens'] == 7
+    logs = _pending()
+    logs.update(loss=8.0, extra=1)
+    assert dict(logs) == {**WANT, 'loss': 8.0, 'extra': 1}
+    logs = _pending()
+    logs |= {'nll_loss': 3.0}
+    assert logs['nll_loss'] == 3.0 and logs['loss'] == WANT['loss']
+    logs = _pending()
+    del logs['loss']
+    assert 'loss' not in logs and logs['num_tokens'] == 7
 
 
 @pytest.mark.gpu

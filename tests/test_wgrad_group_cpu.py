@@ -96,3 +96,19 @@ def test_sink_runs_last_in_its_layer_and_returns_the_gradients(cpu_gemms):
     for w, r in zip(ws, ref):
         assert torch.allclose(w.grad, r.grad, atol=1e-5)
     assert torch.allclose(x.grad, x2.grad, atol=1e-5) and torch.allclose(enc.grad, enc2.grad, atol=1e-5)
+
+
+def test_a_node_that_hands_over_twice_replaces_its_entry(cpu_gemms):
+    """a partial backward (autograd.grad towards an inner activation over a retained graph) runs deferred ops but never
+    reaches the sink; the full backward that follows must not count their gradients twice"""
+    torch.manual_seed(1)
+    w = torch.nn.Parameter(torch.randn(8, 5))
+    g = A.WGradGroup()
+    g.bind([w])
+    dy, x = torch.randn(7, 8), torch.randn(7, 5)
+    g.add(dy, x, [(0, 0, 8)], None, owner=123)       # stale: from the partial backward
+    dy2 = torch.randn(7, 8)
+    g.add(dy2, x, [(0, 0, 8)], None, owner=123)      # the same node again, in the full backward
+    g.add(dy, x, [(0, 0, 8)], None, owner=456)       # ANOTHER node sharing the weight still adds up
+    grads = g.flush()
+    assert torch.allclose(grads[0], (dy2 + dy).t() @ x, atol=1e-5)
