@@ -65,6 +65,9 @@ def parse_args():
     ap.add_argument('--no-live-traffic', action='store_true',
                     help='roofline.traffic from the committed profiles/ instead of two rocprofv3 counter passes now')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
+    ap.add_argument('--no-extra-workloads', action='store_true',
+                    help='skip the c3_big / c4_whisper measurements that follow the headline region at N = 1')
+    ap.add_argument('--extra-steps', type=int, default=10, help='timed steps of each extra workload (3 warm-up steps)')
     ap.add_argument('--rehearse-cpu', action='store_true',
                     help='CPU rehearsal of the multi-rank plumbing (launcher, rendezvous, reducer, fused logs '
                          'all-reduce, timing protocol, JSON): a small torch MLP stands in for the HIP model, which has '
@@ -123,6 +126,8 @@ class GemmTimer:
             return 'gemm8p_ln_kernel<%s>' % t
         if kernel & 0xF == 8 and kernel < 256:  # gemm8p instantiation: <T, A_COL, B_COL, ANY epilogue, TAIL K-tile>
             return 'gemm8p_kernel<%s, %s, %s, %s, %s>' % (t, tf[a_col], tf[b_col], tf[(kernel >> 4) & 1], tf[(kernel >> 5) & 1])
+        if kernel & 0x200:  # the B-stationary kernel (gemmbs.hip): <T, B_COL, K-tiles, ReLU, ReLU-mask>
+            return 'gemmbs_kernel<%s, %s, %d, %s, %s>' % (t, tf[b_col], kernel & 0xF, tf[(kernel >> 4) & 1], tf[(kernel >> 5) & 1])
         if kernel == 256:
             return 'gemm256_kernel<%s, %s, %s, 8>' % (t, tf[a_col], tf[b_col])
         return 'gemm_kernel<%s, %s, %s>' % (t, tf[a_col], tf[b_col])
@@ -178,7 +183,7 @@ def live_pmc_traffic(kernel_key: str, workload: str, dtype: str, timeout_s: floa
         d = tempfile.mkdtemp(prefix='pk_pmc_', dir='/tmp')
         cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable,
                os.path.abspath(__file__), '--workload', workload, '--dtype', dtype, '--steps', '3', '--warmup', '1',
-               '--no-cpu-baseline', '--no-roofline', '--no-live-traffic']
+               '--no-cpu-baseline', '--no-roofline', '--no-live-traffic', '--no-extra-workloads']
         env = dict(os.environ, TMPDIR='/tmp')
         for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
             env.pop(k, None)
@@ -364,58 +369,64 @@ def run(args):
     from pasero_amd.transformer import Transformer
     from pasero_amd.ddp import DistributedDataParallel, reduce_logs
 
-    cfg_name, V, B, S, T = WORKLOADS[args.workload]
-    cfg = getattr(C, cfg_name)()  # dropout 0.1, label smoothing 0.1: the training configuration
     dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
-    torch.manual_seed(1234)  # identical random-init weights on every rank
-    model = Transformer(cfg, C.DistributedConfig(dp_size=world, dp_rank=rank), C.SyntheticTask(V))
-    model = model.to(dtype).to(device)
-    model.train()
-    rng.manual_seed(1 + rank)
-    ddp = DistributedDataParallel(model) if world > 1 or args.force_ddp else model
-    batch = synthetic_batch(B, S if args.workload != 'c4_whisper' else 4, T, V, seed=1 + rank, device=device)
-    wav = None
-    if args.workload == 'c4_whisper':  # wav ~ N(0, 0.1^2) fp32, 30 s at 16 kHz
-        gen = torch.Generator().manual_seed(rank)
-        wav = (0.1 * torch.randn(B, 480000, generator=gen)).to(device)
-        batch['encoder_input_length'] = torch.full((B,), S, dtype=torch.int64, device=device)
-
-    timer = GemmTimer()
-
-    def step():
-        for p in model.parameters():
-            p.grad = None
-        if wav is not None:
-            from pasero_amd import functional as PF
-            batch['encoder_input'] = PF.log_mel(wav).to(dtype)
-        loss, logs = ddp(**batch)
-        loss.backward()
-        if dist.is_initialized():  # Trainer.train_step's per-step log exchange (training.py:431), as ONE all-reduce
-            logs = reduce_logs(logs)
-        return logs['num_tokens']  # N > 1: already the sum over the ranks
 
     def fence():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    if not args.no_roofline:
-        timer.start(400 * args.steps // GemmTimer.STRIDE + 64)
-    t0 = time.perf_counter()
-    tokens = 0
-    for _ in range(args.steps):
-        tokens += step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if not args.no_roofline:
-        timer.stop()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    def measure(workload: str, steps: int, warmup: int, with_ddp: bool):
+        """build `workload`, run `warmup` untimed + `steps` timed steps -> (elapsed s, tokens, GemmTimer, cfg, dims, ddp)"""
+        cfg_name, V, B, S, T = WORKLOADS[workload]
+        cfg = getattr(C, cfg_name)()  # dropout 0.1, label smoothing 0.1: the training configuration
+        torch.manual_seed(1234)  # identical random-init weights on every rank
+        model = Transformer(cfg, C.DistributedConfig(dp_size=world, dp_rank=rank), C.SyntheticTask(V))
+        model = model.to(dtype).to(device)
+        model.train()
+        rng.manual_seed(1 + rank)
+        ddp = DistributedDataParallel(model) if with_ddp else model
+        batch = synthetic_batch(B, S if workload != 'c4_whisper' else 4, T, V, seed=1 + rank, device=device)
+        wav = None
+        if workload == 'c4_whisper':  # SURVEY §8d C4: wav ~ N(0, 0.1^2) fp32, 30 s at 16 kHz
+            gen = torch.Generator().manual_seed(rank)
+            wav = (0.1 * torch.randn(B, 480000, generator=gen)).to(device)
+            batch['encoder_input_length'] = torch.full((B,), S, dtype=torch.int64, device=device)
+
+        def step():
+            for p in model.parameters():
+                p.grad = None
+            if wav is not None:
+                from pasero_amd import functional as PF
+                batch['encoder_input'] = PF.log_mel(wav).to(dtype)
+            loss, logs = ddp(**batch)
+            loss.backward()
+            if dist.is_initialized():  # Trainer.train_step's per-step log exchange (training.py:431), as ONE all-reduce
+                logs = reduce_logs(logs)
+            return logs['num_tokens']  # N > 1: already the sum over the ranks
+
+        timer = GemmTimer()
+        for _ in range(warmup):
+            step()
+        fence()
+        if not args.no_roofline:
+            timer.start(400 * steps // GemmTimer.STRIDE + 64)
+        t0 = time.perf_counter()
+        tokens = 0
+        for _ in range(steps):
+            tokens += step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if not args.no_roofline:
+            timer.stop()
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
+        return elapsed, tokens, timer, cfg, (cfg_name, V, B, S, T), ddp
+
+    elapsed, tokens, timer, cfg, (cfg_name, V, B, S, T), ddp = measure(args.workload, args.steps, args.warmup,
+                                                                       world > 1 or args.force_ddp)
 
     if rank == 0:
         # SURVEY §8d algorithmic FLOPs of one fwd+bwd batch (speech: the encoder runs on the S/2 subsampled positions;
@@ -423,7 +434,8 @@ def run(args):
         step_flops = count_flops(cfg, B, S if args.workload != 'c4_whisper' else S // 2, T, V)
         out = {
             'metric': 'target tokens/sec (fwd+bwd), Transformer-base d=512',
-            'value': tokens / elapsed,
+            'value': tokens / elapsed,  # whole job: the sum over the N GPUs
+            'value_per_gpu': tokens / elapsed / world,  # BASELINE's metric is quoted per GPU; identical at N = 1
             'unit': 'target tokens/s',
             'n_gpus': world,
             'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
@@ -464,6 +476,30 @@ def run(args):
                 traffic, how = committed_pmc_traffic(dom), f'committed profiles/ ({how})'
             out['roofline']['traffic'] = traffic
             out['roofline']['traffic_source'] = how
+        if world == 1 and not args.no_extra_workloads and args.workload == 'c2_base_bf16':
+            # the other BASELINE configurations that fit one GPU, timed by THIS run after the headline region (same
+            # process, same protocol, a few steps each): d = 1024 is where north_star states its 40 % target
+            del ddp
+            out['extra_workloads'] = {}
+            for name in ('c3_big', 'c4_whisper'):
+                torch.cuda.empty_cache()
+                e_el, e_tok, e_timer, e_cfg, (_, eV, eB, eS, eT), _m = measure(name, args.extra_steps, 3, False)
+                del _m
+                fl = count_flops(e_cfg, eB, eS if name != 'c4_whisper' else eS // 2, eT, eV)
+                rec = {'config': f'{WORKLOADS[name][0]} V={eV}, batch (B,S,T)=({eB},{eS},{eT}), {args.dtype}',
+                       'steps': args.extra_steps, 'warmup': 3, 'ms_per_step': 1e3 * e_el / args.extra_steps,
+                       'value': e_tok / e_el, 'unit': 'target tokens/s',
+                       'algorithmic_tflop_per_step': fl / 1e12,
+                       'mfma_peak_fraction_whole_step': fl * args.extra_steps / e_el / 1e12 / PEAK_BF16_TFLOPS}
+                if not args.no_roofline and e_timer.samples:
+                    es = e_timer.summary()
+                    edom = max(es, key=lambda k: es[k]['total_ms'])
+                    rec.update({'dominant_kernel': edom, 'achieved_tflops': es[edom]['tflops'],
+                                'frac': es[edom]['tflops'] / PEAK_BF16_TFLOPS, 'avg_launch_us': es[edom]['avg_us'],
+                                'sampled_launches': es[edom]['launches'],
+                                'all_gemm_kernels': {k: {'tflops': round(v['tflops'], 1), 'avg_us': round(v['avg_us'], 1),
+                                                         'sampled_launches': v['launches']} for k, v in es.items()}})
+                out['extra_workloads'][name] = rec
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         _JSON_LINE.append(json.dumps(out))

@@ -66,6 +66,11 @@ int pk_gemm_timing_start(int max_samples, int stride);
  * 2 additionally sends every eligible GEMM with M, N >= 256 there, whether or not its tiles fill the chip (tests);
  * a negative argument only queries.  Returns the previous setting (env PK_GEMM_8P sets the initial one). */
 int pk_gemm_use_8p(int on);
+/* diagnostic: 1 / 0 lets pk_gemm send short-contraction GEMMs (K = 512 / 256, row-form A, bias / ReLU epilogue, thousands
+ * of rows) to the B-stationary kernel (gemmbs.hip, default) / keeps them on the tiled kernels; negative: query only.
+ * Returns the previous setting (env PK_GEMM_BS sets the initial one).  Sample tag in pk_gemm_timing_read: 0x200 | number
+ * of K-tiles | 0x10 with the ReLU epilogue | 0x20 with the ReLU-mask epilogue (mode 2). */
+int pk_gemm_use_bs(int on);
 int pk_gemm_timing_stop(void);
 int pk_gemm_timing_read(int i, int* kernel, int* a_col, int* b_col, int* splitk, int* dtype, double* flops, float* ms);
 

@@ -712,6 +712,13 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict
 }
 
 // PK_GEMM_8P=0 / pk_gemm_use_8p(0): keep the 256-tile GEMMs on gemm256.hip (A/B of the two K loops inside one process)
+// B-stationary kernel for K = 512 / 256 (gemmbs.hip)
+extern "C" int pk_gemmbs_eligible(const void* A, const void* B, const void* C, long long M, long long N, long long K,
+                                  long long lda, long long ldb, int a_col, int b_col, const EpiParams* ep);
+extern "C" int pk_gemmbs_launch(const void* A, const void* B, void* C, long long M, long long N, long long K,
+                                long long lda, long long ldb, int b_col, EpiParams ep, int dtype, void* stream);
+extern "C" int pk_gemmbs_use(int on);
+
 int g_use_8p = [] { const char* e = getenv("PK_GEMM_8P"); return (!e || atoi(e) != 0) ? 1 : 0; }();
 
 // ---- optional launch timing (bench.py's roofline leg): HIP events around exactly the main GEMM kernel, on its stream ----
@@ -764,6 +771,15 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         if (!a_col && !b_col && (M <= 64 || (M <= 256 && N <= 8192)) && splitk <= 1 && !asum_out && !no_skinny) {
             int rc = pk_gemm_skinny_launch(A, B, C, M, N, K, lda, ldb, ep, dtype16, stream);
             if (rc != 0) return rc == 1 ? 0 : rc;  // 1 = launched, 0 = not eligible, anything else = error
+        }
+        // short contraction (K = 512 / 256), many rows, lean epilogue: the B-stationary walk (gemmbs.hip) — no epilogue phase
+        // (sample tag 0x200 | K-tiles | 0x10 ReLU | 0x20 ReLU-mask epilogue of mode 2)
+        if (splitk <= 1 && !asum_out && pk_gemmbs_eligible(A, B, C, M, N, K, lda, ldb, a_col, b_col, &ep)) {
+            const int tagbs = 0x200 | (int)(K / 64) | (ep.mode == 2 ? 0x20 : ep.act == PK_ACT_RELU ? 0x10 : 0);
+            GemmSample* sm = timing_begin(tagbs, a_col, b_col, 1, dtype16, M, N, K, stream);
+            const int rc = pk_gemmbs_launch(A, B, C, M, N, K, lda, ldb, b_col, ep, dtype16, stream);
+            timing_end(sm, stream);
+            return rc == 1 ? 0 : rc;
         }
         // 256x256-tile kernel (gemm256.hip): LDS-DMA only, so it needs 16-byte addressable operands, K in whole 64-tiles
         // and one of the lean epilogues; it pays when its (4x fewer) tiles still fill the chip.
@@ -948,6 +964,8 @@ extern "C" int pk_gemm_ln_fwd(const void* A, const void* W, const void* bias, co
     timing_end(sm, s);
     return rc;
 }
+
+extern "C" int pk_gemm_use_bs(int on) { return pk_gemmbs_use(on); }
 
 extern "C" int pk_gemm_use_8p(int on) {
     const int old = g_use_8p;

@@ -1,0 +1,472 @@
+// B-stationary bf16 / fp16 MFMA GEMM for short contractions (K = 512: every projection of a d = 512 model that reads the
+// hidden state — q|k|v, cross q, cross k|v, fc1 forward; out-proj dX, fc2 dX — pasero/models/modules.py:92-96).
+//
+// Why another kernel.  gemm8p.hip's 256 x 256 tile spends 12 us in the K loop of a K = 512 tile and then 4.5-5 us in an
+// epilogue that every workgroup of the launch enters at the same moment (the chip's write rate): 26 % of
+// the tile, with the matrix cores idle — one workgroup fills a CU (accumulators = half the register file, stages = the
+// LDS), so nothing else can run meanwhile.  Hiding it needs a home for a finished tile while the next one accumulates.
+// For K <= 512 there is one: the WHOLE B panel of a 256-column strip, split over the waves, fits in REGISTERS —
+//   * workgroup = 8 waves side by side (1 x 8); it owns ONE strip of 256 output columns and walks down M in steps of 32
+//     rows (persistent: one workgroup per CU, `steps_per` consecutive steps each);
+//   * wave w keeps B[n0 + 32 w .. + 32][0 .. K) as MFMA fragments for the whole walk: K / 32 k-steps x 2 column tiles x
+//     4 registers = 128 registers at K = 512.  B is read from memory once per workgroup and never from LDS in the loop;
+//     every wave reads the SAME 32 x 64 A tile, so L2 -> LDS traffic is 4 KiB per 32 x 256 x 64 MACs: HALF the bytes per
+//     FLOP of the 256 x 256 tile (the LDS-DMA stream, not the matrix pipe, paces these kernels: ~33-45 GB/s per CU with
+//     64-96 KiB in flight — a first version with 128-column strips ran at that limit, 1.0 PFLOP/s);
+//   * the accumulators of a step are 32 rows x 32 columns per wave = 16 registers, in TWO sets: step s + 1 accumulates into
+//     one while the results of step s leave from the other — bias / activation / rounding and ONE 16-byte store per 16-row
+//     tile, in the first two K-tiles of the next step.  No epilogue phase, no LDS staging of the output (the column order
+//     of the B fragments is permuted so that a lane's eight accumulator values of a row are eight CONSECUTIVE columns:
+//     16 rows x 64 B per store instruction), and the stores of the 256 workgroups are spread over the whole launch instead
+//     of arriving as one burst;
+//   * LDS is a 32-slot ring of A tiles (32 rows x 64 k, 4 KiB each = four 1-KiB LDS-DMA pieces: waves 0-3 bring the even
+//     tiles, waves 4-7 the odd ones), 20 tiles of look-ahead; every wave software-pipelines itself — the fragments of tile
+//     t + 1 are read (into a second fragment set) while the 8 MFMAs of tile t run — so the workgroup only meets at a
+//     barrier every FOURTH K-tile, in front of which each wave waits for its own pieces of the next four tiles with a
+//     counted `s_waitcnt vmcnt(7)`.
+// Hazards (t = position in the ring, tile t lives in slot t % 32).  RAW: tile t + 1 is read at position t; the barrier at
+// position 4 b is preceded on every wave by the wait for its pieces of the tiles <= 4 b + 4, so all of them are in LDS for
+// every reader of positions 4 b .. 4 b + 3.  WAR: the DMA issued at position t overwrites tile t - 12, read 13 positions
+// (three barriers) ago.  vmcnt is ONE in-order queue of loads and stores: the wait leaves the 7 youngest operations open —
+// this wave's pieces among the tiles 4 b + 5 .. 4 b + 19 are 7 (even tiles) or 8 (odd tiles), fewer when a store is among
+// them: never an unlanded tile <= 4 b + 4.
+// Past the last step of a workgroup the same DMA instructions run against an EMPTY descriptor (nothing fetched), so one
+// loop body serves every length; rows past M read as zeros (the descriptor's range check) and their stores are dropped
+// the same way (rows) or by a per-lane dead offset (columns past N).
+#include <algorithm>
+#include <type_traits>
+#include "common.h"
+#include "gemm_epi.h"
+#include "gemm8p_common.h"
+
+namespace {
+
+constexpr int BMS = 32, BNT = 256, BK = 64;
+constexpr int TILE = 4096, RS = 32;            // A ring: 32 slots of 32 rows x 64 k = four steps
+constexpr int BIMG = 16384;                    // col-form prologue: a B image of 128 columns x 64 k
+constexpr int SMEM = RS * TILE;                // 128 KiB
+constexpr int LA = 20, SYNC = 4;               // DMA look-ahead (tiles), K-tiles between barriers
+constexpr unsigned DEAD_OFF = 0x80000000u;
+
+// column of the wave's 32-column slab that row `nu` (0..15) of B-fragment tile j holds: lane (q = l >> 4) then owns the
+// output columns 8 q + 4 j + r, r = 0..3, of tile j — eight consecutive columns over j = 0, 1
+__device__ __forceinline__ int bcol(int j, int nu) { return 8 * (nu >> 2) + 4 * j + (nu & 3); }
+
+// MASK: the epilogue of the dH = dY W2 GEMM of a ReLU feed-forward (pk_gemm mode 2, pasero/models/transformer.py:999-1019
+// backward): C = aux > 0 ? alpha * acc : 0, `bias` then points at aux [M][ldaux] (no bias in that mode)
+template <typename T, bool B_COL, int NK, bool RELU, bool MASK>
+__global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A, const T* __restrict__ B,
+                                                       T* __restrict__ C, const T* __restrict__ bias, long long M,
+                                                       long long N, long long lda, long long ldb, long long ldc,
+                                                       long long ldaux, unsigned a_bytes, unsigned b_bytes,
+                                                       unsigned c_bytes, unsigned aux_bytes, int nt_n, int steps_per,
+                                                       int total_steps, float alpha, unsigned long long* stamps) {
+    static_assert(NK == 8, "two steps = half a turn of the 32-slot ring: K = 512");
+    static_assert(NK * BIMG <= SMEM && LA + 6 <= RS && LA == 20, "LDS map / counted wait below");
+    typedef typename M16<T>::vec V;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(3))) char lds_char;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wcls = wave >> 2, wpiece = wave & 3;  // tiles of parity `wcls`, rows 8 wpiece .. + 8, are this wave's to bring
+    // strip and row range of this workgroup: consecutive positions of the XCD-contiguous remap share their rows of A
+    // (the strips of one row range run on one XCD and find each other's A tiles in its L2)
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_tile = lin % nt_n, mg = lin / nt_n;
+    const int s_begin = mg * steps_per, s_end = min(total_steps, s_begin + steps_per);
+    if (s_begin >= s_end) return;
+    const long long n0 = (long long)n_tile * BNT;
+    // diagnostic build (-DPKBS_STAMPS, tools/gemmbs_stamps.py): s_memrealtime / s_memtime at the seams, into a buffer of
+    // their own (never into an output); the shipped build has no stamp
+#ifdef PKBS_STAMPS
+    int stamp_i = 0;
+#define PK_STAMP() do { if (stamps && tid == 0) { stamps[(size_t)blockIdx.x * 64 + (stamp_i & 31)] = __builtin_amdgcn_s_memrealtime(); \
+        stamps[(size_t)blockIdx.x * 64 + 32 + (stamp_i & 31)] = __builtin_amdgcn_s_memtime(); ++stamp_i; } } while (0)
+#else
+#define PK_STAMP() do { } while (0)
+#endif
+    PK_STAMP();  // start
+
+    // ---- A stream: a wave's 1-KiB piece (8 rows x 128 B) of a 32 x 64 tile; the step's rows and the K-tile ride in the
+    // SGPR offset (part of the range check: rows >= M read zeros) ----
+    unsigned offa;
+    {
+        const int row = wpiece * 8 + (lane >> 3), chunk = (lane & 7) ^ HT<false>::swz(row);
+        offa = (unsigned)((row * lda + chunk * 8) * 2);
+    }
+    const unsigned step_bytes = (unsigned)(BMS * lda * 2);
+    auto dma_a = [&](int step, int ktile, int slot) {  // (tile parity = slot parity = the calling wave's class)
+        const bool live = step < s_end;
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, live ? (int)a_bytes : 0, 0x00020000);
+        const unsigned so = live ? (unsigned)step * step_bytes + (unsigned)ktile * (BK * 2) : 0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(smem + slot * TILE + wpiece * 1024), 16, offa, so, 0, 0);
+    };
+#define PK_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+    // bias of this lane's eight columns, output addressing
+    const int q = lane >> 4;
+    const long long col0 = n0 + 32 * wave + 8 * q;
+    const bool col_ok = col0 + 8 <= N;
+    const unsigned c_voff = col_ok ? (unsigned)((((long long)(lane & 15)) * ldc + 32 * wave + 8 * q) * 2) : DEAD_OFF;
+    const unsigned c_tile_bytes = __builtin_amdgcn_readfirstlane((unsigned)(16 * ldc * 2));
+    const unsigned c_step_bytes = __builtin_amdgcn_readfirstlane((unsigned)(BMS * ldc * 2));
+    const unsigned c_col_bytes = __builtin_amdgcn_readfirstlane((unsigned)(n0 * 2));
+    Vec16<T> bv;
+    bv.raw = uint4{0u, 0u, 0u, 0u};
+    if (!MASK && bias && col_ok) bv = load16<T>(bias + col0);
+    // MASK: the 16 x 8 piece of aux under each of the step's two output tiles, requested a step's worth of K-tiles before
+    // it is used (it comes from HBM); rows >= M / columns >= N read as zeros (descriptor range / dead offset)
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, MASK ? (int)aux_bytes : 0, 0x00020000);
+    const unsigned x_voff = col_ok ? (unsigned)((((long long)(lane & 15)) * ldaux + 32 * wave + 8 * q) * 2) : DEAD_OFF;
+    const unsigned x_tile_bytes = __builtin_amdgcn_readfirstlane((unsigned)(16 * ldaux * 2));
+    const unsigned x_step_bytes = __builtin_amdgcn_readfirstlane((unsigned)(BMS * ldaux * 2));
+    u32x4 auxv[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    auto load_aux = [&](int step) {
+        if constexpr (MASK) {
+            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)step * x_step_bytes + c_col_bytes);
+            auxv[0] = __builtin_amdgcn_raw_buffer_load_b128(rx, x_voff, so, 0);
+            auxv[1] = __builtin_amdgcn_raw_buffer_load_b128(rx, x_voff, so + x_tile_bytes, 0);
+        }
+    };
+    __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)c_bytes, 0x00020000);
+
+    // ---- B panel -> registers: bfr[kt][j][kk] = rows {bcol(j, l & 15)} of the wave's slab, k = 64 kt + 32 kk + 8 (l >> 4) + 0..7 ----
+    V bfr[NK][2][2];
+    {
+        // Through LDS, one half of the strip (128 columns = the slabs of four waves) at a time: NK images fill the ring
+        // area — [128 n][64 k] for row-form B ([N][K], k contiguous), [64 k][128 n] for col-form B ([K][N], n contiguous) —
+        // by LDS-DMA in whole 128-byte lines, the four waves of that half read their fragments, next half.  (Row-form
+        // fragments are 16 contiguous bytes of B per lane and could come straight from memory: measured, that prologue was
+        // ~10 us longer — 16 rows x 64 B per load instruction, 256 KiB per workgroup through the CU's 64 B/clk vector path.)
+        // col form: lane group p = l & 3 of a 16-lane group reads the column quad 8 p + 4 j of its slab with the transposing
+        // read, so lane nu of the result holds column bcol(j, nu); rows k, k + 4: same swizzle.
+        __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)b_bytes, 0x00020000);
+        const unsigned kstep_b = B_COL ? (unsigned)(BK * ldb * 2) : (unsigned)(BK * 2);
+        const unsigned base = (unsigned)(unsigned long)(lds_char*)smem;
+        const int p = lane & 3, krow = 8 * (lane >> 4) + ((lane & 15) >> 2);
+        unsigned cb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = 32 * wpiece + 8 * p + 4 * j;
+            cb[j] = base + HT<true>::offset(krow, col >> 3) + (col & 7) * 2;
+        }
+#define PK_TR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
+        asm volatile("; PKBS_BFRAG_BEGIN" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned offb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) offb[i] = src_offset<B_COL>(wave * 2 + i, lane, ldb, n0 + 128 * h, N);
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) {
+                char* dst = smem + kt * BIMG + wave * 2048;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)dst, 16, offb[0], (unsigned)kt * kstep_b, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(dst + 1024), 16, offb[1], (unsigned)kt * kstep_b, 0, 0);
+            }
+            PK_WAIT(0);
+            __builtin_amdgcn_s_barrier();
+            if (wcls == h) {
+#pragma unroll
+                for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (!B_COL) {
+#pragma unroll
+                            for (int kk = 0; kk < 2; ++kk)
+                                bfr[kt][j][kk] = *reinterpret_cast<const V*>(
+                                    smem + kt * BIMG + HT<false>::offset(32 * wpiece + bcol(j, lane & 15), kk * 4 + (lane >> 4)));
+                        } else {
+                            const unsigned a = cb[j] + kt * BIMG;
+#pragma unroll
+                            for (int kk = 0; kk < 2; ++kk) {
+                                s16x4 lo, hi;
+                                if (kk == 0) {
+                                    PK_TR(lo, a, 0);
+                                    PK_TR(hi, a, 4 * HT<true>::ROWB);
+                                } else {
+                                    PK_TR(lo, a, 32 * HT<true>::ROWB);
+                                    PK_TR(hi, a, 36 * HT<true>::ROWB);
+                                }
+                                s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                                bfr[kt][j][kk] = __builtin_bit_cast(V, f);
+                            }
+                        }
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();  // the images are consumed: the next half / the ring may overwrite them
+        }
+        asm volatile("; PKBS_BFRAG_END" ::: "memory");
+#undef PK_TR
+    }
+    PK_STAMP();  // B panel in registers
+
+    float bias_f[8];  // (converted here, behind the staging's vmcnt(0): no wait of the compiler's between the ring's requests)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias_f[e] = bv.get(e);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bias_f[e]));
+
+    // ---- the ring's first LA tiles (this wave: those of its parity) ----
+#pragma unroll
+    for (int t = 0; t < LA; t += 2) dma_a(s_begin + t / NK, t % NK + wcls, t + wcls);
+
+    f32x4 acc[2][2][2];  // [step parity][m-tile][n-tile]: D'[n][m] of the swapped product — lane: m = l & 15, n = 4 (l >> 4) + r
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    V fa[2][2][2];  // [set][m-tile][kk]
+    // row-form fragment of rows 16 i + (l & 15), k-step kk, of a tile: lane l reads chunk (4 kk + (l >> 4)) ^ swizzle of its
+    // row — the swizzle ((row >> 1) & 7) only sees l & 15, so ONE per-lane offset serves kk = 0 and, with bit 6 flipped,
+    // kk = 1.  The loop body is two steps = 16 ring positions = HALF the ring: slot and m-tile are immediates (< 64 KiB, the
+    // reach of the ds_read offset field), the half of the ring is added to the two base registers once per iteration.
+    const int frag_off0 = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4);
+    const int frag_off1 = frag_off0 ^ 64;
+    auto read_a = [&](V (&dst)[2][2], int base0, int base1, int slot16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dst[i][0] = *reinterpret_cast<const V*>(smem + base0 + (slot16 * TILE + i * 2048));
+            dst[i][1] = *reinterpret_cast<const V*>(smem + base1 + (slot16 * TILE + i * 2048));
+        }
+    };
+
+    // one 16-row tile of a finished step leaves: bias, activation, rounding, ONE 16-byte store per lane (row 16 i + (l & 15),
+    // columns 8 q .. 8 q + 7 of the wave's slab); the accumulators are cleared for the step after next.
+    // HAZARD (measured on gfx950, not in hipcc's tables): a 16-byte buffer store WITH an SGPR offset reads its data registers
+    // some instructions after it issues — the accumulator clear / the next tile's conversion that hipcc placed right behind
+    // it landed in the last lanes of the stored rows (zeros or garbage in lanes 12..15 of every 16, one register pair).
+    // hipcc only guards the form without an SGPR offset (GCNHazardRecognizer: "no hazard if soffset is a register").  So
+    // the packed tile is RETURNED and the caller keeps it alive (an empty asm use) until the position's MFMAs have issued.
+    auto emit = [&](f32x4 (&ac)[2][2], int i, unsigned c_so) -> u32x4 {
+        float x[8] = {ac[i][0][0], ac[i][0][1], ac[i][0][2], ac[i][0][3], ac[i][1][0], ac[i][1][1], ac[i][1][2], ac[i][1][3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = x[e] * alpha;
+            if constexpr (MASK) {
+                Vec16<T> av;
+                av.raw = __builtin_bit_cast(uint4, auxv[i]);
+                y = av.get(e) > 0.f ? y : 0.f;
+            } else {
+                y += bias_f[e];
+                if (RELU) y = fmaxf(y, 0.f);
+            }
+            x[e] = y;
+        }
+        typedef __attribute__((ext_vector_type(8))) float f32x8;
+        f32x8 f = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
+        const u32x4 o = __builtin_bit_cast(u32x4, __builtin_convertvector(f, typename H16<T>::vec));
+        // (the row offset is wave-uniform: said explicitly, or hipcc serialises the store in a waterfall loop)
+        const unsigned so = __builtin_amdgcn_readfirstlane(c_so + (unsigned)i * c_tile_bytes);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rc, c_voff, so, 2 /* nt */);
+        ac[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ac[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        return o;
+    };
+
+    // One PAIR of ring positions = K-tiles 2 U, 2 U + 1 of a step of parity P (slots 8 P + 2 U, + 1 of the iteration's half):
+    // ONE basic block — 16 MFMAs, 8 fragment reads, ONE LDS-DMA piece per wave (waves 0-3: the even tile of the pair 20 ahead,
+    // waves 4-7: the odd one — the same instruction, the wave's class only shifts its scalar operands), and in the first pair
+    // of a step the two tiles of the previous step that leave.  An in-order wave pays the issue cost of everything that is not
+    // an MFMA (a DMA piece 60-180 cycles, a 16-byte LDS read ~10, ...) on top of its MFMAs unless they are interleaved: the
+    // instruction order is pinned below, one non-MFMA group per MFMA gap (measured before that: 370 cycles per K-tile
+    // against the 256 the matrix pipe needs).
+    auto pair = [&](auto u_c, auto p_c, int step, unsigned c_so_prev, int ring_off, int cur0, int cur1) {
+        constexpr int U = decltype(u_c)::value, P = decltype(p_c)::value;
+        constexpr int SL = NK * P + 2 * U;  // even, 0..14 within the half
+#ifndef PKBS_ABL_NOBAR  // (ablation builds, tools/gemmbs_ablate.sh: timing only, results are wrong)
+        if constexpr (SL % SYNC == 0) {
+            PK_WAIT(7);  // this wave's pieces of the tiles <= t + 4 have landed
+            __builtin_amdgcn_s_barrier();
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        auto mma = [&](auto kt_c, V (&a)[2][2]) {
+            constexpr int KT = decltype(kt_c)::value;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[P][i][j] = M16<T>::mfma(bfr[KT][j][kk], a[i][kk], acc[P][i][j]);
+        };
+        u32x4 keep0 = {0u, 0u, 0u, 0u}, keep1 = {0u, 0u, 0u, 0u};
+#ifndef PKBS_ABL_NOREAD
+        read_a(fa[1], cur0, cur1, SL + 1);  // fa[0] holds tile SL
+#endif
+#ifndef PKBS_ABL_NOSTORE
+        if constexpr (U == 0) keep0 = emit(acc[P ^ 1], 0, c_so_prev);
+#endif
+        mma(std::integral_constant<int, 2 * U>{}, fa[0]);
+#ifndef PKBS_ABL_NOREAD
+        if constexpr (SL + 2 < 16) read_a(fa[0], cur0, cur1, SL + 2);
+        else read_a(fa[0], cur0 ^ 65536, cur1 ^ 65536, 0);  // (the first slot of the other half)
+#endif
+#ifndef PKBS_ABL_NOSTORE
+        if constexpr (U == 0) keep1 = emit(acc[P ^ 1], 1, c_so_prev);
+#endif
+        mma(std::integral_constant<int, 2 * U + 1>{}, fa[1]);
+        // tiles t + 20, t + 21 -> slots (t + 20) % 32, + 1: the other half's slot SL + 4, or (SL >= 12) this half's slot SL - 12
+#ifndef PKBS_ABL_NODMA
+        constexpr int DSL = (SL + LA) % 16;
+        const int doff = (SL + LA < RS) ? (ring_off ^ 65536) : ring_off;
+        dma_a(step + (2 * U + LA) / NK, (2 * U + LA) % NK + wcls, DSL + wcls + (doff >> 12));
+#endif
+        // instruction order: the first eight MFMA gaps take one fragment read each, the DMA piece sits in the middle of the
+        // second tile's MFMAs, the departing tiles' arithmetic (first pair of a step) fills the gaps it fits in
+#ifndef PKBS_NO_SGB
+#define PK_GAP_DS __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#define PK_GAP_VALU(N) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, N, 0);
+        if constexpr (U == 0) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            PK_GAP_VALU(6) PK_GAP_VALU(6) PK_GAP_VALU(6) PK_GAP_VALU(6)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+            PK_GAP_DS PK_GAP_DS PK_GAP_DS PK_GAP_DS
+            PK_GAP_VALU(6) PK_GAP_VALU(6) PK_GAP_VALU(6) PK_GAP_VALU(6)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        } else {
+            PK_GAP_DS PK_GAP_DS PK_GAP_DS PK_GAP_DS PK_GAP_DS PK_GAP_DS PK_GAP_DS PK_GAP_DS
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+        }
+#undef PK_GAP_VALU
+#undef PK_GAP_DS
+#endif
+        if constexpr (U == 0) asm volatile("" :: "v"(keep0), "v"(keep1));  // (the stores' data registers stay untouched until here)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (U == 0) load_aux(step);  // (this step's mask operand: used when its tiles leave, 8 K-tiles from here)
+    };
+    auto step_body = [&](auto p_c, int step, unsigned c_so_prev, int ring_off, int cur0, int cur1) {
+        pair(std::integral_constant<int, 0>{}, p_c, step, c_so_prev, ring_off, cur0, cur1);
+        pair(std::integral_constant<int, 1>{}, p_c, step, c_so_prev, ring_off, cur0, cur1);
+        pair(std::integral_constant<int, 2>{}, p_c, step, c_so_prev, ring_off, cur0, cur1);
+        pair(std::integral_constant<int, 3>{}, p_c, step, c_so_prev, ring_off, cur0, cur1);
+    };
+
+    PK_WAIT(7);
+    __builtin_amdgcn_s_barrier();
+    read_a(fa[0], frag_off0, frag_off1, 0);  // tile 0
+    PK_STAMP();  // ring primed
+#ifdef PKBS_PRIO
+    if (wcls == 1) __builtin_amdgcn_s_setprio(PKBS_PRIO);
+#endif
+    asm volatile("; PK8P_LOOP_BEGIN" ::: "memory");
+    // (MASK: hipcc's own wait for the aux loads — all but the 3 DMA pieces issued behind them — is the smallest in the loop)
+    if constexpr (MASK) asm volatile("; PK8P_MIN_VMCNT 3" ::: "memory");
+    else asm volatile("; PK8P_MIN_VMCNT 7" ::: "memory");
+    int last_parity = 0, ring_off = 0;
+    for (int s = s_begin; s < s_end; s += 2) {
+        const int cur0 = frag_off0 + ring_off, cur1 = frag_off1 + ring_off;
+        // (the first step has no predecessor: its two "departing" tiles are zeros sent to a dead offset — no branch in the block)
+        const unsigned so0 = s > s_begin ? (unsigned)(s - 1) * c_step_bytes + c_col_bytes : DEAD_OFF;
+        step_body(std::integral_constant<int, 0>{}, s, so0, ring_off, cur0, cur1);
+        last_parity = 0;
+        if (s + 1 >= s_end) break;
+        step_body(std::integral_constant<int, 1>{}, s + 1, (unsigned)s * c_step_bytes + c_col_bytes, ring_off, cur0, cur1);
+        last_parity = 1;
+        ring_off ^= 65536;
+    }
+    asm volatile("; PK8P_LOOP_END" ::: "memory");
+    PK_STAMP();  // loop done
+    PK_WAIT(0);  // (the trailing DMAs are empty, but they still target LDS)
+#undef PK_WAIT
+    // the last step leaves from whichever set it used
+    const unsigned c_so_last = (unsigned)(s_end - 1) * c_step_bytes + c_col_bytes;
+    u32x4 keep0, keep1;
+    if (last_parity == 0) {
+        keep0 = emit(acc[0], 0, c_so_last);
+        keep1 = emit(acc[0], 1, c_so_last);
+    } else {
+        keep0 = emit(acc[1], 0, c_so_last);
+        keep1 = emit(acc[1], 1, c_so_last);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(keep0), "v"(keep1) : "memory");  // (both tiles' data alive until the stores are done)
+    PK_STAMP();  // stores acknowledged
+#undef PK_STAMP
+}
+
+int g_use_bs = [] { const char* e = getenv("PK_GEMM_BS"); return (!e || atoi(e) != 0) ? 1 : 0; }();
+
+// extent of each operand in bytes (last row: only its valid part)
+inline long long extent(long long rows, long long cols, long long ld) { return ((rows - 1) * ld + cols) * 2; }
+
+}  // namespace
+
+// 1 if pk_gemm may send this problem here: A in row form, K = 512, a lean mode-0 epilogue (bias, none / ReLU), every
+// operand 16-byte addressable and below 2 GiB (32-bit buffer offsets), and enough rows that each workgroup walks several
+// steps (the B panel is loaded once per workgroup: ~2-4 us against ~1.2 us per step)
+extern "C" int pk_gemmbs_eligible(const void* A, const void* B, const void* C, long long M, long long N, long long K,
+                                  long long lda, long long ldb, int a_col, int b_col, const EpiParams* ep) {
+    if (!g_use_bs || a_col || K != 512) return 0;
+    const bool mask = ep->mode == 2 && ep->act == PK_ACT_RELU && ep->aux;  // dH = (dY W2) * relu'(h)
+    if (ep->preact || (ep->act != PK_ACT_NONE && ep->act != PK_ACT_RELU) || (ep->mode != 0 && !mask)) return 0;
+    if (N < BNT || N % 8 || M < 32 * BMS) return 0;
+    auto al = [](const void* p, long long ld) { return ((uintptr_t)p % 16) == 0 && (ld % 8) == 0; };
+    if (!al(A, lda) || !al(B, ldb) || !al(C, ep->ldc) || (ep->bias && ((uintptr_t)ep->bias % 16))) return 0;
+    if (mask && (!al(ep->aux, ep->ldaux) || extent(M, N, ep->ldaux) > 0x7FFFFFFFLL - (1 << 20))) return 0;
+    const long long lim = 0x7FFFFFFFLL - (1 << 20);
+    const long long a_bytes = extent(M, K, lda), b_bytes = b_col ? extent(K, N, ldb) : extent(N, K, ldb);
+    const long long c_bytes = extent(M, N, ep->ldc);
+    if (a_bytes > lim - 4 * BMS * lda * 2 || b_bytes > lim || c_bytes > lim) return 0;
+    const long long nt_n = (N + BNT - 1) / BNT, steps = (M + BMS - 1) / BMS;
+    if (nt_n > 256) return 0;
+    const long long G = std::min<long long>(steps, std::max<long long>(1, 256 / nt_n));
+    return (steps + G - 1) / G >= 8;
+}
+
+// Returns 1 if the GEMM was launched or a hip error code (the caller has asked pk_gemmbs_eligible).
+extern "C" int pk_gemmbs_launch(const void* A, const void* B, void* C, long long M, long long N, long long K,
+                                long long lda, long long ldb, int b_col, EpiParams ep, int dtype, void* stream) {
+    const long long nt_n = (N + BNT - 1) / BNT, steps = (M + BMS - 1) / BMS;
+    const long long G0 = std::min<long long>(steps, std::max<long long>(1, 256 / nt_n));
+    const int steps_per = (int)((steps + G0 - 1) / G0);
+    const int G = (int)((steps + steps_per - 1) / steps_per);
+    const unsigned a_bytes = (unsigned)extent(M, K, lda);
+    const unsigned b_bytes = (unsigned)(b_col ? extent(K, N, ldb) : extent(N, K, ldb));
+    const unsigned c_bytes = (unsigned)extent(M, N, ep.ldc);
+    dim3 grid((unsigned)(nt_n * G)), block(512);
+    hipStream_t s = (hipStream_t)stream;
+    const bool mask = ep.mode == 2;
+    const bool relu = ep.act == PK_ACT_RELU && !mask;
+    const unsigned aux_bytes = mask ? (unsigned)extent(M, N, ep.ldaux) : 0u;
+    unsigned long long* stamps = nullptr;  // PK8P_STAMP_PTR: device buffer of the diagnostic build's time stamps
+    if (const char* e = getenv("PK8P_STAMP_PTR")) stamps = (unsigned long long*)strtoull(e, nullptr, 0);
+#define PK_K(TT, BC, NKV, RL, MK)                                                                                      \
+    hipLaunchKernelGGL((gemmbs_kernel<TT, BC, NKV, RL, MK>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C,     \
+                       (const TT*)(mask ? ep.aux : ep.bias), M, N, lda, ldb, ep.ldc, ep.ldaux, a_bytes, b_bytes,        \
+                       c_bytes, aux_bytes, (int)nt_n, steps_per, (int)steps, ep.alpha, stamps)
+#define PK_R(TT, BC, NKV)                               \
+    do {                                                \
+        if (mask) PK_K(TT, BC, NKV, false, true);       \
+        else if (relu) PK_K(TT, BC, NKV, true, false);  \
+        else PK_K(TT, BC, NKV, false, false);           \
+    } while (0)
+#define PK_N(TT, BC) PK_R(TT, BC, 8)
+#define PK_B(TT)                                \
+    do {                                        \
+        if (b_col) PK_N(TT, true);              \
+        else PK_N(TT, false);                   \
+    } while (0)
+    if (dtype == PK_F16) PK_B(f16);
+    else PK_B(bf16);
+#undef PK_B
+#undef PK_N
+#undef PK_R
+#undef PK_K
+    PK_LAUNCH_CHECK();
+    return 1;
+}
+
+extern "C" int pk_gemmbs_use(int on) {
+    const int old = g_use_bs;
+    if (on >= 0) g_use_bs = on ? 1 : 0;
+    return old;
+}

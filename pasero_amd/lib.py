@@ -23,6 +23,7 @@ SIGNATURES = {
     'pk_last_error': (c_char_p, []),
     'pk_gemm': (I, [P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, SZ, P, P]),
     'pk_gemm_use_8p': (I, [I]),
+    'pk_gemm_use_bs': (I, [I]),
     'pk_gemm_timing_start': (I, [I, I]),
     'pk_gemm_timing_stop': (I, []),
     'pk_gemm_timing_read': (I, [I, P, P, P, P, P, P, P]),

@@ -1,0 +1,129 @@
+"""The B-stationary GEMM (csrc/gemmbs.hip: K = 512, row-form A, thousands of rows, bias / ReLU epilogue) behind pk_gemm:
+random problems around its tile and step boundaries against an fp64 product AND bitwise against the tiled kernels (the
+MFMA shape, the k order and the epilogue arithmetic are the same, so every bit must agree); padded leading dimensions
+with NaN in the padding, rows / columns that are not multiples of the step or the strip, an output that is a column
+slice of a wider tensor, and the untouched bytes around the output."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def F():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from pasero_amd import functional
+    return functional
+
+
+def _operand(rs, rows, cols, pad, dtype):
+    buf = torch.full((rows, cols + pad), float('nan'), dtype=dtype)
+    buf[:, :cols] = torch.from_numpy(rs.standard_normal((rows, cols)).astype(np.float32)).to(dtype)
+    return buf.cuda()[:, :cols], buf[:, :cols].double()
+
+
+def _timed_kernels(L, fn):
+    """kernel tags of the GEMM launches `fn` makes (the library's own launch sampling, stride 1)"""
+    import ctypes
+    from pasero_amd import lib
+    lib.check(L.pk_gemm_timing_start(16, 1), 'start')
+    fn()
+    n = L.pk_gemm_timing_stop()
+    tags = []
+    for i in range(n):
+        ints = [ctypes.c_int() for _ in range(5)]
+        fl, ms = ctypes.c_double(), ctypes.c_float()
+        lib.check(L.pk_gemm_timing_read(i, *[ctypes.byref(x) for x in ints], ctypes.byref(fl), ctypes.byref(ms)), 'read')
+        tags.append(ints[0].value)
+    return tags
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_gemmbs_fuzz_against_fp64_and_the_tiled_kernel(F, seed):
+    from pasero_amd import lib
+    L = lib.load()
+    rs = np.random.RandomState(7000 + seed)
+    rows = [8192, 12296, 16384, 24000, 30008, 32768]
+    cols = [512, 520, 1024, 1032, 1536, 2048]
+
+    def takes(M, N):  # pk_gemmbs_eligible's size rule: every workgroup walks at least eight 32-row steps
+        nt_n, steps = -(-N // 256), -(-M // 32)
+        g = min(steps, max(1, 256 // nt_n))
+        return -(-steps // g) >= 8
+
+    taken = 0
+    for case in range(12):
+        dtype = [torch.bfloat16, torch.float16][rs.randint(2)]
+        M, N, K = int(rs.choice(rows)), int(rs.choice(cols)), 512
+        b_col = bool(rs.randint(2))
+        pad_a, pad_b, pad_c = int(rs.choice([0, 8, 64])), int(rs.choice([0, 8])), int(rs.choice([0, 8, 24]))
+        a, a64 = _operand(rs, M, K, pad_a, dtype)
+        b, b64 = _operand(rs, *((K, N) if b_col else (N, K)), pad_b, dtype)
+        bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(dtype) if rs.randint(2) else None
+        act = ['none', 'relu', 'mask'][rs.randint(3)]
+        alpha = float(rs.choice([1.0, 1.0, 0.5]))
+        ref = a64 @ (b64 if b_col else b64.t())
+        ref = ref * alpha
+        aux = None
+        if act == 'mask':  # mode 2: v * relu'(aux), no bias (the dH GEMM of a ReLU feed-forward)
+            bias = None
+            pad_x = int(rs.choice([0, 8]))
+            aux, aux64 = _operand(rs, M, N, pad_x, dtype)
+            ref = ref * (aux64 > 0)
+        if bias is not None:
+            ref = ref + bias.double()
+        if act == 'relu':
+            ref = ref.clamp(min=0)
+        outs = {}
+        for mode in (1, 0):
+            L.pk_gemm_use_bs(mode)
+            buf = torch.full((M + 1, N + pad_c), 7.0, dtype=dtype, device='cuda')
+            out = buf[:M, :N]
+            if act == 'mask':
+                tags = _timed_kernels(L, lambda: F.gemm(a, b, b_col=b_col, aux=aux, act='relu', mode=2, alpha=alpha, out=out))
+            else:
+                tags = _timed_kernels(L, lambda: F.gemm(a, b, b_col=b_col, bias=None if bias is None else bias.cuda(),
+                                                        act=act, alpha=alpha, out=out))
+            outs[mode] = (buf, tags)
+        L.pk_gemm_use_bs(1)
+        what = (seed, case, str(dtype), M, N, b_col, pad_a, pad_b, pad_c, act, alpha, bias is not None)
+        (buf1, tags1), (buf0, tags0) = outs[1], outs[0]
+        assert any(t & 0x200 for t in tags1) == takes(M, N) and not any(t & 0x200 for t in tags0), (what, tags1, tags0)
+        taken += takes(M, N)
+        got = buf1[:M, :N]
+        assert torch.isfinite(got.float()).all(), what
+        err = (got.double().cpu() - ref).abs().max().item()
+        assert err <= 8e-3 * np.sqrt(K) * 4, (what, err)
+        assert torch.equal(buf1.view(torch.int16), buf0.view(torch.int16)), what  # output AND the bytes around it
+        assert bool((buf1[M] == 7.0).all()) and (pad_c == 0 or bool((buf1[:, N:] == 7.0).all())), what
+    assert taken >= 4, taken
+
+
+def test_gemmbs_declines_what_it_does_not_take(F):
+    """other contractions, few rows, col-form A, residual / general epilogues stay on the tiled kernels"""
+    from pasero_amd import lib
+    L = lib.load()
+    L.pk_gemm_use_bs(1)
+    a = torch.randn(16384, 512, device='cuda').bfloat16()
+    w = torch.randn(1024, 512, device='cuda').bfloat16()
+    aux = torch.randn(16384, 1024, device='cuda').bfloat16()
+    assert any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(a, w)))
+    assert not any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(a, w, aux=aux, mode=1)))
+    assert not any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(a, w, act='gelu')))
+    assert not any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(a[:512], w)))
+    a2 = torch.randn(16384, 1024, device='cuda').bfloat16()
+    w2 = torch.randn(1024, 1024, device='cuda').bfloat16()
+    assert not any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(a2, w2)))
+    at = torch.randn(512, 16384, device='cuda').bfloat16()
+    assert not any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(at, w.t().contiguous()[:, :1024], a_col=True, b_col=True)))
+
+
+def test_gemmbs_is_bitwise_reproducible(F):
+    a = torch.randn(32768, 512, device='cuda').bfloat16()
+    w = torch.randn(2048, 512, device='cuda').bfloat16()
+    bias = torch.randn(2048, device='cuda').bfloat16()
+    first = F.gemm(a, w, bias=bias, act='relu')
+    for _ in range(20):
+        assert torch.equal(F.gemm(a, w, bias=bias, act='relu').view(torch.int16), first.view(torch.int16))

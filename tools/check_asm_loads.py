@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Audit of the gemm8p kernels' assembly (pasero_amd/csrc/gemm8p.hip), run by __graft_entry__.build() and the CPU tests:
+"""Audit of the assembly of the kernels with hand-counted waits (pasero_amd/csrc/gemm8p.hip, gemmln.hip, gemmbs.hip), run
+by __graft_entry__.build() and the CPU tests:
 
   1. between the PK8P_LOOP_BEGIN / PK8P_LOOP_END markers no `s_waitcnt` may drain the vector-memory counter below the
      hand-placed counted waits (hipcc adds `vmcnt(0)` in front of LDS accesses it cannot disambiguate from an LDS-DMA
@@ -8,6 +9,8 @@
      registers become valid: from each `ds_read_b64_tr_b16` to the next `s_waitcnt lgkmcnt(0)` nothing else may read or
      write those registers (a compiler copy there would move stale data);
   3. no scratch (spill) traffic inside the K loop (spills in the prologue / epilogue are reported, not refused).
+The smallest counted wait a kernel places in its loop is 6 unless the kernel says otherwise with a `; PK8P_MIN_VMCNT n`
+marker; rule 2 also covers a `PKBS_BFRAG_BEGIN / _END` region (gemmbs.hip's one-time transposed reads of the B panel).
 
 Usage: check_asm_loads.py <file.s>     (exit code 1 and a report if a rule is broken)"""
 import re
@@ -39,7 +42,7 @@ def audit(path: str):
     notes = []
     i = 0
     while i < len(lines):
-        m = re.match(r'^(_ZN[^:]*gemm8p_(?:group_|ln_)?kernel[^:]*):', lines[i])
+        m = re.match(r'^(_ZN[^:]*(?:gemm8p_(?:group_|ln_)?|gemmbs_)kernel[^:]*):', lines[i])
         if not m:
             i += 1
             continue
@@ -59,9 +62,34 @@ def audit(path: str):
             continue
         if n_scratch:
             notes.append(f'{name}: {n_scratch} scratch instructions outside the K loop')
+        min_vmcnt = 6
+        for ln in body:
+            mm = re.search(r'PK8P_MIN_VMCNT (\d+)', ln)
+            if mm:
+                min_vmcnt = int(mm.group(1))
+        spans = [(b, e, True)]
+        try:
+            spans.append((next(k for k, ln in enumerate(body) if 'PKBS_BFRAG_BEGIN' in ln),
+                          next(k for k, ln in enumerate(body) if 'PKBS_BFRAG_END' in ln), False))
+        except StopIteration:
+            pass
         pending = {}  # register -> line of the asm tr read that wrote it
-        for k in range(b, e):
+        for k, in_loop in [(k, lp) for (s0, s1, lp) in spans for k in range(s0, s1)]:
             ln = body[k]
+            if not in_loop:  # the B-fragment region: only rule 2
+                op, ops = operands(ln)
+                if op == 's_waitcnt' and 'lgkmcnt(0)' in ln:
+                    pending.clear()
+                elif op == 'ds_read_b64_tr_b16':
+                    for r in regs(ops[0]):
+                        pending[r] = k
+                elif ops:
+                    touched = set().union(*[regs(t) for t in ops])
+                    bad = touched & set(pending)
+                    if bad:
+                        problems.append(f'{name}: line {k}: `{ln.strip()}` touches v{sorted(bad)} before the lgkmcnt(0) '
+                                        f'that covers the asm read at line {pending[sorted(bad)[0]]}')
+                continue
             if 'scratch_' in ln:
                 problems.append(f'{name}: line {k}: spill traffic inside the K loop: `{ln.strip()}`')
                 n_scratch -= 1
@@ -71,7 +99,7 @@ def audit(path: str):
                 continue
             if op == 's_waitcnt':
                 mm = re.search(r'vmcnt\((\d+)\)', ln)
-                if mm and int(mm.group(1)) < 6:
+                if mm and int(mm.group(1)) < min_vmcnt:
                     problems.append(f'{name}: line {k}: `{ln.strip()}` inside the K loop drains the LDS-DMA prefetch')
                 if 'lgkmcnt(0)' in ln:
                     pending.clear()
@@ -89,7 +117,7 @@ def audit(path: str):
                 problems.append(f'{name}: line {k}: `{ln.strip()}` touches v{sorted(bad)} before the lgkmcnt(0) that '
                                 f'covers the asm read at line {pending[sorted(bad)[0]]}')
     if kernels == 0:
-        problems.append('no gemm8p kernels found in ' + path)
+        problems.append('no audited kernels found in ' + path)
     return kernels, problems
 
 
