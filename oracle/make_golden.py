@@ -589,6 +589,58 @@ def gen_optim():
     save('adam_step', **out)
 
 
+def gen_train_curve():
+    """north_star: "loss curve matching CPU reference within 1e-3 on TED de-en" — the corpus is not in the image
+    (examples/TED/de-en holds only dict.txt and bpecodes), so the closest thing the REAL reference can be run on here: a
+    base-width 2 + 2-layer Transformer over the TED vocabulary size (8028 dict.txt entries + 4 specials = 8032) trained
+    for 120 steps on a learnable synthetic translation task (target = source reversed, paramgen.make_reverse_batch), with
+    the reference's own training arithmetic — Transformer.forward (loss summed over tokens), gradients / num_tokens
+    (training.py:455-470), optimization.clip_grad_norm_ (390-427), optimization.Adam.step (56-149), LRScheduler
+    (21-52: linear warm-up, inverse-sqrt decay).  Stored: the per-step loss sum, token count, gradient norm and lr."""
+    V, B, L, STEPS = 8032, 16, 20, 120
+    hp = dict(lr=1e-3, init_lr=1e-7, min_lr=1e-9, warmup=40, max_steps=STEPS, clip_norm=1.0, betas=(0.9, 0.98), eps=1e-8,
+              weight_decay=0.0)
+    cfg, model = build_model(V, encoder_layers=2, decoder_layers=2, dropout=0.0)
+    ns = load_params(model, 77)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = optimization.Adam(params, lr=hp['lr'], betas=hp['betas'], eps=hp['eps'], weight_decay=hp['weight_decay'])
+    tcfg = types.SimpleNamespace(warmup=hp['warmup'], init_lr=hp['init_lr'], lr=hp['lr'], max_steps=hp['max_steps'],
+                                 min_lr=hp['min_lr'])
+    # (the reference passes `verbose` to torch's scheduler base class, an argument torch 2.10 no longer has: the base
+    # constructor is wrapped for the duration of this call so that the reference's own __init__ / get_lr run unchanged)
+    base = torch.optim.lr_scheduler._LRScheduler
+    base_init = base.__init__
+    base.__init__ = lambda self, optimizer, last_epoch=-1, verbose=False: base_init(self, optimizer, last_epoch)
+    try:
+        sched = optimization.LRScheduler(tcfg, opt)
+    finally:
+        base.__init__ = base_init
+    loss_sum, ntok, gnorms, lrs = [], [], [], []
+    for step in range(STEPS):
+        b = paramgen.make_reverse_batch(1000 + step, B, L)
+        opt.zero_grad(set_to_none=True)
+        loss, logs = model(**{k: t(v) for k, v in b.items()})
+        loss.backward()
+        for p in params:
+            if p.grad is not None:
+                p.grad.data.mul_(1.0 / logs['num_tokens'])
+        gnorm = optimization.clip_grad_norm_(params, hp['clip_norm'])
+        lrs.append(sched.get_last_lr()[0])
+        opt.step()
+        sched.step()
+        loss_sum.append(float(loss.item()))
+        ntok.append(int(logs['num_tokens']))
+        gnorms.append(float(gnorm))
+        if step % 20 == 0 or step == STEPS - 1:
+            print(f'  step {step}: loss/token {loss_sum[-1] / ntok[-1]:.4f} gnorm {gnorms[-1]:.3f} lr {lrs[-1]:.2e}')
+    assert loss_sum[-1] / ntok[-1] < 0.6 * loss_sum[0] / ntok[0], 'the task must be learnable in the stored steps'
+    save('train_curve', V=V, B=B, L=L, S=L + 1, T=L + 1, steps=STEPS, seed=77, batch_seed0=1000, cfg=cfg_json(cfg),
+         **names_shapes_arrays(ns), loss_sum=np.array(loss_sum, np.float64), num_tokens=np.array(ntok, np.int64), gnorm=np.array(gnorms, np.float64),
+         lr=np.array(lrs, np.float64), hp=np.array([hp['lr'], hp['init_lr'], hp['min_lr'], hp['warmup'], hp['clip_norm'],
+                                                    hp['betas'][0], hp['betas'][1], hp['eps'], hp['weight_decay']]))
+
+
 def gen_logmel():
     """K8: third-party arithmetic — transformers.WhisperFeatureExtractor as called from
     examples/Whisper/extract-features.py:107-117 (pinned to the transformers version installed here)"""
@@ -668,6 +720,7 @@ GENERATORS = {
     'beam_trace': gen_beam,
     'return_layers': gen_return_layers,
     'adam_step': gen_optim,
+    'train_curve': gen_train_curve,
     'logmel': gen_logmel,
     'features_file': gen_features_file,
 }

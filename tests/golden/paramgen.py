@@ -75,5 +75,26 @@ def make_text_batch(seed: int, B: int, S: int, T: int, V: int, ragged: bool = Tr
     }
 
 
+def make_reverse_batch(seed: int, B: int, L: int, lo: int = 4, hi: int = 36, pad: int = 1, eos: int = 2) -> dict:
+    """A learnable synthetic translation task (tests/golden/train_curve.npz): the target is the source read backwards.
+    Sources are `n` tokens ~ U[lo, hi), n ~ U[L/2, L], + EOS; `decoder_input` = BOS + reversed tokens + EOS (+ pad)."""
+    rs = np.random.RandomState(seed)
+    n = rs.randint(max(1, L // 2), L + 1, size=B)
+    n[0] = L
+    enc = np.full((B, L + 1), pad, dtype=np.int64)
+    dec = np.full((B, L + 2), pad, dtype=np.int64)
+    for b in range(B):
+        toks = rs.randint(lo, hi, size=n[b])
+        enc[b, :n[b]] = toks
+        enc[b, n[b]] = eos
+        dec[b, 0] = eos
+        dec[b, 1:n[b] + 1] = toks[::-1]
+        dec[b, n[b] + 1] = eos
+    prompt_mask = np.zeros((B, L + 2), dtype=bool)
+    prompt_mask[:, 0] = True
+    return {'encoder_input': enc, 'encoder_input_length': (n + 1).astype(np.int64), 'decoder_input': dec,
+            'prompt_mask': prompt_mask}
+
+
 def make_array(seed: int, name: str, shape: tuple, scale: float = 1.0) -> np.ndarray:
     return (_rs(seed, name).standard_normal(tuple(shape)) * scale).astype(np.float32)

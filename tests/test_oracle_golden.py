@@ -293,3 +293,36 @@ def test_log_mel():
         # fp32-vs-fp64 STFT round-off on a log scale; features are O(1)
         assert np.abs(f[:240] - g['feats'][i]).max() < 2e-4
         assert np.abs(f[-4:] - g['feats_tail'][i]).max() < 2e-4
+
+
+def test_first_steps_of_the_reference_training_curve():
+    """tests/golden/train_curve.npz (120 steps of the REAL reference: model + gradient normalisation + clip + Adam +
+    warm-up schedule on a reverse-the-source task): the oracle with its restatement of the optimizer reproduces the first
+    12 steps — loss per token within 1e-4, gradient norm within 1e-3 (the CPU suite's share; the HIP path runs all 120
+    steps on the GPU box, tests/test_training_curve_gpu.py)."""
+    g = load_golden('train_curve')
+    cfg = golden_cfg(g)
+    P = {k: v.clone().requires_grad_() for k, v in O.to_torch_state(paramgen.make_state_dict(int(g['seed']), golden_names_shapes(g))).items()}
+    P['decoder.embed_tokens.weight'] = P['encoder.embed_tokens.weight']
+    names = [n for n in P if n != 'decoder.embed_tokens.weight']
+    m = {n: torch.zeros_like(P[n]) for n in names}
+    v = {n: torch.zeros_like(P[n]) for n in names}
+    lr, init_lr, min_lr, warmup, clip, b1, b2, eps, wd = [float(x) for x in g['hp']]
+    for step in range(12):
+        b = paramgen.make_reverse_batch(int(g['batch_seed0']) + step, int(g['B']), int(g['L']))
+        for n in names:
+            P[n].grad = None
+        loss, logs = O.transformer_forward(P, cfg, **{k: torch.from_numpy(x) for k, x in b.items()})
+        loss.backward()
+        assert logs['num_tokens'] == int(g['num_tokens'][step])
+        ref = float(g['loss_sum'][step]) / int(g['num_tokens'][step])
+        assert abs(loss.item() / logs['num_tokens'] - ref) <= 1e-4 * ref, (step, loss.item() / logs['num_tokens'], ref)
+        used = [n for n in names if P[n].grad is not None]
+        total, grads = O.clip_grad_norm([P[n].grad / logs['num_tokens'] for n in used], clip)
+        assert abs(float(total) - float(g['gnorm'][step])) <= 1e-3 * float(g['gnorm'][step]), step
+        cur = init_lr + step * (lr - init_lr) / warmup if step < warmup else lr * (warmup / step) ** 0.5
+        assert abs(max(cur, min_lr) - float(g['lr'][step])) <= 1e-12
+        with torch.no_grad():
+            for n, gr in zip(used, grads):
+                p_new, m[n], v[n] = O.adam_step(P[n].detach(), gr, m[n], v[n], step + 1, max(cur, min_lr), b1, b2, eps, wd)
+                P[n].copy_(p_new)
