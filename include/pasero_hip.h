@@ -322,6 +322,55 @@ int pk_argmax_rows(const void* x, long long rows, long long n, long long ld, lon
 int pk_pad_rows(const void* src, int src_dtype, const long long* offsets, void* out, int out_dtype, int B,
                 long long Tmax, int D, void* stream);
 
+/* ---- One Transformer layer per call (host side of the hot path): forward and backward launch sequences of the STOCK
+ * post-norm layer — `TransformerEncoderLayer.forward` / `TransformerDecoderLayer.forward`, pasero/models/transformer.py:
+ * 1056-1099 and 1341-1417 (self-attention [-> cross-attention] -> feed-forward, each `x = LayerNorm(residual +
+ * dropout(f(x)))`, :1043-1054) and what autograd makes of them — issued by ONE C call each instead of ~13 / ~27 Python
+ * dispatches: the same entry points of this header in the same order with the same arguments (pk_gemm, pk_attn_fwd/bwd,
+ * pk_gemm_ln_fwd or pk_gemm + pk_residual_ln_fwd, pk_residual_ln_bwd, pk_gemm_wgrad_group), so the results are bit-for-bit
+ * those of the per-op path.  The caller allocates every buffer (activations kept for backward, outputs, gradients,
+ * scratch); pointers are device memory, the structs themselves host memory.
+ *   sub-block `self`: proj = x W_in^T + b_in ([q|k|v], W_in [3d][d]);  attn = softmax(q k^T scale [+ causal / key_pad]) v;
+ *                     y = LN(x + dropout(attn W_o^T + b_o))          (z = the LayerNorm input, mean / rstd its statistics)
+ *   sub-block `cross` (decoder): proj = y_self W_in[0:d]^T + b_in[0:d];  kv = enc W_in[d:3d]^T + b_in[d:3d];  as above
+ *   sub-block `ffn`:  h = act(y W_1^T + b_1)  (pre = the pre-activation when act is not none / ReLU);  y = LN(y + dropout(h W_2^T + b_2))
+ *   dropout of sub-block i draws Philox(seed, drop_offset_i) (conventions above); attention-probability dropout: not here.
+ *   fused_tail: the block ends run as pk_gemm_ln_fwd (needs d = 512), else pk_gemm + pk_residual_ln_fwd.
+ * pk_layer_bwd_sizes: bytes of `scratch` (gradient temporaries) and `ws` (split-K / grouped weight-gradient / LayerNorm
+ * parameter-gradient workspaces) the backward call needs.  Weight gradients: dw_in [3d][d], db_in [3d], dw_o [d][d], ...
+ * in the operands' type, all of one layer in ONE grouped launch. */
+typedef struct {
+    const void *w_in, *b_in, *w_o, *b_o, *ln_g, *ln_b; /* parameters (biases may be NULL) */
+    void *proj, *kv, *attn, *z, *y;                     /* kept by forward: [rows][3d] (cross: [rows][d]), cross [B*S][2d], [rows][d] x 3 */
+    float *lse, *mean, *rstd;                           /* [B][H][T], [rows], [rows] */
+    void *dw_in, *db_in, *dw_o, *db_o, *dln_g, *dln_b;  /* written by backward */
+    unsigned long long drop_offset;
+} PkAttnBlock;
+typedef struct {
+    const void *w1, *b1, *w2, *b2, *ln_g, *ln_b;
+    void *h, *pre, *z, *y;                              /* [rows][f], [rows][f] or NULL, [rows][d], [rows][d] */
+    float *mean, *rstd;
+    void *dw1, *db1, *dw2, *db2, *dln_g, *dln_b;
+    unsigned long long drop_offset;
+} PkFfnBlock;
+typedef struct {
+    int dtype, is_decoder, fused_tail, act, B, T, S, d, f, heads;
+    float eps, drop_p, attn_scale;
+    unsigned long long seed;
+    const void *x, *enc;                                /* layer input [B*T][d]; encoder output [B*S][d] (decoder) */
+    const unsigned char *self_pad, *cross_pad;          /* (B,T) / (B,S) bool key-padding masks or NULL */
+    PkAttnBlock self, cross;
+    PkFfnBlock ffn;
+    const void* dy;                                     /* backward: gradient of ffn.y */
+    void *dx, *denc;                                    /* backward: gradients of x and (decoder) enc */
+    void *scratch, *ws;
+    size_t scratch_bytes, ws_bytes;
+    void* stream;
+} PkLayer;
+int pk_layer_fwd(const PkLayer* layer);
+int pk_layer_bwd_sizes(const PkLayer* layer, size_t* scratch_bytes, size_t* ws_bytes);
+int pk_layer_bwd(const PkLayer* layer);
+
 #ifdef __cplusplus
 }
 #endif

@@ -597,8 +597,8 @@ def gen_train_curve():
     the reference's own training arithmetic — Transformer.forward (loss summed over tokens), gradients / num_tokens
     (training.py:455-470), optimization.clip_grad_norm_ (390-427), optimization.Adam.step (56-149), LRScheduler
     (21-52: linear warm-up, inverse-sqrt decay).  Stored: the per-step loss sum, token count, gradient norm and lr."""
-    V, B, L, STEPS = 8032, 16, 20, 120
-    hp = dict(lr=1e-3, init_lr=1e-7, min_lr=1e-9, warmup=40, max_steps=STEPS, clip_norm=1.0, betas=(0.9, 0.98), eps=1e-8,
+    V, B, L, STEPS = 8032, 32, 20, 120
+    hp = dict(lr=3e-4, init_lr=1e-7, min_lr=1e-9, warmup=40, max_steps=STEPS, clip_norm=1.0, betas=(0.9, 0.98), eps=1e-8,
               weight_decay=0.0)
     cfg, model = build_model(V, encoder_layers=2, decoder_layers=2, dropout=0.0)
     ns = load_params(model, 77)

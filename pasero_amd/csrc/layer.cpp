@@ -1,0 +1,255 @@
+// One Transformer layer per call: the launch sequences of the stock post-norm encoder / decoder layer, forward and
+// backward, issued from C (include/pasero_hip.h: pk_layer_fwd / pk_layer_bwd).  Nothing is computed here: every step is
+// a call of another entry point of this library, in the order and with the arguments the per-op path
+// (pasero_amd/autograd.py: PackedLinearFn, AttentionFn, LinearResidualLnFn / LinearFn + ResidualLayerNormFn,
+// FFNResidualLnFn / FFNFn, WGradSinkFn) uses — which is what makes the two paths agree bit for bit — minus ~25 Python
+// dispatches, tensor allocations and ctypes marshallings per layer and direction.
+#include <stddef.h>
+#include <stdint.h>
+#include <algorithm>
+#include "../../include/pasero_hip.h"
+
+extern "C" void pk_set_error(const char* fmt, ...);
+
+namespace {
+
+#define PK_TRY(call)                 \
+    do {                             \
+        int rc_ = (call);            \
+        if (rc_ != 0) return rc_;    \
+    } while (0)
+#define PK_REQ(cond, ...)            \
+    do {                             \
+        if (!(cond)) {               \
+            pk_set_error(__VA_ARGS__); \
+            return -1;               \
+        }                            \
+    } while (0)
+
+inline size_t esz(int dtype) { return dtype == PK_F32 ? 4 : 2; }
+inline char* at(const void* p, long long elems, int dtype) { return (char*)p + (size_t)elems * esz(dtype); }
+
+// pasero_amd/functional.py: choose_splitk — split the contraction of a GEMM whose output has too few tiles
+int choose_splitk(long long M, long long N, long long K) {
+    const long long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles > 256 || K < 1024) {
+        const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
+        return (80 <= t256 && t256 < 160 && K >= 2048 && M % 8 == 0 && N % 8 == 0 && K % 64 == 0) ? 2 : 1;
+    }
+    return (int)std::max(1LL, std::min(512 / tiles, K / 512));
+}
+inline size_t splitk_ws(int sk, long long M, long long N) { return sk > 1 ? (size_t)2 * sk * M * (N + 1) * 4 : 0; }
+
+struct Bump {  // the backward's gradient temporaries: one region of `scratch` each (256-byte aligned)
+    char* base;
+    size_t off = 0;
+    void* take(size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+struct Bwd {  // where everything of one backward call lives
+    void *dres_f, *dsub_f, *dh, *dy_mid, *dres_c, *dsub_c, *dcattn, *dq, *dkv, *dy_self, *dres_s, *dsub_s, *dattn, *dproj;
+    float* delta;
+    size_t scratch_bytes, ws_split, ws_group, ws_ln;
+};
+
+// the plan of the backward call: regions of `scratch`, sizes of the three workspaces (regions of `ws`)
+int plan_bwd(const PkLayer& L, char* scratch, Bwd* b) {
+    const long long rows = (long long)L.B * L.T, rows_kv = (long long)L.B * L.S, d = L.d, f = L.f;
+    const size_t e = esz(L.dtype);
+    const bool drop = L.drop_p > 0.f;
+    Bump bump{scratch};
+    b->dres_f = bump.take(rows * d * e);
+    b->dsub_f = drop ? bump.take(rows * d * e) : b->dres_f;
+    b->dh = bump.take(rows * f * e);
+    b->dy_mid = bump.take(rows * d * e);  // gradient of the feed-forward block's input
+    b->dres_c = b->dsub_c = b->dcattn = b->dq = b->dkv = b->dy_self = nullptr;
+    if (L.is_decoder) {
+        b->dres_c = bump.take(rows * d * e);
+        b->dsub_c = drop ? bump.take(rows * d * e) : b->dres_c;
+        b->dcattn = bump.take(rows * d * e);
+        b->dq = bump.take(rows * d * e);
+        b->dkv = bump.take(rows_kv * 2 * d * e);
+        b->dy_self = bump.take(rows * d * e);
+    }
+    b->dres_s = bump.take(rows * d * e);
+    b->dsub_s = drop ? bump.take(rows * d * e) : b->dres_s;
+    b->dattn = bump.take(rows * d * e);
+    b->dproj = bump.take(rows * 3 * d * e);
+    b->delta = (float*)bump.take((size_t)L.B * L.heads * std::max(L.T, 1) * sizeof(float));
+    b->scratch_bytes = bump.off;
+    // split-K workspaces of the dX GEMMs that go through `_dx_gemm` (autograd.py): the largest one
+    size_t ws = 0;
+    ws = std::max(ws, splitk_ws(choose_splitk(rows, d, d), rows, d));          // out-proj dX (self / cross), cross q dX
+    ws = std::max(ws, splitk_ws(choose_splitk(rows, d, 3 * d), rows, d));      // q|k|v dX
+    if (!L.fused_tail) ws = std::max(ws, splitk_ws(choose_splitk(rows, d, f), rows, d));  // fc1 dX (FFNFn path)
+    if (L.is_decoder) ws = std::max(ws, splitk_ws(choose_splitk(rows_kv, d, 2 * d), rows_kv, d));  // k|v dX
+    b->ws_split = (ws + 255) & ~(size_t)255;
+    b->ws_ln = (pk_residual_ln_bwd_workspace(rows, (int)d) + 255) & ~(size_t)255;
+    return 0;
+}
+
+// the layer's weight-gradient problems in the order the per-op path hands them to its group
+int wgrad_problems(const PkLayer& L, const Bwd& b, PkWgradProblem* p) {
+    const long long rows = (long long)L.B * L.T, rows_kv = (long long)L.B * L.S, d = L.d, f = L.f;
+    const void* ffn_in = L.is_decoder ? L.cross.y : L.self.y;
+    int n = 0;
+    p[n++] = PkWgradProblem{b.dsub_f, L.ffn.h, L.ffn.dw2, L.ffn.db2, d, f, rows, d, f, f};        // fc2: dZ^T H
+    p[n++] = PkWgradProblem{b.dh, ffn_in, L.ffn.dw1, L.ffn.db1, f, d, rows, f, d, d};             // fc1: dH^T Y
+    if (L.is_decoder) {
+        p[n++] = PkWgradProblem{b.dsub_c, L.cross.attn, L.cross.dw_o, L.cross.db_o, d, d, rows, d, d, d};
+        p[n++] = PkWgradProblem{b.dkv, L.enc, at(L.cross.dw_in, d * d, L.dtype), L.cross.db_in ? at(L.cross.db_in, d, L.dtype) : nullptr,
+                                2 * d, d, rows_kv, 2 * d, d, d};
+        p[n++] = PkWgradProblem{b.dq, L.self.y, L.cross.dw_in, L.cross.db_in, d, d, rows, d, d, d};
+    }
+    p[n++] = PkWgradProblem{b.dsub_s, L.self.attn, L.self.dw_o, L.self.db_o, d, d, rows, d, d, d};
+    p[n++] = PkWgradProblem{b.dproj, L.x, L.self.dw_in, L.self.db_in, 3 * d, d, rows, 3 * d, d, d};
+    return n;
+}
+
+int check(const PkLayer& L) {
+    PK_REQ(L.dtype == PK_BF16 || L.dtype == PK_F16, "pk_layer: 16-bit layers only (dtype %d)", L.dtype);
+    PK_REQ(L.B > 0 && L.T > 0 && L.d > 0 && L.f > 0 && L.heads > 0 && L.d % L.heads == 0, "pk_layer: bad sizes");
+    PK_REQ(L.x && L.self.w_in && L.self.w_o && L.self.ln_g && L.ffn.w1 && L.ffn.w2 && L.ffn.ln_g, "pk_layer: null parameter");
+    PK_REQ(!L.is_decoder || (L.enc && L.S > 0 && L.cross.w_in && L.cross.w_o && L.cross.ln_g), "pk_layer: decoder layer without encoder output");
+    return 0;
+}
+
+// the end of a post-norm sub-block: y = LN(residual + dropout(a W^T + b)), z and the statistics kept
+int block_end(const PkLayer& L, const void* a, long long K, const void* w, const void* bias, const void* residual,
+              const void* g, const void* be, void* z, void* y, float* mean, float* rstd, unsigned long long offset) {
+    const long long rows = (long long)L.B * L.T, d = L.d;
+    if (L.fused_tail)
+        return pk_gemm_ln_fwd(a, w, bias, residual, g, be, z, y, mean, rstd, rows, d, K, K, K, d, L.eps, L.drop_p, L.seed,
+                              offset, L.dtype, L.stream);
+    // the projection's output passes through the z buffer (the LayerNorm kernel holds a row in registers: in place is safe)
+    PK_TRY(pk_gemm(a, w, z, bias, nullptr, nullptr, rows, d, K, K, K, d, 0, 0, 0, 0, PK_ACT_NONE, 0, 1.f, L.dtype, 1, nullptr, 0,
+                   nullptr, L.stream));
+    return pk_residual_ln_fwd(z, residual, g, be, z, y, mean, rstd, rows, (int)d, L.eps, L.drop_p, L.seed, offset, L.dtype,
+                              L.stream);
+}
+
+}  // namespace
+
+extern "C" int pk_layer_fwd(const PkLayer* lp) {
+    PK_REQ(lp, "pk_layer_fwd: null layer");
+    const PkLayer& L = *lp;
+    PK_TRY(check(L));
+    const long long rows = (long long)L.B * L.T, rows_kv = (long long)L.B * L.S, d = L.d, f = L.f;
+    const int hd = L.d / L.heads, dt = L.dtype;
+    // ---- self-attention: one packed projection, attention straight on its columns, block end ----
+    PK_TRY(pk_gemm(L.x, L.self.w_in, L.self.proj, L.self.b_in, nullptr, nullptr, rows, 3 * d, d, d, d, 3 * d, 0, 0, 0, 0, PK_ACT_NONE, 0,
+                   1.f, dt, 1, nullptr, 0, nullptr, L.stream));
+    PK_TRY(pk_attn_fwd(L.self.proj, at(L.self.proj, d, dt), at(L.self.proj, 2 * d, dt), L.self.attn, L.self.lse,
+                       L.is_decoder ? nullptr : L.self_pad, L.B, L.heads, L.T, L.T, hd, (long long)L.T * 3 * d, 3 * d,
+                       (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * d, d,
+                       L.is_decoder && L.T > 1, L.attn_scale, 0.f, 0, 0, nullptr, dt, L.stream));
+    PK_TRY(block_end(L, L.self.attn, d, L.self.w_o, L.self.b_o, L.x, L.self.ln_g, L.self.ln_b, L.self.z, L.self.y, L.self.mean,
+                     L.self.rstd, L.self.drop_offset));
+    const void* y = L.self.y;
+    // ---- cross-attention (decoder): q from the block input, k|v from the encoder output ----
+    if (L.is_decoder) {
+        PK_TRY(pk_gemm(y, L.cross.w_in, L.cross.proj, L.cross.b_in, nullptr, nullptr, rows, d, d, d, d, d, 0, 0, 0, 0, PK_ACT_NONE, 0, 1.f,
+                       dt, 1, nullptr, 0, nullptr, L.stream));
+        PK_TRY(pk_gemm(L.enc, at(L.cross.w_in, d * d, dt), L.cross.kv, L.cross.b_in ? at(L.cross.b_in, d, dt) : nullptr, nullptr,
+                       nullptr, rows_kv, 2 * d, d, d, d, 2 * d, 0, 0, 0, 0, PK_ACT_NONE, 0, 1.f, dt, 1, nullptr, 0, nullptr, L.stream));
+        PK_TRY(pk_attn_fwd(L.cross.proj, L.cross.kv, at(L.cross.kv, d, dt), L.cross.attn, L.cross.lse, L.cross_pad, L.B, L.heads,
+                           L.T, L.S, hd, (long long)L.T * d, d, (long long)L.S * 2 * d, 2 * d, (long long)L.S * 2 * d, 2 * d,
+                           (long long)L.T * d, d, 0, L.attn_scale, 0.f, 0, 0, nullptr, dt, L.stream));
+        PK_TRY(block_end(L, L.cross.attn, d, L.cross.w_o, L.cross.b_o, y, L.cross.ln_g, L.cross.ln_b, L.cross.z, L.cross.y,
+                         L.cross.mean, L.cross.rstd, L.cross.drop_offset));
+        y = L.cross.y;
+    }
+    // ---- feed-forward ----
+    PK_TRY(pk_gemm(y, L.ffn.w1, L.ffn.h, L.ffn.b1, nullptr, L.ffn.pre, rows, f, d, d, d, f, 0, f, 0, 0, L.act, 0, 1.f, dt, 1, nullptr,
+                   0, nullptr, L.stream));
+    return block_end(L, L.ffn.h, f, L.ffn.w2, L.ffn.b2, y, L.ffn.ln_g, L.ffn.ln_b, L.ffn.z, L.ffn.y, L.ffn.mean, L.ffn.rstd,
+                     L.ffn.drop_offset);
+}
+
+extern "C" int pk_layer_bwd_sizes(const PkLayer* lp, size_t* scratch_bytes, size_t* ws_bytes) {
+    PK_REQ(lp && scratch_bytes && ws_bytes, "pk_layer_bwd_sizes: null argument");
+    PK_TRY(check(*lp));
+    Bwd b;
+    PK_TRY(plan_bwd(*lp, nullptr, &b));
+    // the grouped launch's workspace depends only on the problems' shapes: placeholder addresses do
+    PkLayer L = *lp;
+    PkWgradProblem probs[PK_WGRAD_MAX];
+    const int n = wgrad_problems(L, b, probs);
+    b.ws_group = (pk_gemm_wgrad_group_workspace(probs, n) + 255) & ~(size_t)255;
+    *scratch_bytes = b.scratch_bytes;
+    *ws_bytes = std::max(b.ws_split, b.ws_group) + b.ws_ln;
+    return 0;
+}
+
+extern "C" int pk_layer_bwd(const PkLayer* lp) {
+    PK_REQ(lp, "pk_layer_bwd: null layer");
+    const PkLayer& L = *lp;
+    PK_TRY(check(L));
+    PK_REQ(L.dy && L.dx && (!L.is_decoder || L.denc), "pk_layer_bwd: null gradient buffer");
+    const long long rows = (long long)L.B * L.T, rows_kv = (long long)L.B * L.S, d = L.d, f = L.f;
+    const int hd = L.d / L.heads, dt = L.dtype;
+    const bool drop = L.drop_p > 0.f;
+    Bwd b;
+    PK_TRY(plan_bwd(L, (char*)L.scratch, &b));
+    PkWgradProblem probs[PK_WGRAD_MAX];
+    const int nprob = wgrad_problems(L, b, probs);
+    b.ws_group = (pk_gemm_wgrad_group_workspace(probs, nprob) + 255) & ~(size_t)255;
+    const size_t ws_main = std::max(b.ws_split, b.ws_group);
+    PK_REQ(L.scratch && L.scratch_bytes >= b.scratch_bytes, "pk_layer_bwd: scratch too small (%zu < %zu)", L.scratch_bytes, b.scratch_bytes);
+    PK_REQ(L.ws && L.ws_bytes >= ws_main + b.ws_ln, "pk_layer_bwd: workspace too small (%zu < %zu)", L.ws_bytes, ws_main + b.ws_ln);
+    void* ws = L.ws;
+    void* ws_ln = (char*)L.ws + ws_main;
+    // LayerNorm + dropout backward of a block end: gradient of the residual branch, (masked, scaled) gradient of the
+    // projection's output, parameter gradients
+    auto ln_bwd = [&](const void* dy, const void* z, const void* g, const float* mean, const float* rstd, void* dres, void* dsub,
+                      void* dg, void* db, unsigned long long offset) {
+        return pk_residual_ln_bwd(dy, nullptr, z, g, mean, rstd, dres, drop ? dsub : nullptr, dg, db, ws_ln, b.ws_ln, rows, (int)d,
+                                  L.drop_p, L.seed, offset, dt, L.stream);
+    };
+    // dX = dY W (+ aux) with the per-op path's split rule (`_dx_gemm`)
+    auto dx_gemm = [&](const void* dy, const void* w, void* out, const void* aux, long long M, long long N, long long K, bool rule) {
+        const int sk = rule ? choose_splitk(M, N, K) : 1;
+        return pk_gemm(dy, w, out, nullptr, aux, nullptr, M, N, K, K, N, N, aux ? N : 0, 0, 0, 1, PK_ACT_NONE, aux ? 1 : 0, 1.f, dt, sk,
+                       sk > 1 ? ws : nullptr, sk > 1 ? splitk_ws(sk, M, N) : 0, nullptr, L.stream);
+    };
+    // ---- feed-forward block ----
+    PK_TRY(ln_bwd(L.dy, L.ffn.z, L.ffn.ln_g, L.ffn.mean, L.ffn.rstd, b.dres_f, b.dsub_f, L.ffn.dln_g, L.ffn.dln_b, L.ffn.drop_offset));
+    if (L.act == PK_ACT_NONE)
+        PK_TRY(pk_gemm(b.dsub_f, L.ffn.w2, b.dh, nullptr, nullptr, nullptr, rows, f, d, d, f, f, 0, 0, 0, 1, PK_ACT_NONE, 0, 1.f, dt, 1,
+                       nullptr, 0, nullptr, L.stream));
+    else  // dH = (dZ W2) * act'(.)
+        PK_TRY(pk_gemm(b.dsub_f, L.ffn.w2, b.dh, nullptr, L.ffn.pre ? L.ffn.pre : L.ffn.h, nullptr, rows, f, d, d, f, f, f, 0, 0, 1, L.act, 2,
+                       1.f, dt, 1, nullptr, 0, nullptr, L.stream));
+    // gradient of the block input: dH W1 + the residual branch (fused block end: no split rule, as FFNResidualLnFn)
+    PK_TRY(dx_gemm(b.dh, L.ffn.w1, b.dy_mid, b.dres_f, rows, d, f, !L.fused_tail));
+    const void* dy_blk = b.dy_mid;
+    // ---- cross-attention block (decoder) ----
+    if (L.is_decoder) {
+        PK_TRY(ln_bwd(dy_blk, L.cross.z, L.cross.ln_g, L.cross.mean, L.cross.rstd, b.dres_c, b.dsub_c, L.cross.dln_g, L.cross.dln_b,
+                      L.cross.drop_offset));
+        PK_TRY(dx_gemm(b.dsub_c, L.cross.w_o, b.dcattn, nullptr, rows, d, d, true));
+        PK_TRY(pk_attn_bwd(L.cross.proj, L.cross.kv, at(L.cross.kv, d, dt), L.cross.attn, b.dcattn, L.cross.lse, b.delta, b.dq, b.dkv,
+                           at(b.dkv, d, dt), L.cross_pad, L.B, L.heads, L.T, L.S, hd, (long long)L.T * d, d, (long long)L.S * 2 * d,
+                           2 * d, (long long)L.S * 2 * d, 2 * d, (long long)L.T * d, d, (long long)L.T * d, d, (long long)L.T * d, d,
+                           (long long)L.S * 2 * d, 2 * d, (long long)L.S * 2 * d, 2 * d, 0, L.attn_scale, 0.f, nullptr, dt, L.stream));
+        PK_TRY(dx_gemm(b.dkv, at(L.cross.w_in, d * d, dt), L.denc, nullptr, rows_kv, d, 2 * d, true));
+        PK_TRY(dx_gemm(b.dq, L.cross.w_in, b.dy_self, b.dres_c, rows, d, d, true));
+        dy_blk = b.dy_self;
+    }
+    // ---- self-attention block ----
+    PK_TRY(ln_bwd(dy_blk, L.self.z, L.self.ln_g, L.self.mean, L.self.rstd, b.dres_s, b.dsub_s, L.self.dln_g, L.self.dln_b,
+                  L.self.drop_offset));
+    PK_TRY(dx_gemm(b.dsub_s, L.self.w_o, b.dattn, nullptr, rows, d, d, true));
+    PK_TRY(pk_attn_bwd(L.self.proj, at(L.self.proj, d, dt), at(L.self.proj, 2 * d, dt), L.self.attn, b.dattn, L.self.lse, b.delta, b.dproj,
+                       at(b.dproj, d, dt), at(b.dproj, 2 * d, dt), L.is_decoder ? nullptr : L.self_pad, L.B, L.heads, L.T, L.T, hd,
+                       (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * d, d,
+                       (long long)L.T * d, d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d,
+                       L.is_decoder && L.T > 1, L.attn_scale, 0.f, nullptr, dt, L.stream));
+    PK_TRY(dx_gemm(b.dproj, L.self.w_in, L.dx, b.dres_s, rows, d, 3 * d, true));
+    // ---- every weight gradient of the layer in one grouped launch ----
+    return pk_gemm_wgrad_group(probs, nprob, dt, ws, b.ws_group, L.stream);
+}

@@ -69,6 +69,9 @@ SIGNATURES = {
     'pk_comm_size': (I, []),
     'pk_comm_all_reduce_mean': (I, [P, LL, I, I, P, P]),
     'pk_comm_direct_plan': (I, [LL, I, I, P, P, P, P]),
+    'pk_layer_fwd': (I, [P]),
+    'pk_layer_bwd_sizes': (I, [P, P, P]),
+    'pk_layer_bwd': (I, [P]),
     'pk_logmel_workspace': (SZ, [I]),
     'pk_logmel': (I, [P, P, LL, P, P, SZ, I, P]),
 }
@@ -80,6 +83,24 @@ class PkWgradProblem(ctypes.Structure):
     """include/pasero_hip.h: one weight-gradient problem of a grouped launch"""
     _fields_ = [('A', P), ('B', P), ('C', P), ('asum_out', P),
                 ('M', LL), ('N', LL), ('K', LL), ('lda', LL), ('ldb', LL), ('ldc', LL)]
+
+
+class PkAttnBlock(ctypes.Structure):
+    """include/pasero_hip.h: an attention sub-block of pk_layer_fwd / pk_layer_bwd"""
+    _fields_ = [(n, P) for n in ('w_in', 'b_in', 'w_o', 'b_o', 'ln_g', 'ln_b', 'proj', 'kv', 'attn', 'z', 'y', 'lse', 'mean',
+                                 'rstd', 'dw_in', 'db_in', 'dw_o', 'db_o', 'dln_g', 'dln_b')] + [('drop_offset', ULL)]
+
+
+class PkFfnBlock(ctypes.Structure):
+    _fields_ = [(n, P) for n in ('w1', 'b1', 'w2', 'b2', 'ln_g', 'ln_b', 'h', 'pre', 'z', 'y', 'mean', 'rstd', 'dw1', 'db1',
+                                 'dw2', 'db2', 'dln_g', 'dln_b')] + [('drop_offset', ULL)]
+
+
+class PkLayer(ctypes.Structure):
+    _fields_ = ([(n, I) for n in ('dtype', 'is_decoder', 'fused_tail', 'act', 'B', 'T', 'S', 'd', 'f', 'heads')] +
+                [('eps', F), ('drop_p', F), ('attn_scale', F), ('seed', ULL), ('x', P), ('enc', P), ('self_pad', P),
+                 ('cross_pad', P), ('self_', PkAttnBlock), ('cross', PkAttnBlock), ('ffn', PkFfnBlock), ('dy', P), ('dx', P),
+                 ('denc', P), ('scratch', P), ('ws', P), ('scratch_bytes', SZ), ('ws_bytes', SZ), ('stream', P)])
 
 
 _lib = None

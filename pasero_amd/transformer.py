@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor, LongTensor, BoolTensor
 
-from . import modules
+from . import modules, native_layer
 from .profiling import block as _bench_block, region as _bench_region
 from .modules import Embedding, Identity
 from .autograd import (FFNFn, GatedFFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn,
@@ -754,6 +754,8 @@ class TransformerEncoderLayer(_LayerBase):
         """:1056-1099"""
         if self.cfg.check_inf:
             raise NotImplementedError('pasero_amd: --check-inf clamping (fp16 T5) is not implemented')
+        if native_layer.takes(self, x, None, None, return_layers, False):  # the stock layer: one C call per direction
+            return native_layer.run(self, x, None, padding_mask, None, False), {}
         self.return_layers = return_layers
         x = self._wgrad_open(x, (self.self_attn,))
         residual = x
@@ -861,6 +863,8 @@ class TransformerDecoderLayer(_LayerBase):
         """:1341-1417"""
         if self.cfg.check_inf:
             raise NotImplementedError('pasero_amd: --check-inf clamping (fp16 T5) is not implemented')
+        if self_attn_mask is None and native_layer.takes(self, x, encoder_out, state, return_layers, True):
+            return native_layer.run(self, x, encoder_out, None, encoder_mask, True), {}
         self.return_layers = return_layers
         if state is None:
             x = self._wgrad_open(x, (self.self_attn, self.encoder_attn))

@@ -9,6 +9,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _per_op_path(monkeypatch):
+    """these tests watch the Python-level dispatch of the per-op path (which kernels a layer launches, in which group);
+    the native layer call (pasero_amd/native_layer.py), which issues the same launches from C, is checked against that
+    path bit for bit in tests/test_native_layer_gpu.py"""
+    from pasero_amd import native_layer
+    monkeypatch.setattr(native_layer, '_OFF', True)
+
+
 @pytest.fixture(scope='module', autouse=True)
 def _need_gpu():
     if not torch.cuda.is_available():
