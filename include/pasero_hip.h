@@ -336,12 +336,17 @@ int pk_pad_rows(const void* src, int src_dtype, const long long* offsets, void* 
  *   sub-block `ffn`:  h = act(y W_1^T + b_1)  (pre = the pre-activation when act is not none / ReLU);  y = LN(y + dropout(h W_2^T + b_2))
  *   dropout of sub-block i draws Philox(seed, drop_offset_i) (conventions above); attention-probability dropout: not here.
  *   fused_tail: the block ends run as pk_gemm_ln_fwd (needs d = 512), else pk_gemm + pk_residual_ln_fwd.
+ *   prenorm (`--encoder-prenorm` / `--decoder-prenorm`, transformer.py:1049-1054): every sub-block is
+ *     z = x + dropout(f(LN(x))) instead — `ln_out` keeps LN(x), `z` the sub-block's output (the layer's output is ffn.z),
+ *     mean / rstd are the statistics of the sub-block's INPUT, `y` is scratch; in backward the gradient of the residual
+ *     branch enters the LayerNorm backward kernel as its `dz_extra` (the per-op path adds it in a separate pass).
  * pk_layer_bwd_sizes: bytes of `scratch` (gradient temporaries) and `ws` (split-K / grouped weight-gradient / LayerNorm
  * parameter-gradient workspaces) the backward call needs.  Weight gradients: dw_in [3d][d], db_in [3d], dw_o [d][d], ...
  * in the operands' type, all of one layer in ONE grouped launch. */
 typedef struct {
     const void *w_in, *b_in, *w_o, *b_o, *ln_g, *ln_b; /* parameters (biases may be NULL) */
     void *proj, *kv, *attn, *z, *y;                     /* kept by forward: [rows][3d] (cross: [rows][d]), cross [B*S][2d], [rows][d] x 3 */
+    void* ln_out;                                       /* pre-norm only: LayerNorm(block input) [rows][d] */
     float *lse, *mean, *rstd;                           /* [B][H][T], [rows], [rows] */
     void *dw_in, *db_in, *dw_o, *db_o, *dln_g, *dln_b;  /* written by backward */
     unsigned long long drop_offset;
@@ -349,19 +354,20 @@ typedef struct {
 typedef struct {
     const void *w1, *b1, *w2, *b2, *ln_g, *ln_b;
     void *h, *pre, *z, *y;                              /* [rows][f], [rows][f] or NULL, [rows][d], [rows][d] */
+    void* ln_out;                                       /* pre-norm only */
     float *mean, *rstd;
     void *dw1, *db1, *dw2, *db2, *dln_g, *dln_b;
     unsigned long long drop_offset;
 } PkFfnBlock;
 typedef struct {
-    int dtype, is_decoder, fused_tail, act, B, T, S, d, f, heads;
+    int dtype, is_decoder, fused_tail, act, B, T, S, d, f, heads, prenorm;
     float eps, drop_p, attn_scale;
     unsigned long long seed;
     const void *x, *enc;                                /* layer input [B*T][d]; encoder output [B*S][d] (decoder) */
     const unsigned char *self_pad, *cross_pad;          /* (B,T) / (B,S) bool key-padding masks or NULL */
     PkAttnBlock self, cross;
     PkFfnBlock ffn;
-    const void* dy;                                     /* backward: gradient of ffn.y */
+    const void* dy;                                     /* backward: gradient of the layer output (ffn.y; pre-norm: ffn.z) */
     void *dx, *denc;                                    /* backward: gradients of x and (decoder) enc */
     void *scratch, *ws;
     size_t scratch_bytes, ws_bytes;

@@ -52,6 +52,7 @@ struct Bump {  // the backward's gradient temporaries: one region of `scratch` e
 
 struct Bwd {  // where everything of one backward call lives
     void *dres_f, *dsub_f, *dh, *dy_mid, *dres_c, *dsub_c, *dcattn, *dq, *dkv, *dy_self, *dres_s, *dsub_s, *dattn, *dproj;
+    void* dln;  // pre-norm: gradient of a LayerNorm output (one at a time)
     float* delta;
     size_t scratch_bytes, ws_split, ws_group, ws_ln;
 };
@@ -79,13 +80,14 @@ int plan_bwd(const PkLayer& L, char* scratch, Bwd* b) {
     b->dsub_s = drop ? bump.take(rows * d * e) : b->dres_s;
     b->dattn = bump.take(rows * d * e);
     b->dproj = bump.take(rows * 3 * d * e);
+    b->dln = L.prenorm ? bump.take(rows * d * e) : nullptr;
     b->delta = (float*)bump.take((size_t)L.B * L.heads * std::max(L.T, 1) * sizeof(float));
     b->scratch_bytes = bump.off;
     // split-K workspaces of the dX GEMMs that go through `_dx_gemm` (autograd.py): the largest one
     size_t ws = 0;
     ws = std::max(ws, splitk_ws(choose_splitk(rows, d, d), rows, d));          // out-proj dX (self / cross), cross q dX
     ws = std::max(ws, splitk_ws(choose_splitk(rows, d, 3 * d), rows, d));      // q|k|v dX
-    if (!L.fused_tail) ws = std::max(ws, splitk_ws(choose_splitk(rows, d, f), rows, d));  // fc1 dX (FFNFn path)
+    if (!L.fused_tail || L.prenorm) ws = std::max(ws, splitk_ws(choose_splitk(rows, d, f), rows, d));  // fc1 dX (FFNFn path)
     if (L.is_decoder) ws = std::max(ws, splitk_ws(choose_splitk(rows_kv, d, 2 * d), rows_kv, d));  // k|v dX
     b->ws_split = (ws + 255) & ~(size_t)255;
     b->ws_ln = (pk_residual_ln_bwd_workspace(rows, (int)d) + 255) & ~(size_t)255;
@@ -95,7 +97,10 @@ int plan_bwd(const PkLayer& L, char* scratch, Bwd* b) {
 // the layer's weight-gradient problems in the order the per-op path hands them to its group
 int wgrad_problems(const PkLayer& L, const Bwd& b, PkWgradProblem* p) {
     const long long rows = (long long)L.B * L.T, rows_kv = (long long)L.B * L.S, d = L.d, f = L.f;
-    const void* ffn_in = L.is_decoder ? L.cross.y : L.self.y;
+    // what each projection read: post-norm — the previous sub-block's output; pre-norm — its own LayerNorm's output
+    const void* ffn_in = L.prenorm ? L.ffn.ln_out : (L.is_decoder ? L.cross.y : L.self.y);
+    const void* cross_in = L.prenorm ? L.cross.ln_out : L.self.y;
+    const void* self_in = L.prenorm ? L.self.ln_out : L.x;
     int n = 0;
     p[n++] = PkWgradProblem{b.dsub_f, L.ffn.h, L.ffn.dw2, L.ffn.db2, d, f, rows, d, f, f};        // fc2: dZ^T H
     p[n++] = PkWgradProblem{b.dh, ffn_in, L.ffn.dw1, L.ffn.db1, f, d, rows, f, d, d};             // fc1: dH^T Y
@@ -103,10 +108,10 @@ int wgrad_problems(const PkLayer& L, const Bwd& b, PkWgradProblem* p) {
         p[n++] = PkWgradProblem{b.dsub_c, L.cross.attn, L.cross.dw_o, L.cross.db_o, d, d, rows, d, d, d};
         p[n++] = PkWgradProblem{b.dkv, L.enc, at(L.cross.dw_in, d * d, L.dtype), L.cross.db_in ? at(L.cross.db_in, d, L.dtype) : nullptr,
                                 2 * d, d, rows_kv, 2 * d, d, d};
-        p[n++] = PkWgradProblem{b.dq, L.self.y, L.cross.dw_in, L.cross.db_in, d, d, rows, d, d, d};
+        p[n++] = PkWgradProblem{b.dq, cross_in, L.cross.dw_in, L.cross.db_in, d, d, rows, d, d, d};
     }
     p[n++] = PkWgradProblem{b.dsub_s, L.self.attn, L.self.dw_o, L.self.db_o, d, d, rows, d, d, d};
-    p[n++] = PkWgradProblem{b.dproj, L.x, L.self.dw_in, L.self.db_in, 3 * d, d, rows, 3 * d, d, d};
+    p[n++] = PkWgradProblem{b.dproj, self_in, L.self.dw_in, L.self.db_in, 3 * d, d, rows, 3 * d, d, d};
     return n;
 }
 
@@ -132,12 +137,59 @@ int block_end(const PkLayer& L, const void* a, long long K, const void* w, const
                               L.stream);
 }
 
+// pre-norm sub-block pieces: ln_out = LN(in) (statistics kept), and z = in + dropout(o) at its end
+int pre_norm(const PkLayer& L, const void* in, const void* g, const void* be, void* ln_out, float* mean, float* rstd) {
+    return pk_residual_ln_fwd(in, nullptr, g, be, nullptr, ln_out, mean, rstd, (long long)L.B * L.T, L.d, L.eps, 0.f, 0, 0, L.dtype, L.stream);
+}
+int pre_end(const PkLayer& L, const void* o, const void* in, void* z, unsigned long long offset) {
+    return pk_residual_ln_fwd(o, in, nullptr, nullptr, z, nullptr, nullptr, nullptr, (long long)L.B * L.T, L.d, 0.f, L.drop_p, L.seed,
+                              offset, L.dtype, L.stream);
+}
+
+int layer_fwd_prenorm(const PkLayer& L) {
+    const long long rows = (long long)L.B * L.T, rows_kv = (long long)L.B * L.S, d = L.d, f = L.f;
+    const int hd = L.d / L.heads, dt = L.dtype;
+    auto linear = [&](const void* a, const void* w, const void* bias, void* out, long long M, long long N, long long K, int act, void* pre) {
+        return pk_gemm(a, w, out, bias, nullptr, pre, M, N, K, K, K, N, 0, pre ? N : 0, 0, 0, act, 0, 1.f, dt, 1, nullptr, 0, nullptr, L.stream);
+    };
+    PK_REQ(L.self.ln_out && L.ffn.ln_out && (!L.is_decoder || L.cross.ln_out), "pk_layer_fwd: pre-norm layer without ln_out buffers");
+    // ---- self-attention ----
+    PK_TRY(pre_norm(L, L.x, L.self.ln_g, L.self.ln_b, L.self.ln_out, L.self.mean, L.self.rstd));
+    PK_TRY(linear(L.self.ln_out, L.self.w_in, L.self.b_in, L.self.proj, rows, 3 * d, d, PK_ACT_NONE, nullptr));
+    PK_TRY(pk_attn_fwd(L.self.proj, at(L.self.proj, d, dt), at(L.self.proj, 2 * d, dt), L.self.attn, L.self.lse,
+                       L.is_decoder ? nullptr : L.self_pad, L.B, L.heads, L.T, L.T, hd, (long long)L.T * 3 * d, 3 * d,
+                       (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * d, d,
+                       L.is_decoder && L.T > 1, L.attn_scale, 0.f, 0, 0, nullptr, dt, L.stream));
+    PK_TRY(linear(L.self.attn, L.self.w_o, L.self.b_o, L.self.y, rows, d, d, PK_ACT_NONE, nullptr));
+    PK_TRY(pre_end(L, L.self.y, L.x, L.self.z, L.self.drop_offset));
+    const void* z = L.self.z;
+    // ---- cross-attention (decoder) ----
+    if (L.is_decoder) {
+        PK_TRY(pre_norm(L, z, L.cross.ln_g, L.cross.ln_b, L.cross.ln_out, L.cross.mean, L.cross.rstd));
+        PK_TRY(linear(L.cross.ln_out, L.cross.w_in, L.cross.b_in, L.cross.proj, rows, d, d, PK_ACT_NONE, nullptr));
+        PK_TRY(linear(L.enc, at(L.cross.w_in, d * d, dt), L.cross.b_in ? at(L.cross.b_in, d, dt) : nullptr, L.cross.kv, rows_kv, 2 * d, d,
+                      PK_ACT_NONE, nullptr));
+        PK_TRY(pk_attn_fwd(L.cross.proj, L.cross.kv, at(L.cross.kv, d, dt), L.cross.attn, L.cross.lse, L.cross_pad, L.B, L.heads,
+                           L.T, L.S, hd, (long long)L.T * d, d, (long long)L.S * 2 * d, 2 * d, (long long)L.S * 2 * d, 2 * d,
+                           (long long)L.T * d, d, 0, L.attn_scale, 0.f, 0, 0, nullptr, dt, L.stream));
+        PK_TRY(linear(L.cross.attn, L.cross.w_o, L.cross.b_o, L.cross.y, rows, d, d, PK_ACT_NONE, nullptr));
+        PK_TRY(pre_end(L, L.cross.y, z, L.cross.z, L.cross.drop_offset));
+        z = L.cross.z;
+    }
+    // ---- feed-forward ----
+    PK_TRY(pre_norm(L, z, L.ffn.ln_g, L.ffn.ln_b, L.ffn.ln_out, L.ffn.mean, L.ffn.rstd));
+    PK_TRY(linear(L.ffn.ln_out, L.ffn.w1, L.ffn.b1, L.ffn.h, rows, f, d, L.act, L.ffn.pre));
+    PK_TRY(linear(L.ffn.h, L.ffn.w2, L.ffn.b2, L.ffn.y, rows, d, f, PK_ACT_NONE, nullptr));
+    return pre_end(L, L.ffn.y, z, L.ffn.z, L.ffn.drop_offset);
+}
+
 }  // namespace
 
 extern "C" int pk_layer_fwd(const PkLayer* lp) {
     PK_REQ(lp, "pk_layer_fwd: null layer");
     const PkLayer& L = *lp;
     PK_TRY(check(L));
+    if (L.prenorm) return layer_fwd_prenorm(L);
     const long long rows = (long long)L.B * L.T, rows_kv = (long long)L.B * L.S, d = L.d, f = L.f;
     const int hd = L.d / L.heads, dt = L.dtype;
     // ---- self-attention: one packed projection, attention straight on its columns, block end ----
@@ -216,6 +268,59 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
         return pk_gemm(dy, w, out, nullptr, aux, nullptr, M, N, K, K, N, N, aux ? N : 0, 0, 0, 1, PK_ACT_NONE, aux ? 1 : 0, 1.f, dt, sk,
                        sk > 1 ? ws : nullptr, sk > 1 ? splitk_ws(sk, M, N) : 0, nullptr, L.stream);
     };
+    if (L.prenorm) {
+        // z = in + dropout(f(LN(in))): the incoming gradient dz goes (i) through the dropout mask into f's backward and
+        // (ii), as the residual branch, into the LayerNorm backward kernel's `dz_extra`
+        auto undrop = [&](const void* dz, void* out, unsigned long long offset) -> int {
+            return drop ? pk_dropout(dz, out, rows * d, L.drop_p, L.seed, offset, dt, L.stream) : 0;
+        };
+        auto ln_in_bwd = [&](const void* dln, const void* dz, const void* in, const void* g, const float* mean, const float* rstd,
+                             void* d_in, void* dg, void* db) {
+            return pk_residual_ln_bwd(dln, dz, in, g, mean, rstd, d_in, nullptr, dg, db, ws_ln, b.ws_ln, rows, (int)d, 0.f, 0, 0, dt, L.stream);
+        };
+        const void* in_f = L.is_decoder ? L.cross.z : L.self.z;
+        // feed-forward
+        PK_TRY(undrop(L.dy, b.dsub_f, L.ffn.drop_offset));
+        const void* do_f = drop ? b.dsub_f : L.dy;
+        if (L.act == PK_ACT_NONE)
+            PK_TRY(pk_gemm(do_f, L.ffn.w2, b.dh, nullptr, nullptr, nullptr, rows, f, d, d, f, f, 0, 0, 0, 1, PK_ACT_NONE, 0, 1.f, dt, 1, nullptr,
+                           0, nullptr, L.stream));
+        else
+            PK_TRY(pk_gemm(do_f, L.ffn.w2, b.dh, nullptr, L.ffn.pre ? L.ffn.pre : L.ffn.h, nullptr, rows, f, d, d, f, f, f, 0, 0, 1, L.act, 2,
+                           1.f, dt, 1, nullptr, 0, nullptr, L.stream));
+        PK_TRY(dx_gemm(b.dh, L.ffn.w1, b.dln, nullptr, rows, d, f, true));
+        PK_TRY(ln_in_bwd(b.dln, L.dy, in_f, L.ffn.ln_g, L.ffn.mean, L.ffn.rstd, b.dy_mid, L.ffn.dln_g, L.ffn.dln_b));
+        const void* dz = b.dy_mid;
+        PkWgradProblem pr[PK_WGRAD_MAX];
+        int n = wgrad_problems(L, b, pr);
+        pr[0].A = do_f;  // (fc2's dY is the un-dropped gradient, wherever it lives)
+        if (L.is_decoder) {
+            PK_TRY(undrop(dz, b.dsub_c, L.cross.drop_offset));
+            const void* do_c = drop ? b.dsub_c : dz;
+            pr[2].A = do_c;
+            PK_TRY(dx_gemm(do_c, L.cross.w_o, b.dcattn, nullptr, rows, d, d, true));
+            PK_TRY(pk_attn_bwd(L.cross.proj, L.cross.kv, at(L.cross.kv, d, dt), L.cross.attn, b.dcattn, L.cross.lse, b.delta, b.dq, b.dkv,
+                               at(b.dkv, d, dt), L.cross_pad, L.B, L.heads, L.T, L.S, hd, (long long)L.T * d, d, (long long)L.S * 2 * d,
+                               2 * d, (long long)L.S * 2 * d, 2 * d, (long long)L.T * d, d, (long long)L.T * d, d, (long long)L.T * d, d,
+                               (long long)L.S * 2 * d, 2 * d, (long long)L.S * 2 * d, 2 * d, 0, L.attn_scale, 0.f, nullptr, dt, L.stream));
+            PK_TRY(dx_gemm(b.dkv, at(L.cross.w_in, d * d, dt), L.denc, nullptr, rows_kv, d, 2 * d, true));
+            PK_TRY(dx_gemm(b.dq, L.cross.w_in, b.dln, nullptr, rows, d, d, true));
+            PK_TRY(ln_in_bwd(b.dln, dz, L.self.z, L.cross.ln_g, L.cross.mean, L.cross.rstd, b.dy_self, L.cross.dln_g, L.cross.dln_b));
+            dz = b.dy_self;
+        }
+        PK_TRY(undrop(dz, b.dsub_s, L.self.drop_offset));
+        const void* do_s = drop ? b.dsub_s : dz;
+        pr[L.is_decoder ? 5 : 2].A = do_s;
+        PK_TRY(dx_gemm(do_s, L.self.w_o, b.dattn, nullptr, rows, d, d, true));
+        PK_TRY(pk_attn_bwd(L.self.proj, at(L.self.proj, d, dt), at(L.self.proj, 2 * d, dt), L.self.attn, b.dattn, L.self.lse, b.delta, b.dproj,
+                           at(b.dproj, d, dt), at(b.dproj, 2 * d, dt), L.is_decoder ? nullptr : L.self_pad, L.B, L.heads, L.T, L.T, hd,
+                           (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * d, d,
+                           (long long)L.T * d, d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d,
+                           L.is_decoder && L.T > 1, L.attn_scale, 0.f, nullptr, dt, L.stream));
+        PK_TRY(dx_gemm(b.dproj, L.self.w_in, b.dln, nullptr, rows, d, 3 * d, true));
+        PK_TRY(ln_in_bwd(b.dln, dz, L.x, L.self.ln_g, L.self.mean, L.self.rstd, L.dx, L.self.dln_g, L.self.dln_b));
+        return pk_gemm_wgrad_group(pr, n, dt, ws, b.ws_group, L.stream);
+    }
     // ---- feed-forward block ----
     PK_TRY(ln_bwd(L.dy, L.ffn.z, L.ffn.ln_g, L.ffn.mean, L.ffn.rstd, b.dres_f, b.dsub_f, L.ffn.dln_g, L.ffn.dln_b, L.ffn.drop_offset));
     if (L.act == PK_ACT_NONE)

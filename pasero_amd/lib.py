@@ -87,17 +87,17 @@ class PkWgradProblem(ctypes.Structure):
 
 class PkAttnBlock(ctypes.Structure):
     """include/pasero_hip.h: an attention sub-block of pk_layer_fwd / pk_layer_bwd"""
-    _fields_ = [(n, P) for n in ('w_in', 'b_in', 'w_o', 'b_o', 'ln_g', 'ln_b', 'proj', 'kv', 'attn', 'z', 'y', 'lse', 'mean',
-                                 'rstd', 'dw_in', 'db_in', 'dw_o', 'db_o', 'dln_g', 'dln_b')] + [('drop_offset', ULL)]
+    _fields_ = [(n, P) for n in ('w_in', 'b_in', 'w_o', 'b_o', 'ln_g', 'ln_b', 'proj', 'kv', 'attn', 'z', 'y', 'ln_out', 'lse',
+                                 'mean', 'rstd', 'dw_in', 'db_in', 'dw_o', 'db_o', 'dln_g', 'dln_b')] + [('drop_offset', ULL)]
 
 
 class PkFfnBlock(ctypes.Structure):
-    _fields_ = [(n, P) for n in ('w1', 'b1', 'w2', 'b2', 'ln_g', 'ln_b', 'h', 'pre', 'z', 'y', 'mean', 'rstd', 'dw1', 'db1',
-                                 'dw2', 'db2', 'dln_g', 'dln_b')] + [('drop_offset', ULL)]
+    _fields_ = [(n, P) for n in ('w1', 'b1', 'w2', 'b2', 'ln_g', 'ln_b', 'h', 'pre', 'z', 'y', 'ln_out', 'mean', 'rstd', 'dw1',
+                                 'db1', 'dw2', 'db2', 'dln_g', 'dln_b')] + [('drop_offset', ULL)]
 
 
 class PkLayer(ctypes.Structure):
-    _fields_ = ([(n, I) for n in ('dtype', 'is_decoder', 'fused_tail', 'act', 'B', 'T', 'S', 'd', 'f', 'heads')] +
+    _fields_ = ([(n, I) for n in ('dtype', 'is_decoder', 'fused_tail', 'act', 'B', 'T', 'S', 'd', 'f', 'heads', 'prenorm')] +
                 [('eps', F), ('drop_p', F), ('attn_scale', F), ('seed', ULL), ('x', P), ('enc', P), ('self_pad', P),
                  ('cross_pad', P), ('self_', PkAttnBlock), ('cross', PkAttnBlock), ('ffn', PkFfnBlock), ('dy', P), ('dx', P),
                  ('denc', P), ('scratch', P), ('ws', P), ('scratch_bytes', SZ), ('ws_bytes', SZ), ('stream', P)])

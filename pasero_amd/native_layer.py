@@ -5,8 +5,8 @@ layer's whole launch sequence from C — the same kernels, in the same order, wi
 as the per-op path (pasero_amd/autograd.py), so both paths agree bit for bit (tests/test_native_layer_gpu.py) — instead of
 ~13 / ~27 Python dispatches with their tensor allocations and ctypes marshalling.  Host time of a C2 step: 9.6 -> ~4 ms.
 
-A layer takes this path only when it is exactly the stock layer: post-norm, LayerNorm with bias, every Linear with bias,
-no LoRA / adapters / gated feed-forward / rotary positions / attention or activation dropout, no subclass hook
+A layer takes this path only when it is exactly the stock layer: post- or pre-norm, LayerNorm with bias, every Linear with
+bias (the key projection may have none: Whisper), no LoRA / adapters / gated feed-forward / rotary positions / attention or activation dropout, no subclass hook
 overridden, 16-bit parameters that all require a gradient, training-mode autograd on, no `return_layers`, no incremental
 state, shapes the grouped weight-gradient launch takes.  Everything else stays on the per-op path (`takes` says which).
 PASERO_NO_NATIVE_LAYER=1 switches it off."""
@@ -50,7 +50,7 @@ def _static_ok(layer, is_decoder: bool) -> bool:
     if any(getattr(type(layer), h) is not getattr(cls, h) for h in (HOOKS_DEC if is_decoder else HOOKS_ENC)):
         return False
     cfg = layer.cfg
-    if layer.prenorm or cfg.check_inf or cfg.checkpoint_activations or layer.fc3 is not None or cfg.shared_norm:
+    if cfg.check_inf or cfg.checkpoint_activations or layer.fc3 is not None or cfg.shared_norm:
         return False
     if layer.activation_dropout.p > 0 or layer.activation_fn.name not in ('relu', 'gelu', 'gelu_tanh', 'silu', 'none'):
         return False
@@ -62,7 +62,9 @@ def _static_ok(layer, is_decoder: bool) -> bool:
     for a in attns:
         if a.dropout > 0 or a.rotary_embed is not None or a.head_dim not in (64, 128):
             return False
-        if any(m.lora is not None or m.bias is None for m in (a.q_proj, a.k_proj, a.v_proj, a.out_proj)):
+        if any(m.lora is not None for m in (a.q_proj, a.k_proj, a.v_proj, a.out_proj)):
+            return False
+        if any(m.bias is None for m in (a.q_proj, a.v_proj, a.out_proj)):  # (k_proj may have no bias: attention_key_bias)
             return False
     if any(m.lora is not None or m.bias is None for m in (layer.fc1, layer.fc2)):
         return False
@@ -77,7 +79,7 @@ def takes(layer, x, enc, state, return_layers, is_decoder: bool) -> bool:
     key = (layer.training, x.dtype)
     ok = layer.__dict__.get('_native_static')
     if ok is None or ok[0] != key:  # (once per layer, mode and dtype: the configuration and the parameters' state)
-        good = _static_ok(layer, is_decoder) and all(p.dtype == x.dtype and p.requires_grad and p.is_cuda
+        good = _static_ok(layer, is_decoder) and all(p is None or (p.dtype == x.dtype and p.requires_grad and p.is_cuda)
                                                      for p in layer_params(layer, is_decoder))
         ok = (key, good)
         layer.__dict__['_native_static'] = ok
@@ -114,7 +116,8 @@ class NativeLayerFn(Function):
         need_pre = act not in ('none', 'relu')
         p = float(layer.dropout.p) if layer.training else 0.0
         norm = layer.self_attn_layer_norm
-        fused = (not _NO_FUSED_TAIL and block_tail_eligible(rows, a_self.out_proj.weight, x, norm.weight)
+        prenorm = bool(layer.prenorm)
+        fused = (not prenorm and not _NO_FUSED_TAIL and block_tail_eligible(rows, a_self.out_proj.weight, x, norm.weight)
                  and block_tail_eligible(rows, layer.fc2.weight, x, layer.final_layer_norm.weight))
         # activations kept for backward: one 16-bit arena + one fp32 arena per layer call
         n16 = rows * (3 * d + 3 * d) + rows * (f * (2 if need_pre else 1) + 2 * d)
@@ -122,6 +125,8 @@ class NativeLayerFn(Function):
         if is_decoder:
             n16 += rows * 4 * d + rows_kv * 2 * d
             n32 += B * H * T + 2 * rows
+        if prenorm:  # + LayerNorm(block input) of every sub-block
+            n16 += rows * d * (3 if is_decoder else 2)
         a16 = torch.empty(n16, dtype=dt, device=dev)
         a32 = torch.empty(n32, dtype=torch.float32, device=dev)
         es = 2
@@ -139,7 +144,7 @@ class NativeLayerFn(Function):
 
         lay = PkLayer()
         lay.dtype, lay.is_decoder, lay.fused_tail, lay.act = dtype_code(x), int(is_decoder), int(fused), ACT[act]
-        lay.B, lay.T, lay.S, lay.d, lay.f, lay.heads = B, T, S, d, f, H
+        lay.B, lay.T, lay.S, lay.d, lay.f, lay.heads, lay.prenorm = B, T, S, d, f, H, int(prenorm)
         lay.eps, lay.drop_p = float(norm.eps), p
         lay.attn_scale = 1.0 / (a_self.head_dim ** 0.5) if a_self.scaled else 1.0
         lay.x, lay.enc = x.data_ptr(), (enc.data_ptr() if is_decoder else None)
@@ -155,6 +160,7 @@ class NativeLayerFn(Function):
             blk.proj = t16(rows * (d if cross else 3 * d))
             blk.kv = t16(rows_kv * 2 * d) if cross else None
             blk.attn, blk.z, blk.y = t16(rows * d), t16(rows * d), t16(rows * d)
+            blk.ln_out = t16(rows * d) if prenorm else None
             blk.lse, blk.mean, blk.rstd = t32(B * H * T), t32(rows), t32(rows)
 
         # dropout offsets in the per-op path's order: self block end, cross block end, feed-forward block end
@@ -172,7 +178,9 @@ class NativeLayerFn(Function):
         fb.h = t16(rows * f)
         fb.pre = t16(rows * f) if need_pre else None
         fb.z = t16(rows * d)
-        y_ptr = fb.y = t16(rows * d)
+        fb.y = t16(rows * d)
+        fb.ln_out = t16(rows * d) if prenorm else None
+        y_ptr = fb.z if prenorm else fb.y  # the layer's output
         fb.mean, fb.rstd = t32(rows), t32(rows)
         if p > 0:
             seed, fb.drop_offset = rng.next_offset()
@@ -242,6 +250,7 @@ class NativeLayerFn(Function):
                       vs_[6 * k + 3], vs_[6 * k + 4], vs_[6 * k + 5]]
         v0 = 6 * nblk
         grads += [ws_[4 * nblk], vs_[v0], w2, vs_[v0 + 1], vs_[v0 + 2], vs_[v0 + 3]]
+        grads = [g if prm is not None else None for g, prm in zip(grads, params)]  # (a projection without bias)
         return (dx, denc, None, None, None, None, *grads)
 
 
