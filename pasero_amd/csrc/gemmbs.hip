@@ -263,7 +263,10 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
         const u32x4 o = __builtin_bit_cast(u32x4, __builtin_convertvector(f, typename H16<T>::vec));
         // (the row offset is wave-uniform: said explicitly, or hipcc serialises the store in a waterfall loop)
         const unsigned so = __builtin_amdgcn_readfirstlane(c_so + (unsigned)i * c_tile_bytes);
-        __builtin_amdgcn_raw_buffer_store_b128(o, rc, c_voff, so, 2 /* nt */);
+#ifndef PKBS_STORE_AUX
+#define PKBS_STORE_AUX 2 /* nt */
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(o, rc, c_voff, so, PKBS_STORE_AUX);
         ac[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         ac[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         return o;
