@@ -69,8 +69,21 @@ int pk_gemm_use_8p(int on);
 /* diagnostic: 1 / 0 lets pk_gemm send short-contraction GEMMs (K = 512 / 256, row-form A, bias / ReLU epilogue, thousands
  * of rows) to the B-stationary kernel (gemmbs.hip, default) / keeps them on the tiled kernels; negative: query only.
  * Returns the previous setting (env PK_GEMM_BS sets the initial one).  Sample tag in pk_gemm_timing_read: 0x200 | number
- * of K-tiles | 0x10 with the ReLU epilogue | 0x20 with the ReLU-mask epilogue (mode 2). */
+ * of K-tiles | 0x10 with the ReLU epilogue | 0x20 with the ReLU-mask epilogue (mode 2) | 0x40 with the mask as bits. */
 int pk_gemm_use_bs(int on);
+/* The ReLU feed-forward's mask as ONE BIT per element (fc1 forward / fc2 dX of pasero/models/transformer.py:999-1019 at
+ * K = 512): `bits` [M][ldbits] bytes, bit (n & 7) of byte n >> 3 of row m = (C[m][n] > 0) of the forward call.
+ *   mode 0:  C = relu(alpha * A B^T + bias), bits written next to it          (fc1 forward)
+ *   mode 2:  C = bit ? alpha * A B : 0                                        (dH = (dZ W2) * relu'(h): reads 1/16 of what
+ *            the activations as the mask operand of pk_gemm mode 2 would — that GEMM is memory-bound at C2)
+ * Only shapes of the B-stationary kernel (pk_gemm_relu_bits_eligible: row-form A, K = 512, N >= 256, thousands of rows, 16-bit);
+ * for everything else pk_gemm with act = PK_ACT_RELU and, in backward, aux = the activations. */
+int pk_gemm_relu_bits_eligible(const void* A, const void* B, const void* C, const void* bias, long long M, long long N,
+                               long long K, long long lda, long long ldb, long long ldc, long long ldbits, int b_col,
+                               int mode, int dtype);
+int pk_gemm_relu_bits(const void* A, const void* B, void* C, const void* bias, unsigned char* bits, long long M, long long N,
+                      long long K, long long lda, long long ldb, long long ldc, long long ldbits, int b_col, int mode,
+                      float alpha, int dtype, void* stream);
 int pk_gemm_timing_stop(void);
 int pk_gemm_timing_read(int i, int* kernel, int* a_col, int* b_col, int* splitk, int* dtype, double* flops, float* ms);
 
@@ -355,6 +368,7 @@ typedef struct {
     const void *w1, *b1, *w2, *b2, *ln_g, *ln_b;
     void *h, *pre, *z, *y;                              /* [rows][f], [rows][f] or NULL, [rows][d], [rows][d] */
     void* ln_out;                                       /* pre-norm only */
+    unsigned char* bits;                                /* ReLU mask as bits [rows][f / 8] (pk_gemm_relu_bits) or NULL */
     float *mean, *rstd;
     void *dw1, *db1, *dw2, *db2, *dln_g, *dln_b;
     unsigned long long drop_offset;

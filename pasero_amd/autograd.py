@@ -252,19 +252,25 @@ class FFNFn(Function):
         grad = any(wants_grad(ctx))
         need_pre = grad and act not in ('none', 'relu')
         pre = torch.empty(x2.size(0), w1.size(0), dtype=x.dtype, device=x.device) if need_pre else None
-        h = F.gemm(x2, w1, bias=b1, act=act, preact=pre)
+        bits = None
+        if grad and act == 'relu' and F.relu_bits_eligible(x2, w1):  # the mask for backward as one bit per element
+            h, bits = F.gemm_relu_bits(x2, w1, b1)
+        else:
+            h = F.gemm(x2, w1, bias=b1, act=act, preact=pre)
         y = F.gemm(h, w2, bias=b2)
         ctx.act = act
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
-        ctx.save_for_backward(x2, w1, w2, h, pre)
+        ctx.save_for_backward(x2, w1, w2, h, pre, bits)
         return y.view(*x.shape[:-1], w2.size(0))
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w1, w2, h, pre = ctx.saved_tensors
+        x2, w1, w2, h, pre, bits = ctx.saved_tensors
         dy2 = _2d(_contig(dy))
         aux = h if pre is None else pre
-        if ctx.act == 'none':
+        if bits is not None:
+            dh = F.gemm_mask_bits(dy2, w2, bits)
+        elif ctx.act == 'none':
             dh = F.gemm(dy2, w2, b_col=True)
         else:
             dh = F.gemm(dy2, w2, b_col=True, act=ctx.act, aux=aux, mode=2)
@@ -526,23 +532,29 @@ class FFNResidualLnFn(Function):
         grad = any(wants_grad(ctx))
         need_pre = grad and act not in ('none', 'relu')
         pre = torch.empty(x2.size(0), w1.size(0), dtype=x.dtype, device=x.device) if need_pre else None
-        h = F.gemm(x2, w1, bias=b1, act=act, preact=pre)
+        bits = None
+        if grad and act == 'relu' and F.relu_bits_eligible(x2, w1):
+            h, bits = F.gemm_relu_bits(x2, w1, b1)
+        else:
+            h = F.gemm(x2, w1, bias=b1, act=act, preact=pre)
         seed, offset = rng.next_offset() if p > 0 else (0, 0)
         y, z, mean, rstd = F.gemm_ln_fwd(h, w2, b2, x2, gamma, beta, eps, p, seed, offset, want_z=grad)
         ctx.group, ctx.biases = group, ((b1, b2) if group is not None else (None, None))
         ctx.act, ctx.p, ctx.seed, ctx.offset = act, p, seed, offset
         ctx.has_b1, ctx.has_b2, ctx.has_beta = b1 is not None, b2 is not None, beta is not None
-        ctx.save_for_backward(x2, w1, w2, h, pre, z, gamma, mean, rstd)
+        ctx.save_for_backward(x2, w1, w2, h, pre, z, gamma, mean, rstd, bits)
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w1, w2, h, pre, z, gamma, mean, rstd = ctx.saved_tensors
+        x2, w1, w2, h, pre, z, gamma, mean, rstd, bits = ctx.saved_tensors
         ng = ctx.needs_input_grad  # x, w1, b1, w2, b2, act, gamma, beta
         ctx.need_gamma, ctx.need_beta = ng[6], ctx.has_beta and ng[7]
         dres, dsub, dgamma, dbeta = _ln_tail_backward(ctx, dy, z, gamma, mean, rstd)
         dy2 = _2d(dsub)
-        if ctx.act == 'none':
+        if bits is not None:
+            dh = F.gemm_mask_bits(dy2, w2, bits)
+        elif ctx.act == 'none':
             dh = F.gemm(dy2, w2, b_col=True)
         else:
             dh = F.gemm(dy2, w2, b_col=True, act=ctx.act, aux=h if pre is None else pre, mode=2)

@@ -716,7 +716,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict
 extern "C" int pk_gemmbs_eligible(const void* A, const void* B, const void* C, long long M, long long N, long long K,
                                   long long lda, long long ldb, int a_col, int b_col, const EpiParams* ep);
 extern "C" int pk_gemmbs_launch(const void* A, const void* B, void* C, long long M, long long N, long long K,
-                                long long lda, long long ldb, int b_col, EpiParams ep, int dtype, void* stream);
+                                long long lda, long long ldb, int b_col, EpiParams ep, int dtype, void* stream,
+                                unsigned char* bits, long long ldbits);
 extern "C" int pk_gemmbs_use(int on);
 
 int g_use_8p = [] { const char* e = getenv("PK_GEMM_8P"); return (!e || atoi(e) != 0) ? 1 : 0; }();
@@ -777,7 +778,7 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         if (splitk <= 1 && !asum_out && pk_gemmbs_eligible(A, B, C, M, N, K, lda, ldb, a_col, b_col, &ep)) {
             const int tagbs = 0x200 | (int)(K / 64) | (ep.mode == 2 ? 0x20 : ep.act == PK_ACT_RELU ? 0x10 : 0);
             GemmSample* sm = timing_begin(tagbs, a_col, b_col, 1, dtype16, M, N, K, stream);
-            const int rc = pk_gemmbs_launch(A, B, C, M, N, K, lda, ldb, b_col, ep, dtype16, stream);
+            const int rc = pk_gemmbs_launch(A, B, C, M, N, K, lda, ldb, b_col, ep, dtype16, stream, nullptr, 0);
             timing_end(sm, stream);
             return rc == 1 ? 0 : rc;
         }
@@ -966,6 +967,45 @@ extern "C" int pk_gemm_ln_fwd(const void* A, const void* W, const void* bias, co
 }
 
 extern "C" int pk_gemm_use_bs(int on) { return pk_gemmbs_use(on); }
+
+// ---- ReLU feed-forward with the mask as one bit per element (see include/pasero_hip.h) ----
+namespace {
+EpiParams relu_bits_epi(const void* bias, void* C, long long ldc, int mode, float alpha) {
+    EpiParams ep;
+    ep.bias = mode == 0 ? bias : nullptr;
+    ep.aux = mode == 2 ? C : nullptr;  // (stands in for the mask operand in the eligibility check: the bits replace it)
+    ep.preact = nullptr;
+    ep.ldaux = mode == 2 ? ldc : 0; ep.ldc = ldc; ep.ldpre = 0;
+    ep.act = PK_ACT_RELU; ep.mode = mode; ep.alpha = alpha;
+    return ep;
+}
+}  // namespace
+
+extern "C" int pk_gemm_relu_bits_eligible(const void* A, const void* B, const void* C, const void* bias, long long M,
+                                          long long N, long long K, long long lda, long long ldb, long long ldc,
+                                          long long ldbits, int b_col, int mode, int dtype) {
+    static const int on = [] { const char* e = getenv("PK_GEMM_RELU_BITS"); return (!e || atoi(e) != 0) ? 1 : 0; }();  // (diagnostic switch)
+    if (!on) return 0;
+    if ((dtype != PK_BF16 && dtype != PK_F16) || (mode != 0 && mode != 2) || N % 32 || ldbits < N / 8 || ldbits % 4) return 0;
+    const EpiParams ep = relu_bits_epi(bias, const_cast<void*>(C), ldc, mode, 1.f);
+    return pk_gemmbs_eligible(A, B, C, M, N, K, lda, ldb, 0, b_col, &ep);
+}
+
+extern "C" int pk_gemm_relu_bits(const void* A, const void* B, void* C, const void* bias, unsigned char* bits, long long M,
+                                 long long N, long long K, long long lda, long long ldb, long long ldc, long long ldbits,
+                                 int b_col, int mode, float alpha, int dtype, void* stream) {
+    PK_CHECK_ARG(A && B && C && bits, "pk_gemm_relu_bits: null operand");
+    PK_CHECK_ARG(pk_gemm_relu_bits_eligible(A, B, C, bias, M, N, K, lda, ldb, ldc, ldbits, b_col, mode, dtype),
+                 "pk_gemm_relu_bits: M=%lld N=%lld K=%lld mode %d is not a shape of the B-stationary kernel; ask "
+                 "pk_gemm_relu_bits_eligible and use pk_gemm with the activations as the mask operand", M, N, K, mode);
+    EpiParams ep = relu_bits_epi(bias, C, ldc, mode, alpha);
+    ep.aux = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    GemmSample* sm = timing_begin(0x200 | (int)(K / 64) | (mode == 2 ? 0x20 : 0x10) | 0x40, 0, b_col, 1, dtype, M, N, K, s);
+    const int rc = pk_gemmbs_launch(A, B, C, M, N, K, lda, ldb, b_col, ep, dtype, stream, bits, ldbits);
+    timing_end(sm, s);
+    return rc == 1 ? 0 : rc;
+}
 
 extern "C" int pk_gemm_use_8p(int on) {
     const int old = g_use_8p;

@@ -47,6 +47,9 @@ constexpr int BIMG = 16384;                    // col-form prologue: a B image o
 constexpr int SMEM = RS * TILE;                // 128 KiB
 constexpr int LA = 20, SYNC = 4;               // DMA look-ahead (tiles), K-tiles between barriers
 constexpr unsigned DEAD_OFF = 0x80000000u;
+#ifndef PKBS_EMIT_VALU
+#define PKBS_EMIT_VALU 5  // VALU instructions of a departing tile per MFMA gap
+#endif
 
 // column of the wave's 32-column slab that row `nu` (0..15) of B-fragment tile j holds: lane (q = l >> 4) then owns the
 // output columns 8 q + 4 j + r, r = 0..3, of tile j — eight consecutive columns over j = 0, 1
@@ -54,19 +57,26 @@ __device__ __forceinline__ int bcol(int j, int nu) { return 8 * (nu >> 2) + 4 * 
 
 // MASK: the epilogue of the dH = dY W2 GEMM of a ReLU feed-forward (pk_gemm mode 2, pasero/models/transformer.py:999-1019
 // backward): C = aux > 0 ? alpha * acc : 0, `bias` then points at aux [M][ldaux] (no bias in that mode)
-template <typename T, bool B_COL, int NK, bool RELU, bool MASK>
+// BITS: the ReLU mask as ONE BIT per element instead of the activations themselves — `bits` [M][ldbits] bytes, bit (n & 7) of
+// byte n >> 3 of a row = (the stored 16-bit output > 0).  The RELU epilogue writes it next to h (fc1 forward); the MASK
+// epilogue reads it instead of aux (fc2 dX: 17 MB instead of 134 MB at C2 — that GEMM is memory-bound).
+template <typename T, bool B_COL, int NK, bool RELU, bool MASK, bool BITS>
 __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A, const T* __restrict__ B,
                                                        T* __restrict__ C, const T* __restrict__ bias, long long M,
                                                        long long N, long long lda, long long ldb, long long ldc,
                                                        long long ldaux, unsigned a_bytes, unsigned b_bytes,
                                                        unsigned c_bytes, unsigned aux_bytes, int nt_n, int steps_per,
-                                                       int total_steps, float alpha, unsigned long long* stamps) {
+                                                       int total_steps, float alpha, unsigned long long* stamps,
+                                                       unsigned char* __restrict__ bits, long long ldbits) {
+    static_assert(!BITS || (RELU != MASK), "BITS: written by the ReLU epilogue, read by the mask epilogue");
     static_assert(NK == 8, "two steps = half a turn of the 32-slot ring: K = 512");
     static_assert(NK * BIMG <= SMEM && LA + 6 <= RS && LA == 20, "LDS map / counted wait below");
     typedef typename M16<T>::vec V;
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(3))) char lds_char;
-    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    // (mask as bits: four steps' worth of the workgroup's mask bytes behind the ring — 8 waves x 256 B per step)
+    constexpr int BITS_LDS = 8 * 256, BITS_RING = 4;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM + (MASK && BITS ? BITS_RING * BITS_LDS : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wcls = wave >> 2, wpiece = wave & 3;  // tiles of parity `wcls`, rows 8 wpiece .. + 8, are this wave's to bring
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
         const unsigned so = live ? (unsigned)step * step_bytes + (unsigned)ktile * (BK * 2) : 0u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(smem + slot * TILE + wpiece * 1024), 16, offa, so, 0, 0);
     };
-#define PK_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define PK_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
     // bias of this lane's eight columns, output addressing
     const int q = lane >> 4;
@@ -123,8 +133,23 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
     const unsigned x_tile_bytes = __builtin_amdgcn_readfirstlane((unsigned)(16 * ldaux * 2));
     const unsigned x_step_bytes = __builtin_amdgcn_readfirstlane((unsigned)(BMS * ldaux * 2));
     u32x4 auxv[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-    auto load_aux = [&](int step) {
-        if constexpr (MASK) {
+    // BITS: this lane's byte of a tile = row (l & 15), columns 8 q .. 8 q + 7 of the wave's slab
+    __amdgpu_buffer_rsrc_t rbit = __builtin_amdgcn_make_buffer_rsrc((void*)bits, 0, BITS ? (int)(M * ldbits) : 0, 0x00020000);
+    // (the writer: lanes 0..15 store the row's dword; a strip's last slab is whole or absent — N % 32 == 0 with BITS)
+    const unsigned bit_wvoff = (lane < 16 && n0 + 32 * wave + 32 <= N) ? (unsigned)((long long)lane * ldbits + 4 * wave) : DEAD_OFF;
+    const unsigned bit_tile = __builtin_amdgcn_readfirstlane((unsigned)(16 * ldbits));
+    const unsigned bit_step = __builtin_amdgcn_readfirstlane((unsigned)(BMS * ldbits));
+    const unsigned bit_col = __builtin_amdgcn_readfirstlane((unsigned)(n0 >> 3));
+    // (the reader: a step's 32 rows x 4 bytes of the wave's slab come by ONE 4-byte LDS-DMA, lane r < 32 = row r, into the
+    // wave's own 256 bytes of the step's slot — like a ring piece it rides the in-order queue, no register waits for it)
+    const unsigned bit_rvoff = (lane < 32 && n0 + 32 * wave + 32 <= N) ? (unsigned)((long long)lane * ldbits + 4 * wave) : DEAD_OFF;
+    const int bit_lds = SMEM + wave * 256 + (lane & 15) * 4 + q;  // + slot * BITS_LDS + 64 i: this lane's byte of tile i
+    auto load_aux = [&](int step) {  // MASK && BITS: step -> slot (step - s_begin) % 4;  MASK: the step whose tiles leave next
+        if constexpr (MASK && BITS) {
+            const unsigned so = (unsigned)step * bit_step + bit_col;
+            const int slot = (step - s_begin) & (BITS_RING - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbit, (lds_void*)(smem + SMEM + slot * BITS_LDS + wave * 256), 4, bit_rvoff, so, 0, 0);
+        } else if constexpr (MASK) {
             const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)step * x_step_bytes + c_col_bytes);
             auxv[0] = __builtin_amdgcn_raw_buffer_load_b128(rx, x_voff, so, 0);
             auxv[1] = __builtin_amdgcn_raw_buffer_load_b128(rx, x_voff, so + x_tile_bytes, 0);
@@ -210,6 +235,10 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
 #pragma unroll
     for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bias_f[e]));
 
+    if constexpr (MASK && BITS) {  // (the first two steps' mask bytes; the others are requested in the loop)
+        load_aux(s_begin);
+        load_aux(s_begin + 1);
+    }
     // ---- the ring's first LA tiles (this wave: those of its parity) ----
 #pragma unroll
     for (int t = 0; t < LA; t += 2) dma_a(s_begin + t / NK, t % NK + wcls, t + wcls);
@@ -243,12 +272,18 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
     // it landed in the last lanes of the stored rows (zeros or garbage in lanes 12..15 of every 16, one register pair).
     // hipcc only guards the form without an SGPR offset (GCNHazardRecognizer: "no hazard if soffset is a register").  So
     // the packed tile is RETURNED and the caller keeps it alive (an empty asm use) until the position's MFMAs have issued.
-    auto emit = [&](f32x4 (&ac)[2][2], int i, unsigned c_so) -> u32x4 {
+    auto emit = [&](f32x4 (&ac)[2][2], int i, int step_out) -> u32x4 {  // (step_out < 0: nothing to store — dead offsets)
+        const unsigned c_so = step_out < 0 ? DEAD_OFF : (unsigned)step_out * c_step_bytes + c_col_bytes;
         float x[8] = {ac[i][0][0], ac[i][0][1], ac[i][0][2], ac[i][0][3], ac[i][1][0], ac[i][1][1], ac[i][1][2], ac[i][1][3]};
+        unsigned mbyte = 0;
+        if constexpr (MASK && BITS)  // (step_out < 0: whatever the slot holds — the tile goes nowhere)
+            mbyte = *reinterpret_cast<const unsigned char*>(smem + bit_lds + ((step_out - s_begin) & (BITS_RING - 1)) * BITS_LDS + 64 * i);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float y = x[e] * alpha;
-            if constexpr (MASK) {
+            if constexpr (MASK && BITS) {
+                y = ((mbyte >> e) & 1u) ? y : 0.f;
+            } else if constexpr (MASK) {
                 Vec16<T> av;
                 av.raw = __builtin_bit_cast(uint4, auxv[i]);
                 y = av.get(e) > 0.f ? y : 0.f;
@@ -263,6 +298,29 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
         const u32x4 o = __builtin_bit_cast(u32x4, __builtin_convertvector(f, typename H16<T>::vec));
         // (the row offset is wave-uniform: said explicitly, or hipcc serialises the store in a waterfall loop)
         const unsigned so = __builtin_amdgcn_readfirstlane(c_so + (unsigned)i * c_tile_bytes);
+        if constexpr (RELU && BITS) {  // bit e = (the stored value > 0) — without compares (each leaves its result in an SGPR
+            // pair and the select behind it waits two states for it, sixteen times a tile; and hipcc turns min/max forms back
+            // into compares): after max(0, .) no 16-bit pattern has its sign set (v_max_f32 orders -0 below +0), so adding
+            // 0x7FFF carries into bit 15 exactly where the pattern is not zero, and never beyond it.
+            unsigned u = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {  // flags of dword w (elements 2 w, 2 w + 1) to bits 9 + 2 w and 25 + 2 w
+                const unsigned ow = o[w];  // (a copy: a bit_cast of the vector ELEMENT reads element 0 whatever w — hipcc 7.2)
+                u |= ((ow + 0x7FFF7FFFu) >> (6 - 2 * w)) & (0x80008000u >> (6 - 2 * w));
+            }
+            const unsigned byte = ((u >> 9) | (u >> 24)) & 0xFFu;  // bits 0, 2, 4, 6 <- the low halves, 1, 3, 5, 7 <- the high ones
+            // the four bytes of a row (lane groups q = 0..3) travel to the lanes of group 0 — v_permlane16_swap brings group
+            // 1's byte next to group 0's (and 3's next to 2's), v_permlane32_swap the upper pair next to the lower — and leave
+            // as ONE dword per row (64 single-byte stores per tile cost the fc1 forward 17 us)
+            const auto s16 = __builtin_amdgcn_permlane16_swap(byte, byte, false, false);  // [0]: own (even groups), [1]: the odd neighbour's
+            const unsigned pair2 = s16[0] | (s16[1] << 8);
+            const auto s32 = __builtin_amdgcn_permlane32_swap(pair2, pair2, false, false);  // lanes < 32: [0] own pair, [1] the upper half's
+            const unsigned word = s32[0] | (s32[1] << 16);
+            // (a select, not a branch: the pinned instruction order below only holds within one basic block)
+            const unsigned bso = __builtin_amdgcn_readfirstlane(
+                step_out < 0 ? DEAD_OFF : (unsigned)step_out * bit_step + bit_col + (unsigned)i * bit_tile);
+            __builtin_amdgcn_raw_buffer_store_b32(word, rbit, bit_wvoff, bso, 0);
+        }
 #ifndef PKBS_STORE_AUX
 #define PKBS_STORE_AUX 2 /* nt */
 #endif
@@ -279,12 +337,15 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
     // an MFMA (a DMA piece 60-180 cycles, a 16-byte LDS read ~10, ...) on top of its MFMAs unless they are interleaved: the
     // instruction order is pinned below, one non-MFMA group per MFMA gap (measured before that: 370 cycles per K-tile
     // against the 256 the matrix pipe needs).
-    auto pair = [&](auto u_c, auto p_c, int step, unsigned c_so_prev, int ring_off, int cur0, int cur1) {
+    auto pair = [&](auto u_c, auto p_c, int step, int step_prev, int ring_off, int cur0, int cur1) {
         constexpr int U = decltype(u_c)::value, P = decltype(p_c)::value;
         constexpr int SL = NK * P + 2 * U;  // even, 0..14 within the half
 #ifndef PKBS_ABL_NOBAR  // (ablation builds, tools/gemmbs_ablate.sh: timing only, results are wrong)
         if constexpr (SL % SYNC == 0) {
-            PK_WAIT(7);  // this wave's pieces of the tiles <= t + 4 have landed
+            // this wave's pieces of the tiles <= t + 4 have landed: its 7 youngest DMA pieces may still fly.  (The queue is in
+            // order and stores and mask requests sit in it too: counting them — 7 + 2..4 per store of a departing tile — was
+            // measured and changed nothing; without them the wait is only stricter.)
+            PK_WAIT(7);
             __builtin_amdgcn_s_barrier();
         }
 #endif
@@ -298,20 +359,17 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[P][i][j] = M16<T>::mfma(bfr[KT][j][kk], a[i][kk], acc[P][i][j]);
         };
-        u32x4 keep0 = {0u, 0u, 0u, 0u}, keep1 = {0u, 0u, 0u, 0u};
+        u32x4 keep0 = {0u, 0u, 0u, 0u};
 #ifndef PKBS_ABL_NOREAD
         read_a(fa[1], cur0, cur1, SL + 1);  // fa[0] holds tile SL
 #endif
 #ifndef PKBS_ABL_NOSTORE
-        if constexpr (U == 0) keep0 = emit(acc[P ^ 1], 0, c_so_prev);
+        if constexpr (U < 2) keep0 = emit(acc[P ^ 1], U, step_prev);  // tile 0 of the previous step leaves in the first pair, tile 1 in the second
 #endif
         mma(std::integral_constant<int, 2 * U>{}, fa[0]);
 #ifndef PKBS_ABL_NOREAD
         if constexpr (SL + 2 < 16) read_a(fa[0], cur0, cur1, SL + 2);
         else read_a(fa[0], cur0 ^ 65536, cur1 ^ 65536, 0);  // (the first slot of the other half)
-#endif
-#ifndef PKBS_ABL_NOSTORE
-        if constexpr (U == 0) keep1 = emit(acc[P ^ 1], 1, c_so_prev);
 #endif
         mma(std::integral_constant<int, 2 * U + 1>{}, fa[1]);
         // tiles t + 20, t + 21 -> slots (t + 20) % 32, + 1: the other half's slot SL + 4, or (SL >= 12) this half's slot SL - 12
@@ -324,34 +382,36 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
         // second tile's MFMAs, the departing tiles' arithmetic (first pair of a step) fills the gaps it fits in
 #ifndef PKBS_NO_SGB
 #define PK_GAP_DS __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#define PK_GAP_VALU(N) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, N, 0);
-        if constexpr (U == 0) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            PK_GAP_VALU(6) PK_GAP_VALU(6) PK_GAP_VALU(6) PK_GAP_VALU(6)
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-            PK_GAP_DS PK_GAP_DS PK_GAP_DS PK_GAP_DS
-            PK_GAP_VALU(6) PK_GAP_VALU(6) PK_GAP_VALU(6) PK_GAP_VALU(6)
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#define PK_GAP_DSV(N) PK_GAP_DS __builtin_amdgcn_sched_group_barrier(0x002, N, 0);
+        if constexpr (U < 2) {  // + a departing tile: its arithmetic in the gaps that also carry a read, its store(s) behind them
+            PK_GAP_DSV(PKBS_EMIT_VALU) PK_GAP_DSV(PKBS_EMIT_VALU) PK_GAP_DSV(PKBS_EMIT_VALU) PK_GAP_DSV(PKBS_EMIT_VALU)
+            PK_GAP_DSV(PKBS_EMIT_VALU) PK_GAP_DSV(PKBS_EMIT_VALU) PK_GAP_DSV(PKBS_EMIT_VALU) PK_GAP_DSV(PKBS_EMIT_VALU)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
         } else {
             PK_GAP_DS PK_GAP_DS PK_GAP_DS PK_GAP_DS PK_GAP_DS PK_GAP_DS PK_GAP_DS PK_GAP_DS
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
         }
-#undef PK_GAP_VALU
+#undef PK_GAP_DSV
 #undef PK_GAP_DS
 #endif
-        if constexpr (U == 0) asm volatile("" :: "v"(keep0), "v"(keep1));  // (the stores' data registers stay untouched until here)
+        if constexpr (U < 2) asm volatile("" :: "v"(keep0));  // (the store's data registers stay untouched until here)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (U == 0) load_aux(step);  // (this step's mask operand: used when its tiles leave, 8 K-tiles from here)
+        // the mask operand, behind the second departing tile.  Registers (MASK): this step's, used when its tiles leave, 6
+        // K-tiles from here — hipcc's wait in front of that use leaves only the 3 requests behind it in flight.  LDS (MASK
+        // && BITS): the step after next's — 11 ring pieces follow it into the in-order queue before its first read, the
+        // ring's own wait (7 in flight) has retired it by then, and the slot it overwrites was read a step ago.
+        if constexpr (U == 1) load_aux(MASK && BITS ? step + 2 : step);
     };
-    auto step_body = [&](auto p_c, int step, unsigned c_so_prev, int ring_off, int cur0, int cur1) {
-        pair(std::integral_constant<int, 0>{}, p_c, step, c_so_prev, ring_off, cur0, cur1);
-        pair(std::integral_constant<int, 1>{}, p_c, step, c_so_prev, ring_off, cur0, cur1);
-        pair(std::integral_constant<int, 2>{}, p_c, step, c_so_prev, ring_off, cur0, cur1);
-        pair(std::integral_constant<int, 3>{}, p_c, step, c_so_prev, ring_off, cur0, cur1);
+    auto step_body = [&](auto p_c, int step, int step_prev, int ring_off, int cur0, int cur1) {
+        pair(std::integral_constant<int, 0>{}, p_c, step, step_prev, ring_off, cur0, cur1);
+        pair(std::integral_constant<int, 1>{}, p_c, step, step_prev, ring_off, cur0, cur1);
+        pair(std::integral_constant<int, 2>{}, p_c, step, step_prev, ring_off, cur0, cur1);
+        pair(std::integral_constant<int, 3>{}, p_c, step, step_prev, ring_off, cur0, cur1);
     };
 
     PK_WAIT(7);
@@ -362,18 +422,17 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
     if (wcls == 1) __builtin_amdgcn_s_setprio(PKBS_PRIO);
 #endif
     asm volatile("; PK8P_LOOP_BEGIN" ::: "memory");
-    // (MASK: hipcc's own wait for the aux loads — all but the 3 DMA pieces issued behind them — is the smallest in the loop)
-    if constexpr (MASK) asm volatile("; PK8P_MIN_VMCNT 3" ::: "memory");
+    // (MASK without BITS: hipcc's own wait for the register mask loads — 3 requests behind them — is the smallest in the loop)
+    if constexpr (MASK && !BITS) asm volatile("; PK8P_MIN_VMCNT 3" ::: "memory");
     else asm volatile("; PK8P_MIN_VMCNT 7" ::: "memory");
     int last_parity = 0, ring_off = 0;
     for (int s = s_begin; s < s_end; s += 2) {
         const int cur0 = frag_off0 + ring_off, cur1 = frag_off1 + ring_off;
         // (the first step has no predecessor: its two "departing" tiles are zeros sent to a dead offset — no branch in the block)
-        const unsigned so0 = s > s_begin ? (unsigned)(s - 1) * c_step_bytes + c_col_bytes : DEAD_OFF;
-        step_body(std::integral_constant<int, 0>{}, s, so0, ring_off, cur0, cur1);
+        step_body(std::integral_constant<int, 0>{}, s, s > s_begin ? s - 1 : -1, ring_off, cur0, cur1);
         last_parity = 0;
         if (s + 1 >= s_end) break;
-        step_body(std::integral_constant<int, 1>{}, s + 1, (unsigned)s * c_step_bytes + c_col_bytes, ring_off, cur0, cur1);
+        step_body(std::integral_constant<int, 1>{}, s + 1, s, ring_off, cur0, cur1);
         last_parity = 1;
         ring_off ^= 65536;
     }
@@ -382,14 +441,13 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
     PK_WAIT(0);  // (the trailing DMAs are empty, but they still target LDS)
 #undef PK_WAIT
     // the last step leaves from whichever set it used
-    const unsigned c_so_last = (unsigned)(s_end - 1) * c_step_bytes + c_col_bytes;
     u32x4 keep0, keep1;
     if (last_parity == 0) {
-        keep0 = emit(acc[0], 0, c_so_last);
-        keep1 = emit(acc[0], 1, c_so_last);
+        keep0 = emit(acc[0], 0, s_end - 1);
+        keep1 = emit(acc[0], 1, s_end - 1);
     } else {
-        keep0 = emit(acc[1], 0, c_so_last);
-        keep1 = emit(acc[1], 1, c_so_last);
+        keep0 = emit(acc[1], 0, s_end - 1);
+        keep1 = emit(acc[1], 1, s_end - 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" :: "v"(keep0), "v"(keep1) : "memory");  // (both tiles' data alive until the stores are done)
     PK_STAMP();  // stores acknowledged
@@ -427,7 +485,8 @@ extern "C" int pk_gemmbs_eligible(const void* A, const void* B, const void* C, l
 
 // Returns 1 if the GEMM was launched or a hip error code (the caller has asked pk_gemmbs_eligible).
 extern "C" int pk_gemmbs_launch(const void* A, const void* B, void* C, long long M, long long N, long long K,
-                                long long lda, long long ldb, int b_col, EpiParams ep, int dtype, void* stream) {
+                                long long lda, long long ldb, int b_col, EpiParams ep, int dtype, void* stream,
+                                unsigned char* bits, long long ldbits) {
     const long long nt_n = (N + BNT - 1) / BNT, steps = (M + BMS - 1) / BMS;
     const long long G0 = std::min<long long>(steps, std::max<long long>(1, 256 / nt_n));
     const int steps_per = (int)((steps + G0 - 1) / G0);
@@ -439,18 +498,20 @@ extern "C" int pk_gemmbs_launch(const void* A, const void* B, void* C, long long
     hipStream_t s = (hipStream_t)stream;
     const bool mask = ep.mode == 2;
     const bool relu = ep.act == PK_ACT_RELU && !mask;
-    const unsigned aux_bytes = mask ? (unsigned)extent(M, N, ep.ldaux) : 0u;
+    const unsigned aux_bytes = (mask && !bits) ? (unsigned)extent(M, N, ep.ldaux) : 0u;
     unsigned long long* stamps = nullptr;  // PK8P_STAMP_PTR: device buffer of the diagnostic build's time stamps
     if (const char* e = getenv("PK8P_STAMP_PTR")) stamps = (unsigned long long*)strtoull(e, nullptr, 0);
-#define PK_K(TT, BC, NKV, RL, MK)                                                                                      \
-    hipLaunchKernelGGL((gemmbs_kernel<TT, BC, NKV, RL, MK>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C,     \
-                       (const TT*)(mask ? ep.aux : ep.bias), M, N, lda, ldb, ep.ldc, ep.ldaux, a_bytes, b_bytes,        \
-                       c_bytes, aux_bytes, (int)nt_n, steps_per, (int)steps, ep.alpha, stamps)
-#define PK_R(TT, BC, NKV)                               \
-    do {                                                \
-        if (mask) PK_K(TT, BC, NKV, false, true);       \
-        else if (relu) PK_K(TT, BC, NKV, true, false);  \
-        else PK_K(TT, BC, NKV, false, false);           \
+#define PK_K(TT, BC, NKV, RL, MK, BT)                                                                                  \
+    hipLaunchKernelGGL((gemmbs_kernel<TT, BC, NKV, RL, MK, BT>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, \
+                       (const TT*)(mask && !bits ? ep.aux : ep.bias), M, N, lda, ldb, ep.ldc, ep.ldaux, a_bytes,        \
+                       b_bytes, c_bytes, aux_bytes, (int)nt_n, steps_per, (int)steps, ep.alpha, stamps, bits, ldbits)
+#define PK_R(TT, BC, NKV)                                           \
+    do {                                                            \
+        if (mask && bits) PK_K(TT, BC, NKV, false, true, true);     \
+        else if (mask) PK_K(TT, BC, NKV, false, true, false);       \
+        else if (relu && bits) PK_K(TT, BC, NKV, true, false, true); \
+        else if (relu) PK_K(TT, BC, NKV, true, false, false);       \
+        else PK_K(TT, BC, NKV, false, false, false);                \
     } while (0)
 #define PK_N(TT, BC) PK_R(TT, BC, 8)
 #define PK_B(TT)                                \

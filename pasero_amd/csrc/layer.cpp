@@ -120,6 +120,7 @@ int check(const PkLayer& L) {
     PK_REQ(L.B > 0 && L.T > 0 && L.d > 0 && L.f > 0 && L.heads > 0 && L.d % L.heads == 0, "pk_layer: bad sizes");
     PK_REQ(L.x && L.self.w_in && L.self.w_o && L.self.ln_g && L.ffn.w1 && L.ffn.w2 && L.ffn.ln_g, "pk_layer: null parameter");
     PK_REQ(!L.is_decoder || (L.enc && L.S > 0 && L.cross.w_in && L.cross.w_o && L.cross.ln_g), "pk_layer: decoder layer without encoder output");
+    PK_REQ(!L.ffn.bits || (L.act == PK_ACT_RELU && L.f % 8 == 0), "pk_layer: the bit mask is the ReLU feed-forward's");
     return 0;
 }
 
@@ -178,7 +179,10 @@ int layer_fwd_prenorm(const PkLayer& L) {
     }
     // ---- feed-forward ----
     PK_TRY(pre_norm(L, z, L.ffn.ln_g, L.ffn.ln_b, L.ffn.ln_out, L.ffn.mean, L.ffn.rstd));
-    PK_TRY(linear(L.ffn.ln_out, L.ffn.w1, L.ffn.b1, L.ffn.h, rows, f, d, L.act, L.ffn.pre));
+    if (L.ffn.bits)
+        PK_TRY(pk_gemm_relu_bits(L.ffn.ln_out, L.ffn.w1, L.ffn.h, L.ffn.b1, L.ffn.bits, rows, f, d, d, d, f, f / 8, 0, 0, 1.f, dt, L.stream));
+    else
+        PK_TRY(linear(L.ffn.ln_out, L.ffn.w1, L.ffn.b1, L.ffn.h, rows, f, d, L.act, L.ffn.pre));
     PK_TRY(linear(L.ffn.h, L.ffn.w2, L.ffn.b2, L.ffn.y, rows, d, f, PK_ACT_NONE, nullptr));
     return pre_end(L, L.ffn.y, z, L.ffn.z, L.ffn.drop_offset);
 }
@@ -215,9 +219,12 @@ extern "C" int pk_layer_fwd(const PkLayer* lp) {
                          L.cross.mean, L.cross.rstd, L.cross.drop_offset));
         y = L.cross.y;
     }
-    // ---- feed-forward ----
-    PK_TRY(pk_gemm(y, L.ffn.w1, L.ffn.h, L.ffn.b1, nullptr, L.ffn.pre, rows, f, d, d, d, f, 0, f, 0, 0, L.act, 0, 1.f, dt, 1, nullptr,
-                   0, nullptr, L.stream));
+    // ---- feed-forward (ReLU at base width: the mask also leaves as one bit per element, for the dH GEMM of backward) ----
+    if (L.ffn.bits)
+        PK_TRY(pk_gemm_relu_bits(y, L.ffn.w1, L.ffn.h, L.ffn.b1, L.ffn.bits, rows, f, d, d, d, f, f / 8, 0, 0, 1.f, dt, L.stream));
+    else
+        PK_TRY(pk_gemm(y, L.ffn.w1, L.ffn.h, L.ffn.b1, nullptr, L.ffn.pre, rows, f, d, d, d, f, 0, f, 0, 0, L.act, 0, 1.f, dt, 1, nullptr,
+                       0, nullptr, L.stream));
     return block_end(L, L.ffn.h, f, L.ffn.w2, L.ffn.b2, y, L.ffn.ln_g, L.ffn.ln_b, L.ffn.z, L.ffn.y, L.ffn.mean, L.ffn.rstd,
                      L.ffn.drop_offset);
 }
@@ -282,7 +289,9 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
         // feed-forward
         PK_TRY(undrop(L.dy, b.dsub_f, L.ffn.drop_offset));
         const void* do_f = drop ? b.dsub_f : L.dy;
-        if (L.act == PK_ACT_NONE)
+        if (L.ffn.bits)
+            PK_TRY(pk_gemm_relu_bits(do_f, L.ffn.w2, b.dh, nullptr, L.ffn.bits, rows, f, d, d, f, f, f / 8, 1, 2, 1.f, dt, L.stream));
+        else if (L.act == PK_ACT_NONE)
             PK_TRY(pk_gemm(do_f, L.ffn.w2, b.dh, nullptr, nullptr, nullptr, rows, f, d, d, f, f, 0, 0, 0, 1, PK_ACT_NONE, 0, 1.f, dt, 1, nullptr,
                            0, nullptr, L.stream));
         else
@@ -323,7 +332,9 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
     }
     // ---- feed-forward block ----
     PK_TRY(ln_bwd(L.dy, L.ffn.z, L.ffn.ln_g, L.ffn.mean, L.ffn.rstd, b.dres_f, b.dsub_f, L.ffn.dln_g, L.ffn.dln_b, L.ffn.drop_offset));
-    if (L.act == PK_ACT_NONE)
+    if (L.ffn.bits)
+        PK_TRY(pk_gemm_relu_bits(b.dsub_f, L.ffn.w2, b.dh, nullptr, L.ffn.bits, rows, f, d, d, f, f, f / 8, 1, 2, 1.f, dt, L.stream));
+    else if (L.act == PK_ACT_NONE)
         PK_TRY(pk_gemm(b.dsub_f, L.ffn.w2, b.dh, nullptr, nullptr, nullptr, rows, f, d, d, f, f, 0, 0, 0, 1, PK_ACT_NONE, 0, 1.f, dt, 1,
                        nullptr, 0, nullptr, L.stream));
     else  // dH = (dZ W2) * act'(.)

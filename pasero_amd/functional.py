@@ -60,6 +60,47 @@ def gemm(a: Tensor, b: Tensor, *, a_col: bool = False, b_col: bool = False, bias
     return out
 
 
+def relu_bits_eligible(x: Tensor, w1: Tensor) -> bool:
+    """can the ReLU feed-forward over x [M, K] with fc1 weight w1 [f, K] keep its mask as one bit per element
+    (pk_gemm_relu_bits: fc1 forward writes it, the dH GEMM of backward reads it instead of the activations)?"""
+    if not (x.is_cuda and w1.is_cuda) or x.dtype != w1.dtype or x.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    if x.dim() != 2 or w1.dim() != 2 or x.size(1) != w1.size(1) or x.stride(1) != 1 or w1.stride(1) != 1 or w1.size(0) % 32:
+        return False
+    M, K, N = x.size(0), x.size(1), w1.size(0)
+    L = lib.load()
+    # forward shape (row-form W1) and backward shape (dZ [M, K] times col-form W2 [K, N]): same sizes, other pointers
+    return bool(L.pk_gemm_relu_bits_eligible(ptr(x), ptr(w1), ptr(x), None, M, N, K, _ld(x), _ld(w1), N, N // 8, 0, 0,
+                                             dtype_code(x))) and \
+        bool(L.pk_gemm_relu_bits_eligible(ptr(x), ptr(w1), ptr(x), None, M, N, K, _ld(x), N, N, N // 8, 1, 2, dtype_code(x)))
+
+
+def gemm_relu_bits(x: Tensor, w1: Tensor, bias: Optional[Tensor]):
+    """h = relu(x w1ᵀ + bias) and its mask as bits [M, f / 8] uint8"""
+    require_gpu(x, w1, bias)
+    _same(x, w1, bias, what='gemm_relu_bits')
+    M, K = x.shape
+    N = w1.size(0)
+    h = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    bits = torch.empty(M, N // 8, dtype=torch.uint8, device=x.device)
+    check(lib.load().pk_gemm_relu_bits(ptr(x), ptr(w1), ptr(h), ptr(bias), ptr(bits), M, N, K, _ld(x), _ld(w1), N, N // 8, 0, 0,
+                                       1.0, dtype_code(x), stream_ptr()), 'pk_gemm_relu_bits')
+    return h, bits
+
+
+def gemm_mask_bits(dy: Tensor, w2: Tensor, bits: Tensor) -> Tensor:
+    """dh = (dy w2) where the bit is set, 0 elsewhere; dy [M, K], w2 [K, f] (fc2's weight: col form), bits [M, f / 8]"""
+    require_gpu(dy, w2, bits)
+    _same(dy, w2, what='gemm_mask_bits')
+    M, K = dy.shape
+    N = w2.size(1)
+    assert w2.size(0) == K and bits.shape == (M, N // 8) and bits.dtype == torch.uint8 and bits.is_contiguous()
+    dh = torch.empty(M, N, dtype=dy.dtype, device=dy.device)
+    check(lib.load().pk_gemm_relu_bits(ptr(dy), ptr(w2), ptr(dh), None, ptr(bits), M, N, K, _ld(dy), _ld(w2), N, N // 8, 1, 2,
+                                       1.0, dtype_code(dy), stream_ptr()), 'pk_gemm_relu_bits')
+    return dh
+
+
 def _wgrad_problem(dy: Tensor, x: Tensor, dw: Optional[Tensor], db: Optional[Tensor]) -> 'lib.PkWgradProblem':
     return lib.PkWgradProblem(ptr(dy), ptr(x), ptr(dw), ptr(db), dy.size(1), x.size(1), dy.size(0), _ld(dy), _ld(x),
                               _ld(dw) if dw is not None else x.size(1))

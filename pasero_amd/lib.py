@@ -24,6 +24,8 @@ SIGNATURES = {
     'pk_gemm': (I, [P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, SZ, P, P]),
     'pk_gemm_use_8p': (I, [I]),
     'pk_gemm_use_bs': (I, [I]),
+    'pk_gemm_relu_bits_eligible': (I, [P, P, P, P, LL, LL, LL, LL, LL, LL, LL, I, I, I]),
+    'pk_gemm_relu_bits': (I, [P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, I, I, F, I, P]),
     'pk_gemm_timing_start': (I, [I, I]),
     'pk_gemm_timing_stop': (I, []),
     'pk_gemm_timing_read': (I, [I, P, P, P, P, P, P, P]),
@@ -92,8 +94,8 @@ class PkAttnBlock(ctypes.Structure):
 
 
 class PkFfnBlock(ctypes.Structure):
-    _fields_ = [(n, P) for n in ('w1', 'b1', 'w2', 'b2', 'ln_g', 'ln_b', 'h', 'pre', 'z', 'y', 'ln_out', 'mean', 'rstd', 'dw1',
-                                 'db1', 'dw2', 'db2', 'dln_g', 'dln_b')] + [('drop_offset', ULL)]
+    _fields_ = [(n, P) for n in ('w1', 'b1', 'w2', 'b2', 'ln_g', 'ln_b', 'h', 'pre', 'z', 'y', 'ln_out', 'bits', 'mean', 'rstd',
+                                 'dw1', 'db1', 'dw2', 'db2', 'dln_g', 'dln_b')] + [('drop_offset', ULL)]
 
 
 class PkLayer(ctypes.Structure):

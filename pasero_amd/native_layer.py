@@ -127,6 +127,16 @@ class NativeLayerFn(Function):
             n32 += B * H * T + 2 * rows
         if prenorm:  # + LayerNorm(block input) of every sub-block
             n16 += rows * d * (3 if is_decoder else 2)
+        # ReLU at base width: the mask for backward also as one bit per element (pk_gemm_relu_bits; same rule as the per-op path)
+        from . import functional as PF
+        key = ('bits', rows, d, f, dt)
+        use_bits = layer.__dict__.get('_native_bits')
+        if use_bits is None or use_bits[0] != key:
+            use_bits = (key, act == 'relu' and PF.relu_bits_eligible(x.view(rows, d), layer.fc1.weight))
+            layer.__dict__['_native_bits'] = use_bits
+        use_bits = use_bits[1]
+        if use_bits:
+            n16 += rows * f // 16
         a16 = torch.empty(n16, dtype=dt, device=dev)
         a32 = torch.empty(n32, dtype=torch.float32, device=dev)
         es = 2
@@ -177,6 +187,7 @@ class NativeLayerFn(Function):
         fb.ln_g, fb.ln_b = layer.final_layer_norm.weight.data_ptr(), layer.final_layer_norm.bias.data_ptr()
         fb.h = t16(rows * f)
         fb.pre = t16(rows * f) if need_pre else None
+        fb.bits = t16(rows * f // 16) if use_bits else None
         fb.z = t16(rows * d)
         fb.y = t16(rows * d)
         fb.ln_out = t16(rows * d) if prenorm else None

@@ -127,3 +127,28 @@ def test_gemmbs_is_bitwise_reproducible(F):
     first = F.gemm(a, w, bias=bias, act='relu')
     for _ in range(20):
         assert torch.equal(F.gemm(a, w, bias=bias, act='relu').view(torch.int16), first.view(torch.int16))
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_relu_mask_as_bits(F, dtype):
+    """pk_gemm_relu_bits: fc1 forward writes h and, next to it, one bit per element (h > 0); the dH GEMM reads the bits
+    instead of h.  h must equal pk_gemm's ReLU output bit for bit, the bits must be numpy's packbits of (h > 0) in little
+    bit order, and the masked product must equal pk_gemm mode 2 with h as the mask operand bit for bit — ragged rows too."""
+    rs = np.random.RandomState(5)
+    for M, N in ((32768, 2048), (12296 + 8, 1536)):
+        K = 512
+        x = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(dtype).cuda()
+        w1 = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32)).to(dtype).cuda()
+        b1 = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(dtype).cuda()
+        w2 = torch.from_numpy(rs.standard_normal((K, N)).astype(np.float32)).to(dtype).cuda()
+        dy = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(dtype).cuda()
+        assert F.relu_bits_eligible(x, w1)
+        h, bits = F.gemm_relu_bits(x, w1, b1)
+        h_ref = F.gemm(x, w1, bias=b1, act='relu')
+        assert torch.equal(h.view(torch.int16), h_ref.view(torch.int16))
+        want = np.packbits((h_ref.float() > 0).cpu().numpy(), axis=1, bitorder='little')
+        assert np.array_equal(bits.cpu().numpy(), want)
+        dh = F.gemm_mask_bits(dy, w2, bits)
+        dh_ref = F.gemm(dy, w2, b_col=True, act='relu', aux=h_ref, mode=2)
+        assert torch.equal(dh.view(torch.int16), dh_ref.view(torch.int16))
+    assert not F.relu_bits_eligible(x[:512], w1)  # too few rows: the tiled kernels, the activations as the mask
