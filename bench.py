@@ -126,9 +126,9 @@ class GemmTimer:
             return 'gemm8p_ln_kernel<%s>' % t
         if kernel & 0xF == 8 and kernel < 256:  # gemm8p instantiation: <T, A_COL, B_COL, ANY epilogue, TAIL K-tile>
             return 'gemm8p_kernel<%s, %s, %s, %s, %s>' % (t, tf[a_col], tf[b_col], tf[(kernel >> 4) & 1], tf[(kernel >> 5) & 1])
-        if kernel & 0x200:  # the B-stationary kernel (gemmbs.hip): <T, B_COL, K-tiles, ReLU, ReLU-mask, mask as bits>
-            return 'gemmbs_kernel<%s, %s, %d, %s, %s, %s>' % (t, tf[b_col], kernel & 0xF, tf[(kernel >> 4) & 1],
-                                                            tf[(kernel >> 5) & 1], tf[(kernel >> 6) & 1])
+        if kernel & 0x200:  # the B-stationary kernel (gemmbs.hip): <T, B_COL, K-tiles, activation, act'-mask, mask as bits, preact>
+            return 'gemmbs_kernel<%s, %s, %d, %d, %s, %s, %s>' % (t, tf[b_col], kernel & 0xF, (kernel >> 4) & 3, tf[(kernel >> 6) & 1],
+                                                                tf[(kernel >> 7) & 1], tf[(kernel >> 8) & 1])
         if kernel == 256:
             return 'gemm256_kernel<%s, %s, %s, 8>' % (t, tf[a_col], tf[b_col])
         return 'gemm_kernel<%s, %s, %s>' % (t, tf[a_col], tf[b_col])

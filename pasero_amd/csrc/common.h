@@ -188,22 +188,25 @@ __device__ __forceinline__ float act_bwd(int act, float x) {
 // tanhf cost 40-60 VALU instructions per element: in the epilogue of the C4 feed-forward GEMMs (GELU, 24 000 x 2048
 // outputs) that was as long as the GEMM itself (157 us at 308 TFLOP/s; gelu' in the dH GEMM: 196 us at 257).  The fp32
 // kernels keep the exact forms above (parity with the reference to 1e-6).
+// (v_rcp_f32, 1 ulp: `__frcp_rn` is a correctly rounded division — v_div_scale / v_rcp / four fma / v_div_fmas / v_div_fixup,
+// ten instructions per call, a third of GELU's cost in an epilogue)
+__device__ __forceinline__ float pk_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float act_fwd_fast(int act, float x) {
     switch (act) {
         case PK_ACT_RELU: return fmaxf(x, 0.f);
         case PK_ACT_GELU: {
             const float ax = fabsf(x) * 0.70710678118654752f;
-            const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+            const float t = pk_rcp(fmaf(0.3275911f, ax, 1.f));
             const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
             const float erf_abs = 1.f - poly * __expf(-ax * ax);
             return 0.5f * x * (1.f + copysignf(erf_abs, x));
         }
         case PK_ACT_GELU_TANH: {
             const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-            const float th = 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * u));  // exp -> inf: 1; exp -> 0: -1
+            const float th = 1.f - 2.f * pk_rcp(1.f + __expf(2.f * u));  // exp -> inf: 1; exp -> 0: -1
             return 0.5f * x * (1.f + th);
         }
-        case PK_ACT_SILU: return x * __frcp_rn(1.f + __expf(-x));
+        case PK_ACT_SILU: return x * pk_rcp(1.f + __expf(-x));
         default: return x;
     }
 }
@@ -212,7 +215,7 @@ __device__ __forceinline__ float act_bwd_fast(int act, float x) {
         case PK_ACT_RELU: return x > 0.f ? 1.f : 0.f;
         case PK_ACT_GELU: {  // cdf + x pdf: erf(x / sqrt 2) and the density share exp(-x^2 / 2)
             const float ax = fabsf(x) * 0.70710678118654752f;
-            const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+            const float t = pk_rcp(fmaf(0.3275911f, ax, 1.f));
             const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
             const float e = __expf(-ax * ax);
             const float cdf = 0.5f * (1.f + copysignf(1.f - poly * e, x));
@@ -221,12 +224,12 @@ __device__ __forceinline__ float act_bwd_fast(int act, float x) {
         case PK_ACT_GELU_TANH: {
             const float x2 = x * x;
             const float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
-            const float t = 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * u));
+            const float t = 1.f - 2.f * pk_rcp(1.f + __expf(2.f * u));
             const float du = 0.7978845608028654f * (1.f + 3.f * 0.044715f * x2);
             return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
         }
         case PK_ACT_SILU: {
-            const float s = __frcp_rn(1.f + __expf(-x));
+            const float s = pk_rcp(1.f + __expf(-x));
             return s * (1.f + x * (1.f - s));
         }
         default: return 1.f;

@@ -774,9 +774,9 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
             if (rc != 0) return rc == 1 ? 0 : rc;  // 1 = launched, 0 = not eligible, anything else = error
         }
         // short contraction (K = 512 / 256), many rows, lean epilogue: the B-stationary walk (gemmbs.hip) — no epilogue phase
-        // (sample tag 0x200 | K-tiles | 0x10 ReLU | 0x20 ReLU-mask epilogue of mode 2)
+        // (sample tag 0x200 | K-tiles | activation << 4 | 0x40 act'-mask epilogue of mode 2 | 0x80 mask as bits | 0x100 preact)
         if (splitk <= 1 && !asum_out && pk_gemmbs_eligible(A, B, C, M, N, K, lda, ldb, a_col, b_col, &ep)) {
-            const int tagbs = 0x200 | (int)(K / 64) | (ep.mode == 2 ? 0x20 : ep.act == PK_ACT_RELU ? 0x10 : 0);
+            const int tagbs = 0x200 | (int)(K / 64) | (ep.act << 4) | (ep.mode == 2 ? 0x40 : 0) | (ep.preact ? 0x100 : 0);
             GemmSample* sm = timing_begin(tagbs, a_col, b_col, 1, dtype16, M, N, K, stream);
             const int rc = pk_gemmbs_launch(A, B, C, M, N, K, lda, ldb, b_col, ep, dtype16, stream, nullptr, 0);
             timing_end(sm, stream);
@@ -1001,7 +1001,7 @@ extern "C" int pk_gemm_relu_bits(const void* A, const void* B, void* C, const vo
     EpiParams ep = relu_bits_epi(bias, C, ldc, mode, alpha);
     ep.aux = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    GemmSample* sm = timing_begin(0x200 | (int)(K / 64) | (mode == 2 ? 0x20 : 0x10) | 0x40, 0, b_col, 1, dtype, M, N, K, s);
+    GemmSample* sm = timing_begin(0x200 | (int)(K / 64) | (PK_ACT_RELU << 4) | (mode == 2 ? 0x40 : 0) | 0x80, 0, b_col, 1, dtype, M, N, K, s);
     const int rc = pk_gemmbs_launch(A, B, C, M, N, K, lda, ldb, b_col, ep, dtype, stream, bits, ldbits);
     timing_end(sm, s);
     return rc == 1 ? 0 : rc;

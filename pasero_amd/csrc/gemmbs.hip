@@ -48,7 +48,10 @@ constexpr int SMEM = RS * TILE;                // 128 KiB
 constexpr int LA = 20, SYNC = 4;               // DMA look-ahead (tiles), K-tiles between barriers
 constexpr unsigned DEAD_OFF = 0x80000000u;
 #ifndef PKBS_EMIT_VALU
-#define PKBS_EMIT_VALU 5  // VALU instructions of a departing tile per MFMA gap
+#define PKBS_EMIT_VALU 5  // VALU instructions of a departing tile per MFMA gap (lean epilogues)
+#endif
+#ifndef PKBS_EMIT_VALU_ACT
+#define PKBS_EMIT_VALU_ACT 22  // the same with GELU / GELU' in the tile (~170 VALU instructions per lane)
 #endif
 
 // column of the wave's 32-column slab that row `nu` (0..15) of B-fragment tile j holds: lane (q = l >> 4) then owns the
@@ -60,15 +63,25 @@ __device__ __forceinline__ int bcol(int j, int nu) { return 8 * (nu >> 2) + 4 * 
 // BITS: the ReLU mask as ONE BIT per element instead of the activations themselves — `bits` [M][ldbits] bytes, bit (n & 7) of
 // byte n >> 3 of a row = (the stored 16-bit output > 0).  The RELU epilogue writes it next to h (fc1 forward); the MASK
 // epilogue reads it instead of aux (fc2 dX: 17 MB instead of 134 MB at C2 — that GEMM is memory-bound).
-template <typename T, bool B_COL, int NK, bool RELU, bool MASK, bool BITS>
+// ACT: the activation of the forward epilogue (PK_ACT_NONE / RELU / GELU), or — MASK — whose derivative multiplies the
+// product: ReLU' from the stored activations (or their bits), GELU' from the stored pre-activations.  PRE: the value before
+// the activation leaves too (`preact`, same leading dimension as C), rounded like C.  GELU as the tiled kernels evaluate it
+// (act_fwd_fast / act_bwd_fast, common.h): ~20 VALU instructions per element, here between the walk's MFMAs instead of in
+// an epilogue phase of their own (the C4 feed-forward GEMMs: 149 / 182 us on the tiled kernel at 24 000 x 2048 x 512).
+template <typename T, bool B_COL, int NK, int ACT, bool MASK, bool BITS, bool PRE>
 __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A, const T* __restrict__ B,
                                                        T* __restrict__ C, const T* __restrict__ bias, long long M,
                                                        long long N, long long lda, long long ldb, long long ldc,
                                                        long long ldaux, unsigned a_bytes, unsigned b_bytes,
                                                        unsigned c_bytes, unsigned aux_bytes, int nt_n, int steps_per,
                                                        int total_steps, float alpha, unsigned long long* stamps,
-                                                       unsigned char* __restrict__ bits, long long ldbits) {
-    static_assert(!BITS || (RELU != MASK), "BITS: written by the ReLU epilogue, read by the mask epilogue");
+                                                       unsigned char* __restrict__ bits, long long ldbits,
+                                                       T* __restrict__ preact) {
+    constexpr bool RELU = ACT == PK_ACT_RELU && !MASK;
+    static_assert(ACT == PK_ACT_NONE || ACT == PK_ACT_RELU || ACT == PK_ACT_GELU, "activations of this kernel");
+    static_assert(!MASK || ACT != PK_ACT_NONE, "MASK: the derivative of an activation");
+    static_assert(!PRE || (!MASK && ACT == PK_ACT_GELU), "PRE: the forward epilogue of an activation that needs it in backward");
+    static_assert(!BITS || ACT == PK_ACT_RELU, "BITS: the ReLU mask");
     static_assert(NK == 8, "two steps = half a turn of the 32-slot ring: K = 512");
     static_assert(NK * BIMG <= SMEM && LA + 6 <= RS && LA == 20, "LDS map / counted wait below");
     typedef typename M16<T>::vec V;
@@ -156,6 +169,8 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
         }
     };
     __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)c_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rpre = __builtin_amdgcn_make_buffer_rsrc((void*)preact, 0, PRE ? (int)c_bytes : 0, 0x00020000);
+
 
     // ---- B panel -> registers: bfr[kt][j][kk] = rows {bcol(j, l & 15)} of the wave's slab, k = 64 kt + 32 kk + 8 (l >> 4) + 0..7 ----
     V bfr[NK][2][2];
@@ -272,9 +287,11 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
     // it landed in the last lanes of the stored rows (zeros or garbage in lanes 12..15 of every 16, one register pair).
     // hipcc only guards the form without an SGPR offset (GCNHazardRecognizer: "no hazard if soffset is a register").  So
     // the packed tile is RETURNED and the caller keeps it alive (an empty asm use) until the position's MFMAs have issued.
-    auto emit = [&](f32x4 (&ac)[2][2], int i, int step_out) -> u32x4 {  // (step_out < 0: nothing to store — dead offsets)
+    auto emit = [&](f32x4 (&ac)[2][2], int i, int step_out, u32x4& keep_pre) -> u32x4 {  // (keep_pre: PRE's second store, as the return value)
+         // (step_out < 0: nothing to store — dead offsets)
         const unsigned c_so = step_out < 0 ? DEAD_OFF : (unsigned)step_out * c_step_bytes + c_col_bytes;
         float x[8] = {ac[i][0][0], ac[i][0][1], ac[i][0][2], ac[i][0][3], ac[i][1][0], ac[i][1][1], ac[i][1][2], ac[i][1][3]};
+        float pre[8];
         unsigned mbyte = 0;
         if constexpr (MASK && BITS)  // (step_out < 0: whatever the slot holds — the tile goes nowhere)
             mbyte = *reinterpret_cast<const unsigned char*>(smem + bit_lds + ((step_out - s_begin) & (BITS_RING - 1)) * BITS_LDS + 64 * i);
@@ -286,10 +303,13 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
             } else if constexpr (MASK) {
                 Vec16<T> av;
                 av.raw = __builtin_bit_cast(uint4, auxv[i]);
-                y = av.get(e) > 0.f ? y : 0.f;
+                if constexpr (ACT == PK_ACT_RELU) y = av.get(e) > 0.f ? y : 0.f;
+                else y *= act_bwd_fast(ACT, av.get(e));
             } else {
                 y += bias_f[e];
-                if (RELU) y = fmaxf(y, 0.f);
+                if constexpr (PRE) pre[e] = y;
+                if constexpr (ACT == PK_ACT_RELU) y = fmaxf(y, 0.f);
+                else if constexpr (ACT != PK_ACT_NONE) y = act_fwd_fast(ACT, y);
             }
             x[e] = y;
         }
@@ -325,6 +345,12 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
 #define PKBS_STORE_AUX 2 /* nt */
 #endif
         __builtin_amdgcn_raw_buffer_store_b128(o, rc, c_voff, so, PKBS_STORE_AUX);
+        if constexpr (PRE) {  // (same rows, columns and pitch as C: only the descriptor differs)
+            f32x8 pf = {pre[0], pre[1], pre[2], pre[3], pre[4], pre[5], pre[6], pre[7]};
+            const u32x4 po = __builtin_bit_cast(u32x4, __builtin_convertvector(pf, typename H16<T>::vec));
+            __builtin_amdgcn_raw_buffer_store_b128(po, rpre, c_voff, so, PKBS_STORE_AUX);
+            keep_pre = po;
+        }
         ac[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         ac[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         return o;
@@ -359,12 +385,12 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[P][i][j] = M16<T>::mfma(bfr[KT][j][kk], a[i][kk], acc[P][i][j]);
         };
-        u32x4 keep0 = {0u, 0u, 0u, 0u};
+        u32x4 keep0 = {0u, 0u, 0u, 0u}, keepp = {0u, 0u, 0u, 0u};
 #ifndef PKBS_ABL_NOREAD
         read_a(fa[1], cur0, cur1, SL + 1);  // fa[0] holds tile SL
 #endif
 #ifndef PKBS_ABL_NOSTORE
-        if constexpr (U < 2) keep0 = emit(acc[P ^ 1], U, step_prev);  // tile 0 of the previous step leaves in the first pair, tile 1 in the second
+        if constexpr (U < 2) keep0 = emit(acc[P ^ 1], U, step_prev, keepp);  // tile 0 of the previous step leaves in the first pair, tile 1 in the second
 #endif
         mma(std::integral_constant<int, 2 * U>{}, fa[0]);
 #ifndef PKBS_ABL_NOREAD
@@ -383,9 +409,10 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
 #ifndef PKBS_NO_SGB
 #define PK_GAP_DS __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #define PK_GAP_DSV(N) PK_GAP_DS __builtin_amdgcn_sched_group_barrier(0x002, N, 0);
+        constexpr int EV = ACT == PK_ACT_GELU ? PKBS_EMIT_VALU_ACT : PKBS_EMIT_VALU;
         if constexpr (U < 2) {  // + a departing tile: its arithmetic in the gaps that also carry a read, its store(s) behind them
-            PK_GAP_DSV(PKBS_EMIT_VALU) PK_GAP_DSV(PKBS_EMIT_VALU) PK_GAP_DSV(PKBS_EMIT_VALU) PK_GAP_DSV(PKBS_EMIT_VALU)
-            PK_GAP_DSV(PKBS_EMIT_VALU) PK_GAP_DSV(PKBS_EMIT_VALU) PK_GAP_DSV(PKBS_EMIT_VALU) PK_GAP_DSV(PKBS_EMIT_VALU)
+            PK_GAP_DSV(EV) PK_GAP_DSV(EV) PK_GAP_DSV(EV) PK_GAP_DSV(EV)
+            PK_GAP_DSV(EV) PK_GAP_DSV(EV) PK_GAP_DSV(EV) PK_GAP_DSV(EV)
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -400,6 +427,7 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
 #undef PK_GAP_DS
 #endif
         if constexpr (U < 2) asm volatile("" :: "v"(keep0));  // (the store's data registers stay untouched until here)
+        if constexpr (U < 2 && PRE) asm volatile("" :: "v"(keepp));
         __builtin_amdgcn_sched_barrier(0);
         // the mask operand, behind the second departing tile.  Registers (MASK): this step's, used when its tiles leave, 6
         // K-tiles from here — hipcc's wait in front of that use leaves only the 3 requests behind it in flight.  LDS (MASK
@@ -441,15 +469,15 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
     PK_WAIT(0);  // (the trailing DMAs are empty, but they still target LDS)
 #undef PK_WAIT
     // the last step leaves from whichever set it used
-    u32x4 keep0, keep1;
+    u32x4 keep0 = {0u, 0u, 0u, 0u}, keep1 = {0u, 0u, 0u, 0u}, keepp0 = {0u, 0u, 0u, 0u}, keepp1 = {0u, 0u, 0u, 0u};
     if (last_parity == 0) {
-        keep0 = emit(acc[0], 0, s_end - 1);
-        keep1 = emit(acc[0], 1, s_end - 1);
+        keep0 = emit(acc[0], 0, s_end - 1, keepp0);
+        keep1 = emit(acc[0], 1, s_end - 1, keepp1);
     } else {
-        keep0 = emit(acc[1], 0, s_end - 1);
-        keep1 = emit(acc[1], 1, s_end - 1);
+        keep0 = emit(acc[1], 0, s_end - 1, keepp0);
+        keep1 = emit(acc[1], 1, s_end - 1, keepp1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" :: "v"(keep0), "v"(keep1) : "memory");  // (both tiles' data alive until the stores are done)
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(keep0), "v"(keep1), "v"(keepp0), "v"(keepp1) : "memory");  // (both tiles' data alive until the stores are done)
     PK_STAMP();  // stores acknowledged
 #undef PK_STAMP
 }
@@ -467,8 +495,13 @@ inline long long extent(long long rows, long long cols, long long ld) { return (
 extern "C" int pk_gemmbs_eligible(const void* A, const void* B, const void* C, long long M, long long N, long long K,
                                   long long lda, long long ldb, int a_col, int b_col, const EpiParams* ep) {
     if (!g_use_bs || a_col || K != 512) return 0;
-    const bool mask = ep->mode == 2 && ep->act == PK_ACT_RELU && ep->aux;  // dH = (dY W2) * relu'(h)
-    if (ep->preact || (ep->act != PK_ACT_NONE && ep->act != PK_ACT_RELU) || (ep->mode != 0 && !mask)) return 0;
+    // dH = (dY W2) * relu'(h) / * gelu'(pre);  forward: none, ReLU, or GELU with the pre-activation as a second output
+    const bool mask = ep->mode == 2 && (ep->act == PK_ACT_RELU || ep->act == PK_ACT_GELU) && ep->aux;
+    if (ep->mode != 0 && !mask) return 0;
+    if (!mask) {
+        const bool gelu = ep->act == PK_ACT_GELU && ep->preact && ep->ldpre == ep->ldc && ((uintptr_t)ep->preact % 16) == 0;
+        if (!gelu && (ep->preact || (ep->act != PK_ACT_NONE && ep->act != PK_ACT_RELU))) return 0;
+    }
     if (N < BNT || N % 8 || M < 32 * BMS) return 0;
     auto al = [](const void* p, long long ld) { return ((uintptr_t)p % 16) == 0 && (ld % 8) == 0; };
     if (!al(A, lda) || !al(B, ldb) || !al(C, ep->ldc) || (ep->bias && ((uintptr_t)ep->bias % 16))) return 0;
@@ -497,21 +530,24 @@ extern "C" int pk_gemmbs_launch(const void* A, const void* B, void* C, long long
     dim3 grid((unsigned)(nt_n * G)), block(512);
     hipStream_t s = (hipStream_t)stream;
     const bool mask = ep.mode == 2;
-    const bool relu = ep.act == PK_ACT_RELU && !mask;
+    const bool relu = ep.act == PK_ACT_RELU && !mask, gelu = ep.act == PK_ACT_GELU;
     const unsigned aux_bytes = (mask && !bits) ? (unsigned)extent(M, N, ep.ldaux) : 0u;
     unsigned long long* stamps = nullptr;  // PK8P_STAMP_PTR: device buffer of the diagnostic build's time stamps
     if (const char* e = getenv("PK8P_STAMP_PTR")) stamps = (unsigned long long*)strtoull(e, nullptr, 0);
-#define PK_K(TT, BC, NKV, RL, MK, BT)                                                                                  \
-    hipLaunchKernelGGL((gemmbs_kernel<TT, BC, NKV, RL, MK, BT>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, \
-                       (const TT*)(mask && !bits ? ep.aux : ep.bias), M, N, lda, ldb, ep.ldc, ep.ldaux, a_bytes,        \
-                       b_bytes, c_bytes, aux_bytes, (int)nt_n, steps_per, (int)steps, ep.alpha, stamps, bits, ldbits)
-#define PK_R(TT, BC, NKV)                                           \
-    do {                                                            \
-        if (mask && bits) PK_K(TT, BC, NKV, false, true, true);     \
-        else if (mask) PK_K(TT, BC, NKV, false, true, false);       \
-        else if (relu && bits) PK_K(TT, BC, NKV, true, false, true); \
-        else if (relu) PK_K(TT, BC, NKV, true, false, false);       \
-        else PK_K(TT, BC, NKV, false, false, false);                \
+#define PK_K(TT, BC, NKV, AC, MK, BT, PR)                                                                                  \
+    hipLaunchKernelGGL((gemmbs_kernel<TT, BC, NKV, AC, MK, BT, PR>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, \
+                       (const TT*)(mask && !bits ? ep.aux : ep.bias), M, N, lda, ldb, ep.ldc, ep.ldaux, a_bytes,            \
+                       b_bytes, c_bytes, aux_bytes, (int)nt_n, steps_per, (int)steps, ep.alpha, stamps, bits, ldbits,       \
+                       (TT*)ep.preact)
+#define PK_R(TT, BC, NKV)                                                               \
+    do {                                                                                \
+        if (mask && gelu) PK_K(TT, BC, NKV, PK_ACT_GELU, true, false, false);           \
+        else if (mask && bits) PK_K(TT, BC, NKV, PK_ACT_RELU, true, true, false);       \
+        else if (mask) PK_K(TT, BC, NKV, PK_ACT_RELU, true, false, false);              \
+        else if (gelu) PK_K(TT, BC, NKV, PK_ACT_GELU, false, false, true);              \
+        else if (relu && bits) PK_K(TT, BC, NKV, PK_ACT_RELU, false, true, false);      \
+        else if (relu) PK_K(TT, BC, NKV, PK_ACT_RELU, false, false, false);             \
+        else PK_K(TT, BC, NKV, PK_ACT_NONE, false, false, false);                       \
     } while (0)
 #define PK_N(TT, BC) PK_R(TT, BC, 8)
 #define PK_B(TT)                                \

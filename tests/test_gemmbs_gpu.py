@@ -111,7 +111,10 @@ def test_gemmbs_declines_what_it_does_not_take(F):
     aux = torch.randn(16384, 1024, device='cuda').bfloat16()
     assert any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(a, w)))
     assert not any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(a, w, aux=aux, mode=1)))
-    assert not any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(a, w, act='gelu')))
+    assert not any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(a, w, act='gelu')))  # (GELU only with its preact output)
+    assert not any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(a, w, act='silu', preact=torch.empty_like(aux))))
+    wide = torch.empty(16384, 1032, device='cuda').bfloat16()
+    assert not any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(a, w, act='gelu', preact=wide[:, :1024])))  # pitch != C's
     assert not any(t & 0x200 for t in _timed_kernels(L, lambda: F.gemm(a[:512], w)))
     a2 = torch.randn(16384, 1024, device='cuda').bfloat16()
     w2 = torch.randn(1024, 1024, device='cuda').bfloat16()
@@ -152,3 +155,57 @@ def test_relu_mask_as_bits(F, dtype):
         dh_ref = F.gemm(dy, w2, b_col=True, act='relu', aux=h_ref, mode=2)
         assert torch.equal(dh.view(torch.int16), dh_ref.view(torch.int16))
     assert not F.relu_bits_eligible(x[:512], w1)  # too few rows: the tiled kernels, the activations as the mask
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_gelu_epilogues_between_the_mfmas(F, dtype):
+    """the GELU feed-forward of the speech / BERT-style configurations (pasero/models/modules.py:220-228): fc1 forward
+    writes gelu(pre) AND pre, the dH GEMM multiplies by gelu'(pre).  Both must equal the tiled kernel bit for bit (the
+    same act_fwd_fast / act_bwd_fast on the same fp32 sums) and the fp64 erf formulas to storage precision — ragged
+    rows, padded pitches, the bytes around the outputs."""
+    from pasero_amd import lib
+    L = lib.load()
+    rs = np.random.RandomState(11)
+    for M, N, pad in ((24000, 2048, 0), (12296, 1536, 8), (32768, 520, 24)):
+        K = 512
+        x, x64 = _operand(rs, M, K, 0, dtype)
+        w1, w164 = _operand(rs, N, K, 8, dtype)
+        w1, w164 = w1 * 0.05, w164 * 0.05
+        w164 = w1.double().cpu()
+        b1 = (torch.from_numpy(rs.standard_normal(N).astype(np.float32)) * 0.5).to(dtype)
+        res = {}
+        for mode in (1, 0):
+            L.pk_gemm_use_bs(mode)
+            hbuf = torch.full((M + 1, N + pad), 7.0, dtype=dtype, device='cuda')
+            pbuf = torch.full((M + 1, N + pad), 5.0, dtype=dtype, device='cuda')
+            tags = _timed_kernels(L, lambda: F.gemm(x, w1, bias=b1.cuda(), act='gelu', out=hbuf[:M, :N], preact=pbuf[:M, :N]))
+            assert any(t & 0x200 for t in tags) == bool(mode), (M, N, mode, tags)
+            res[mode] = (hbuf, pbuf)
+        L.pk_gemm_use_bs(1)
+        (h1, p1), (h0, p0) = res[1], res[0]
+        assert torch.equal(h1.view(torch.int16), h0.view(torch.int16)) and torch.equal(p1.view(torch.int16), p0.view(torch.int16)), (M, N)
+        assert bool((h1[M] == 7.0).all()) and bool((p1[M] == 5.0).all()), (M, N)
+        pre64 = x64 @ w164.t() + b1.double()
+        h64 = 0.5 * pre64 * (1 + torch.erf(pre64 / np.sqrt(2.0)))
+        eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        assert (p1[:M, :N].double().cpu() - pre64).abs().max().item() <= eps * pre64.abs().max().item() + 1e-3
+        assert (h1[:M, :N].double().cpu() - h64).abs().max().item() <= eps * h64.abs().max().item() + 1e-3
+        # backward: dH = (dZ W2) * gelu'(pre), W2 [K, N] in col form
+        dz, dz64 = _operand(rs, M, K, 8, dtype)
+        w2, w264 = _operand(rs, K, N, 0, dtype)
+        w2 = w2 * 0.05
+        w264 = w2.double().cpu()
+        pre = p1[:M, :N]
+        out = {}
+        for mode in (1, 0):
+            L.pk_gemm_use_bs(mode)
+            buf = torch.full((M + 1, N + pad), 3.0, dtype=dtype, device='cuda')
+            tags = _timed_kernels(L, lambda: F.gemm(dz, w2, b_col=True, aux=pre, act='gelu', mode=2, out=buf[:M, :N]))
+            assert any(t & 0x200 for t in tags) == bool(mode), (M, N, mode, tags)
+            out[mode] = buf
+        L.pk_gemm_use_bs(1)
+        assert torch.equal(out[1].view(torch.int16), out[0].view(torch.int16)), (M, N)
+        p64 = pre.double().cpu()
+        dgelu = 0.5 * (1 + torch.erf(p64 / np.sqrt(2.0))) + p64 * torch.exp(-0.5 * p64 * p64) / np.sqrt(2 * np.pi)
+        ref = (dz64 @ w264) * dgelu
+        assert (out[1][:M, :N].double().cpu() - ref).abs().max().item() <= eps * ref.abs().max().item() + 2e-3, (M, N)
