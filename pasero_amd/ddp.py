@@ -230,6 +230,7 @@ class DistributedDataParallel(nn.Module):
         self._is_cuda = bool(self._params) and self._params[0].is_cuda
         self._comm_stream = torch.cuda.Stream() if self._is_cuda else None
         self._buckets: List[_Bucket] = []
+        self._arena_layers = []  # layers whose backward writes its gradients into their bucket (native_layer.py)
         self._where = {}
         self._native: Optional[RcclComm] = None
         if (self._reduce_enabled and self._is_cuda and dist.get_backend(process_group) == 'nccl'
@@ -237,23 +238,78 @@ class DistributedDataParallel(nn.Module):
             self._native = RcclComm.get(process_group, self._params[0].device)
         self._build_buckets(int(bucket_cap_mb * (1 << 20)))
         self._callback_queued = False
+        self.packed_copies = 0  # gradients copied into their bucket so far (diagnostic: 0 for natively written layers)
         self._next = 0  # first bucket not launched yet
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(p)) for p in self._params]
         if self.world_size > 1:
             self._broadcast_state()
 
     # ---- setup ----
+    def _native_groups(self):
+        """{parameter: (layer, [its parameters in gradient-arena order])} for every layer whose backward is one native call
+        (pasero_amd/native_layer.py): such a layer's parameters sit together in one bucket, in the order pk_layer_bwd
+        writes their gradients, so that backward can write them straight into the bucket"""
+        groups = {}
+        if not (self._reduce_enabled and self._is_cuda):
+            return groups
+        try:
+            from . import native_layer, transformer
+        except Exception:  # (the package without its extension: CPU tests)
+            return groups
+        mine = set(self._params)
+        for m in self.module.modules():
+            is_dec = isinstance(m, transformer.TransformerDecoderLayer)
+            if not (is_dec or isinstance(m, transformer.TransformerEncoderLayer)) or not native_layer._static_ok(m, is_dec):
+                continue
+            pieces = native_layer.grad_arena_params(m, is_dec)
+            flat = [p for piece in pieces for p in piece]
+            if any(p is None or p not in mine or p in groups or p.numel() % 8 or p.dtype != flat[0].dtype
+                   or p.dtype not in (torch.bfloat16, torch.float16) for p in flat) or len(set(flat)) != len(flat):
+                continue  # (a projection without bias, a frozen or shared parameter: the layer keeps the packed path)
+            for p in flat:
+                groups[p] = (m, pieces)
+        return groups
+
     def _build_buckets(self, cap_bytes: int) -> None:
-        cur, cur_bytes = [], 0
+        groups = self._native_groups()
+        # units in reverse registration order (gradients arrive roughly so); a native layer is one unit, placed where its
+        # last-registered parameter falls
+        units, seen = [], set()
         for p in reversed(self._params):
-            nbytes = p.numel() * p.element_size()
-            if cur and (cur_bytes + nbytes > cap_bytes or p.dtype != cur[0].dtype):
-                self._buckets.append(_Bucket(cur, 8 * self.world_size))
-                cur, cur_bytes = [], 0
-            cur.append(p)
+            if p in seen:
+                continue
+            if p in groups:
+                layer, pieces = groups[p]
+                unit = [q for piece in pieces for q in piece]
+                units.append((unit, (layer, pieces)))
+            else:
+                unit = [p]
+                units.append((unit, None))
+            seen.update(unit)
+        cur, cur_bytes, cur_layers = [], 0, []
+
+        def close():
+            nonlocal cur, cur_bytes, cur_layers
+            if not cur:
+                return
+            b = _Bucket(cur, 8 * self.world_size)
+            self._buckets.append(b)
+            index = {p: i for i, p in enumerate(cur)}
+            for layer, pieces in cur_layers:  # (whole 16-byte slices: the pieces are contiguous in the bucket)
+                layer.__dict__['_pk_grad_arena'] = (b.flat,) + tuple(b.offsets[index[piece[0]]] for piece in pieces)
+                layer.__dict__['_pk_live_max'] = 0
+                self._arena_layers.append(layer)
+            cur, cur_bytes, cur_layers = [], 0, []
+
+        for unit, native in units:
+            nbytes = sum(p.numel() * p.element_size() for p in unit)
+            if cur and (cur_bytes + nbytes > cap_bytes or unit[0].dtype != cur[0].dtype):
+                close()
+            cur += unit
             cur_bytes += nbytes
-        if cur:
-            self._buckets.append(_Bucket(cur, 8 * self.world_size))
+            if native is not None:
+                cur_layers.append(native)
+        close()
         for bi, b in enumerate(self._buckets):
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
@@ -335,9 +391,14 @@ class DistributedDataParallel(nn.Module):
         # accumulated under no_sync() by earlier micro-batches (update_freq > 1 with rank- or batch-dependent adapters,
         # training.py:392-408) are reduced with the rest and must come back (`_finalize` keeps what was packed)
         b.packed = [p.grad is not None for p in b.params]
-        idx = [i for i, had in enumerate(b.packed) if had]
-        if len(idx) < len(b.params):
-            b.flat.zero_()  # parameters without a gradient on this rank contribute zeros
+        if not all(b.packed):  # parameters without a gradient on this rank contribute zeros
+            for i, had in enumerate(b.packed):
+                if not had:
+                    b.view(i).zero_()
+        # gradients a native layer's backward wrote into their slice (native_layer.py) are already where they belong
+        base, es = b.flat.data_ptr(), b.flat.element_size()
+        idx = [i for i, had in enumerate(b.packed) if had and b.params[i].grad.data_ptr() != base + b.offsets[i] * es]
+        self.packed_copies += len(idx)
         if not idx:
             return
         views = [b.view(i) for i in idx]
@@ -416,6 +477,8 @@ class DistributedDataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         if self._callback_queued and torch.is_grad_enabled():
             self._reset()  # the previous backward never reached its end-of-backward callback
+        for layer in self._arena_layers:
+            layer.__dict__['_pk_live_max'] = 0
         return self.module(*args, **kwargs)
 
     @contextlib.contextmanager

@@ -43,6 +43,22 @@ def layer_params(layer, is_decoder: bool):
     return ps
 
 
+def grad_arena_params(layer, is_decoder: bool):
+    """the layer's parameters in the order pk_layer_bwd lays their gradients out — three contiguous pieces: the [*, d]
+    weights (q | k | v | out [| the same of the cross block] | fc1), fc2's weight, and the vectors (q k v out biases,
+    LayerNorm weight and bias per attention block; fc1 bias, fc2 bias, final LayerNorm).  A gradient bucket that keeps
+    these pieces contiguous (pasero_amd/ddp.py) receives the layer's gradients straight from the backward call."""
+    blocks = [layer.self_attn] + ([layer.encoder_attn] if is_decoder else [])
+    norms = [layer.self_attn_layer_norm] + ([layer.encoder_attn_layer_norm] if is_decoder else [])
+    wd, vec = [], []
+    for a, n in zip(blocks, norms):
+        wd += [a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.out_proj.weight]
+        vec += [a.q_proj.bias, a.k_proj.bias, a.v_proj.bias, a.out_proj.bias, n.weight, n.bias]
+    wd.append(layer.fc1.weight)
+    vec += [layer.fc1.bias, layer.fc2.bias, layer.final_layer_norm.weight, layer.final_layer_norm.bias]
+    return wd, [layer.fc2.weight], vec
+
+
 def _static_ok(layer, is_decoder: bool) -> bool:
     """what does not change from call to call (decided once per layer object and training mode)"""
     from . import modules, transformer
@@ -199,6 +215,9 @@ class NativeLayerFn(Function):
         lay.stream = lib.stream_ptr()
         check(L.pk_layer_fwd(ctypes.byref(lay)), 'pk_layer_fwd')
         ctx.lay, ctx.layer, ctx.is_decoder = lay, layer, is_decoder
+        # (how often the layer ran since the reducer last looked: a layer applied twice in one graph must not write both
+        # gradients into the same bucket slice, see backward)
+        layer.__dict__['_pk_live_max'] = layer.__dict__.get('_pk_live_max', 0) + 1
         ctx.keep = (x, enc, self_pad, cross_pad, a16, a32, params)  # (parameters: kept alive, the optimizer runs after backward)
         ctx.dims = (B, T, S, d, f, H)
         off = (y_ptr - a16.data_ptr()) // es
@@ -219,10 +238,22 @@ class NativeLayerFn(Function):
         # its own, biases and LayerNorm parameters as pieces of one vector — three allocations, two splits
         nblk = 2 if is_decoder else 1
         wrows = [d, d, d, d] * nblk + [f]
-        wd = torch.empty(sum(wrows), d, dtype=dt, device=dev)
-        w2 = torch.empty(d, f, dtype=dt, device=dev)
         vsz = [d, d, d, d, d, d] * nblk + [f, d, d, d]  # q k v biases, out bias, ln weight, ln bias; ... fc1 b, fc2 b, ln w, ln b
-        vec = torch.empty(sum(vsz), dtype=dt, device=dev)
+        # Under the data-parallel reducer the three pieces are slices of the layer's gradient bucket (ddp.py lays the bucket
+        # out in this order): autograd adopts the returned views as `.grad` and the reducer has nothing to pack.  Only for
+        # fresh gradients (`.grad is None`: an accumulating micro-batch adds to what is there) of a layer that ran once in
+        # this graph (two applications would both write the same slice before either is accumulated).
+        arena = layer.__dict__.get('_pk_grad_arena')
+        if (arena is not None and layer.__dict__.get('_pk_live_max', 0) == 1 and arena[0].dtype == dt
+                and all(prm is not None and prm.grad is None for prm in params)):
+            flat, o_wd, o_w2, o_vec = arena
+            wd = flat[o_wd: o_wd + sum(wrows) * d].view(sum(wrows), d)
+            w2 = flat[o_w2: o_w2 + d * f].view(d, f)
+            vec = flat[o_vec: o_vec + sum(vsz)]
+        else:
+            wd = torch.empty(sum(wrows), d, dtype=dt, device=dev)
+            w2 = torch.empty(d, f, dtype=dt, device=dev)
+            vec = torch.empty(sum(vsz), dtype=dt, device=dev)
         ws_ = wd.split(wrows, 0)
         vs_ = vec.split(vsz, 0)
         es = 2

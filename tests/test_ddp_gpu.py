@@ -87,6 +87,16 @@ def test_rccl_bucketed_all_reduce_single_rank(monkeypatch, dtype):
         if launches is not None:  # both steps launched their weight gradients per layer, under the reducer's hooks too
             # (per-op path: one grouped launch per layer from Python; native layer calls launch theirs from C)
             assert launches == ([7, 7, 4, 4] * 2 if per_op else []), launches
+        if launches is not None:
+            # a natively run layer writes its gradients into its bucket slice itself (pk_layer_bwd's outputs ARE the slices,
+            # native_layer.py / ddp._build_buckets): the reducer packed only what lives outside the layers; op by op every
+            # gradient is a tensor of its own and is packed
+            in_layers = {p for layer in ddp._arena_layers for piece in native_layer.grad_arena_params(
+                layer, hasattr(layer, 'encoder_attn')) for p in piece}
+            assert len(ddp._arena_layers) == 4 and len(in_layers) == 2 * 16 + 2 * 26
+            with_grad = [p for n, p in model.named_parameters() if n in plain]
+            expect = len(with_grad) if per_op else len([p for p in with_grad if p not in in_layers])
+            assert ddp.packed_copies == expect, (ddp.packed_copies, expect, len(with_grad))
         rtol = 1e-5 if dtype == torch.float32 else 2e-2
         for n, p in model.named_parameters():
             if n in plain:
