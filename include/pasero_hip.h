@@ -142,6 +142,21 @@ int pk_residual_ln_bwd(const void* dy, const void* dz_extra, const void* z, cons
                        const float* rstd, void* dres_out, void* dx_out, void* dgamma, void* dbeta, void* workspace,
                        size_t ws_bytes, long long rows, int d, float drop_p, unsigned long long seed,
                        unsigned long long offset, int dtype, void* stream);
+/*   The same with the parameter gradients DEFERRED: pk_residual_ln_bwd_partials leaves the per-workgroup partial sums of
+ *   dgamma / dbeta in `workspace` (pk_residual_ln_bwd_workspace bytes, one workspace per LayerNorm), pk_ln_param_grads
+ *   finishes up to PK_LN_GROUP_MAX LayerNorms of the same (rows, d) in ONE launch — a layer's two or three LayerNorms
+ *   (pk_layer_bwd); each result equals pk_residual_ln_bwd's bit for bit (the same reduction in the same order). */
+#define PK_LN_GROUP_MAX 4
+typedef struct PkLnParamGrad {
+    const void* workspace; /* written by pk_residual_ln_bwd_partials */
+    void* dgamma;          /* [d] or NULL */
+    void* dbeta;           /* [d] or NULL */
+} PkLnParamGrad;
+int pk_residual_ln_bwd_partials(const void* dy, const void* dz_extra, const void* z, const void* gamma, const float* mean,
+                                const float* rstd, void* dres_out, void* dx_out, void* workspace, size_t ws_bytes,
+                                long long rows, int d, float drop_p, unsigned long long seed, unsigned long long offset,
+                                int dtype, void* stream);
+int pk_ln_param_grads(const PkLnParamGrad* items, int n, long long rows, int d, int dtype, void* stream);
 
 /* ---- Scaled-dot-product attention, head_dim 64 or 128 (K3): replaces F.scaled_dot_product_attention and the mask
  * assembly around it, pasero/models/modules.py:654-677,707-720 (fallback :742-771).

@@ -9,6 +9,13 @@
 #define PK_F16 2
 
 // activation ids (pasero/models/modules.py:220-228)
+// (include/pasero_hip.h: deferred LayerNorm parameter gradients)
+#define PK_LN_GROUP_MAX 4
+struct PkLnParamGrad {
+    const void* workspace;
+    void* dgamma;
+    void* dbeta;
+};
 #define PK_ACT_NONE 0
 #define PK_ACT_RELU 1
 #define PK_ACT_GELU 2       // erf

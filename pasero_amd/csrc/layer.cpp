@@ -240,7 +240,7 @@ extern "C" int pk_layer_bwd_sizes(const PkLayer* lp, size_t* scratch_bytes, size
     const int n = wgrad_problems(L, b, probs);
     b.ws_group = (pk_gemm_wgrad_group_workspace(probs, n) + 255) & ~(size_t)255;
     *scratch_bytes = b.scratch_bytes;
-    *ws_bytes = std::max(b.ws_split, b.ws_group) + b.ws_ln;
+    *ws_bytes = std::max(b.ws_split, b.ws_group) + (L.is_decoder ? 3 : 2) * b.ws_ln;  // (one partial-sum area per LayerNorm)
     return 0;
 }
 
@@ -259,15 +259,27 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
     b.ws_group = (pk_gemm_wgrad_group_workspace(probs, nprob) + 255) & ~(size_t)255;
     const size_t ws_main = std::max(b.ws_split, b.ws_group);
     PK_REQ(L.scratch && L.scratch_bytes >= b.scratch_bytes, "pk_layer_bwd: scratch too small (%zu < %zu)", L.scratch_bytes, b.scratch_bytes);
-    PK_REQ(L.ws && L.ws_bytes >= ws_main + b.ws_ln, "pk_layer_bwd: workspace too small (%zu < %zu)", L.ws_bytes, ws_main + b.ws_ln);
+    const int nln = L.is_decoder ? 3 : 2;
+    PK_REQ(L.ws && L.ws_bytes >= ws_main + nln * b.ws_ln, "pk_layer_bwd: workspace too small (%zu < %zu)", L.ws_bytes,
+           ws_main + nln * b.ws_ln);
     void* ws = L.ws;
-    void* ws_ln = (char*)L.ws + ws_main;
+    // the LayerNorms' parameter gradients: every backward pass leaves its partial sums in an area of its own, ONE launch
+    // reduces the layer's two or three at the end (as separate launches: three 5 us kernels of 64 workgroups each)
+    PkLnParamGrad ln_items[3];
+    int n_ln = 0;
+    auto ln_ws = [&](void* dg, void* db) -> void* {
+        void* area = (char*)L.ws + ws_main + n_ln * b.ws_ln;
+        ln_items[n_ln].workspace = area; ln_items[n_ln].dgamma = dg; ln_items[n_ln].dbeta = db;
+        ++n_ln;
+        return area;
+    };
+    auto ln_finish = [&]() { return pk_ln_param_grads(ln_items, n_ln, rows, (int)d, dt, L.stream); };
     // LayerNorm + dropout backward of a block end: gradient of the residual branch, (masked, scaled) gradient of the
     // projection's output, parameter gradients
     auto ln_bwd = [&](const void* dy, const void* z, const void* g, const float* mean, const float* rstd, void* dres, void* dsub,
                       void* dg, void* db, unsigned long long offset) {
-        return pk_residual_ln_bwd(dy, nullptr, z, g, mean, rstd, dres, drop ? dsub : nullptr, dg, db, ws_ln, b.ws_ln, rows, (int)d,
-                                  L.drop_p, L.seed, offset, dt, L.stream);
+        return pk_residual_ln_bwd_partials(dy, nullptr, z, g, mean, rstd, dres, drop ? dsub : nullptr, ln_ws(dg, db), b.ws_ln, rows,
+                                           (int)d, L.drop_p, L.seed, offset, dt, L.stream);
     };
     // dX = dY W (+ aux) with the per-op path's split rule (`_dx_gemm`)
     auto dx_gemm = [&](const void* dy, const void* w, void* out, const void* aux, long long M, long long N, long long K, bool rule) {
@@ -283,7 +295,8 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
         };
         auto ln_in_bwd = [&](const void* dln, const void* dz, const void* in, const void* g, const float* mean, const float* rstd,
                              void* d_in, void* dg, void* db) {
-            return pk_residual_ln_bwd(dln, dz, in, g, mean, rstd, d_in, nullptr, dg, db, ws_ln, b.ws_ln, rows, (int)d, 0.f, 0, 0, dt, L.stream);
+            return pk_residual_ln_bwd_partials(dln, dz, in, g, mean, rstd, d_in, nullptr, ln_ws(dg, db), b.ws_ln, rows, (int)d, 0.f, 0, 0,
+                                               dt, L.stream);
         };
         const void* in_f = L.is_decoder ? L.cross.z : L.self.z;
         // feed-forward
@@ -328,6 +341,7 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
                            L.is_decoder && L.T > 1, L.attn_scale, 0.f, nullptr, dt, L.stream));
         PK_TRY(dx_gemm(b.dproj, L.self.w_in, b.dln, nullptr, rows, d, 3 * d, true));
         PK_TRY(ln_in_bwd(b.dln, dz, L.x, L.self.ln_g, L.self.mean, L.self.rstd, L.dx, L.self.dln_g, L.self.dln_b));
+        PK_TRY(ln_finish());
         return pk_gemm_wgrad_group(pr, n, dt, ws, b.ws_group, L.stream);
     }
     // ---- feed-forward block ----
@@ -366,6 +380,7 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
                        (long long)L.T * d, d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d,
                        L.is_decoder && L.T > 1, L.attn_scale, 0.f, nullptr, dt, L.stream));
     PK_TRY(dx_gemm(b.dproj, L.self.w_in, L.dx, b.dres_s, rows, d, 3 * d, true));
+    PK_TRY(ln_finish());
     // ---- every weight gradient of the layer in one grouped launch ----
     return pk_gemm_wgrad_group(probs, nprob, dt, ws, b.ws_group, L.stream);
 }

@@ -337,13 +337,19 @@ __global__ __launch_bounds__(256, NCH == 4 ? 3 : NCH == 8 ? 2 : 1) void residual
 
 // partials[nslabs][2][d] fp32 -> dgamma / dbeta in T.  Workgroup (x, y): 16 columns of gamma (y = 0) or beta (y = 1);
 // its 64 thread-rows each sum every 64th slab with all loads in flight at once, then a tree reduction through LDS
+// (blockIdx.z: one of up to PK_LN_GROUP_MAX LayerNorms whose backward passes left their slabs — pk_ln_param_grads)
+struct LnReduceItems {
+    const float* partials[PK_LN_GROUP_MAX];
+    void* dgamma[PK_LN_GROUP_MAX];
+    void* dbeta[PK_LN_GROUP_MAX];
+};
 template <typename T>
-__global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* __restrict__ partials, int nslabs,
-                                                             T* __restrict__ dgamma, T* __restrict__ dbeta, int d) {
+__global__ __launch_bounds__(1024) void ln_param_grad_kernel(LnReduceItems items, int nslabs, int d) {
     __shared__ float red[64][16];
     const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + c, which = blockIdx.y;
-    T* out = which == 0 ? dgamma : dbeta;
+    const float* partials = items.partials[blockIdx.z];
+    T* out = reinterpret_cast<T*>(which == 0 ? items.dgamma[blockIdx.z] : items.dbeta[blockIdx.z]);
     if (!out) return;
     float s = 0.f;
     if (col < d) {
@@ -404,7 +410,8 @@ int launch_fwd(const void* x, const void* res, const void* gamma, const void* be
 template <typename T>
 int launch_bwd(const void* dy, const void* dz_extra, const void* z, const void* gamma, const float* mean,
                const float* rstd, void* dres, void* dx, void* dgamma, void* dbeta, float* ws, size_t ws_bytes,
-               long long rows, int d, float p, unsigned long long seed, unsigned long long offset, hipStream_t s) {
+               long long rows, int d, float p, unsigned long long seed, unsigned long long offset, hipStream_t s,
+               bool defer = false) {
     constexpr int EPV = 16 / sizeof(T);
     PK_CHECK_ARG(d % EPV == 0 && d <= 64 * EPV * 8, "pk_residual_ln_bwd: d=%d unsupported", d);
     unsigned thr = p > 0.f ? dropout_threshold(p) : 0u;
@@ -412,7 +419,7 @@ int launch_bwd(const void* dy, const void* dz_extra, const void* z, const void* 
     int nch = (d / EPV + 63) / 64;
     int nblocks = ln_grid(rows);
     if (nblocks > ln_bwd_max_blocks(d)) nblocks = ln_bwd_max_blocks(d);
-    bool want_pg = gamma && (dgamma || dbeta);
+    bool want_pg = gamma && (dgamma || dbeta || defer);
     if (want_pg) {
         size_t need = (size_t)nblocks * 2 * d * sizeof(float);
         PK_CHECK_ARG(ws && ws_bytes >= need, "pk_residual_ln_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -428,9 +435,10 @@ int launch_bwd(const void* dy, const void* dz_extra, const void* z, const void* 
     else PK_L(8);
 #undef PK_L
     PK_LAUNCH_CHECK();
-    if (want_pg) {
-        hipLaunchKernelGGL((ln_param_grad_kernel<T>), dim3((d + 15) / 16, 2), dim3(1024), 0, s, ws, nblocks,
-                           (T*)dgamma, (T*)dbeta, d);
+    if (want_pg && !defer) {
+        LnReduceItems it = {};
+        it.partials[0] = ws; it.dgamma[0] = dgamma; it.dbeta[0] = dbeta;
+        hipLaunchKernelGGL((ln_param_grad_kernel<T>), dim3((d + 15) / 16, 2, 1), dim3(1024), 0, s, it, nblocks, d);
         PK_LAUNCH_CHECK();
     }
     return 0;
@@ -486,4 +494,47 @@ extern "C" int pk_residual_ln_bwd(const void* dy, const void* dz_extra, const vo
         return launch_bwd<float>(dy, dz_extra, z, gamma, mean, rstd, dres_out, dx_out, dgamma, dbeta,
                                  (float*)workspace, ws_bytes, rows, d, drop_p, seed, offset, s);
     PK_CHECK_ARG(false, "pk_residual_ln_bwd: dtype %d not supported", dtype);
+}
+
+// pk_residual_ln_bwd that leaves dgamma / dbeta as per-workgroup partial sums in `workspace`; pk_ln_param_grads finishes them
+extern "C" int pk_residual_ln_bwd_partials(const void* dy, const void* dz_extra, const void* z, const void* gamma,
+                                           const float* mean, const float* rstd, void* dres_out, void* dx_out,
+                                           void* workspace, size_t ws_bytes, long long rows, int d, float drop_p,
+                                           unsigned long long seed, unsigned long long offset, int dtype, void* stream) {
+    PK_CHECK_ARG(gamma && dy && z && rstd && workspace, "pk_residual_ln_bwd_partials: LN inputs missing");
+    PK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pk_residual_ln_bwd_partials: bad dropout %f", drop_p);
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PK_BF16)
+        return launch_bwd<bf16>(dy, dz_extra, z, gamma, mean, rstd, dres_out, dx_out, nullptr, nullptr, (float*)workspace,
+                                ws_bytes, rows, d, drop_p, seed, offset, s, true);
+    if (dtype == PK_F16)
+        return launch_bwd<f16>(dy, dz_extra, z, gamma, mean, rstd, dres_out, dx_out, nullptr, nullptr, (float*)workspace,
+                               ws_bytes, rows, d, drop_p, seed, offset, s, true);
+    if (dtype == PK_F32)
+        return launch_bwd<float>(dy, dz_extra, z, gamma, mean, rstd, dres_out, dx_out, nullptr, nullptr, (float*)workspace,
+                                 ws_bytes, rows, d, drop_p, seed, offset, s, true);
+    PK_CHECK_ARG(false, "pk_residual_ln_bwd_partials: dtype %d not supported", dtype);
+}
+
+// the parameter gradients of up to PK_LN_GROUP_MAX LayerNorms (same rows, same d) from their partial sums, in ONE launch —
+// the same reduction, slab order included, as pk_residual_ln_bwd runs for one
+extern "C" int pk_ln_param_grads(const PkLnParamGrad* items, int n, long long rows, int d, int dtype, void* stream) {
+    PK_CHECK_ARG(items && n >= 1 && n <= PK_LN_GROUP_MAX, "pk_ln_param_grads: 1..%d items", PK_LN_GROUP_MAX);
+    if (rows == 0) return 0;
+    int nblocks = ln_grid(rows);
+    if (nblocks > ln_bwd_max_blocks(d)) nblocks = ln_bwd_max_blocks(d);
+    LnReduceItems it = {};
+    for (int i = 0; i < n; ++i) {
+        PK_CHECK_ARG(items[i].workspace, "pk_ln_param_grads: item %d has no workspace", i);
+        it.partials[i] = (const float*)items[i].workspace; it.dgamma[i] = items[i].dgamma; it.dbeta[i] = items[i].dbeta;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((d + 15) / 16, 2, n), block(1024);
+    if (dtype == PK_BF16) hipLaunchKernelGGL((ln_param_grad_kernel<bf16>), grid, block, 0, s, it, nblocks, d);
+    else if (dtype == PK_F16) hipLaunchKernelGGL((ln_param_grad_kernel<f16>), grid, block, 0, s, it, nblocks, d);
+    else if (dtype == PK_F32) hipLaunchKernelGGL((ln_param_grad_kernel<float>), grid, block, 0, s, it, nblocks, d);
+    else PK_CHECK_ARG(false, "pk_ln_param_grads: dtype %d not supported", dtype);
+    PK_LAUNCH_CHECK();
+    return 0;
 }

@@ -41,6 +41,8 @@ SIGNATURES = {
     'pk_residual_ln_fwd': (I, [P, P, P, P, P, P, P, P, LL, I, F, F, ULL, ULL, I, P]),
     'pk_residual_ln_bwd_workspace': (SZ, [LL, I]),
     'pk_residual_ln_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, SZ, LL, I, F, ULL, ULL, I, P]),
+    'pk_residual_ln_bwd_partials': (I, [P, P, P, P, P, P, P, P, P, SZ, LL, I, F, ULL, ULL, I, P]),
+    'pk_ln_param_grads': (I, [P, I, LL, I, I, P]),
     'pk_attn_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I] + [LL] * 8 + [I, F, F, ULL, ULL, P, I, P]),
     'pk_attn_bwd': (I, [P] * 11 + [I, I, I, I, I] + [LL] * 16 + [I, F, F, P, I, P]),
     'pk_attn_probs': (I, [P, P, P, P, I, I, I, I, I, LL, LL, LL, LL, I, F, I, P]),
