@@ -32,6 +32,21 @@ constexpr int q_min_waves(int mode, int hd) { return mode == 0 ? (hd == 64 ? PK_
 constexpr int dkv_min_waves(int hd) { return hd == 64 ? 2 : 1; }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+// 16-byte global loads / stores of the attention kernels; PKATT_NT (diagnostic builds): 1 = the fused backward's tile loads
+// streaming, 2 = fragment / tile loads of every kernel, 4 = the row stores (o, dq, dk, dv)
+#ifndef PKATT_NT
+#define PKATT_NT 0
+#endif
+template <int BIT, typename T> __device__ __forceinline__ uint4 att_ld(const T* p) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    if constexpr ((PKATT_NT & BIT) != 0) return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
+    else return *reinterpret_cast<const uint4*>(p);
+}
+template <typename T> __device__ __forceinline__ void att_st(T* p, uint4 v) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    if constexpr ((PKATT_NT & 4) != 0) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
+    else *reinterpret_cast<uint4*>(p) = v;
+}
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4 lds_s4;
@@ -305,7 +320,7 @@ __device__ __forceinline__ void tile_g2r(uint4 (&regs)[NR], const T* __restrict_
         int c = tid + i * 256;
         int r = c / CPR, cc = (c % CPR) * 8;
         regs[i] = make_uint4(0, 0, 0, 0);
-        if (r0 + r < lim) regs[i] = *reinterpret_cast<const uint4*>(base + (long long)(r0 + r) * rs + cc);
+        if (r0 + r < lim) regs[i] = att_ld<2>(base + (long long)(r0 + r) * rs + cc);
     }
 }
 template <int P, int NR>
@@ -356,7 +371,7 @@ __device__ __forceinline__ void load_row_frags(bf16x8_t (&f)[NF], const T* __res
 #pragma unroll
     for (int kk = 0; kk < NF; ++kk) {
         uint4 val = {0, 0, 0, 0};
-        if (valid) val = *reinterpret_cast<const uint4*>(base + (long long)row * rs + kk * 16 + 8 * (lane >> 5));
+        if (valid) val = att_ld<2>(base + (long long)row * rs + kk * 16 + 8 * (lane >> 5));
         f[kk] = __builtin_bit_cast(bf16x8_t, val);
     }
 }
@@ -393,7 +408,7 @@ __device__ __forceinline__ void store_rowT(T* __restrict__ base, long long rs, i
             // h = 0: group 2j = {own cols 0-3, partner's cols 4-7};  h = 1: group 2j + 1 = {partner's cols 0-3, own cols 4-7}
             const uint4 v = h ? make_uint4(recv_lo, recv_hi, lo[1], hi[1]) : make_uint4(lo[0], hi[0], recv_lo, recv_hi);
             const int d = dt * 32 + 8 * (2 * j + h);
-            if (valid) *reinterpret_cast<uint4*>(base + (long long)row * rs + d) = v;
+            if (valid) att_st(base + (long long)row * rs + d, v);
         }
 }
 
@@ -763,11 +778,11 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
         uint4 qv = {0, 0, 0, 0}, dov = {0, 0, 0, 0}, ov = {0, 0, 0, 0};
         kreg[i] = make_uint4(0, 0, 0, 0);
         if (r < p.T) {
-            qv = *reinterpret_cast<const uint4*>(qbase + (long long)r * p.q_rs + ch * 8);
-            dov = *reinterpret_cast<const uint4*>(dobase + (long long)r * p.do_rs + ch * 8);
-            ov = *reinterpret_cast<const uint4*>(obase + (long long)r * p.o_rs + ch * 8);
+            qv = att_ld<1>(qbase + (long long)r * p.q_rs + ch * 8);
+            dov = att_ld<1>(dobase + (long long)r * p.do_rs + ch * 8);
+            ov = att_ld<1>(obase + (long long)r * p.o_rs + ch * 8);
         }
-        if (r < p.S) kreg[i] = *reinterpret_cast<const uint4*>(kbase + (long long)r * p.k_rs + ch * 8);
+        if (r < p.S) kreg[i] = att_ld<1>(kbase + (long long)r * p.k_rs + ch * 8);
         *reinterpret_cast<uint4*>(q_lds + lds_off<DUAL>(r, ch)) = qv;
         *reinterpret_cast<uint4*>(do_lds + lds_off<DUAL>(r, ch)) = dov;
         float part = frag_dot<T>(__builtin_bit_cast(bf16x8_t, dov), __builtin_bit_cast(bf16x8_t, ov));

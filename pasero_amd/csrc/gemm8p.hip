@@ -108,11 +108,13 @@ __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, T* _
         f32x8 f = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
         Vec16<T> o;
         o.raw = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename H16<T>::vec));
-#ifdef PK8P_PLAIN_STORES
-        store16<T>(C + gm * ep.ldc + gn, o);
-#else
-        store16_nt<T>(C + gm * ep.ldc + gn, o);
+#ifndef PK8P_PLAIN_MASK
+#define PK8P_PLAIN_MASK 0 /* diagnostic: bit 0 = plain stores for mode 0 without activation, 1 = mode 1 (+ aux), 2 = ReLU / mode 2 */
 #endif
+        constexpr bool PLAIN = ((PK8P_PLAIN_MASK & 1) && MODE == 0 && ACT == PK_ACT_NONE) || ((PK8P_PLAIN_MASK & 2) && MODE == 1) ||
+                               ((PK8P_PLAIN_MASK & 4) && (MODE == 2 || (MODE == 0 && ACT != PK_ACT_NONE)));
+        if constexpr (PLAIN) store16<T>(C + gm * ep.ldc + gn, o);
+        else store16_nt<T>(C + gm * ep.ldc + gn, o);
     }
 }
 

@@ -344,7 +344,16 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
 #ifndef PKBS_STORE_AUX
 #define PKBS_STORE_AUX 2 /* nt */
 #endif
-        __builtin_amdgcn_raw_buffer_store_b128(o, rc, c_voff, so, PKBS_STORE_AUX);
+        // Which outputs stream past the caches (`nt`) was measured per instantiation, on the whole step (same box): the lean
+        // ones (q | k | v, cross k | v: read next by the attention kernels; out-proj dX: by the attention backward) PLAIN —
+        // C2 13.52 -> 13.33 ms; the ReLU forward (134 MB of h, one reader a GEMM later) streaming — plain cost that kernel
+        // 62 -> 74 us and the step 0.15 ms; the masked dH GEMM streaming — plain: +0.1 ms.
+#ifndef PKBS_PLAIN_MASK
+#define PKBS_PLAIN_MASK 1 /* bit 0 = plain stores for the lean instantiations (no activation), 1 = ReLU forward, 2 = mask */
+#endif
+        constexpr int ST_AUX = ((PKBS_PLAIN_MASK & 1) && !MASK && ACT == PK_ACT_NONE) || ((PKBS_PLAIN_MASK & 2) && RELU) ||
+                                       ((PKBS_PLAIN_MASK & 4) && MASK) ? 0 : PKBS_STORE_AUX;
+        __builtin_amdgcn_raw_buffer_store_b128(o, rc, c_voff, so, ST_AUX);
         if constexpr (PRE) {  // (same rows, columns and pitch as C: only the descriptor differs)
             f32x8 pf = {pre[0], pre[1], pre[2], pre[3], pre[4], pre[5], pre[6], pre[7]};
             const u32x4 po = __builtin_bit_cast(u32x4, __builtin_convertvector(pf, typename H16<T>::vec));

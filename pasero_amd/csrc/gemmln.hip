@@ -265,7 +265,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_ln_kernel(const T* __restrict__
                 f32x8 f = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
                 zv.raw = __builtin_bit_cast(uint4, __builtin_convertvector(f, HV));
             }
-            if (zo) store16<T>(zo + off, zv);
+            // z is only read again in the backward pass: a streaming store (C2 step 13.90 -> 13.85 ms); y feeds the next GEMM,
+            // which re-reads it once per column strip — stored streaming, the step LOST 0.6 ms (14.49): it stays a plain store
+            if (zo) store16_nt<T>(zo + off, zv);
             float sum = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
