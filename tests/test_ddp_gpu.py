@@ -124,7 +124,7 @@ def test_rccl_bucketed_all_reduce_single_rank(monkeypatch, dtype):
 # ------------------------------------------------------------------------------------------------------------
 # two ranks, the real HIP model: both processes share the box's one card (gloo carries the CUDA buckets)
 # ------------------------------------------------------------------------------------------------------------
-def _two_rank_worker(rank, world, port, ret):
+def _two_rank_worker(rank, world, port, ret, base_width=False):
     import sys
     from conftest import ROOT
     sys.path.insert(0, ROOT)
@@ -133,11 +133,27 @@ def _two_rank_worker(rank, world, port, ret):
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
+        from pasero_amd import rng
         from pasero_amd.ddp import DistributedDataParallel
-        g = load_golden('tiny_encdec_post')
-        cfg, model = build_model(g, torch.float32, 'cuda')
+        if base_width:  # bf16, d = 512, no dropout: the natively run layers write their gradients into their buckets
+            def build():
+                import paramgen
+                from model_utils import load_paramgen
+                from pasero_amd.config import TransformerConfig, DistributedConfig, SyntheticTask
+                from pasero_amd.transformer import Transformer
+                m = Transformer(TransformerConfig(dropout=0.0, encoder_layers=2, decoder_layers=2), DistributedConfig(),
+                                SyntheticTask(2000))
+                load_paramgen(m, 3)
+                return m.to(torch.bfloat16).cuda()
+            import paramgen
+            model = build()
+            full = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(5, 16, 64, 64, 2000, ragged=True).items()}
+        else:
+            g = load_golden('tiny_encdec_post')
+            build = lambda: build_model(g, torch.float32, 'cuda')[1]
+            model = build()
+            full = text_batch(g, 'cuda')
         model.train()
-        full = text_batch(g, 'cuda')
         B = full['encoder_input'].size(0)
         rows = [b for b in range(B) if b % world == rank]  # rank r takes every world-th sentence
         mine = {k: v[rows].contiguous() for k, v in full.items()}
@@ -146,36 +162,40 @@ def _two_rank_worker(rank, world, port, ret):
         loss.backward()
         torch.cuda.synchronize()
         # single-process truth on the full batch: the loss is a SUM over tokens, DDP AVERAGES over ranks
-        _, ref = build_model(g, torch.float32, 'cuda')
+        ref = build()
         ref.train()
         ref_loss, _ = ref(**full)
         ref_loss.backward()
         worst, name = 0.0, None
         for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-            want = q.grad / world
-            err = ((p.grad - want).abs().max() / want.abs().max().clamp_min(1e-12)).item()
+            want = q.grad.float() / world
+            err = ((p.grad.float() - want).abs().max() / want.abs().max().clamp_min(1e-12)).item()
             if want.abs().max().item() > 1e-6 and err > worst:
                 worst, name = err, n
         tot = torch.tensor([loss.item()], dtype=torch.float64)
         dist.all_reduce(tot)
         ret[rank] = {'worst': worst, 'name': name, 'loss_sum': tot.item(), 'ref_loss': ref_loss.item(),
-                     'buckets': len(ddp._buckets)}
+                     'buckets': len(ddp._buckets), 'arena_layers': len(ddp._arena_layers), 'packed': ddp.packed_copies,
+                     'with_grad': sum(p.grad is not None for p in model.parameters())}
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_average_the_gradients_of_the_hip_model():
+@pytest.mark.parametrize('base_width', [False, True])
+def test_two_ranks_average_the_gradients_of_the_hip_model(base_width):
     """world_size 2 with the real model: rank r trains on its share of the batch, the bucketed reducer leaves on every
     rank (sum of the per-rank gradients) / 2 = (full-batch gradient) / 2, and the per-rank losses add up to the
-    full-batch loss (fp32: 2e-4 relative, summation order only)"""
+    full-batch loss (fp32: 2e-4 relative, summation order only).  base_width: the bf16 base model, whose natively run
+    layers write their gradients straight into their bucket slices on both ranks (bf16 round-off: 3e-2 of the largest
+    entry, loss 2e-3)"""
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     ctx = mp.get_context('spawn')
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret, base_width)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -184,8 +204,10 @@ def test_two_ranks_average_the_gradients_of_the_hip_model():
     for r in range(world):
         out = ret[r]
         assert out['buckets'] > 1
-        assert out['worst'] <= 2e-4, (r, out['name'], out['worst'])
-        assert abs(out['loss_sum'] - out['ref_loss']) <= 1e-5 * abs(out['ref_loss'])
+        assert out['worst'] <= (3e-2 if base_width else 2e-4), (r, out['name'], out['worst'])
+        assert abs(out['loss_sum'] - out['ref_loss']) <= (2e-3 if base_width else 1e-5) * abs(out['ref_loss'])
+        if base_width:  # every layer gradient went in place: only the parameters outside the four layers were packed
+            assert out['arena_layers'] == 4 and out['packed'] == out['with_grad'] - (2 * 16 + 2 * 26), out
 
 
 @pytest.mark.timeout(300)
