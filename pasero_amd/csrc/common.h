@@ -126,13 +126,6 @@ template <typename T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
 template <typename T> __device__ __forceinline__ void store16(T* p, const Vec16<T>& v) {
     *reinterpret_cast<decltype(v.raw)*>(p) = v.raw;
 }
-// streaming load (`nt`): for operands this is the LAST reader of (diagnostic builds first: see layernorm.hip PKLNB_NT)
-template <typename T> __device__ __forceinline__ Vec16<T> load16_nt(const T* p) {
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    Vec16<T> v;
-    v.raw = __builtin_bit_cast(decltype(v.raw), __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
-    return v;
-}
 // streaming store (`nt`): for outputs no later instruction of this kernel reads — the next kernel finds them in HBM /
 // Infinity Cache either way, and the L2 keeps the operand tiles that ARE re-read.  Measured on the 256-tile GEMM
 // epilogue: C2 step 18.74 -> 18.41 ms (same box, 4 alternations).

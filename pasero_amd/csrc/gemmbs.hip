@@ -455,9 +455,6 @@ __global__ __launch_bounds__(512, 2) void gemmbs_kernel(const T* __restrict__ A,
     __builtin_amdgcn_s_barrier();
     read_a(fa[0], frag_off0, frag_off1, 0);  // tile 0
     PK_STAMP();  // ring primed
-#ifdef PKBS_PRIO
-    if (wcls == 1) __builtin_amdgcn_s_setprio(PKBS_PRIO);
-#endif
     asm volatile("; PK8P_LOOP_BEGIN" ::: "memory");
     // (MASK without BITS: hipcc's own wait for the register mask loads — 3 requests behind them — is the smallest in the loop)
     if constexpr (MASK && !BITS) asm volatile("; PK8P_MIN_VMCNT 3" ::: "memory");
