@@ -179,6 +179,24 @@ int pk_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
                 long long v_rs, long long o_bs, long long o_rs, long long do_bs, long long do_rs, long long dq_bs,
                 long long dq_rs, long long dk_bs, long long dk_rs, long long dv_bs, long long dv_rs, int causal,
                 float scale, float drop_p, const unsigned char* drop_mask, int dtype, void* stream);
+/*   The same with ROTARY POSITIONS applied inside the kernels (RotaryEmbedding.forward on q and k, pasero/models/modules.py:
+ *   617-623, 982-1025 — the "fused QKV-projection + RoPE" of the north_star, folded into the consumer instead of a pass of its
+ *   own): q and k are the UNROTATED projection outputs; every kernel rotates the rows it loads (query t by the angle of position
+ *   q_pos0 + t, key s by k_pos0 + s; fp32 arithmetic, rounded once, as pk_rope does) and the backward kernels rotate dQ / dK
+ *   back as they leave, so dq / dk are the gradients of the unrotated projection and no pk_rope pass runs in either direction.
+ *   cos_t / sin_t: fp32 [max_pos][hd / 2], 16-byte aligned (the tables pk_rope takes). */
+int pk_attn_fwd_rope(const void* q, const void* k, const void* v, void* o, float* lse, const unsigned char* key_pad,
+                     int B, int H, int T, int S, int hd, long long q_bs, long long q_rs, long long k_bs, long long k_rs,
+                     long long v_bs, long long v_rs, long long o_bs, long long o_rs, int causal, float scale, float drop_p,
+                     unsigned long long seed, unsigned long long offset, unsigned char* drop_mask, const float* cos_t,
+                     const float* sin_t, int max_pos, int q_pos0, int k_pos0, int dtype, void* stream);
+int pk_attn_bwd_rope(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                     float* delta, void* dq, void* dk, void* dv, const unsigned char* key_pad, int B, int H, int T, int S,
+                     int hd, long long q_bs, long long q_rs, long long k_bs, long long k_rs, long long v_bs, long long v_rs,
+                     long long o_bs, long long o_rs, long long do_bs, long long do_rs, long long dq_bs, long long dq_rs,
+                     long long dk_bs, long long dk_rs, long long dv_bs, long long dv_rs, int causal, float scale,
+                     float drop_p, const unsigned char* drop_mask, const float* cos_t, const float* sin_t, int max_pos,
+                     int q_pos0, int k_pos0, int dtype, void* stream);
 
 /*   Attention weights softmax(q k^T * scale + masks) as a (B, T, H, S) tensor, fully masked rows = 0: what the reference's
  *   explicit path returns for `return_attn` / return_layers (modules.py:742-771).  Not used in training. */

@@ -385,15 +385,17 @@ class AttentionFn(Function):
         return a.size(-1), a, b, c
 
     @staticmethod
-    def forward(ctx, a, b, c, key_pad, num_heads: int, causal: bool, scale: float, p: float = 0.0):
+    def forward(ctx, a, b, c, key_pad, num_heads: int, causal: bool, scale: float, p: float = 0.0, rope=None):
+        # rope = (cos_t, sin_t, q_pos0, k_pos0): rotary positions applied INSIDE the kernels — q and k stay the unrotated
+        # projection, backward returns the gradient of that (modules.py:617-623 without a pass of its own)
         D, q, k, v = AttentionFn._split(a, b, c)
         mask = None
         if p > 0:  # attention-probability dropout: the keep bits are drawn in the forward kernel and kept for backward
             seed, offset = rng.next_offset()
-            o, lse, mask = F.attn_fwd(q, k, v, num_heads, key_pad, causal, scale, p, seed, offset)
+            o, lse, mask = F.attn_fwd(q, k, v, num_heads, key_pad, causal, scale, p, seed, offset, rope=rope)
         else:
-            o, lse = F.attn_fwd(q, k, v, num_heads, key_pad, causal, scale)
-        ctx.num_heads, ctx.causal, ctx.scale, ctx.p = num_heads, causal, scale, p
+            o, lse = F.attn_fwd(q, k, v, num_heads, key_pad, causal, scale, rope=rope)
+        ctx.num_heads, ctx.causal, ctx.scale, ctx.p, ctx.rope = num_heads, causal, scale, p, rope
         ctx.save_for_backward(a, b, c, key_pad, o, lse, mask)
         return o
 
@@ -406,8 +408,8 @@ class AttentionFn(Function):
         dc = torch.empty_like(c) if c is not None else None
         _, dq, dk, dv = AttentionFn._split(da, db, dc)
         F.attn_bwd(q, k, v, o, _contig(d_o), lse, ctx.num_heads, key_pad, ctx.causal, ctx.scale, dq=dq, dk=dk, dv=dv,
-                   drop_p=ctx.p, drop_mask=mask)
-        return da, db, dc, None, None, None, None, None
+                   drop_p=ctx.p, drop_mask=mask, rope=ctx.rope)
+        return da, db, dc, None, None, None, None, None, None
 
 
 class ResidualLayerNormFn(Function):

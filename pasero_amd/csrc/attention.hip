@@ -72,6 +72,13 @@ struct AttnParams {
     unsigned long long seed, offset;
     unsigned char* drop_mask;      // [B][H][T][mask_pitch]
     long long mask_pitch;
+    // rotary positions folded into the kernels (RotaryEmbedding.forward, pasero/models/modules.py:982-1025, applied to q and
+    // k at modules.py:617-623): q and k arrive UNROTATED, every kernel rotates the rows it loads (query t by the angle of
+    // position rope_q0 + t, key s by rope_k0 + s) and the backward kernels rotate dQ / dK back as they leave — the gradients
+    // are those of the unrotated projection.  cos / sin: fp32 [rope_max][head_dim / 2]; rope_cos == NULL: no rotation.
+    const float* rope_cos;
+    const float* rope_sin;
+    int rope_max, rope_q0, rope_k0;
 };
 
 __device__ __forceinline__ bool drop_keep1(const AttnParams& p, long long row, int s) {
@@ -87,6 +94,51 @@ __device__ __forceinline__ bool key_masked(const AttnParams& p, int b, int t, in
     if (p.key_pad && p.key_pad[(long long)b * p.S + s]) return true;
     if (p.causal && s > t + (p.S - p.T)) return true;
     return false;
+}
+
+// ---- rotary helpers (GPT-J halves: y[i] = x[i] c_i - x[i + hd/2] s_i ; y[i + hd/2] = x[i + hd/2] c_i + x[i] s_i) ----
+__device__ __forceinline__ int rope_row(const AttnParams& p, int pos) { return min(max(pos, 0), p.rope_max - 1); }
+// a whole fp32 row in registers, in place; INV: the transposed rotation (gradients)
+template <int HD, bool INV>
+__device__ __forceinline__ void rope_row_f32(float (&x)[HD], const AttnParams& p, int pos) {
+    const float* cs = p.rope_cos + (long long)rope_row(p, pos) * (HD / 2);
+    const float* sn = p.rope_sin + (long long)rope_row(p, pos) * (HD / 2);
+#pragma unroll
+    for (int i = 0; i < HD / 2; ++i) {
+        const float c = cs[i], s = INV ? -sn[i] : sn[i];
+        const float a = x[i], b = x[i + HD / 2];
+        x[i] = a * c - b * s;
+        x[i + HD / 2] = b * c + a * s;
+    }
+}
+// one element of a row read from memory: element d of head row `base` at position pos
+template <int HD>
+__device__ __forceinline__ float rope_elem_f32(const float* __restrict__ base, int d, const AttnParams& p, int pos) {
+    const int i = d & (HD / 2 - 1);
+    const long long r = (long long)rope_row(p, pos) * (HD / 2) + i;
+    const float c = p.rope_cos[r], s = p.rope_sin[r];
+    return d < HD / 2 ? base[d] * c - base[d + HD / 2] * s : base[d] * c + base[d - HD / 2] * s;
+}
+// 8 consecutive 16-bit elements of a head row (`own`) and the 8 of the other half (`oth`): own, rotated.  cs / sn point at
+// the 8 angles; upper: own is the second half; inverse: rotate back.  fp32 arithmetic, rounded once (as pk_rope does).
+template <typename T>
+__device__ __forceinline__ uint4 rope8(uint4 own, uint4 oth, const float* __restrict__ cs, const float* __restrict__ sn,
+                                        bool upper, bool inverse) {
+    const float4 c0 = *reinterpret_cast<const float4*>(cs), c1 = *reinterpret_cast<const float4*>(cs + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(sn), s1 = *reinterpret_cast<const float4*>(sn + 4);
+    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float sg = (upper != inverse) ? 1.f : -1.f;  // forward: lower a c - b s, upper a c + b s
+    const unsigned ow[4] = {own.x, own.y, own.z, own.w}, ot[4] = {oth.x, oth.y, oth.z, oth.w};
+    unsigned out[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float a0 = H16<T>::val((unsigned short)(ow[w] & 0xffff)), a1 = H16<T>::val((unsigned short)(ow[w] >> 16));
+        const float b0 = H16<T>::val((unsigned short)(ot[w] & 0xffff)), b1 = H16<T>::val((unsigned short)(ot[w] >> 16));
+        const float y0 = a0 * c[2 * w] + sg * b0 * sv[2 * w], y1 = a1 * c[2 * w + 1] + sg * b1 * sv[2 * w + 1];
+        out[w] = (unsigned)H16<T>::bits(y0) | ((unsigned)H16<T>::bits(y1) << 16);
+    }
+    return make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 // =====================================================================================================
@@ -107,6 +159,7 @@ __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restri
         qr[d] = valid ? q[b * p.q_bs + (long long)t * p.q_rs + h * HD + d] : 0.f;
         acc[d] = 0.f;
     }
+    if (p.rope_cos) rope_row_f32<HD, false>(qr, p, p.rope_q0 + t);
     float m = -INFINITY, l = 0.f;
     const float c = p.scale * LOG2E;
     const long long row = ((long long)b * p.H + h) * p.T + t;
@@ -115,7 +168,8 @@ __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restri
         __syncthreads();
         for (int i = threadIdx.x; i < F32_TILE * HD; i += 128) {
             int r = i / HD, d = i % HD, s = s0 + r;
-            ks[r][d] = s < p.S ? k[b * p.k_bs + (long long)s * p.k_rs + h * HD + d] : 0.f;
+            const float* krow = k + b * p.k_bs + (long long)s * p.k_rs + h * HD;
+            ks[r][d] = s < p.S ? (p.rope_cos ? rope_elem_f32<HD>(krow, d, p, p.rope_k0 + s) : krow[d]) : 0.f;
             vs[r][d] = s < p.S ? v[b * p.v_bs + (long long)s * p.v_rs + h * HD + d] : 0.f;
         }
         __syncthreads();
@@ -172,6 +226,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_f32_kernel(const float* __res
         dl += dor[d] * ov;
         acc[d] = 0.f;
     }
+    if (p.rope_cos) rope_row_f32<HD, false>(qr, p, p.rope_q0 + t);
     const long long row = ((long long)b * p.H + h) * p.T + t;
     const float L2 = valid ? lse[row] * LOG2E : 0.f;
     if (valid) delta[row] = dl;
@@ -180,7 +235,8 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_f32_kernel(const float* __res
         __syncthreads();
         for (int i = threadIdx.x; i < F32_TILE * HD; i += 128) {
             int r = i / HD, d = i % HD, s = s0 + r;
-            ks[r][d] = s < p.S ? k[b * p.k_bs + (long long)s * p.k_rs + h * HD + d] : 0.f;
+            const float* krow = k + b * p.k_bs + (long long)s * p.k_rs + h * HD;
+            ks[r][d] = s < p.S ? (p.rope_cos ? rope_elem_f32<HD>(krow, d, p, p.rope_k0 + s) : krow[d]) : 0.f;
             vs[r][d] = s < p.S ? v[b * p.v_bs + (long long)s * p.v_rs + h * HD + d] : 0.f;
         }
         __syncthreads();
@@ -201,6 +257,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_f32_kernel(const float* __res
         }
     }
     if (!valid) return;
+    if (p.rope_cos) rope_row_f32<HD, true>(acc, p, p.rope_q0 + t);  // (the gradient of the UNROTATED query)
 #pragma unroll
     for (int d = 0; d < HD; ++d) dq[b * p.dq_bs + (long long)t * p.dq_rs + h * HD + d] = acc[d];
 }
@@ -224,12 +281,14 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_f32_kernel(const float* __re
         dka[d] = 0.f;
         dva[d] = 0.f;
     }
+    if (p.rope_cos) rope_row_f32<HD, false>(kr, p, p.rope_k0 + s);
     const float c = p.scale * LOG2E;
     for (int t0 = 0; t0 < p.T; t0 += F32_TILE) {
         __syncthreads();
         for (int i = threadIdx.x; i < F32_TILE * HD; i += 128) {
             int r = i / HD, d = i % HD, t = t0 + r;
-            qs[r][d] = t < p.T ? q[b * p.q_bs + (long long)t * p.q_rs + h * HD + d] : 0.f;
+            const float* qrow = q + b * p.q_bs + (long long)t * p.q_rs + h * HD;
+            qs[r][d] = t < p.T ? (p.rope_cos ? rope_elem_f32<HD>(qrow, d, p, p.rope_q0 + t) : qrow[d]) : 0.f;
             dos[r][d] = t < p.T ? d_o[b * p.do_bs + (long long)t * p.do_rs + h * HD + d] : 0.f;
         }
         if (threadIdx.x < F32_TILE) {
@@ -264,6 +323,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_f32_kernel(const float* __re
         }
     }
     if (!valid) return;
+    if (p.rope_cos) rope_row_f32<HD, true>(dka, p, p.rope_k0 + s);
 #pragma unroll
     for (int d = 0; d < HD; ++d) {
         dk[b * p.dk_bs + (long long)s * p.dk_rs + h * HD + d] = dka[d];
@@ -376,6 +436,63 @@ __device__ __forceinline__ void load_row_frags(bf16x8_t (&f)[NF], const T* __res
     }
 }
 
+// ---- rotary positions on the operands as they are loaded (AttnParams::rope_cos) ----
+// row fragments (load_row_frags): lane (r, h) holds chunk 2 kk + h of its row for every kk; the partner chunk hd/2
+// elements away is fragment kk + NF/2 of the SAME lane
+template <int NF, typename T>
+__device__ __forceinline__ void rope_frags(bf16x8_t (&f)[NF], const AttnParams& p, int pos, int lane) {
+    constexpr int HALF = NF * 8;  // head_dim / 2
+    const float* cs = p.rope_cos + (long long)rope_row(p, pos) * HALF + 8 * (lane >> 5);
+    const float* sn = p.rope_sin + (long long)rope_row(p, pos) * HALF + 8 * (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < NF / 2; ++kk) {
+        const uint4 lo = __builtin_bit_cast(uint4, f[kk]), hi = __builtin_bit_cast(uint4, f[kk + NF / 2]);
+        f[kk] = __builtin_bit_cast(bf16x8_t, rope8<T>(lo, hi, cs + 16 * kk, sn + 16 * kk, false, false));
+        f[kk + NF / 2] = __builtin_bit_cast(bf16x8_t, rope8<T>(hi, lo, cs + 16 * kk, sn + 16 * kk, true, false));
+    }
+}
+// one 16-byte chunk `ch` (of CPR per row) of row `row` held by this lane: the partner chunk CPR / 2 away sits CPR / 2 lanes
+// away (tile_g2r and the fused backward's loads walk a row with consecutive lanes)
+template <int CPR, typename T>
+__device__ __forceinline__ uint4 rope_chunk(uint4 v, int ch, const AttnParams& p, int pos) {
+    constexpr int HC = CPR / 2;
+    uint4 o;
+    o.x = __shfl_xor(v.x, HC, 64); o.y = __shfl_xor(v.y, HC, 64); o.z = __shfl_xor(v.z, HC, 64); o.w = __shfl_xor(v.w, HC, 64);
+    const long long r = (long long)rope_row(p, pos) * (CPR * 4) + 8 * (ch & (HC - 1));
+    return rope8<T>(v, o, p.rope_cos + r, p.rope_sin + r, ch >= HC, false);
+}
+template <int NR, typename T>
+__device__ __forceinline__ void rope_tile(uint4 (&regs)[NR], const AttnParams& p, int pos0, int tid) {
+    constexpr int CPR = 4 * NR;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int c = tid + i * 256;
+        regs[i] = rope_chunk<CPR, T>(regs[i], c % CPR, p, pos0 + c / CPR);
+    }
+}
+// accumulators dQᵀ / dKᵀ [d-tile][d rows] x row-on-lane, rotated BACK in place (register 4g + j of d-tile dt is element
+// d = 32 dt + 8 g + 4 (l >> 5) + j of the lane's row; its partner is the same register of d-tile dt + ND / 2)
+template <int ND>
+__device__ __forceinline__ void rope_acc_inverse(f32x16 (&acc)[ND], const AttnParams& p, int pos, int lane) {
+    constexpr int HALF = ND * 16;  // head_dim / 2
+    const float* cs = p.rope_cos + (long long)rope_row(p, pos) * HALF + 4 * (lane >> 5);
+    const float* sn = p.rope_sin + (long long)rope_row(p, pos) * HALF + 4 * (lane >> 5);
+#pragma unroll
+    for (int dt = 0; dt < ND / 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 c4 = *reinterpret_cast<const float4*>(cs + 32 * dt + 8 * g);
+            const float4 s4 = *reinterpret_cast<const float4*>(sn + 32 * dt + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c = (&c4.x)[j], sv = (&s4.x)[j];
+                const float a = acc[dt][4 * g + j], b = acc[dt + ND / 2][4 * g + j];
+                acc[dt][4 * g + j] = a * c + b * sv;
+                acc[dt + ND / 2][4 * g + j] = b * c - a * sv;
+            }
+        }
+}
+
 template <typename T>
 __device__ __forceinline__ float frag_dot(const bf16x8_t& a, const bf16x8_t& b) {
     s16x8 x = __builtin_bit_cast(s16x8, a), y = __builtin_bit_cast(s16x8, b);
@@ -432,6 +549,7 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
 
     bf16x8_t qf[NF], dof[NF];
     load_row_frags(qf, q + b * p.q_bs + h * HD, p.q_rs, t, valid, lane);
+    if (p.rope_cos) rope_frags<NF, T>(qf, p, p.rope_q0 + t, lane);
     float m = -INFINITY, l = 0.f, L2 = 0.f, dl = 0.f;
     f32x16 acc[ND];  // Oᵀ (MODE 0) or dQᵀ (MODE 1): [d-tile][d rows] x query lane
 #pragma unroll
@@ -464,6 +582,7 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
     if (s_end > 0) {
         tile_g2r(kreg, kbase, p.k_rs, 0, p.S, tid);
         tile_g2r(vreg, vbase, p.v_rs, 0, p.S, tid);
+        if (p.rope_cos) rope_tile<2 * NI, T>(kreg, p, p.rope_k0, tid);
     }
     for (int s0 = 0; s0 < s_end; s0 += KT) {
         __syncthreads();  // previous tile fully consumed
@@ -477,6 +596,7 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
         if (s0 + KT < s_end) {  // prefetch the next tile into registers
             tile_g2r(kreg, kbase, p.k_rs, s0 + KT, p.S, tid);
             tile_g2r(vreg, vbase, p.v_rs, s0 + KT, p.S, tid);
+            if (p.rope_cos) rope_tile<2 * NI, T>(kreg, p, p.rope_k0 + s0 + KT, tid);
         }
         __syncthreads();
         // causal classification of (this wave's 32 queries) x (this tile's 64 keys): wave-uniform
@@ -613,6 +733,7 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
         store_rowT(o + b * p.o_bs + h * HD, p.o_rs, t, valid, acc, inv, lane);
         if (valid && lane < 32) lse[((long long)b * p.H + h) * p.T + t] = l > 0.f ? (m + log2f(l)) * LN2 : 0.f;
     } else {
+        if (p.rope_cos) rope_acc_inverse<ND>(acc, p, p.rope_q0 + t, lane);  // (the gradient of the UNROTATED query)
         store_rowT(dq + b * p.dq_bs + h * HD, p.dq_rs, t, valid, acc, p.scale, lane);
     }
 }
@@ -640,6 +761,7 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
     bf16x8_t kf[NF], vf[NF];
     load_row_frags(kf, k + b * p.k_bs + h * HD, p.k_rs, s, s < p.S, lane);
     load_row_frags(vf, v + b * p.v_bs + h * HD, p.v_rs, s, s < p.S, lane);
+    if (p.rope_cos) rope_frags<NF, T>(kf, p, p.rope_k0 + s, lane);
     f32x16 dka[ND], dva[ND];  // dKᵀ, dVᵀ: [d-tile][d rows] x key lane
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt)
@@ -658,6 +780,7 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
     if (t_begin < p.T) {
         tile_g2r(qreg, qbase, p.q_rs, t_begin, p.T, tid);
         tile_g2r(doreg, dobase, p.do_rs, t_begin, p.T, tid);
+        if (p.rope_cos) rope_tile<2 * NI, T>(qreg, p, p.rope_q0 + t_begin, tid);
     }
     for (int t0 = t_begin; t0 < p.T; t0 += KT) {
         __syncthreads();
@@ -672,6 +795,7 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
         if (t0 + KT < p.T) {  // prefetch the next query tile into registers
             tile_g2r(qreg, qbase, p.q_rs, t0 + KT, p.T, tid);
             tile_g2r(doreg, dobase, p.do_rs, t0 + KT, p.T, tid);
+            if (p.rope_cos) rope_tile<2 * NI, T>(qreg, p, p.rope_q0 + t0 + KT, tid);
         }
         __syncthreads();
         // causal classification of (this tile's 64 queries) x (this wave's 32 keys): wave-uniform
@@ -726,7 +850,10 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
             }
         }
     }
-    if constexpr (DO_K) store_rowT(dk + b * p.dk_bs + h * HD, p.dk_rs, s, s < p.S, dka, p.scale, lane);
+    if constexpr (DO_K) {
+        if (p.rope_cos) rope_acc_inverse<ND>(dka, p, p.rope_k0 + s, lane);
+        store_rowT(dk + b * p.dk_bs + h * HD, p.dk_rs, s, s < p.S, dka, p.scale, lane);
+    }
     if constexpr (DO_V) store_rowT(dv + b * p.dv_bs + h * HD, p.dv_rs, s, s < p.S, dva, 1.f, lane);
 }
 
@@ -783,6 +910,10 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
             ov = att_ld<1>(obase + (long long)r * p.o_rs + ch * 8);
         }
         if (r < p.S) kreg[i] = att_ld<1>(kbase + (long long)r * p.k_rs + ch * 8);
+        if (p.rope_cos) {
+            qv = rope_chunk<8, T>(qv, ch, p, p.rope_q0 + r);
+            kreg[i] = rope_chunk<8, T>(kreg[i], ch, p, p.rope_k0 + r);
+        }
         *reinterpret_cast<uint4*>(q_lds + lds_off<DUAL>(r, ch)) = qv;
         *reinterpret_cast<uint4*>(do_lds + lds_off<DUAL>(r, ch)) = dov;
         float part = frag_dot<T>(__builtin_bit_cast(bf16x8_t, dov), __builtin_bit_cast(bf16x8_t, ov));
@@ -801,6 +932,7 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
     bf16x8_t kf[4], vf[4];
     load_row_frags(kf, kbase, p.k_rs, s, s < p.S, lane);
     load_row_frags(vf, v + b * p.v_bs + h * HD64, p.v_rs, s, s < p.S, lane);
+    if (p.rope_cos) rope_frags<4, T>(kf, p, p.rope_k0 + s, lane);
     f32x16 dka[2], dva[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -860,6 +992,7 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
             }
         }
     }
+    if (p.rope_cos) rope_acc_inverse<2>(dka, p, p.rope_k0 + s, lane);
     store_rowT(dk + b * p.dk_bs + h * HD64, p.dk_rs, s, s < p.S, dka, p.scale, lane);
     store_rowT(dv + b * p.dv_bs + h * HD64, p.dv_rs, s, s < p.S, dva, 1.f, lane);
     __syncthreads();  // dSᵀ complete; the dO tile is dead
@@ -890,6 +1023,7 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
                                                                   acc[dt]);
         }
     }
+    if (p.rope_cos) rope_acc_inverse<2>(acc, p, p.rope_q0 + t, lane);
     store_rowT(dq + b * p.dq_bs + h * HD64, p.dq_rs, t, t < p.T, acc, p.scale, lane);
 }
 
@@ -953,16 +1087,31 @@ int check_common(const AttnParams& p, int hd, int dtype, const char* who) {
     return 0;
 }
 
-}  // namespace
+struct RopeArg {
+    const float* cos_t;
+    const float* sin_t;
+    int max_pos, q0, k0;
+};
+int set_rope(AttnParams& p, const RopeArg* r, int hd, const char* who) {
+    if (!r || !r->cos_t) return 0;
+    PK_CHECK_ARG(r->sin_t && r->max_pos > 0 && r->q0 >= 0 && r->k0 >= 0, "%s: bad rotary tables / offsets", who);
+    PK_CHECK_ARG(r->q0 + p.T <= r->max_pos && r->k0 + p.S <= r->max_pos, "%s: positions exceed the cos/sin table (%d rows)", who,
+                 r->max_pos);
+    PK_CHECK_ARG(((uintptr_t)r->cos_t % 16) == 0 && ((uintptr_t)r->sin_t % 16) == 0, "%s: cos/sin tables must be 16-byte aligned", who);
+    p.rope_cos = r->cos_t; p.rope_sin = r->sin_t; p.rope_max = r->max_pos; p.rope_q0 = r->q0; p.rope_k0 = r->k0;
+    (void)hd;
+    return 0;
+}
 
-extern "C" int pk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse,
                            const unsigned char* key_pad, int B, int H, int T, int S, int hd, long long q_bs,
                            long long q_rs, long long k_bs, long long k_rs, long long v_bs, long long v_rs,
                            long long o_bs, long long o_rs, int causal, float scale, float drop_p,
                            unsigned long long seed, unsigned long long offset, unsigned char* drop_mask, int dtype,
-                           void* stream) {
+                           void* stream, const RopeArg* rope) {
     AttnParams p = {};
     p.B = B; p.H = H; p.T = T; p.S = S;
+    if (int rc = set_rope(p, rope, hd, "pk_attn_fwd_rope")) return rc;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.key_pad = key_pad; p.causal = causal; p.scale = scale;
     PK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pk_attn_fwd: bad dropout %f", drop_p);
@@ -1004,16 +1153,17 @@ extern "C" int pk_attn_fwd(const void* q, const void* k, const void* v, void* o,
     return 0;
 }
 
-extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                            const float* lse, float* delta, void* dq, void* dk, void* dv,
                            const unsigned char* key_pad, int B, int H, int T, int S, int hd, long long q_bs,
                            long long q_rs, long long k_bs, long long k_rs, long long v_bs, long long v_rs,
                            long long o_bs, long long o_rs, long long do_bs, long long do_rs, long long dq_bs,
                            long long dq_rs, long long dk_bs, long long dk_rs, long long dv_bs, long long dv_rs,
                            int causal, float scale, float drop_p, const unsigned char* drop_mask, int dtype,
-                           void* stream) {
+                           void* stream, const RopeArg* rope) {
     AttnParams p = {};
     p.B = B; p.H = H; p.T = T; p.S = S;
+    if (int rc = set_rope(p, rope, hd, "pk_attn_bwd_rope")) return rc;
     PK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pk_attn_bwd: bad dropout %f", drop_p);
     PK_CHECK_ARG(drop_p == 0.f || drop_mask, "pk_attn_bwd: dropout needs the drop_mask of the forward call");
     if (drop_p > 0.f) {
@@ -1104,6 +1254,63 @@ extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const vo
 #undef PK_T16
     PK_LAUNCH_CHECK();
     return 0;
+}
+
+}  // namespace
+
+extern "C" int pk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                           const unsigned char* key_pad, int B, int H, int T, int S, int hd, long long q_bs,
+                           long long q_rs, long long k_bs, long long k_rs, long long v_bs, long long v_rs,
+                           long long o_bs, long long o_rs, int causal, float scale, float drop_p,
+                           unsigned long long seed, unsigned long long offset, unsigned char* drop_mask, int dtype,
+                           void* stream) {
+    return attn_fwd_impl(q, k, v, o, lse, key_pad, B, H, T, S, hd, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, causal, scale,
+                         drop_p, seed, offset, drop_mask, dtype, stream, nullptr);
+}
+
+extern "C" int pk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                           const float* lse, float* delta, void* dq, void* dk, void* dv,
+                           const unsigned char* key_pad, int B, int H, int T, int S, int hd, long long q_bs,
+                           long long q_rs, long long k_bs, long long k_rs, long long v_bs, long long v_rs,
+                           long long o_bs, long long o_rs, long long do_bs, long long do_rs, long long dq_bs,
+                           long long dq_rs, long long dk_bs, long long dk_rs, long long dv_bs, long long dv_rs,
+                           int causal, float scale, float drop_p, const unsigned char* drop_mask, int dtype,
+                           void* stream) {
+    return attn_bwd_impl(q, k, v, o, d_o, lse, delta, dq, dk, dv, key_pad, B, H, T, S, hd, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
+                         o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, causal, scale, drop_p, drop_mask,
+                         dtype, stream, nullptr);
+}
+
+// The same with rotary positions applied inside the kernels (AttnParams::rope_cos): q and k are the UNROTATED projection,
+// dq and dk the gradients with respect to it.  cos_t / sin_t: fp32 [max_pos][hd / 2]; query t sits at position q_pos0 + t,
+// key s at k_pos0 + s.
+extern "C" int pk_attn_fwd_rope(const void* q, const void* k, const void* v, void* o, float* lse,
+                                const unsigned char* key_pad, int B, int H, int T, int S, int hd, long long q_bs,
+                                long long q_rs, long long k_bs, long long k_rs, long long v_bs, long long v_rs,
+                                long long o_bs, long long o_rs, int causal, float scale, float drop_p,
+                                unsigned long long seed, unsigned long long offset, unsigned char* drop_mask,
+                                const float* cos_t, const float* sin_t, int max_pos, int q_pos0, int k_pos0, int dtype,
+                                void* stream) {
+    PK_CHECK_ARG(cos_t && sin_t, "pk_attn_fwd_rope: null cos/sin table");
+    const RopeArg r = {cos_t, sin_t, max_pos, q_pos0, k_pos0};
+    return attn_fwd_impl(q, k, v, o, lse, key_pad, B, H, T, S, hd, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, causal, scale,
+                         drop_p, seed, offset, drop_mask, dtype, stream, &r);
+}
+
+extern "C" int pk_attn_bwd_rope(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                const float* lse, float* delta, void* dq, void* dk, void* dv,
+                                const unsigned char* key_pad, int B, int H, int T, int S, int hd, long long q_bs,
+                                long long q_rs, long long k_bs, long long k_rs, long long v_bs, long long v_rs,
+                                long long o_bs, long long o_rs, long long do_bs, long long do_rs, long long dq_bs,
+                                long long dq_rs, long long dk_bs, long long dk_rs, long long dv_bs, long long dv_rs,
+                                int causal, float scale, float drop_p, const unsigned char* drop_mask,
+                                const float* cos_t, const float* sin_t, int max_pos, int q_pos0, int k_pos0, int dtype,
+                                void* stream) {
+    PK_CHECK_ARG(cos_t && sin_t, "pk_attn_bwd_rope: null cos/sin table");
+    const RopeArg r = {cos_t, sin_t, max_pos, q_pos0, k_pos0};
+    return attn_bwd_impl(q, k, v, o, d_o, lse, delta, dq, dk, dv, key_pad, B, H, T, S, hd, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
+                         o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, causal, scale, drop_p, drop_mask,
+                         dtype, stream, &r);
 }
 
 extern "C" int pk_attn_probs(const void* q, const void* k, void* probs, const unsigned char* key_pad, int B, int H, int T,

@@ -265,8 +265,17 @@ def _bs_rs(t: Tensor):
     return t.stride(0), t.stride(1)
 
 
+def _rope_args(rope, T: int, S: int, hd: int):
+    """rope = (cos_t, sin_t, q_pos0, k_pos0): fp32 [max_pos, hd / 2] tables and the positions of query 0 / key 0"""
+    cos_t, sin_t, q0, k0 = rope
+    require_gpu(cos_t, sin_t)
+    assert cos_t.dtype == torch.float32 and sin_t.dtype == torch.float32 and cos_t.is_contiguous() and sin_t.is_contiguous()
+    assert cos_t.shape == sin_t.shape and cos_t.size(1) * 2 == hd  # (the library checks the positions against the table)
+    return ptr(cos_t), ptr(sin_t), cos_t.size(0), int(q0), int(k0)
+
+
 def attn_fwd(q: Tensor, k: Tensor, v: Tensor, num_heads: int, key_pad: Optional[Tensor], causal: bool,
-             scale: float, drop_p: float = 0.0, seed: int = 0, offset: int = 0):
+             scale: float, drop_p: float = 0.0, seed: int = 0, offset: int = 0, rope=None):
     """q (B,T,D), k/v (B,S,D) (views with arbitrary batch/row strides), D = num_heads * head_dim (64 or 128).
     Returns (o (B,T,D) contiguous, lse (B,H,T) fp32) — and, with drop_p > 0 (attention-probability dropout), the keep-bit
     mask (B,H,T,8*ceil(S/64)) uint8 that attn_bwd needs."""
@@ -282,6 +291,12 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, num_heads: int, key_pad: Optional[
     if key_pad is not None:
         assert key_pad.dtype == torch.bool and key_pad.shape == (B, S) and key_pad.is_contiguous()
     L = lib.load()
+    if rope is not None:  # rotary positions inside the kernel: q, k are the unrotated projection
+        check(L.pk_attn_fwd_rope(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(key_pad), B, num_heads, T, S, hd,
+                                 *_bs_rs(q), *_bs_rs(k), *_bs_rs(v), *_bs_rs(o), int(causal), float(scale), float(drop_p),
+                                 int(seed), int(offset), ptr(mask), *_rope_args(rope, T, S, hd), dtype_code(q),
+                                 stream_ptr()), 'pk_attn_fwd_rope')
+        return (o, lse, mask) if drop_p > 0 else (o, lse)
     check(L.pk_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(key_pad), B, num_heads, T, S, hd,
                         *_bs_rs(q), *_bs_rs(k), *_bs_rs(v), *_bs_rs(o), int(causal), float(scale), float(drop_p),
                         int(seed), int(offset), ptr(mask), dtype_code(q), stream_ptr()), 'pk_attn_fwd')
@@ -290,7 +305,7 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, num_heads: int, key_pad: Optional[
 
 def attn_bwd(q, k, v, o, d_o, lse, num_heads: int, key_pad, causal: bool, scale: float,
              dq: Optional[Tensor] = None, dk: Optional[Tensor] = None, dv: Optional[Tensor] = None,
-             drop_p: float = 0.0, drop_mask: Optional[Tensor] = None):
+             drop_p: float = 0.0, drop_mask: Optional[Tensor] = None, rope=None):
     require_gpu(q, k, v, o, d_o, lse, key_pad, drop_mask)
     B, T, D = q.shape
     S = k.size(1)
@@ -310,6 +325,13 @@ def attn_bwd(q, k, v, o, d_o, lse, num_heads: int, key_pad, causal: bool, scale:
     dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device) if dv is None else dv
     delta = torch.empty(B, num_heads, T, dtype=torch.float32, device=q.device)
     L = lib.load()
+    if rope is not None:  # dq, dk: gradients of the UNROTATED q, k
+        check(L.pk_attn_bwd_rope(ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                                 ptr(key_pad), B, num_heads, T, S, hd, *_bs_rs(q), *_bs_rs(k), *_bs_rs(v), *_bs_rs(o),
+                                 *_bs_rs(d_o), *_bs_rs(dq), *_bs_rs(dk), *_bs_rs(dv), int(causal), float(scale),
+                                 float(drop_p), ptr(drop_mask), *_rope_args(rope, T, S, hd), dtype_code(q), stream_ptr()),
+              'pk_attn_bwd_rope')
+        return dq, dk, dv
     check(L.pk_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                         ptr(key_pad), B, num_heads, T, S, hd, *_bs_rs(q), *_bs_rs(k), *_bs_rs(v), *_bs_rs(o),
                         *_bs_rs(d_o), *_bs_rs(dq), *_bs_rs(dk), *_bs_rs(dv), int(causal), float(scale),

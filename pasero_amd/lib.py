@@ -45,6 +45,8 @@ SIGNATURES = {
     'pk_ln_param_grads': (I, [P, I, LL, I, I, P]),
     'pk_attn_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I] + [LL] * 8 + [I, F, F, ULL, ULL, P, I, P]),
     'pk_attn_bwd': (I, [P] * 11 + [I, I, I, I, I] + [LL] * 16 + [I, F, F, P, I, P]),
+    'pk_attn_fwd_rope': (I, [P, P, P, P, P, P, I, I, I, I, I] + [LL] * 8 + [I, F, F, ULL, ULL, P, P, P, I, I, I, I, P]),
+    'pk_attn_bwd_rope': (I, [P] * 11 + [I, I, I, I, I] + [LL] * 16 + [I, F, F, P, P, P, I, I, I, I, P]),
     'pk_attn_probs': (I, [P, P, P, P, I, I, I, I, I, LL, LL, LL, LL, I, F, I, P]),
     'pk_embed_fwd': (I, [P, P, P, P, LL, I, I, LL, F, I, F, ULL, ULL, I, P]),
     'pk_embed_bwd_workspace': (SZ, [LL, LL, I]),

@@ -7,6 +7,7 @@ eager PyTorch.
 import contextlib
 import functools
 import math
+import os
 from typing import Optional, Union
 
 import torch
@@ -18,6 +19,8 @@ from .profiling import region as _bench_region
 from .autograd import (LinearFn, PackedLinearFn, AttentionFn, ResidualLayerNormFn, DropoutFn, EmbeddingFn,
                        LinearResidualLnFn, block_tail_eligible,
                        ActivationFn, GLUFn, RotaryFn, ResidualLink)
+
+_ROPE_PASS = os.environ.get('PASERO_ROPE_PASS', '0') not in ('', '0')  # rotary positions as a pass of their own (pk_rope), for A/B
 
 
 class Identity(nn.Identity):
@@ -581,6 +584,12 @@ class MultiheadAttention(_PerCallAttrs, nn.Module):
             cos_t, sin_t = self.rotary_embed.tables(offset + T, packed.device)
             return RotaryFn.apply(packed, cos_t, sin_t, 2 * D, offset)
 
+        def rope_in_kernel():  # the rotation folded into the attention kernels (q and k stay unrotated in memory)
+            if self.rotary_embed is None or _ROPE_PASS:
+                return None
+            cos_t, sin_t = self.rotary_embed.tables(T, query.device)
+            return (cos_t, sin_t, 0, 0)
+
         if self.rotary_embed is not None and not (key is query and value is query):
             raise NotImplementedError('pasero_amd: rotary embeddings are implemented for self-attention only')
         weights = None
@@ -590,7 +599,10 @@ class MultiheadAttention(_PerCallAttrs, nn.Module):
             q = self.q_proj(query, link=link)
             k = self.k_proj(key)
             v = self.v_proj(value)
-            if self.rotary_embed is not None:  # modules.py:621-623: the new q and k rows, at their absolute positions
+            fold = None
+            if self.rotary_embed is not None and state is None and not return_attn:
+                fold = rope_in_kernel()
+            if self.rotary_embed is not None and fold is None:  # modules.py:621-623: the new q and k rows, at their absolute positions
                 offset = state['key'].size(1) if (state is not None and 'key' in state) else 0
                 cos_t, sin_t = self.rotary_embed.tables(offset + T, q.device)
                 q = RotaryFn.apply(_contiguous(q), cos_t, sin_t, D, offset)
@@ -605,7 +617,7 @@ class MultiheadAttention(_PerCallAttrs, nn.Module):
                     k4, v4 = torch.cat([prev_k, k4], dim=1), torch.cat([prev_v, v4], dim=1)
                 state['key'], state['value'] = k4, v4
                 k, v = k4.reshape(B, -1, D), v4.reshape(B, -1, D)
-            attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale, drop)
+            attn = AttentionFn.apply(q, k, v, attn_mask, H, self.causal and T > 1, scale, drop, fold)
             if return_attn:  # (B,T,H,S) softmax weights before dropout, as the reference's explicit path returns them
                 with torch.no_grad():
                     weights = F.attn_probs(q.detach(), k.detach(), H, attn_mask, self.causal and T > 1, scale)
@@ -626,8 +638,11 @@ class MultiheadAttention(_PerCallAttrs, nn.Module):
             S = k.size(1)
             attn = AttentionFn.apply(q, k.view(B, S, D), v.view(B, S, D), attn_mask, H, self.causal and T > 1, scale)
         elif key is query and value is query:
-            qkv = rope(PackedLinearFn.apply(query, w, b, 3, link, q_w, k_w, v_w, q_b, k_b, v_b, *gp), 0)
-            attn = AttentionFn.apply(qkv, None, None, attn_mask, H, self.causal and T > 1, scale, drop)
+            fold = rope_in_kernel()
+            qkv = PackedLinearFn.apply(query, w, b, 3, link, q_w, k_w, v_w, q_b, k_b, v_b, *gp)
+            if fold is None:
+                qkv = rope(qkv, 0)
+            attn = AttentionFn.apply(qkv, None, None, attn_mask, H, self.causal and T > 1, scale, drop, fold)
         elif key is value:
             q = LinearFn.apply(query, q_w, q_b, 'none', link, group)
             kv = PackedLinearFn.apply(key, w[D:], None if b is None else b[D:], 2, None, k_w, v_w, k_b, v_b, *gp)

@@ -86,6 +86,29 @@ def test_tiny_rotary_gelu_tanh_fp32_vs_reference():
     _check_encdec('tiny_encdec_rotary')
 
 
+@pytest.mark.parametrize('name', ['tiny_encdec_rotary', 'tiny_encdec_rms', 'tiny_hd128_rotary', 'tiny_lora_rotary'])
+def test_rotary_fixtures_run_without_a_rope_pass(name, monkeypatch):
+    """the rotary fixtures above pass with the rotation INSIDE the attention kernels: a training step (forward and backward,
+    encoder and decoder self-attention, with and without LoRA branches) never calls pk_rope — and gives the same loss as
+    the separate pass it replaces (PASERO_ROPE_PASS=1)"""
+    from pasero_amd import functional as F, modules
+    g = load_golden(name)
+    calls = []
+    real = F.rope
+    monkeypatch.setattr(F, 'rope', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    losses = []
+    for as_pass in (False, True):
+        monkeypatch.setattr(modules, '_ROPE_PASS', as_pass)
+        cfg, model = build_model(g, torch.float32, 'cuda')
+        model.train()
+        del calls[:]
+        loss, _ = model(**text_batch(g, 'cuda'))
+        loss.backward()
+        losses.append(loss.item())
+        assert (len(calls) > 0) == as_pass, (name, as_pass, len(calls))
+    assert abs(losses[0] - losses[1]) <= 2e-6 * abs(losses[1]), losses
+
+
 def test_tiny_swiglu_prenorm_fp32_vs_reference():
     """gated FFN (fc3): the gate product is the fc1 GEMM's epilogue"""
     _check_encdec('tiny_encdec_swiglu')
