@@ -416,6 +416,8 @@ typedef struct {
     PkFfnBlock ffn;
     const void* dy;                                     /* backward: gradient of the layer output (ffn.y; pre-norm: ffn.z) */
     void *dx, *denc;                                    /* backward: gradients of x and (decoder) enc */
+    const void* denc_prev;                              /* decoder: NULL, or the enc gradient accumulated so far by the layers
+                                                          * above (may be denc itself): denc = this layer's + denc_prev */
     void *scratch, *ws;
     size_t scratch_bytes, ws_bytes;
     void* stream;

@@ -325,7 +325,7 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
                                at(b.dkv, d, dt), L.cross_pad, L.B, L.heads, L.T, L.S, hd, (long long)L.T * d, d, (long long)L.S * 2 * d,
                                2 * d, (long long)L.S * 2 * d, 2 * d, (long long)L.T * d, d, (long long)L.T * d, d, (long long)L.T * d, d,
                                (long long)L.S * 2 * d, 2 * d, (long long)L.S * 2 * d, 2 * d, 0, L.attn_scale, 0.f, nullptr, dt, L.stream));
-            PK_TRY(dx_gemm(b.dkv, at(L.cross.w_in, d * d, dt), L.denc, nullptr, rows_kv, d, 2 * d, true));
+            PK_TRY(dx_gemm(b.dkv, at(L.cross.w_in, d * d, dt), L.denc, L.denc_prev, rows_kv, d, 2 * d, true));
             PK_TRY(dx_gemm(b.dq, L.cross.w_in, b.dln, nullptr, rows, d, d, true));
             PK_TRY(ln_in_bwd(b.dln, dz, L.self.z, L.cross.ln_g, L.cross.mean, L.cross.rstd, b.dy_self, L.cross.dln_g, L.cross.dln_b));
             dz = b.dy_self;
@@ -366,7 +366,7 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
                            at(b.dkv, d, dt), L.cross_pad, L.B, L.heads, L.T, L.S, hd, (long long)L.T * d, d, (long long)L.S * 2 * d,
                            2 * d, (long long)L.S * 2 * d, 2 * d, (long long)L.T * d, d, (long long)L.T * d, d, (long long)L.T * d, d,
                            (long long)L.S * 2 * d, 2 * d, (long long)L.S * 2 * d, 2 * d, 0, L.attn_scale, 0.f, nullptr, dt, L.stream));
-        PK_TRY(dx_gemm(b.dkv, at(L.cross.w_in, d * d, dt), L.denc, nullptr, rows_kv, d, 2 * d, true));
+        PK_TRY(dx_gemm(b.dkv, at(L.cross.w_in, d * d, dt), L.denc, L.denc_prev, rows_kv, d, 2 * d, true));
         PK_TRY(dx_gemm(b.dq, L.cross.w_in, b.dy_self, b.dres_c, rows, d, d, true));
         dy_blk = b.dy_self;
     }

@@ -21,6 +21,7 @@ from .lib import ACT, PkLayer, check, dtype_code
 
 _OFF = os.environ.get('PASERO_NO_NATIVE_LAYER', '0') not in ('', '0')
 _NO_FUSED_TAIL = os.environ.get('PASERO_NO_FUSED_TAIL', '0') not in ('', '0')
+_NO_DENC_CHAIN = os.environ.get('PASERO_NO_DENC_CHAIN', '0') not in ('', '0')  # (A/B: every decoder layer returns its own encoder gradient)
 _sizes = {}  # (is_decoder, fused, B, T, S, d, f, heads, dtype, drop) -> (scratch_bytes, ws_bytes)
 
 HOOKS_ENC = ('ffn', 'self_attention', 'self_attn_residual', 'self_attn_prenorm', 'self_attn_postnorm', 'ffn_residual',
@@ -218,6 +219,16 @@ class NativeLayerFn(Function):
         # (how often the layer ran since the reducer last looked: a layer applied twice in one graph must not write both
         # gradients into the same bucket slice, see backward)
         layer.__dict__['_pk_live_max'] = layer.__dict__.get('_pk_live_max', 0) + 1
+        if is_decoder and not _NO_DENC_CHAIN:
+            # every natively run decoder layer of this forward pass reads the same encoder output: their gradients for it are
+            # summed by the kv dX GEMMs themselves, one layer into the next's output (backward), instead of by five
+            # elementwise additions of autograd's.  The tally lives on the tensor: it ends with it.
+            tally = enc.__dict__.get('_pk_denc') if hasattr(enc, '__dict__') else None
+            if tally is None or tally['left'] != tally['n']:  # (none yet, or left behind by a backward that did not finish)
+                tally = {'n': 0, 'left': 0, 'buf': None}
+                enc._pk_denc = tally
+            tally['n'] += 1
+            tally['left'] = tally['n']
         ctx.keep = (x, enc, self_pad, cross_pad, a16, a32, params)  # (parameters: kept alive, the optimizer runs after backward)
         ctx.dims = (B, T, S, d, f, H)
         off = (y_ptr - a16.data_ptr()) // es
@@ -232,7 +243,21 @@ class NativeLayerFn(Function):
         dt, dev = x.dtype, x.device
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dx = torch.empty_like(x)
-        denc = torch.empty_like(enc) if is_decoder else None
+        denc = denc_ret = None
+        lay.denc_prev = None
+        if is_decoder:
+            tally = getattr(enc, '_pk_denc', None) if not _NO_DENC_CHAIN else None
+            if tally is not None and tally['n'] > 1 and tally['left'] > 0:
+                if tally['buf'] is None:
+                    tally['buf'] = torch.empty_like(enc)          # the first of the chain writes it ...
+                else:
+                    lay.denc_prev = tally['buf'].data_ptr()       # ... the others add theirs to it, in place
+                denc = tally['buf']
+                tally['left'] -= 1
+                if tally['left'] == 0:                            # ... the last one hands the sum to autograd
+                    denc_ret, tally['buf'], tally['left'] = denc, None, tally['n']
+            else:
+                denc = denc_ret = torch.empty_like(enc)
         lay.dy, lay.dx, lay.denc = dy.data_ptr(), dx.data_ptr(), (denc.data_ptr() if is_decoder else None)
         # parameter gradients: the [*, d] weights as row blocks of one 2-D tensor (q | k | v | out [| cross ...] | fc1), fc2 on
         # its own, biases and LayerNorm parameters as pieces of one vector — three allocations, two splits
@@ -293,7 +318,7 @@ class NativeLayerFn(Function):
         v0 = 6 * nblk
         grads += [ws_[4 * nblk], vs_[v0], w2, vs_[v0 + 1], vs_[v0 + 2], vs_[v0 + 3]]
         grads = [g if prm is not None else None for g, prm in zip(grads, params)]  # (a projection without bias)
-        return (dx, denc, None, None, None, None, *grads)
+        return (dx, denc_ret, None, None, None, None, *grads)
 
 
 def run(layer, x, enc, self_pad, cross_pad, is_decoder: bool):

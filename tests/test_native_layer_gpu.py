@@ -27,9 +27,12 @@ def _model(V, seed=3, dtype=torch.bfloat16, **over):
     return model.to(dtype).cuda().train()
 
 
-def _step(model, batch, native: bool, seed=11):
+def _step(model, batch, native: bool, seed=11, chain: bool = False):
+    # chain: the decoder layers sum their encoder-output gradients inside the kv dX GEMMs (one rounding per layer) instead of
+    # leaving five bf16 additions to autograd (two roundings per layer) — the default; off for the bit-for-bit comparisons
     from pasero_amd import native_layer, rng
     native_layer._OFF = not native
+    native_layer._NO_DENC_CHAIN = not chain
     calls = {'n': 0}
     orig = native_layer.NativeLayerFn.forward
 
@@ -46,6 +49,7 @@ def _step(model, batch, native: bool, seed=11):
     finally:
         native_layer.NativeLayerFn.forward = staticmethod(orig)
         native_layer._OFF = False
+        native_layer._NO_DENC_CHAIN = False
     grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
     return loss.item(), logs['num_tokens'], grads, calls['n']
 
@@ -72,6 +76,18 @@ def test_native_layer_equals_the_per_op_path_bit_for_bit(over, B, S, T):
     # and twice in a row (grow-only scratch buffers reused across layers and steps)
     l2, _, g2, _ = _step(model, batch, native=True)
     assert l2 == l1 and all(torch.equal(g2[k], g1[k]) for k in g1)
+    # the default: the encoder-output gradient summed by the decoder layers' kv dX GEMMs.  Everything on the decoder side is
+    # untouched (bit for bit); what flows into the encoder differs by the roundings it no longer has
+    l3, _, g3, _ = _step(model, batch, native=True, chain=True)
+    assert l3 == l1
+    for k in g1:
+        if k.startswith('decoder.layers') or over['decoder_layers'] == 1:
+            assert torch.equal(g3[k].view(torch.int16), g1[k].view(torch.int16)), k
+        elif not k.endswith('k_proj.bias'):  # (a key bias's gradient is mathematically zero: round-off only)
+            a, b_ = g3[k].float(), g1[k].float()
+            assert (a - b_).norm().item() <= 3e-2 * b_.norm().item() + 1e-6, (k, (a - b_).norm().item(), b_.norm().item())
+    l4, _, g4, _ = _step(model, batch, native=True, chain=True)
+    assert l4 == l3 and all(torch.equal(g4[k], g3[k]) for k in g3)
 
 
 def test_what_is_not_the_stock_layer_stays_on_the_per_op_path():
