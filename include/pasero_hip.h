@@ -66,10 +66,11 @@ int pk_gemm_timing_start(int max_samples, int stride);
  * 2 additionally sends every eligible GEMM with M, N >= 256 there, whether or not its tiles fill the chip (tests);
  * a negative argument only queries.  Returns the previous setting (env PK_GEMM_8P sets the initial one). */
 int pk_gemm_use_8p(int on);
-/* diagnostic: 1 / 0 lets pk_gemm send short-contraction GEMMs (K = 512 / 256, row-form A, bias / ReLU epilogue, thousands
- * of rows) to the B-stationary kernel (gemmbs.hip, default) / keeps them on the tiled kernels; negative: query only.
- * Returns the previous setting (env PK_GEMM_BS sets the initial one).  Sample tag in pk_gemm_timing_read: 0x200 | number
- * of K-tiles | 0x10 with the ReLU epilogue | 0x20 with the ReLU-mask epilogue (mode 2) | 0x40 with the mask as bits. */
+/* diagnostic: 1 / 0 lets pk_gemm send short-contraction GEMMs (K = 512, row-form A, thousands of rows; mode 0 with bias and
+ * no activation / ReLU / GELU-with-preact, mode 2 with ReLU' or GELU') to the B-stationary kernel (gemmbs.hip, default) /
+ * keeps them on the tiled kernels; negative: query only.  Returns the previous setting (env PK_GEMM_BS sets the initial
+ * one).  Sample tag in pk_gemm_timing_read: 0x200 | number of K-tiles | activation << 4 | 0x40 the act'-mask epilogue
+ * (mode 2) | 0x80 the mask as bits | 0x100 the pre-activation as second output. */
 int pk_gemm_use_bs(int on);
 /* The ReLU feed-forward's mask as ONE BIT per element (fc1 forward / fc2 dX of pasero/models/transformer.py:999-1019 at
  * K = 512): `bits` [M][ldbits] bytes, bit (n & 7) of byte n >> 3 of row m = (C[m][n] > 0) of the forward call.
