@@ -2,7 +2,9 @@
 include/pasero_hip.h, csrc/layer.cpp): `TransformerEncoderLayer.forward` / `TransformerDecoderLayer.forward`
 (pasero/models/transformer.py:1056-1099, 1341-1417) as ONE autograd node whose forward and backward each enqueue the
 layer's whole launch sequence from C — the same kernels, in the same order, with the same arguments and dropout offsets
-as the per-op path (pasero_amd/autograd.py), so both paths agree bit for bit (tests/test_native_layer_gpu.py) — instead of
+as the per-op path (pasero_amd/autograd.py), so both paths agree bit for bit (tests/test_native_layer_gpu.py; across decoder
+layers the encoder-output gradient is summed in the kv dX GEMMs with one rounding less, PASERO_NO_DENC_CHAIN=1 restores
+autograd's additions) — instead of
 ~13 / ~27 Python dispatches with their tensor allocations and ctypes marshalling.  Host time of a C2 step: 9.6 -> ~4 ms.
 
 A layer takes this path only when it is exactly the stock layer: post- or pre-norm, LayerNorm with bias, every Linear with
