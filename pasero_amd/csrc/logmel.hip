@@ -89,21 +89,24 @@ int get_consts(Consts& out) {
     return 0;
 }
 
-__global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wav, const long long* __restrict__ wav_len,
+__global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict__ wav, const long long* __restrict__ wav_len,
                                                      long long wav_stride, float* __restrict__ out,
                                                      float* __restrict__ blockmax, Consts cst) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * NFFT + FT * APITCH + FT * PPITCH];  // 81 KiB
-    float* tw_c = smem;                                     // [400]
-    float* tw_s = tw_c + NFFT;                              // [400]
-    float* a_t = tw_s + NFFT;                               // [32][401] windowed frames
-    float* p_t = a_t + FT * APITCH;                         // [32][225] power spectrum
+    // 52.9 KiB: THREE workgroups per CU (the power spectrum takes the frames' place once the DFT has read them, and the sine
+    // is the cosine table read a quarter period earlier — as 81 KiB, one workgroup per CU with nothing beside it: 782 us
+    // per call against an MFMA time of ~160; two per CU: 505)
+    __shared__ __attribute__((aligned(16))) float smem[NFFT + FT * APITCH];
+    static_assert(FT * PPITCH <= FT * APITCH, "the power tile aliases the frame tile");
+    float* tw_c = smem;                                     // [400] cos(2 pi j / 400); sin(2 pi j / 400) = tw_c[(j + 300) % 400]
+    float* a_t = tw_c + NFFT;                               // [32][401] windowed frames
+    float* p_t = a_t;                                       // [32][225] power spectrum (after the DFT)
     __shared__ float wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int clip = blockIdx.y, f0 = blockIdx.x * FT;
     const float* x = wav + (long long)clip * wav_stride;
     const long long nvalid = wav_len ? min(wav_len[clip], (long long)NSAMP) : NSAMP;
 
-    for (int j = tid; j < NFFT; j += 256) { tw_c[j] = cst.tw_cos[j]; tw_s[j] = cst.tw_sin[j]; }
+    for (int j = tid; j < NFFT; j += 256) tw_c[j] = cst.tw_cos[j];
     for (int i = tid; i < FT * NFFT; i += 256) {
         const int f = i / NFFT, n = i % NFFT;
         long long j = (long long)(f0 + f) * HOP + n - NFFT / 2;       // index into the 30 s zero-padded signal
@@ -135,13 +138,15 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (t == 1 && !two) break;
-            const float c = tw_c[idx[t]], sn = tw_s[idx[t]];
+            const int is = idx[t] + 300 >= NFFT ? idx[t] - 100 : idx[t] + 300;
+            const float c = tw_c[idx[t]], sn = tw_c[is];
             re[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, c, re[t], 0, 0, 0);
             im[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sn, im[t], 0, 0, 0);
             idx[t] += step[t];
             if (idx[t] >= NFFT) idx[t] -= NFFT;
         }
     }
+    __syncthreads();  // every wave has read its last frame samples: the tile may be overwritten
     // power spectrum -> LDS  (accumulator: column = lane & 31 = bin, rows = frames)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
