@@ -293,10 +293,14 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
         auto undrop = [&](const void* dz, void* out, unsigned long long offset) -> int {
             return drop ? pk_dropout(dz, out, rows * d, L.drop_p, L.seed, offset, dt, L.stream) : 0;
         };
+        // d_in = LN_bwd(dln) + dz is the gradient of the block's input = the output z of the block BELOW, whose backward
+        // starts by pushing it through that block's dropout mask: the kernel writes that masked copy too (`below`: its
+        // buffer, `below_offset`: that block's dropout offset) — no pk_dropout pass between the blocks of a layer
         auto ln_in_bwd = [&](const void* dln, const void* dz, const void* in, const void* g, const float* mean, const float* rstd,
-                             void* d_in, void* dg, void* db) {
-            return pk_residual_ln_bwd_partials(dln, dz, in, g, mean, rstd, d_in, nullptr, ln_ws(dg, db), b.ws_ln, rows, (int)d, 0.f, 0, 0,
-                                               dt, L.stream);
+                             void* d_in, void* dg, void* db, void* below, unsigned long long below_offset) {
+            const bool emit = drop && below;
+            return pk_residual_ln_bwd_partials(dln, dz, in, g, mean, rstd, d_in, emit ? below : nullptr, ln_ws(dg, db), b.ws_ln, rows,
+                                               (int)d, emit ? L.drop_p : 0.f, emit ? L.seed : 0, emit ? below_offset : 0, dt, L.stream);
         };
         const void* in_f = L.is_decoder ? L.cross.z : L.self.z;
         // feed-forward
@@ -311,13 +315,14 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
             PK_TRY(pk_gemm(do_f, L.ffn.w2, b.dh, nullptr, L.ffn.pre ? L.ffn.pre : L.ffn.h, nullptr, rows, f, d, d, f, f, f, 0, 0, 1, L.act, 2,
                            1.f, dt, 1, nullptr, 0, nullptr, L.stream));
         PK_TRY(dx_gemm(b.dh, L.ffn.w1, b.dln, nullptr, rows, d, f, true));
-        PK_TRY(ln_in_bwd(b.dln, L.dy, in_f, L.ffn.ln_g, L.ffn.mean, L.ffn.rstd, b.dy_mid, L.ffn.dln_g, L.ffn.dln_b));
+        PK_TRY(ln_in_bwd(b.dln, L.dy, in_f, L.ffn.ln_g, L.ffn.mean, L.ffn.rstd, b.dy_mid, L.ffn.dln_g, L.ffn.dln_b,
+                         L.is_decoder ? b.dsub_c : b.dsub_s, L.is_decoder ? L.cross.drop_offset : L.self.drop_offset));
         const void* dz = b.dy_mid;
         PkWgradProblem pr[PK_WGRAD_MAX];
         int n = wgrad_problems(L, b, pr);
         pr[0].A = do_f;  // (fc2's dY is the un-dropped gradient, wherever it lives)
         if (L.is_decoder) {
-            PK_TRY(undrop(dz, b.dsub_c, L.cross.drop_offset));
+            // (b.dsub_c = dz through the cross block's mask: written by the feed-forward block's LayerNorm backward above)
             const void* do_c = drop ? b.dsub_c : dz;
             pr[2].A = do_c;
             PK_TRY(dx_gemm(do_c, L.cross.w_o, b.dcattn, nullptr, rows, d, d, true));
@@ -327,10 +332,11 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
                                (long long)L.S * 2 * d, 2 * d, (long long)L.S * 2 * d, 2 * d, 0, L.attn_scale, 0.f, nullptr, dt, L.stream));
             PK_TRY(dx_gemm(b.dkv, at(L.cross.w_in, d * d, dt), L.denc, L.denc_prev, rows_kv, d, 2 * d, true));
             PK_TRY(dx_gemm(b.dq, L.cross.w_in, b.dln, nullptr, rows, d, d, true));
-            PK_TRY(ln_in_bwd(b.dln, dz, L.self.z, L.cross.ln_g, L.cross.mean, L.cross.rstd, b.dy_self, L.cross.dln_g, L.cross.dln_b));
+            PK_TRY(ln_in_bwd(b.dln, dz, L.self.z, L.cross.ln_g, L.cross.mean, L.cross.rstd, b.dy_self, L.cross.dln_g, L.cross.dln_b,
+                             b.dsub_s, L.self.drop_offset));
             dz = b.dy_self;
         }
-        PK_TRY(undrop(dz, b.dsub_s, L.self.drop_offset));
+        // (b.dsub_s: written by the LayerNorm backward of the block above)
         const void* do_s = drop ? b.dsub_s : dz;
         pr[L.is_decoder ? 5 : 2].A = do_s;
         PK_TRY(dx_gemm(do_s, L.self.w_o, b.dattn, nullptr, rows, d, d, true));
@@ -340,7 +346,7 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
                            (long long)L.T * d, d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d,
                            L.is_decoder && L.T > 1, L.attn_scale, 0.f, nullptr, dt, L.stream));
         PK_TRY(dx_gemm(b.dproj, L.self.w_in, b.dln, nullptr, rows, d, 3 * d, true));
-        PK_TRY(ln_in_bwd(b.dln, dz, L.x, L.self.ln_g, L.self.mean, L.self.rstd, L.dx, L.self.dln_g, L.self.dln_b));
+        PK_TRY(ln_in_bwd(b.dln, dz, L.x, L.self.ln_g, L.self.mean, L.self.rstd, L.dx, L.self.dln_g, L.self.dln_b, nullptr, 0));
         PK_TRY(ln_finish());
         return pk_gemm_wgrad_group(pr, n, dt, ws, b.ws_group, L.stream);
     }
