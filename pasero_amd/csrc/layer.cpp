@@ -154,6 +154,13 @@ int layer_fwd_prenorm(const PkLayer& L) {
         return pk_gemm(a, w, out, bias, nullptr, pre, M, N, K, K, K, N, 0, pre ? N : 0, 0, 0, act, 0, 1.f, dt, 1, nullptr, 0, nullptr, L.stream);
     };
     PK_REQ(L.self.ln_out && L.ffn.ln_out && (!L.is_decoder || L.cross.ln_out), "pk_layer_fwd: pre-norm layer without ln_out buffers");
+    // the end of a block (z = in + dropout(o)) and the LayerNorm that starts the NEXT block of the layer in one pass: the
+    // same kernel writes z and LN(z) — with the next block's gamma / beta, its statistics taken on the rounded z as a
+    // separate pass over z would take them (bit for bit the two launches it replaces)
+    auto end_and_next_norm = [&](const void* o, const void* in, void* z, unsigned long long offset, const void* g, const void* be,
+                                 void* ln_out, float* mean, float* rstd) {
+        return pk_residual_ln_fwd(o, in, g, be, z, ln_out, mean, rstd, rows, (int)d, L.eps, L.drop_p, L.seed, offset, dt, L.stream);
+    };
     // ---- self-attention ----
     PK_TRY(pre_norm(L, L.x, L.self.ln_g, L.self.ln_b, L.self.ln_out, L.self.mean, L.self.rstd));
     PK_TRY(linear(L.self.ln_out, L.self.w_in, L.self.b_in, L.self.proj, rows, 3 * d, d, PK_ACT_NONE, nullptr));
@@ -162,11 +169,15 @@ int layer_fwd_prenorm(const PkLayer& L) {
                        (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * d, d,
                        L.is_decoder && L.T > 1, L.attn_scale, 0.f, 0, 0, nullptr, dt, L.stream));
     PK_TRY(linear(L.self.attn, L.self.w_o, L.self.b_o, L.self.y, rows, d, d, PK_ACT_NONE, nullptr));
-    PK_TRY(pre_end(L, L.self.y, L.x, L.self.z, L.self.drop_offset));
+    if (L.is_decoder)
+        PK_TRY(end_and_next_norm(L.self.y, L.x, L.self.z, L.self.drop_offset, L.cross.ln_g, L.cross.ln_b, L.cross.ln_out, L.cross.mean,
+                                 L.cross.rstd));
+    else
+        PK_TRY(end_and_next_norm(L.self.y, L.x, L.self.z, L.self.drop_offset, L.ffn.ln_g, L.ffn.ln_b, L.ffn.ln_out, L.ffn.mean,
+                                 L.ffn.rstd));
     const void* z = L.self.z;
     // ---- cross-attention (decoder) ----
     if (L.is_decoder) {
-        PK_TRY(pre_norm(L, z, L.cross.ln_g, L.cross.ln_b, L.cross.ln_out, L.cross.mean, L.cross.rstd));
         PK_TRY(linear(L.cross.ln_out, L.cross.w_in, L.cross.b_in, L.cross.proj, rows, d, d, PK_ACT_NONE, nullptr));
         PK_TRY(linear(L.enc, at(L.cross.w_in, d * d, dt), L.cross.b_in ? at(L.cross.b_in, d, dt) : nullptr, L.cross.kv, rows_kv, 2 * d, d,
                       PK_ACT_NONE, nullptr));
@@ -174,11 +185,11 @@ int layer_fwd_prenorm(const PkLayer& L) {
                            L.T, L.S, hd, (long long)L.T * d, d, (long long)L.S * 2 * d, 2 * d, (long long)L.S * 2 * d, 2 * d,
                            (long long)L.T * d, d, 0, L.attn_scale, 0.f, 0, 0, nullptr, dt, L.stream));
         PK_TRY(linear(L.cross.attn, L.cross.w_o, L.cross.b_o, L.cross.y, rows, d, d, PK_ACT_NONE, nullptr));
-        PK_TRY(pre_end(L, L.cross.y, z, L.cross.z, L.cross.drop_offset));
+        PK_TRY(end_and_next_norm(L.cross.y, z, L.cross.z, L.cross.drop_offset, L.ffn.ln_g, L.ffn.ln_b, L.ffn.ln_out, L.ffn.mean,
+                                 L.ffn.rstd));
         z = L.cross.z;
     }
     // ---- feed-forward ----
-    PK_TRY(pre_norm(L, z, L.ffn.ln_g, L.ffn.ln_b, L.ffn.ln_out, L.ffn.mean, L.ffn.rstd));
     if (L.ffn.bits)
         PK_TRY(pk_gemm_relu_bits(L.ffn.ln_out, L.ffn.w1, L.ffn.h, L.ffn.b1, L.ffn.bits, rows, f, d, d, d, f, f / 8, 0, 0, 1.f, dt, L.stream));
     else
