@@ -711,16 +711,19 @@ class EmbeddingFn(Function):
         return None, dE, dpos, None, None, None, None
 
 
-_CE_BUDGET = int(os.environ.get('PASERO_CE_BUDGET_MB', '512')) << 20  # bytes of logits per chunk (env: the sweep below)
+_CE_BUDGET = int(os.environ.get('PASERO_CE_BUDGET_MB', '1200')) << 20  # bytes of logits per chunk (env: the sweep below)
 
 
 def _ce_chunk_rows(rows: int, V: int, itemsize: int, budget_bytes: int = _CE_BUDGET) -> int:
-    """rows per logits chunk: the (rows, V) logits never exist as a whole, only a chunk of <= 512 MiB at a time.
+    """rows per logits chunk: the (rows, V) logits never exist as a whole, only a chunk of <= 1200 MiB at a time.
     Rounds 1-2 used 128 MiB so that a chunk would stay in the 256 MiB Infinity Cache between the GEMM that writes it, the
     CE kernel that rewrites it in place and the two gradient GEMMs that read it; the GEMM epilogues store streaming since
     then and residency buys nothing, while fewer, larger GEMMs do.  Same-box sweep of the budget (round 3, ms per step):
     C2 (V = 8 032) 64 MiB 13.57, 128 13.23, 256 13.21, >= 512 (one chunk) 13.05-13.08; transformer_big (V = 70 376) 64 MiB
-    57.4, 128 52.1, 256 50.9, 512 50.7-50.9, 1024 53.8, 2048 50.0, 4096 54.2."""
+    57.4, 128 52.1, 256 50.9, 512 50.7-50.9, 1024 53.8, 2048 50.0, 4096 54.2 — the ups and downs were ONE GEMM: the chunk's
+    dX GEMM (rows x d, K = V) ran unsplit on 96-128 of the 256 CUs at 6144 / 8192 rows because `choose_splitk` asked for
+    K % 64 == 0 (1.5 ms instead of 0.8); with that fixed, on a slower box: 512 MiB 52.1, 600 51.8, 900 51.8, 1200 (8192 rows)
+    51.3, 1536 52.3, 2048 51.3; NLLB shapes (V = 256 206) 512 MiB 86.1, 1200 85.4, 2400 85.4."""
     per = max(1, budget_bytes // (V * itemsize))
     per = max(128, (per // 128) * 128)
     if per >= 2048:  # whole waves of 256-row tiles over the 256 CUs: 8320 rows are 33 tile rows, 8192 are 32 (C2: the

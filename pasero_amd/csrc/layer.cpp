@@ -34,7 +34,7 @@ int choose_splitk(long long M, long long N, long long K) {
     const long long tiles = ((M + 127) / 128) * ((N + 127) / 128);
     if (tiles > 256 || K < 1024) {
         const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        return (80 <= t256 && t256 < 160 && K >= 2048 && M % 8 == 0 && N % 8 == 0 && K % 64 == 0) ? 2 : 1;
+        return (80 <= t256 && t256 < 160 && K >= 2048 && M % 8 == 0 && N % 8 == 0 && K % 8 == 0) ? 2 : 1;
     }
     return (int)std::max(1LL, std::min(512 / tiles, K / 512));
 }

@@ -152,7 +152,10 @@ def choose_splitk(M: int, N: int, K: int, target_blocks: int = 512) -> int:
         # as one low-occupancy round of 128-tiles: two K slices on the 256 kernel are faster (8192 x 1024 x 8192, cold
         # operands: weight gradient 201 -> 171 us, dX 185 -> 166 us, split-K reduction included)
         t256 = ((M + 255) // 256) * ((N + 255) // 256)
-        return 2 if (80 <= t256 < 160 and K >= 2048 and M % 8 == 0 and N % 8 == 0 and K % 64 == 0) else 1
+        # (K % 8: the phase-interleaved kernel zero-fills a partial last K-tile — the vocabulary dX GEMMs, K = V.  With
+        # K % 64 required, a 6144- or 8192-row chunk of transformer_big's dX GEMM ran unsplit on 96 / 128 of the 256 CUs:
+        # 1.5 ms instead of 0.8)
+        return 2 if (80 <= t256 < 160 and K >= 2048 and M % 8 == 0 and N % 8 == 0 and K % 8 == 0) else 1
     # tiles * s must stay within one round of 2 workgroups per CU (512): 560 workgroups run as two rounds and take
     # 1.6x as long as 504.  256 tiles are still split in two — one workgroup per CU has nothing to overlap its
     # prologue / epilogue / DMA waits with (transformer_big's 4096 x 1024 weight gradients: 642 -> 363 us)

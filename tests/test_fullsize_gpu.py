@@ -204,8 +204,7 @@ def test_fullsize_cross_entropy_gradient_rows_sum_to_zero():
 @pytest.mark.parametrize('vocab,layers,b', [(70376, 2, 64), (256206, 1, 32)])
 def test_c3_c5_vocabularies_chunked_loss(vocab, layers, b, monkeypatch):
     """BASELINE configs C3 (transformer_big, V = 70376) and C5 (NLLB, V = 256206) at their widths (d = 1024, 16 heads,
-    S = T = 128) with fewer layers: the fused vocabulary loss walks the rows in logits chunks sized for the Infinity
-    Cache — the result must not depend on the chunking, and stays additive over the batch"""
+    S = T = 128) with fewer layers: the fused vocabulary loss walks the rows in logits chunks — the result must not depend on the chunking, and stays additive over the batch"""
     from pasero_amd import autograd
     from pasero_amd.config import TransformerBigConfig, DistributedConfig, SyntheticTask
     from pasero_amd.transformer import Transformer
@@ -225,9 +224,11 @@ def test_c3_c5_vocabularies_chunked_loss(vocab, layers, b, monkeypatch):
 
     chunks = []
     real = autograd._ce_chunk_rows
-    monkeypatch.setattr(autograd, '_ce_chunk_rows', lambda *a, **k: chunks.append(real(*a, **k)) or chunks[-1])
+    # (a quarter of the default budget of 1200 MiB: these rows in several chunks, cut by the same rule)
+    monkeypatch.setattr(autograd, '_ce_chunk_rows',
+                        lambda rows, V, itemsize: chunks.append(real(rows, V, itemsize, budget_bytes=300 << 20)) or chunks[-1])
     full, ntok, g = step()
-    assert chunks[-1] < b * 128, 'the default budget should already split these rows into several chunks'
+    assert chunks[-1] < b * 128, 'a 300 MiB budget should split these rows into several chunks'
     h1, n1, g1 = step(slice(0, b // 2))
     h2, n2, g2 = step(slice(b // 2, b))
     assert ntok == n1 + n2 and abs(full - (h1 + h2)) <= 1e-5 * abs(full)
