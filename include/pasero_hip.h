@@ -111,6 +111,12 @@ typedef struct PkWgradProblem {
 int pk_gemm_wgrad_group_eligible(const PkWgradProblem* problem, int dtype);
 size_t pk_gemm_wgrad_group_workspace(const PkWgradProblem* problems, int n);
 int pk_gemm_wgrad_group(const PkWgradProblem* problems, int n, int dtype, void* workspace, size_t ws_bytes, void* stream);
+/*   pk_gemm_wgrad_group_map (host only, no GPU work): which workgroup of the launch works on what.  The eight XCDs of the
+ *     chip have an L2 each and the hardware deals workgroups to them round-robin (workgroup b runs on XCD b % 8), so the
+ *     tiles of one (problem, K-slab) unit — which re-read the same rows of dY and X — are kept on ONE XCD wherever they fit.
+ *     out[2 b] = problem index, out[2 b + 1] = position in that problem's slab-major (K-slab, tile) walk, both -1 for a
+ *     workgroup that exits at once; at most `cap` workgroups are written.  Returns the grid size, -1 on bad arguments. */
+int pk_gemm_wgrad_group_map(const PkWgradProblem* problems, int n, int* out, int cap);
 
 /* ---- Linear + residual + dropout + LayerNorm in one kernel (K4 fused into K2/K5): replaces the tail of a post-norm
  * sub-block, `x = self.out_proj(x)` / `x = self.fc2(x)` followed by `x = residual + dropout(x); x = LayerNorm(x)`,

@@ -40,6 +40,7 @@ extern "C" int pk_gemm8p_eligible(long long M, long long N, long long K, long lo
                                   int b_col, int want_asum);
 extern "C" int pk_gemm8p_group_eligible(const PkWgradProblem* q);
 extern "C" int pk_gemm8p_group_plan(const PkWgradProblem* p, int n, size_t* ws_bytes, int* workgroups, int* slabs);
+extern "C" int pk_gemm8p_group_map(const PkWgradProblem* p, int n, int* out, int cap);
 extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream);
 extern "C" int pk_gemm8p_group_reduce(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream);
 extern "C" int pk_gemmln_launch(const void* A, const void* W, const void* bias, const void* residual, const void* gamma,
@@ -925,6 +926,11 @@ extern "C" size_t pk_gemm_wgrad_group_workspace(const PkWgradProblem* p, int n) 
     size_t b = 0;
     if (!p || pk_gemm8p_group_plan(p, n, &b, nullptr, nullptr) != 0) return 0;
     return b;
+}
+
+extern "C" int pk_gemm_wgrad_group_map(const PkWgradProblem* p, int n, int* out, int cap) {
+    if (!p || !out) return -1;
+    return pk_gemm8p_group_map(p, n, out, cap);
 }
 
 extern "C" int pk_gemm_wgrad_group(const PkWgradProblem* p, int n, int dtype, void* workspace, size_t ws_bytes,

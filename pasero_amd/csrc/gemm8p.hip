@@ -41,6 +41,7 @@
 // col images: ds_read_b64_tr_b16, chunk ^ 2*((k&3) | ((k>>3)&1)<<2)).
 #include <algorithm>
 #include <type_traits>
+#include <vector>
 #include "common.h"
 #include "gemm_epi.h"
 
@@ -317,41 +318,43 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
         return __builtin_bit_cast(V, f);
     };
 
-    // Fused bias gradient (col-form A = dY: the sum over k of every column), by the tile_n == 0 workgroups, in the two
-    // light load sections of a K-tile: threads 256..511 sum its A0 image in phase 2 (next to the four B1 fragment reads;
-    // the slot is overwritten two phases later), threads 0..255 its A1 image in phase 4.  Thread t: 16-byte chunk t & 15
-    // of rows (t & 255) >> 4 + 16 it, it = 0..3.  Inline-asm reads with their own wait (the compiler would put vmcnt(0)
-    // in front of plain loads of these images).
+    // Fused bias gradient (col-form A = dY: the sum over k of every column), by the tile_n == 0 workgroups, ON THE MATRIX
+    // CORES: one more MFMA per phase whose B operand is all ones — D'[n][m] = sum_k A(m, k) for every n.  Wave (wr, wc)
+    // sums its m-tile i = wc (the four waves of a row half hold the same A fragments): quadrant phases 0, 1 take k-steps
+    // 0, 1 of row half 0, phases 2, 3 those of row half 1, so every phase carries 17 MFMAs instead of 16.  (Round 3 summed
+    // the staged A images with LDS reads + VALU adds in the load sections of phases 2 and 4: those workgroups ran their K
+    // loop 25 % slower than the others — 189 against 146 us at the C2 encoder shapes, tools/gemm_phase_stamps.py — and a
+    // launch lasts as long as its slowest workgroup.)
     const bool do_asum = A_COL && (asum_ws || asum_out) && tile_n == 0;
-    float asum[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) asum[e] = 0.f;
-    unsigned asum_base = 0;  // LDS address of this thread's first chunk in stage 0 (+ STAGE for stage 1)
+    f32x4 acc_s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // [row half]: lane l, any r: m = 16 wc + (l & 15)
+    // (its A fragments are read a second time, into registers of their own, through an address computed once: choosing
+    // among fa[0..3] by wc inside the loop made hipcc index the fragment array through scratch memory)
+    V fs[2];
+    unsigned cs_a[2] = {0u, 0u};
     if constexpr (A_COL) {
         typedef __attribute__((address_space(3))) char lds_char;
-        asum_base = (unsigned)(unsigned long)(lds_char*)smem + (tid < 256 ? SLOT_A1 : SLOT_A0) * HALF +
-                    HT<true>::offset((tid & 255) >> 4, tid & 15);
+        const unsigned base = (unsigned)(unsigned long)(lds_char*)smem;
+        const int q = (lane & 15) >> 2, p = lane & 3, krow = 8 * (lane >> 4) + q, col = wr * 64 + 16 * wc + 4 * p;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) cs_a[st] = base + st * STAGE + HT<true>::offset(krow, col >> 3) + (col & 7) * 2;
     }
-    auto asum_step = [&](unsigned addr) {
-        static_assert(16 * HT<true>::ROWB == 4096, "row step of the immediates below");
-        uint4 r0, r1;
-        Vec16<T> v0, v1;
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(r0), "=&v"(r1) : "v"(addr));
-        v0.raw = r0; v1.raw = r1;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) asum[e] += v0.get(e) + v1.get(e);
-        asm volatile("ds_read_b128 %0, %2 offset:8192\n\tds_read_b128 %1, %2 offset:12288\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(r0), "=&v"(r1) : "v"(addr));
-        v0.raw = r0; v1.raw = r1;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) asum[e] += v0.get(e) + v1.get(e);
-    };
+    V ones;
+    {
+        const short one = std::is_same<T, bf16>::value ? (short)0x3F80 : (short)0x3C00;
+        s16x8 o = {one, one, one, one, one, one, one, one};
+        ones = __builtin_bit_cast(V, o);
+    }
 
     // One phase.  P = 0..3 (quadrant), S = 0 / 1 the K-tile's stage, (dma_kt, dma_slot) the half-tile staged here.
 #define PK_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
     auto load_a = [&](auto s_c, auto slot_c) {
         constexpr int S = decltype(s_c)::value, SLOT = decltype(slot_c)::value;
+        if constexpr (A_COL) {
+            if (do_asum) {
+                fs[0] = col_frag(cs_a[S], std::integral_constant<int, SLOT * HALF>{});
+                fs[1] = col_frag(cs_a[S], std::integral_constant<int, SLOT * HALF + 32 * HT<true>::ROWB>{});
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if constexpr (A_COL) {
@@ -399,19 +402,9 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
         constexpr int P = decltype(p_c)::value, S = decltype(s_c)::value;
         using SN = std::integral_constant<int, S ^ 1>;
         if constexpr (P == 0) load_a(s_c, I0{});                  // A0 of this K-tile
-        if constexpr (P == 1) {
-            load_b(s_c, I3{}, fb1);                               // B1
-            if constexpr (A_COL) {
-                if (do_asum && wr == 1) asum_step(asum_base + S * STAGE);
-            }
-        }
+        if constexpr (P == 1) load_b(s_c, I3{}, fb1);             // B1
         if constexpr (P == 2) load_a(s_c, I1{});                  // A1
-        if constexpr (P == 3) {
-            load_b(SN{}, I2{}, fb0[S ^ 1]);                       // B0 of the NEXT K-tile (other stage)
-            if constexpr (A_COL) {
-                if (do_asum && wr == 0) asum_step(asum_base + S * STAGE);
-            }
-        }
+        if constexpr (P == 3) load_b(SN{}, I2{}, fb0[S ^ 1]);     // B0 of the NEXT K-tile (other stage)
         PK_WAIT(6);  // all but the three youngest half-tiles have landed (what the NEXT phase reads is among them)
         dma(dma_kt, dma_slot);
         __builtin_amdgcn_sched_barrier(0);
@@ -422,6 +415,12 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
         if constexpr (P == 1) mma(0, 1, fb1);
         if constexpr (P == 2) mma(1, 1, fb1);
         if constexpr (P == 3) mma(1, 0, fb0[S]);
+        if constexpr (A_COL) {
+            if (do_asum) {
+                constexpr int MH = P >> 1, KK = P & 1;
+                acc_s[MH] = M16<T>::mfma(ones, fs[KK], acc_s[MH]);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
@@ -458,16 +457,15 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     PK_STAMP();  // K loop done
 
     if constexpr (A_COL) {
-        if (do_asum) {  // 16 row groups -> one sum per column of the tile
-            float* red = reinterpret_cast<float*>(smem);  // [16][256]
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                red[((tid & 255) >> 4) * BM + (tid < 256 ? 128 : 0) + (tid & 15) * 8 + e] = asum[e];
+        if (do_asum) {  // lanes 0..15 of every wave hold the sums of rows 128 mh + 64 wr + 16 wc + lane
+            float* red = reinterpret_cast<float*>(smem);  // [256]
+            if (lane < 16) {
+                red[64 * wr + 16 * wc + lane] = acc_s[0][0];
+                red[128 + 64 * wr + 16 * wc + lane] = acc_s[1][0];
+            }
             __syncthreads();
             if (tid < BM && m0 + tid < M) {
-                float sum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sum += red[r * BM + tid];
+                const float sum = red[tid];
                 if (asum_ws) asum_ws[(long long)kslab * M + m0 + tid] = sum;
                 else asum_out[m0 + tid] = from_f32<T>(sum);
             }
@@ -568,17 +566,39 @@ __device__ __forceinline__ GroupProb group_select(const GroupArgs& g, int first_
     return q;
 }
 
+// Which workgroup works on what: the hardware deals workgroups to the eight XCDs round-robin (blockIdx % 8), and only the
+// workgroups of ONE XCD share an L2.  Every (problem, K-slab) unit — the tiles that re-read the same rows of dY and X — is
+// therefore kept on one XCD where it fits (plan_map: units of <= 32 tiles packed into bins of 32 = one round of an XCD's
+// CUs), as runs of consecutive `lin` positions of a problem's slab-major walk; slot j = blockIdx / 8 of XCD x finds its
+// run in the XCD's list and exits when the list is shorter (all workgroups of a launch run for the same time, so an XCD
+// with fewer of them costs nothing).
+constexpr int MAP_RUNS = 16;
+struct GroupMap {
+    unsigned w0[8][MAP_RUNS];  // first lin of the run | problem << 24
+    unsigned w1[8][MAP_RUNS];  // first slot of the run in the XCD's list | workgroups << 16
+};
+
 template <typename T>
-__global__ __launch_bounds__(512, 2) void gemm8p_group_kernel(GroupArgs g, unsigned long long* stamps) {
-    const int pos = xcd_remap(blockIdx.x, gridDim.x);
-    const GroupProb q = group_select(g, 0, pos);
+__global__ __launch_bounds__(512, 2) void gemm8p_group_kernel(GroupArgs g, GroupMap mp, unsigned long long* stamps) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    int prob = -1, lin = 0;
+#pragma unroll
+    for (int b = 0; b < MAP_RUNS; ++b) {
+        const unsigned w0 = mp.w0[x][b], w1 = mp.w1[x][b];
+        const int beg = (int)(w1 & 0xffffu), cnt = (int)(w1 >> 16);
+        if (j >= beg && j < beg + cnt) { prob = (int)(w0 >> 24); lin = (int)(w0 & 0xffffffu) + j - beg; }
+    }
+    if (prob < 0) return;
+    GroupProb q = g.p[0];
+#pragma unroll
+    for (int i = 1; i < PK_WGRAD_MAX; ++i)
+        if (prob == i) q = g.p[i];
     EpiParams ep;
     ep.bias = nullptr; ep.aux = nullptr; ep.preact = nullptr;
     ep.ldaux = 0; ep.ldc = q.ldc; ep.ldpre = 0;
     ep.act = PK_ACT_NONE; ep.mode = 0; ep.alpha = 1.f;
     gemm8p_tile<T, true, true, false, false>((const T*)q.A, (const T*)q.B, (T*)q.C, q.ws, q.asum_ws, (T*)q.asum_out, q.M,
-                                             q.N, q.K, q.lda, q.ldb, q.kchunk, q.a_bytes, q.b_bytes, pos - q.wg_begin,
-                                             stamps, ep);
+                                             q.N, q.K, q.lda, q.ldb, q.kchunk, q.a_bytes, q.b_bytes, lin, stamps, ep);
 }
 
 // C_p = sum over the K-slabs of problem p (fixed order: deterministic), 16-byte chunks; + the fused bias-gradient sums
@@ -747,6 +767,100 @@ void plan_group(const PkWgradProblem* p, int n, GroupPlan* pl) {
     pl->total_blks = blk;
     pl->ws_floats = off;
 }
+
+// The launch map (GroupMap above).  Units = (problem, K-slab); a unit of more than 32 tiles is cut into runs of 32
+// consecutive tiles of its walk (4 x 8 or 8 x 4 tile blocks: gemm8p_tile's GROUP_M order).  First-fit-decreasing into
+// bins of 32 workgroups, bins dealt to the least loaded XCD.  Falls back to the contiguous split of the slab-major walk
+// (what xcd_remap gives the single-problem kernel) when the packing would need more rounds of the chip, or more runs per
+// XCD than the map holds.  PK_WGRAD_MAP=0 (diagnostic, read once) forces the fallback.
+struct MapRun { int prob, lin, cnt; };
+int plan_map(const PkWgradProblem* p, int n, const GroupPlan& pl, GroupMap* mp) {
+    static const int packed = [] { const char* e = getenv("PK_WGRAD_MAP"); return (!e || atoi(e) != 0) ? 1 : 0; }();
+    std::vector<MapRun> xr[8];
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool ok = packed != 0;
+    if (ok) {
+        std::vector<MapRun> items;
+        for (int i = 0; i < n; ++i) {
+            const int tiles = (int)tiles256(p[i]);
+            for (int s = 0; s < pl.nslab[i]; ++s)
+                for (int t = 0; t < tiles; t += 32) items.push_back(MapRun{i, s * tiles + t, std::min(32, tiles - t)});
+        }
+        // operand panels (256 rows of dY or X per K-tile) a run reads: what its XCD fetches for it per K-step
+        auto panels = [&](const MapRun& r) {
+            const int nt_m = (int)((p[r.prob].M + BM - 1) / BM), nt_n = (int)((p[r.prob].N + BN - 1) / BN);
+            unsigned long long ms[64] = {0}, ns[64] = {0};
+            for (int k = 0; k < r.cnt; ++k) {
+                int t = (r.lin + k) % (nt_m * nt_n);
+                const int GROUP_M = nt_n <= 2 ? 8 : 4, group_size = GROUP_M * nt_n, first_m = (t / group_size) * GROUP_M;
+                const int gsz = std::min(nt_m - first_m, GROUP_M);
+                const int tm = first_m + (t % group_size) % gsz, tn = (t % group_size) / gsz;
+                ms[(tm >> 6) & 63] |= 1ull << (tm & 63);
+                ns[(tn >> 6) & 63] |= 1ull << (tn & 63);
+            }
+            int c = 0;
+            for (int k = 0; k < 64; ++k) c += __builtin_popcountll(ms[k]) + __builtin_popcountll(ns[k]);
+            return c;
+        };
+        // Largest runs first, each into the bin (of 8 x rounds bins of 32 workgroups) that has room and the LEAST panel
+        // load so far: small, poorly sharing units (a d x d problem: 4 tiles, 4 panels) end up spread over the XCDs beside
+        // the large ones instead of eight of them in one bin — an XCD's pace is set by what it fetches per K-step.
+        std::stable_sort(items.begin(), items.end(), [](const MapRun& a, const MapRun& b) { return a.cnt > b.cnt; });
+        const int nbins = 8 * ((pl.total_wgs + 255) / 256);
+        std::vector<int> fill(nbins, 0), pload(nbins, 0);
+        std::vector<std::vector<MapRun>> bins(nbins);
+        for (const MapRun& it : items) {
+            const int pn = panels(it);
+            int best = -1;
+            for (int b = 0; b < nbins; ++b)
+                if (fill[b] + it.cnt <= 32 && (best < 0 || pload[b] < pload[best] || (pload[b] == pload[best] && fill[b] < fill[best])))
+                    best = b;
+            if (best < 0) { ok = false; break; }
+            fill[best] += it.cnt;
+            pload[best] += pn;
+            bins[best].push_back(it);
+        }
+        for (int b = 0; ok && b < nbins; ++b) {  // bin b -> XCD b % 8, round b / 8
+            load[b & 7] += fill[b];
+            for (const MapRun& it : bins[b]) xr[b & 7].push_back(it);
+        }
+        int rounds = 0;
+        for (int x = 0; x < 8; ++x) {
+            rounds = std::max(rounds, (load[x] + 31) / 32);
+            if ((int)xr[x].size() > MAP_RUNS) ok = false;
+        }
+        if (rounds > (pl.total_wgs + 255) / 256) ok = false;
+    }
+    if (!ok) {  // contiguous ranges of the problem-major, slab-major walk
+        const int tot = pl.total_wgs, q = tot >> 3, r = tot & 7;
+        for (int x = 0; x < 8; ++x) {
+            xr[x].clear();
+            int beg = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+            const int end = beg + (x < r ? q + 1 : q);
+            load[x] = end - beg;
+            for (int i = 0; i < n && beg < end; ++i) {
+                const int pe = pl.wg_begin[i] + (int)tiles256(p[i]) * pl.nslab[i];
+                if (beg >= pe) continue;
+                const int e = std::min(end, pe);
+                xr[x].push_back(MapRun{i, beg - pl.wg_begin[i], e - beg});
+                beg = e;
+            }
+        }
+    }
+    int most = 0;
+    for (int x = 0; x < 8; ++x) {
+        int slot = 0, b = 0;
+        for (const MapRun& it : xr[x]) {
+            mp->w0[x][b] = (unsigned)it.lin | ((unsigned)it.prob << 24);
+            mp->w1[x][b] = (unsigned)slot | ((unsigned)it.cnt << 16);
+            slot += it.cnt;
+            ++b;
+        }
+        for (; b < MAP_RUNS; ++b) { mp->w0[x][b] = 0; mp->w1[x][b] = 0; }
+        most = std::max(most, slot);
+    }
+    return 8 * most;  // grid size
+}
 }  // namespace
 
 // 1 if the problem can ride in a grouped launch: what the dispatcher asks of a 256-tile (col,col) GEMM (gemm.hip)
@@ -768,6 +882,26 @@ extern "C" int pk_gemm8p_group_plan(const PkWgradProblem* p, int n, size_t* ws_b
     if (workgroups) *workgroups = pl.total_wgs;
     if (slabs) for (int i = 0; i < n; ++i) slabs[i] = pl.nslab[i];
     return 0;
+}
+
+// Host-only: the launch map as the kernel decodes it — out[2 b] = problem, out[2 b + 1] = position in that problem's
+// slab-major walk for workgroup b (-1, -1: exits at once).  Returns the grid size (or -1); fills at most `cap` entries.
+extern "C" int pk_gemm8p_group_map(const PkWgradProblem* p, int n, int* out, int cap) {
+    if (n < 1 || n > PK_WGRAD_MAX) return -1;
+    GroupPlan pl;
+    plan_group(p, n, &pl);
+    GroupMap mp;
+    const int grid = plan_map(p, n, pl, &mp);
+    for (int b = 0; b < grid && b < cap; ++b) {
+        const int x = b & 7, j = b >> 3;
+        int prob = -1, lin = -1;
+        for (int r = 0; r < MAP_RUNS; ++r) {
+            const int beg = (int)(mp.w1[x][r] & 0xffffu), cnt = (int)(mp.w1[x][r] >> 16);
+            if (j >= beg && j < beg + cnt) { prob = (int)(mp.w0[x][r] >> 24); lin = (int)(mp.w0[x][r] & 0xffffffu) + j - beg; }
+        }
+        out[2 * b] = prob; out[2 * b + 1] = lin;
+    }
+    return grid;
 }
 
 // Returns 1 if launched, a hip error code otherwise.  The caller (gemm.hip: pk_gemm_wgrad_group) has checked eligibility
@@ -793,8 +927,10 @@ extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype,
     unsigned long long* stamps = nullptr;
     if (const char* e = getenv("PK8P_STAMP_PTR")) stamps = (unsigned long long*)strtoull(e, nullptr, 0);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == PK_F16) hipLaunchKernelGGL((gemm8p_group_kernel<f16>), dim3(pl.total_wgs), dim3(512), 0, s, g, stamps);
-    else hipLaunchKernelGGL((gemm8p_group_kernel<bf16>), dim3(pl.total_wgs), dim3(512), 0, s, g, stamps);
+    GroupMap mp;
+    const int grid = plan_map(p, n, pl, &mp);
+    if (dtype == PK_F16) hipLaunchKernelGGL((gemm8p_group_kernel<f16>), dim3(grid), dim3(512), 0, s, g, mp, stamps);
+    else hipLaunchKernelGGL((gemm8p_group_kernel<bf16>), dim3(grid), dim3(512), 0, s, g, mp, stamps);
     PK_LAUNCH_CHECK();
     return 1;
 }

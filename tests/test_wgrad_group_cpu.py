@@ -112,3 +112,61 @@ def test_a_node_that_hands_over_twice_replaces_its_entry(cpu_gemms):
     g.add(dy, x, [(0, 0, 8)], None, owner=456)       # ANOTHER node sharing the weight still adds up
     grads = g.flush()
     assert torch.allclose(grads[0], (dy2 + dy).t() @ x, atol=1e-5)
+
+
+# ---- the launch map of the grouped kernel (host-only entry point of the C ABI: no GPU work) ----
+def _map_of(problems):
+    import ctypes
+    from pasero_amd import lib
+    L = lib.load()
+    arr = (lib.PkWgradProblem * len(problems))(*[lib.PkWgradProblem(16, 16, 16, None, M, N, K, M, N, N)
+                                                 for M, N, K in problems])
+    out = (ctypes.c_int * (2 * 65536))()
+    grid = L.pk_gemm_wgrad_group_map(arr, len(problems), out, 65536)
+    assert grid > 0 and grid % 8 == 0
+    return [(out[2 * b], out[2 * b + 1]) for b in range(grid)]
+
+
+def _layers(d, f, rows):
+    enc = [(3 * d, d, rows), (d, d, rows), (f, d, rows), (d, f, rows)]
+    dec = [(3 * d, d, rows), (d, d, rows), (d, d, rows), (2 * d, d, rows), (d, d, rows), (f, d, rows), (d, f, rows)]
+    return enc, dec
+
+
+@pytest.mark.parametrize('d,f,rows', [(512, 2048, 32768), (1024, 4096, 32768), (1024, 8192, 8192), (512, 2048, 24000),
+                                      (768, 3072, 4096), (512, 2048, 1024)])
+def test_launch_map_covers_every_tile_once(d, f, rows):
+    """every (problem, K-slab, tile) of the plan is worked on by exactly one workgroup, whatever the packing decided"""
+    import math
+    for probs in _layers(d, f, rows):
+        m = _map_of(probs)
+        live = [e for e in m if e[0] >= 0]
+        assert len(set(live)) == len(live)
+        per_prob = {}
+        for p, lin in live:
+            per_prob.setdefault(p, []).append(lin)
+        assert sorted(per_prob) == list(range(len(probs)))
+        for p, lins in per_prob.items():
+            M, N, K = probs[p]
+            tiles = math.ceil(M / 256) * math.ceil(N / 256)
+            assert sorted(lins) == list(range(len(lins))) and len(lins) % tiles == 0   # whole slabs, each position once
+        # one round of the chip where the work fits one round: no XCD gets more than its 32 CUs
+        if len(live) <= 256:
+            for x in range(8):
+                assert sum(1 for b, e in enumerate(m) if b % 8 == x and e[0] >= 0) <= 32
+
+
+def test_launch_map_keeps_a_slab_unit_on_one_xcd_at_base_width():
+    """C2 shapes: the tiles of one (problem, K-slab) — the workgroups that share rows of dY and X — never straddle two XCDs
+    (each XCD has an L2 of its own: a straddling unit is read from memory twice)"""
+    import math
+    for probs in _layers(512, 2048, 32768):
+        m = _map_of(probs)
+        where = {}
+        for b, (p, lin) in enumerate(m):
+            if p < 0:
+                continue
+            M, N, K = probs[p]
+            tiles = math.ceil(M / 256) * math.ceil(N / 256)
+            where.setdefault((p, lin // tiles), set()).add(b % 8)
+        assert all(len(x) == 1 for x in where.values()), where

@@ -49,7 +49,7 @@ def audit(path: str):
         name = m.group(1)
         kernels += 1
         j = i
-        while j < len(lines) and 's_endpgm' not in lines[j]:
+        while j < len(lines) and not lines[j].startswith('.Lfunc_end'):  # (not the first s_endpgm: a kernel may return early)
             j += 1
         body = lines[i:j]
         i = j
