@@ -781,7 +781,7 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         // short contraction (K = 512 / 256), many rows, lean epilogue: the B-stationary walk (gemmbs.hip) — no epilogue phase
         // (sample tag 0x200 | K-tiles | activation << 4 | 0x40 act'-mask epilogue of mode 2 | 0x80 mask as bits | 0x100 preact)
         if (splitk <= 1 && !asum_out && pk_gemmbs_eligible(A, B, C, M, N, K, lda, ldb, a_col, b_col, &ep)) {
-            const int tagbs = 0x200 | (int)(K / 64) | (ep.act << 4) | (ep.mode == 2 ? 0x40 : 0) | (ep.preact ? 0x100 : 0);
+            const int tagbs = 0x200 | (int)(K / 64) | ((ep.act & 3) << 4) | (ep.mode == 2 ? 0x40 : 0) | (ep.preact ? 0x100 : 0);
             GemmSample* sm = timing_begin(tagbs, a_col, b_col, 1, dtype16, M, N, K, stream);
             const int rc = pk_gemmbs_launch(A, B, C, M, N, K, lda, ldb, b_col, ep, dtype16, stream, nullptr, 0);
             timing_end(sm, stream);

@@ -676,7 +676,10 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
     operand_bytes(M, N, K, lda, ldb, a_col, b_col, &a_bytes, &b_bytes);
     const int total = (int)(((M + BM - 1) / BM) * ((N + BN - 1) / BN) * splitk);
     unsigned long long* stamps = nullptr;  // PK8P_STAMP_PTR: device buffer of the diagnostic build's time stamps
-    if (const char* e = getenv("PK8P_STAMP_PTR")) stamps = (unsigned long long*)strtoull(e, nullptr, 0);
+#if defined(PK8P_STAMPS) || defined(PKBS_STAMPS)  /* (diagnostic builds only: the shipped library never reads the variable) */
+    static unsigned long long* const stamp_buf = [] { const char* e = getenv("PK8P_STAMP_PTR"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
+    stamps = stamp_buf;
+#endif
     dim3 grid((unsigned)total), block(512);
     hipStream_t s = (hipStream_t)stream;
     const bool any = ep.preact || ep.mode == 3 || (ep.act != PK_ACT_NONE && ep.act != PK_ACT_RELU);
@@ -925,7 +928,10 @@ extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype,
     }
     for (int i = n; i < PK_WGRAD_MAX; ++i) { g.p[i].wg_begin = 0x7fffffff; g.p[i].blk_begin = 0x7fffffff; }
     unsigned long long* stamps = nullptr;
-    if (const char* e = getenv("PK8P_STAMP_PTR")) stamps = (unsigned long long*)strtoull(e, nullptr, 0);
+#if defined(PK8P_STAMPS) || defined(PKBS_STAMPS)  /* (diagnostic builds only: the shipped library never reads the variable) */
+    static unsigned long long* const stamp_buf = [] { const char* e = getenv("PK8P_STAMP_PTR"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
+    stamps = stamp_buf;
+#endif
     hipStream_t s = (hipStream_t)stream;
     GroupMap mp;
     const int grid = plan_map(p, n, pl, &mp);

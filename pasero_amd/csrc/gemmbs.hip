@@ -539,7 +539,10 @@ extern "C" int pk_gemmbs_launch(const void* A, const void* B, void* C, long long
     const bool relu = ep.act == PK_ACT_RELU && !mask, gelu = ep.act == PK_ACT_GELU;
     const unsigned aux_bytes = (mask && !bits) ? (unsigned)extent(M, N, ep.ldaux) : 0u;
     unsigned long long* stamps = nullptr;  // PK8P_STAMP_PTR: device buffer of the diagnostic build's time stamps
-    if (const char* e = getenv("PK8P_STAMP_PTR")) stamps = (unsigned long long*)strtoull(e, nullptr, 0);
+#if defined(PK8P_STAMPS) || defined(PKBS_STAMPS)  /* (diagnostic builds only: the shipped library never reads the variable) */
+    static unsigned long long* const stamp_buf = [] { const char* e = getenv("PK8P_STAMP_PTR"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
+    stamps = stamp_buf;
+#endif
 #define PK_K(TT, BC, NKV, AC, MK, BT, PR)                                                                                  \
     hipLaunchKernelGGL((gemmbs_kernel<TT, BC, NKV, AC, MK, BT, PR>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, \
                        (const TT*)(mask && !bits ? ep.aux : ep.bias), M, N, lda, ldb, ep.ldc, ep.ldaux, a_bytes,            \

@@ -297,7 +297,7 @@ class DistributedDataParallel(nn.Module):
             index = {p: i for i, p in enumerate(cur)}
             for layer, pieces in cur_layers:  # (whole 16-byte slices: the pieces are contiguous in the bucket)
                 layer.__dict__['_pk_grad_arena'] = (b.flat,) + tuple(b.offsets[index[piece[0]]] for piece in pieces)
-                layer.__dict__['_pk_live_max'] = 0
+                layer.__dict__['_pk_arena_claimed'] = False
                 self._arena_layers.append(layer)
             cur, cur_bytes, cur_layers = [], 0, []
 
@@ -441,6 +441,7 @@ class DistributedDataParallel(nn.Module):
         """autograd engine callback at the end of backward: flush the remaining buckets in order (unused parameters),
         wait for the collectives and re-point `.grad` at the reduced bucket slices"""
         self._callback_queued = False
+        self._release_arenas()
         used_anywhere = None
         if self.find_unused_parameters:
             # "used" = has a gradient to contribute: produced by this backward, or left by an unsynchronised one
@@ -477,9 +478,17 @@ class DistributedDataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         if self._callback_queued and torch.is_grad_enabled():
             self._reset()  # the previous backward never reached its end-of-backward callback
-        for layer in self._arena_layers:
-            layer.__dict__['_pk_live_max'] = 0
+        self._release_arenas()
         return self.module(*args, **kwargs)
+
+    def _release_arenas(self) -> None:
+        """A native layer's backward that writes its gradients straight into the layer's bucket slice CLAIMS the slice
+        (native_layer.py) so that a second application of the layer reaching its backward in the same pass — or a second
+        forward pass back-propagated together with the first — gets tensors of its own.  The claim ends when the reducer
+        has taken the bucket (`_finalize`) and, for a backward that never got there, with the next forward.  (Not in
+        `_reset`: that runs at the first HOOK of a backward pass, after the first layer has already claimed.)"""
+        for layer in self._arena_layers:
+            layer.__dict__['_pk_arena_claimed'] = False
 
     @contextlib.contextmanager
     def no_sync(self):

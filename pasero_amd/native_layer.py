@@ -24,7 +24,47 @@ from .lib import ACT, PkLayer, check, dtype_code
 _OFF = os.environ.get('PASERO_NO_NATIVE_LAYER', '0') not in ('', '0')
 _NO_FUSED_TAIL = os.environ.get('PASERO_NO_FUSED_TAIL', '0') not in ('', '0')
 _NO_DENC_CHAIN = os.environ.get('PASERO_NO_DENC_CHAIN', '0') not in ('', '0')  # (A/B: every decoder layer returns its own encoder gradient)
-_sizes = {}  # (is_decoder, fused, B, T, S, d, f, heads, dtype, drop) -> (scratch_bytes, ws_bytes)
+_sizes = {}  # (is_decoder, fused, prenorm, act, mask bits, B, T, S, d, f, heads, dtype, drop) -> (scratch_bytes, ws_bytes)
+
+
+
+class DencChain:
+    """The decoder layers of ONE decoder pass read the same encoder output: their gradients for it are summed by the kv dX
+    GEMMs themselves, one layer into the next's output, instead of by autograd's elementwise additions.  The tally belongs
+    to the pass (TransformerDecoder.forward opens it around its layer loop), not to the encoder tensor: a pass whose graph
+    is never back-propagated takes its tally with it.  A backward that visits only SOME of the chained layers (autograd.grad
+    towards an inner tensor) cannot hand the sum to autograd — the layer that would return it never runs — and is refused
+    at the end of that backward instead of leaving the encoder without a gradient."""
+    __slots__ = ('key', 'n', 'left', 'buf')
+
+    def __init__(self, enc):
+        self.key = (enc.data_ptr(), tuple(enc.shape), enc.dtype)
+        self.n = self.left = 0
+        self.buf = None
+
+    def check(self):
+        if self.left != self.n:
+            self.left, self.buf = self.n, None
+            raise RuntimeError('pasero_amd: a backward pass visited only some of the decoder layers whose encoder-output '
+                               'gradients are summed in their GEMMs; run it with PASERO_NO_DENC_CHAIN=1 (every layer '
+                               'then returns its own gradient)')
+
+
+_chain = None  # the decoder pass being recorded
+
+
+def open_chain(enc):
+    """TransformerDecoder.forward, in front of its layer loop; returns what `close_chain` restores"""
+    global _chain
+    prev = _chain
+    _chain = DencChain(enc) if (enc is not None and not _NO_DENC_CHAIN and torch.is_grad_enabled()) else None
+    return prev
+
+
+def close_chain(prev):
+    global _chain
+    _chain = prev
+
 
 HOOKS_ENC = ('ffn', 'self_attention', 'self_attn_residual', 'self_attn_prenorm', 'self_attn_postnorm', 'ffn_residual',
              'ffn_prenorm', 'ffn_postnorm', 'forward')
@@ -90,7 +130,13 @@ def _static_ok(layer, is_decoder: bool) -> bool:
     return True
 
 
-def takes(layer, x, enc, state, return_layers, is_decoder: bool) -> bool:
+def _pad_ok(mask, B: int, S: int) -> bool:
+    """the C side reads a key-padding mask as (B, S) bytes: anything else stays on the per-op path, which checks and refuses"""
+    return mask is None or (mask.dtype == torch.bool and mask.is_cuda and tuple(mask.shape) == (B, S))
+
+
+def takes(layer, x, enc, state, return_layers, is_decoder: bool, pad=None) -> bool:
+    """`pad`: the key-padding mask the call would hand to C (encoder: of x; decoder: of the encoder output)"""
     if _OFF or state is not None or return_layers or not torch.is_grad_enabled() or not x.is_cuda or not x.requires_grad:
         return False
     if x.dtype not in (torch.bfloat16, torch.float16) or torch.is_autocast_enabled('cuda') or x.dim() != 3:
@@ -110,7 +156,9 @@ def takes(layer, x, enc, state, return_layers, is_decoder: bool) -> bool:
     # the grouped weight-gradient launch takes outputs of >= 256 x 256 and whole 16-byte rows (pk_gemm_wgrad_group_eligible)
     if rows < 256 or d < 256 or f < 256 or d % 8 or f % 8:
         return False
-    if is_decoder and (enc is None or enc.dtype != x.dtype or enc.size(0) * enc.size(1) < 64):
+    if is_decoder and (enc is None or enc.dtype != x.dtype or enc.dim() != 3 or enc.size(0) != B or enc.size(0) * enc.size(1) < 64):
+        return False
+    if not _pad_ok(pad, B, enc.size(1) if is_decoder else T):
         return False
     return True
 
@@ -148,7 +196,7 @@ class NativeLayerFn(Function):
             n16 += rows * d * (3 if is_decoder else 2)
         # ReLU at base width: the mask for backward also as one bit per element (pk_gemm_relu_bits; same rule as the per-op path)
         from . import functional as PF
-        key = ('bits', rows, d, f, dt)
+        key = ('bits', rows, d, f, dt, x.data_ptr() % 16, layer.fc1.weight.data_ptr() % 16)
         use_bits = layer.__dict__.get('_native_bits')
         if use_bits is None or use_bits[0] != key:
             use_bits = (key, act == 'relu' and PF.relu_bits_eligible(x.view(rows, d), layer.fc1.weight))
@@ -218,19 +266,12 @@ class NativeLayerFn(Function):
         lay.stream = lib.stream_ptr()
         check(L.pk_layer_fwd(ctypes.byref(lay)), 'pk_layer_fwd')
         ctx.lay, ctx.layer, ctx.is_decoder = lay, layer, is_decoder
-        # (how often the layer ran since the reducer last looked: a layer applied twice in one graph must not write both
-        # gradients into the same bucket slice, see backward)
-        layer.__dict__['_pk_live_max'] = layer.__dict__.get('_pk_live_max', 0) + 1
-        if is_decoder and not _NO_DENC_CHAIN:
-            # every natively run decoder layer of this forward pass reads the same encoder output: their gradients for it are
-            # summed by the kv dX GEMMs themselves, one layer into the next's output (backward), instead of by five
-            # elementwise additions of autograd's.  The tally lives on the tensor: it ends with it.
-            tally = enc.__dict__.get('_pk_denc') if hasattr(enc, '__dict__') else None
-            if tally is None or tally['left'] != tally['n']:  # (none yet, or left behind by a backward that did not finish)
-                tally = {'n': 0, 'left': 0, 'buf': None}
-                enc._pk_denc = tally
-            tally['n'] += 1
-            tally['left'] = tally['n']
+        chain = None
+        if is_decoder and _chain is not None and _chain.key == (enc.data_ptr(), tuple(enc.shape), enc.dtype):
+            chain = _chain
+            chain.n += 1
+            chain.left = chain.n
+        ctx.chain = chain
         ctx.keep = (x, enc, self_pad, cross_pad, a16, a32, params)  # (parameters: kept alive, the optimizer runs after backward)
         ctx.dims = (B, T, S, d, f, H)
         off = (y_ptr - a16.data_ptr()) // es
@@ -248,16 +289,17 @@ class NativeLayerFn(Function):
         denc = denc_ret = None
         lay.denc_prev = None
         if is_decoder:
-            tally = getattr(enc, '_pk_denc', None) if not _NO_DENC_CHAIN else None
-            if tally is not None and tally['n'] > 1 and tally['left'] > 0:
-                if tally['buf'] is None:
-                    tally['buf'] = torch.empty_like(enc)          # the first of the chain writes it ...
+            chain = ctx.chain
+            if chain is not None and chain.n > 1:
+                if chain.left == chain.n:                         # the first of the chain in this backward pass
+                    chain.buf = torch.empty_like(enc)             # ... writes the buffer,
+                    torch.autograd.Variable._execution_engine.queue_callback(chain.check)
                 else:
-                    lay.denc_prev = tally['buf'].data_ptr()       # ... the others add theirs to it, in place
-                denc = tally['buf']
-                tally['left'] -= 1
-                if tally['left'] == 0:                            # ... the last one hands the sum to autograd
-                    denc_ret, tally['buf'], tally['left'] = denc, None, tally['n']
+                    lay.denc_prev = chain.buf.data_ptr()          # the others add theirs to it, in place,
+                denc = chain.buf
+                chain.left -= 1
+                if chain.left == 0:                               # and the last one hands the sum to autograd
+                    denc_ret, chain.buf, chain.left = denc, None, chain.n
             else:
                 denc = denc_ret = torch.empty_like(enc)
         lay.dy, lay.dx, lay.denc = dy.data_ptr(), dx.data_ptr(), (denc.data_ptr() if is_decoder else None)
@@ -268,11 +310,14 @@ class NativeLayerFn(Function):
         vsz = [d, d, d, d, d, d] * nblk + [f, d, d, d]  # q k v biases, out bias, ln weight, ln bias; ... fc1 b, fc2 b, ln w, ln b
         # Under the data-parallel reducer the three pieces are slices of the layer's gradient bucket (ddp.py lays the bucket
         # out in this order): autograd adopts the returned views as `.grad` and the reducer has nothing to pack.  Only for
-        # fresh gradients (`.grad is None`: an accumulating micro-batch adds to what is there) of a layer that ran once in
-        # this graph (two applications would both write the same slice before either is accumulated).
+        # fresh gradients (`.grad is None`: an accumulating micro-batch adds to what is there), and only for the FIRST node of
+        # the layer that reaches its backward before the reducer takes the bucket: a layer applied twice in one graph, or two
+        # forward passes back-propagated together, would otherwise both write the same slice before either is accumulated
+        # (both see `.grad is None`: AccumulateGrad runs after both producers) — the later nodes get tensors of their own.
         arena = layer.__dict__.get('_pk_grad_arena')
-        if (arena is not None and layer.__dict__.get('_pk_live_max', 0) == 1 and arena[0].dtype == dt
+        if (arena is not None and not layer.__dict__.get('_pk_arena_claimed', False) and arena[0].dtype == dt
                 and all(prm is not None and prm.grad is None for prm in params)):
+            layer.__dict__['_pk_arena_claimed'] = True  # (until the reducer has taken the bucket: ddp._finalize / _reset)
             flat, o_wd, o_w2, o_vec = arena
             wd = flat[o_wd: o_wd + sum(wrows) * d].view(sum(wrows), d)
             w2 = flat[o_w2: o_w2 + d * f].view(d, f)
@@ -300,7 +345,7 @@ class NativeLayerFn(Function):
         fb.dw2 = w2.data_ptr()
         base = vp + 6 * nblk * d * es
         fb.db1, fb.db2, fb.dln_g, fb.dln_b = base, base + f * es, base + (f + d) * es, base + (f + 2 * d) * es
-        key = (is_decoder, lay.fused_tail, B, T, S, d, f, H, lay.dtype, lay.drop_p > 0)
+        key = (is_decoder, lay.fused_tail, lay.prenorm, lay.act, bool(fb.bits), B, T, S, d, f, H, lay.dtype, lay.drop_p > 0)
         sizes = _sizes.get(key)
         if sizes is None:
             sb, wb = ctypes.c_size_t(), ctypes.c_size_t()

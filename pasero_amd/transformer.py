@@ -554,10 +554,14 @@ class TransformerDecoder(Decoder):
         if embed_norm:
             x = self.dropout(self.layernorm_embedding(x))
         layer_outputs = {}
-        for layer in self.layers:
-            x, layer_output = layer(x, encoder_out, encoder_mask, padding_mask, prompt_mask=prompt_mask, state=state,
-                                    return_layers=return_layers)
-            layer_outputs.update(layer_output)
+        chain = native_layer.open_chain(encoder_out if state is None else None)  # (this pass's encoder-gradient tally)
+        try:
+            for layer in self.layers:
+                x, layer_output = layer(x, encoder_out, encoder_mask, padding_mask, prompt_mask=prompt_mask, state=state,
+                                        return_layers=return_layers)
+                layer_outputs.update(layer_output)
+        finally:
+            native_layer.close_chain(chain)
         x = self.layer_norm(x)
         if not project:
             return x, layer_outputs
@@ -754,7 +758,7 @@ class TransformerEncoderLayer(_LayerBase):
         """:1056-1099"""
         if self.cfg.check_inf:
             raise NotImplementedError('pasero_amd: --check-inf clamping (fp16 T5) is not implemented')
-        if native_layer.takes(self, x, None, None, return_layers, False):  # the stock layer: one C call per direction
+        if native_layer.takes(self, x, None, None, return_layers, False, padding_mask):  # the stock layer: one C call per direction
             return native_layer.run(self, x, None, padding_mask, None, False), {}
         self.return_layers = return_layers
         x = self._wgrad_open(x, (self.self_attn,))
@@ -863,7 +867,7 @@ class TransformerDecoderLayer(_LayerBase):
         """:1341-1417"""
         if self.cfg.check_inf:
             raise NotImplementedError('pasero_amd: --check-inf clamping (fp16 T5) is not implemented')
-        if self_attn_mask is None and native_layer.takes(self, x, encoder_out, state, return_layers, True):
+        if self_attn_mask is None and native_layer.takes(self, x, encoder_out, state, return_layers, True, encoder_mask):
             return native_layer.run(self, x, encoder_out, None, encoder_mask, True), {}
         self.return_layers = return_layers
         if state is None:

@@ -121,6 +121,51 @@ def test_rccl_bucketed_all_reduce_single_rank(monkeypatch, dtype):
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(300)
+def test_two_forwards_back_propagated_together_under_the_reducer(monkeypatch):
+    """l1 = ddp(b1); l2 = ddp(b2); (l1 + l2).backward(): both autograd nodes of a natively run layer reach their backward
+    with `.grad is None` (AccumulateGrad runs after both producers).  Only the first may write the layer's bucket slice —
+    the second gets tensors of its own — so the result is g1 + g2, not 2 * g2 (the round-3 counter was reset
+    by every forward and let both write the same slice)."""
+    from pasero_amd import rng
+    from pasero_amd.ddp import DistributedDataParallel
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', str(_free_port()))
+    monkeypatch.setenv('PASERO_DDP_FORCE_REDUCE', '1')
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        model, b1 = _base_width_model(torch.bfloat16)
+        b2 = {k: (v.flip(0) if v.dim() else v) for k, v in b1.items()}   # another batch: the sentences in reverse order
+        b2 = {k: v.contiguous() for k, v in b2.items()}
+        model.train()
+        want = {}
+        for seed, b in ((5, b1), (6, b2)):
+            for p in model.parameters():
+                p.grad = None
+            rng.manual_seed(seed)
+            model(**b)[0].backward()
+            for n, p in model.named_parameters():
+                if p.grad is not None:
+                    want[n] = want.get(n, 0) + p.grad.float()
+        for p in model.parameters():
+            p.grad = None
+        ddp = DistributedDataParallel(model, bucket_cap_mb=0.05)
+        assert len(ddp._arena_layers) == 4
+        rng.manual_seed(5)
+        l1 = ddp(**b1)[0]
+        rng.manual_seed(6)
+        l2 = ddp(**b2)[0]
+        (l1 + l2).backward()
+        torch.cuda.synchronize()
+        for n, p in model.named_parameters():
+            if n in want:
+                err = (p.grad.float() - want[n]).abs().max()
+                assert err <= 2e-2 * want[n].abs().max(), (n, err.item(), want[n].abs().max().item())
+    finally:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------------------------
 # two ranks, the real HIP model: both processes share the box's one card (gloo carries the CUDA buckets)
 # ------------------------------------------------------------------------------------------------------------

@@ -154,3 +154,51 @@ def test_native_prenorm_layer_against_the_per_op_path(over, B, S, T):
         assert (a - r).norm().item() <= 4e-2 * ref + 1e-6, (k, (a - r).norm().item(), ref)
     l2, _, g2, _ = _step(model, batch, native=True)
     assert l2 == l1 and all(torch.equal(g2[k], g1[k]) for k in g1)
+
+
+def test_encoder_gradient_chain_belongs_to_the_decoder_pass():
+    """the tally of the chained encoder-output gradients lived on the encoder TENSOR — a decoder pass over it that
+    was never back-propagated left a stale count behind and the next pass over the same tensor lost the encoder's gradient
+    silently.  It belongs to the pass now: (i) an abandoned decoder pass changes nothing for the next one, (ii) a second
+    backward over a retained graph gives the same gradients, (iii) a backward that visits only some of the chained layers
+    is refused loudly."""
+    from pasero_amd import rng
+    V = 600
+    model = _model(V, encoder_layers=1, decoder_layers=3, dropout=0.0)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(4, 24, 20, 20, V).items()}
+    dec_in = batch['decoder_input'][:, :-1].contiguous()
+
+    def enc_grad(abandon_first: bool):
+        model.zero_grad(set_to_none=True)
+        enc_out, enc_mask, _ = model.encoder(batch['encoder_input'], batch['encoder_input_length'])
+        if abandon_first:
+            model.decoder(enc_out, enc_mask, dec_in, project=False)   # a grad-mode pass nobody back-propagates
+        feats, _ = model.decoder(enc_out, enc_mask, dec_in, project=False)
+        feats.float().pow(2).sum().backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in model.encoder.named_parameters() if p.grad is not None}
+
+    rng.manual_seed(2)
+    plain = enc_grad(False)
+    rng.manual_seed(2)
+    after = enc_grad(True)
+    assert plain and plain.keys() == after.keys()
+    for n in plain:
+        assert plain[n].float().abs().max() > 0 and torch.equal(plain[n], after[n]), n
+    # (iii) a gradient towards the input of the TOP decoder layer's successor only touches that layer's node
+    enc_out, enc_mask, _ = model.encoder(batch['encoder_input'], batch['encoder_input_length'])
+    mid = {}
+    def grab(m, i, o):
+        mid['x'] = o[0]   # (returns None: the output stays as it is)
+    h = model.decoder.layers[1].register_forward_hook(grab)
+    try:
+        feats, _ = model.decoder(enc_out, enc_mask, dec_in, project=False)
+    finally:
+        h.remove()
+    with pytest.raises(RuntimeError, match='only some of the decoder layers'):
+        torch.autograd.grad(feats.float().sum(), [mid['x']])
+    # and the chain is usable again afterwards
+    rng.manual_seed(2)
+    again = enc_grad(False)
+    for n in plain:
+        assert torch.equal(plain[n], again[n]), n
