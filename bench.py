@@ -47,7 +47,19 @@ WORKLOADS = {
     # C4 (speech): 30 s clips -> log-mel on the device (K8) -> conv subsampler (K7) -> whisper_base-shaped 6+6 enc-dec;
     # S = 3000 mel frames in, 1500 encoder positions; the log-mel kernel is inside the timed step
     'c4_whisper': ('WhisperConfig', 51865, 16, 3000, 64),
+    # C4, second half: the IWSLT2023 recipe as the reference ships it (examples/IWSLT2023/
+    # xlsr+nllb-iwslt2021.yaml): (B, S = 1000, 1024) wav2vec-style features -> in_linear 1024 -> 80 + ReLU -> conv k5 s2 + GLU ->
+    # 500 positions -> NLLB-1.3B-shaped 24 + 24 with bottleneck adapters on encoder layers 3..23; only in_linear, the
+    # subsampler, encoder layers 0-2 and the adapters train (`train_params_regex`, applied as cli/train.py:237-238 does),
+    # dropout 0.3, attention dropout 0.1, label smoothing 0.2
+    'c4_iwslt': ('AdapterNLLB1B3Config', 256206, 32, 1000, 64),
 }
+IWSLT_OVERRIDES = dict(input_dim=1024, conv_input_dim=80, conv_kernel_sizes=[5], encoder_positional_encoding='sinusoidal',
+                       encoder_embed_norm=False, encoder_adapter_layer_ids=list(range(3, 24)), dropout=0.3,
+                       attention_dropout=0.1, label_smoothing=0.2, encoder_max_len=2048, decoder_max_len=128)
+IWSLT_TRAIN_REGEX = r'(.*\.in_linear|.*\.subsample|encoder\.layers\.[0-2]\.|.*\.adapters|encoder\.layernorm_embedding)'
+SPEECH = ('c4_whisper', 'c4_iwslt')       # S counts input frames; the encoder layers see S / 2 positions
+DEVICE_INIT = ('c5_nllb_1b3', 'c4_iwslt')  # 1.4 G parameters: created and drawn on the device (a CPU init takes a minute)
 
 
 def parse_args():
@@ -89,6 +101,47 @@ def self_launch(args) -> int:
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: what RCCL needs on this driver
     env.setdefault('OMP_NUM_THREADS', '4')
     return subprocess.call(cmd, env=env)
+
+
+class ClockSampler:
+    """the shader clock the chip holds during the timed region: the amdgpu hwmon `freq1_input` (Hz) of THIS device (found by
+    its PCI address), read every 20 ms by a side thread — boxes of the pool differ by 3-5 % on the same binary, mostly through
+    the clock their power envelope settles at.  None where the file is not readable."""
+
+    def __init__(self, device):
+        import glob
+        self.path, self.samples, self._stop, self._thread = None, [], False, None
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            bdf = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+            hits = glob.glob(f'/sys/bus/pci/devices/{bdf}/hwmon/hwmon*/freq1_input')
+            self.path = hits[0] if hits else None
+        except Exception:
+            self.path = None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                with open(self.path) as f:
+                    self.samples.append(int(f.read().strip()) / 1e6)
+            except Exception:
+                break
+            time.sleep(0.02)
+
+    def start(self):
+        if self.path:
+            import threading
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(1.0)
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        return {'min': v[0], 'median': v[len(v) // 2], 'max': v[-1], 'samples': len(v), 'source': 'amdgpu hwmon freq1_input, 20 ms'}
 
 
 def synthetic_batch(B, S, T, V, seed, device):
@@ -238,6 +291,7 @@ def cpu_baseline(budget_s: float):
     step()  # warm-up (first call pages in the kernels)
     # a batch of 512 tokens cannot feed every core of a many-socket host: use the thread count that is fastest
     best = (None, 1e9)
+    tried, trial = [], {}
     for nthr in sorted({8, 16, 32, 64, torch.get_num_threads()}):
         if nthr > (os.cpu_count() or 1):
             continue
@@ -245,6 +299,8 @@ def cpu_baseline(budget_s: float):
         t0 = time.perf_counter()
         step()
         dt = time.perf_counter() - t0
+        tried.append(nthr)
+        trial[nthr] = round(dt, 3)
         if dt < best[1]:
             best = (nthr, dt)
     torch.set_num_threads(best[0])
@@ -258,16 +314,25 @@ def cpu_baseline(budget_s: float):
             break
     return {'value': tokens / el, 'unit': 'target tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'oracle/ref_cpu.py fwd+bwd, Transformer-base fp32, batch 8x(64,64), {n} steps in {el:.1f} s '
-                      f'({os.cpu_count()} logical CPUs)'}
+                      f'({os.cpu_count()} logical CPUs)',
+            'cores_choice': f'{best[0]} threads = the fastest of {tried} on one trial step each (seconds per step: '
+                            f'{trial}); a batch of 512 tokens gives torch too little work per thread to gain from more'}
 
 
-def count_flops(cfg, B: int, S: int, T: int, V: int) -> float:
-    """SURVEY §8d algorithmic FLOPs of one fwd+bwd step (2·MACs, bwd = 2x fwd, causal self-attention at half)"""
+def count_flops(cfg, B: int, S: int, T: int, V: int, trained_encoder_layers=None) -> float:
+    """SURVEY §8d algorithmic FLOPs of one fwd+bwd step (2·MACs, bwd = 2x fwd, causal self-attention at half).
+    `trained_encoder_layers` (the IWSLT recipe: a frozen backbone): only that many encoder layers have weight gradients —
+    forward and the gradient towards the input still run through every layer (the trained frontend sits below them), the
+    decoder and the vocabulary projection have none; the adapters' own GEMMs (d x 64) are not counted."""
     d, fe, fd = cfg.embed_dim, cfg.encoder_ffn_dim, cfg.decoder_ffn_dim
     Le, Ld = cfg.encoder_layers, cfg.decoder_layers
-    enc = B * S * Le * (8 * d * d + 4 * d * fe + 4 * S * d)
-    dec = B * T * Ld * (12 * d * d + 4 * d * fd + 2 * T * d + 4 * S * d) + B * S * Ld * 4 * d * d
-    return 3.0 * (enc + dec + B * T * 2 * d * V)
+    enc_lin, enc_att = B * S * Le * (8 * d * d + 4 * d * fe), B * S * Le * 4 * S * d
+    dec_lin = B * T * Ld * (12 * d * d + 4 * d * fd) + B * S * Ld * 4 * d * d
+    dec_att = B * T * Ld * (2 * T * d + 4 * S * d)
+    voc = B * T * 2 * d * V
+    if trained_encoder_layers is None:
+        return 3.0 * (enc_lin + enc_att + dec_lin + dec_att + voc)
+    return (2.0 * (enc_lin + dec_lin + voc) + enc_lin * trained_encoder_layers / Le + 3.0 * (enc_att + dec_att))
 
 
 def rehearse_cpu(args, rank: int, world: int):
@@ -367,7 +432,8 @@ def run(args):
         dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
 
     from pasero_amd import config as C, rng
-    from pasero_amd.transformer import Transformer
+    from pasero_amd import adapters  # noqa: F401  (registers adapter_transformer: the IWSLT recipe's architecture)
+    from pasero_amd.transformer import Transformer  # noqa: F401
     from pasero_amd.ddp import DistributedDataParallel, reduce_logs
 
     dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
@@ -380,18 +446,41 @@ def run(args):
     def measure(workload: str, steps: int, warmup: int, with_ddp: bool):
         """build `workload`, run `warmup` untimed + `steps` timed steps -> (elapsed s, tokens, GemmTimer, cfg, dims, ddp)"""
         cfg_name, V, B, S, T = WORKLOADS[workload]
-        cfg = getattr(C, cfg_name)()  # dropout 0.1, label smoothing 0.1: the training configuration
-        torch.manual_seed(1234)  # identical random-init weights on every rank
-        model = Transformer(cfg, C.DistributedConfig(dp_size=world, dp_rank=rank), C.SyntheticTask(V))
-        model = model.to(dtype).to(device)
+        # dropout 0.1, label smoothing 0.1: the training configuration (the IWSLT recipe brings its own)
+        cfg = getattr(C, cfg_name)(**(IWSLT_OVERRIDES if workload == 'c4_iwslt' else {}))
+        arch = C.get_architecture(cfg)
+        dist_cfg = C.DistributedConfig(dp_size=world, dp_rank=rank)
+        if workload in DEVICE_INIT:
+            from pasero_amd import modules
+            with modules.fast_init(device, dtype):
+                model = arch(cfg, dist_cfg, C.SyntheticTask(V))
+            model = model.to(dtype).to(device)
+            gen = torch.Generator(device=device).manual_seed(1234)  # identical random-init weights on every rank
+            with torch.no_grad():
+                for n, p in model.named_parameters():
+                    if p.dim() == 1:
+                        p.fill_(1.0) if ('norm' in n and n.endswith('weight')) else p.zero_()
+                    else:
+                        p.copy_(torch.randn(p.shape, generator=gen, device=device, dtype=torch.float32) * 0.02)
+        else:
+            torch.manual_seed(1234)  # identical random-init weights on every rank
+            model = arch(cfg, dist_cfg, C.SyntheticTask(V)).to(dtype).to(device)
+        if workload == 'c4_iwslt':  # cli/train.py:237-238
+            import re
+            for n, p in model.named_parameters():
+                p.requires_grad = bool(re.match(IWSLT_TRAIN_REGEX, n))
         model.train()
         rng.manual_seed(1 + rank)
         ddp = DistributedDataParallel(model) if with_ddp else model
-        batch = synthetic_batch(B, S if workload != 'c4_whisper' else 4, T, V, seed=1 + rank, device=device)
+        batch = synthetic_batch(B, S if workload not in SPEECH else 4, T, V, seed=1 + rank, device=device)
         wav = None
         if workload == 'c4_whisper':  # SURVEY §8d C4: wav ~ N(0, 0.1^2) fp32, 30 s at 16 kHz
             gen = torch.Generator().manual_seed(rank)
             wav = (0.1 * torch.randn(B, 480000, generator=gen)).to(device)
+            batch['encoder_input_length'] = torch.full((B,), S, dtype=torch.int64, device=device)
+        if workload == 'c4_iwslt':    # SURVEY §8d C4: features ~ N(0, 1), S = 1000 frames of 1024
+            gen = torch.Generator().manual_seed(rank)
+            batch['encoder_input'] = torch.randn(B, S, cfg.input_dim, generator=gen).to(dtype).to(device)
             batch['encoder_input_length'] = torch.full((B,), S, dtype=torch.int64, device=device)
 
         def step():
@@ -412,12 +501,28 @@ def run(args):
         fence()
         if not args.no_roofline:
             timer.start(400 * steps // GemmTimer.STRIDE + 64)
+        # five sub-windows of the timed region, cut by events on the launch stream (no synchronisation inside the region):
+        # one short sample per round cannot show the 3-5 % the boxes differ by, the spread inside a run can
+        nwin = 5 if steps >= 10 else 1
+        cuts = [round(i * steps / nwin) for i in range(nwin + 1)]
+        marks = []
+        clock = ClockSampler(device)
+        clock.start()
         t0 = time.perf_counter()
         tokens = 0
-        for _ in range(steps):
+        for i in range(steps):
+            if i in cuts:
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[-1].record()
             tokens += step()
+        marks.append(torch.cuda.Event(enable_timing=True))
+        marks[-1].record()
         fence()
         elapsed = time.perf_counter() - t0
+        timer.sclk = clock.stop()
+        w = sorted(marks[k].elapsed_time(marks[k + 1]) / (cuts[k + 1] - cuts[k]) for k in range(nwin))
+        timer.windows = {'ms_per_step_min': w[0], 'ms_per_step_median': w[len(w) // 2], 'ms_per_step_max': w[-1],
+                         'windows': nwin, 'how': 'HIP events on the launch stream at the window boundaries'}
         if not args.no_roofline:
             timer.stop()
         if world > 1:
@@ -432,7 +537,8 @@ def run(args):
     if rank == 0:
         # SURVEY §8d algorithmic FLOPs of one fwd+bwd batch (speech: the encoder runs on the S/2 subsampled positions;
         # the conv frontend's own FLOPs are not counted)
-        step_flops = count_flops(cfg, B, S if args.workload != 'c4_whisper' else S // 2, T, V)
+        step_flops = count_flops(cfg, B, S if args.workload not in SPEECH else S // 2, T, V,
+                                 3 if args.workload == 'c4_iwslt' else None)
         out = {
             'metric': 'target tokens/sec (fwd+bwd), Transformer-base d=512',
             'value': tokens / elapsed,  # whole job: the sum over the N GPUs
@@ -444,6 +550,8 @@ def run(args):
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
+            'ms_per_step_windows': timer.windows,   # spread inside the timed region (rank 0)
+            'sclk_mhz': timer.sclk,                 # the shader clock held during it (rank 0)
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
@@ -482,16 +590,22 @@ def run(args):
             # process, same protocol, a few steps each): d = 1024 is where north_star states its 40 % target
             del ddp
             out['extra_workloads'] = {}
-            for name in ('c3_big', 'c4_whisper'):
+            for name in ('c3_big', 'c4_whisper', 'c5_nllb_1b3', 'c4_iwslt'):
                 torch.cuda.empty_cache()
-                e_el, e_tok, e_timer, e_cfg, (_, eV, eB, eS, eT), _m = measure(name, args.extra_steps, 3, False)
+                e_steps = args.extra_steps if name not in DEVICE_INIT else max(1, args.extra_steps // 2)  # (80-100 ms steps)
+                e_el, e_tok, e_timer, e_cfg, (_, eV, eB, eS, eT), _m = measure(name, e_steps, 3, False)
                 del _m
-                fl = count_flops(e_cfg, eB, eS if name != 'c4_whisper' else eS // 2, eT, eV)
+                fl = count_flops(e_cfg, eB, eS if name not in SPEECH else eS // 2, eT, eV, 3 if name == 'c4_iwslt' else None)
                 rec = {'config': f'{WORKLOADS[name][0]} V={eV}, batch (B,S,T)=({eB},{eS},{eT}), {args.dtype}',
-                       'steps': args.extra_steps, 'warmup': 3, 'ms_per_step': 1e3 * e_el / args.extra_steps,
+                       'steps': e_steps, 'warmup': 3, 'ms_per_step': 1e3 * e_el / e_steps,
                        'value': e_tok / e_el, 'unit': 'target tokens/s',
                        'algorithmic_tflop_per_step': fl / 1e12,
-                       'mfma_peak_fraction_whole_step': fl * args.extra_steps / e_el / 1e12 / PEAK_BF16_TFLOPS}
+                       'mfma_peak_fraction_whole_step': fl * e_steps / e_el / 1e12 / PEAK_BF16_TFLOPS,
+                       'ms_per_step_windows': e_timer.windows, 'sclk_mhz': e_timer.sclk}
+                if name == 'c4_iwslt':
+                    rec['note'] = ('examples/IWSLT2023 recipe: frozen NLLB-1.3B backbone, trainable in_linear + conv k5 + encoder '
+                                   'layers 0-2 + adapters; FLOPs count forward + input gradients everywhere, weight gradients '
+                                   'only where parameters train')
                 if not args.no_roofline and e_timer.samples:
                     es = e_timer.summary()
                     edom = max(es, key=lambda k: es[k]['total_ms'])

@@ -43,6 +43,10 @@ from torch.autograd import Variable
 logger = logging.getLogger('pasero_amd.ddp')
 
 
+# tests only (tests/test_ddp_cpu.py): lay natively run layers' parameters out as gradient arenas on CPU tensors too, so that
+# the bucket-view layout can be driven over gloo with world sizes the one-GPU box cannot host
+_ARENA_ON_ANY_DEVICE = False
+
 class RcclComm:
     """One RCCL communicator per process, created through the C ABI (pk_comm_*): rank 0 draws the unique id, the default
     torch.distributed group carries it to the other ranks (the only use of torch.distributed on this path), every rank
@@ -250,7 +254,7 @@ class DistributedDataParallel(nn.Module):
         (pasero_amd/native_layer.py): such a layer's parameters sit together in one bucket, in the order pk_layer_bwd
         writes their gradients, so that backward can write them straight into the bucket"""
         groups = {}
-        if not (self._reduce_enabled and self._is_cuda):
+        if not (self._reduce_enabled and (self._is_cuda or _ARENA_ON_ANY_DEVICE)):
             return groups
         try:
             from . import native_layer, transformer

@@ -163,6 +163,46 @@ def takes(layer, x, enc, state, return_layers, is_decoder: bool, pad=None) -> bo
     return True
 
 
+def grad_buffers(layer, params, is_decoder: bool, d: int, f: int, dt, dev):
+    """Where pk_layer_bwd writes a layer's parameter gradients: the [*, d] weights as row blocks of one 2-D tensor (q | k | v |
+    out [| cross ...] | fc1), fc2's weight on its own, biases and LayerNorm parameters as pieces of one vector — three
+    allocations, two splits.  Under the data-parallel reducer the three pieces are slices of the layer's gradient bucket
+    (ddp.py lays the bucket out in this order): autograd adopts the returned views as `.grad` and the reducer has nothing to
+    pack.  Only for fresh gradients (`.grad is None`: an accumulating micro-batch adds to what is there), and only for the
+    FIRST node of the layer that reaches its backward before the reducer takes the bucket: a layer applied twice in one
+    graph, or two forward passes back-propagated together, would otherwise both write the same slice before either is
+    accumulated (both see `.grad is None`: AccumulateGrad runs after both producers) — later nodes get tensors of their own.
+    -> (wd, w2, vec, row counts of wd's blocks, sizes of vec's pieces)"""
+    nblk = 2 if is_decoder else 1
+    wrows = [d, d, d, d] * nblk + [f]
+    vsz = [d, d, d, d, d, d] * nblk + [f, d, d, d]  # q k v biases, out bias, ln weight, ln bias; ... fc1 b, fc2 b, ln w, ln b
+    arena = layer.__dict__.get('_pk_grad_arena')
+    if (arena is not None and not layer.__dict__.get('_pk_arena_claimed', False) and arena[0].dtype == dt
+            and all(prm is not None and prm.grad is None for prm in params)):
+        layer.__dict__['_pk_arena_claimed'] = True  # (until the reducer has taken the bucket: ddp._finalize / forward)
+        flat, o_wd, o_w2, o_vec = arena
+        wd = flat[o_wd: o_wd + sum(wrows) * d].view(sum(wrows), d)
+        w2 = flat[o_w2: o_w2 + d * f].view(d, f)
+        vec = flat[o_vec: o_vec + sum(vsz)]
+    else:
+        wd = torch.empty(sum(wrows), d, dtype=dt, device=dev)
+        w2 = torch.empty(d, f, dtype=dt, device=dev)
+        vec = torch.empty(sum(vsz), dtype=dt, device=dev)
+    return wd, w2, vec, wrows, vsz
+
+
+def grads_in_param_order(wd, w2, vec, wrows, vsz, nblk: int, params):
+    """the pieces of `grad_buffers` as the gradients of `layer_params(...)`, in that order (None for an absent parameter)"""
+    ws_, vs_ = wd.split(wrows, 0), vec.split(vsz, 0)
+    grads = []
+    for k in range(nblk):  # q.w k.w v.w q.b k.b v.b out.w out.b ln.w ln.b
+        grads += [ws_[4 * k], ws_[4 * k + 1], ws_[4 * k + 2], vs_[6 * k], vs_[6 * k + 1], vs_[6 * k + 2], ws_[4 * k + 3],
+                  vs_[6 * k + 3], vs_[6 * k + 4], vs_[6 * k + 5]]
+    v0 = 6 * nblk
+    grads += [ws_[4 * nblk], vs_[v0], w2, vs_[v0 + 1], vs_[v0 + 2], vs_[v0 + 3]]
+    return [g if prm is not None else None for g, prm in zip(grads, params)]  # (a projection without bias)
+
+
 class NativeLayerFn(Function):
     """y = layer(x [, encoder_out]) — forward: pk_layer_fwd; backward: pk_layer_bwd (one C call each)"""
 
@@ -303,31 +343,8 @@ class NativeLayerFn(Function):
             else:
                 denc = denc_ret = torch.empty_like(enc)
         lay.dy, lay.dx, lay.denc = dy.data_ptr(), dx.data_ptr(), (denc.data_ptr() if is_decoder else None)
-        # parameter gradients: the [*, d] weights as row blocks of one 2-D tensor (q | k | v | out [| cross ...] | fc1), fc2 on
-        # its own, biases and LayerNorm parameters as pieces of one vector — three allocations, two splits
         nblk = 2 if is_decoder else 1
-        wrows = [d, d, d, d] * nblk + [f]
-        vsz = [d, d, d, d, d, d] * nblk + [f, d, d, d]  # q k v biases, out bias, ln weight, ln bias; ... fc1 b, fc2 b, ln w, ln b
-        # Under the data-parallel reducer the three pieces are slices of the layer's gradient bucket (ddp.py lays the bucket
-        # out in this order): autograd adopts the returned views as `.grad` and the reducer has nothing to pack.  Only for
-        # fresh gradients (`.grad is None`: an accumulating micro-batch adds to what is there), and only for the FIRST node of
-        # the layer that reaches its backward before the reducer takes the bucket: a layer applied twice in one graph, or two
-        # forward passes back-propagated together, would otherwise both write the same slice before either is accumulated
-        # (both see `.grad is None`: AccumulateGrad runs after both producers) — the later nodes get tensors of their own.
-        arena = layer.__dict__.get('_pk_grad_arena')
-        if (arena is not None and not layer.__dict__.get('_pk_arena_claimed', False) and arena[0].dtype == dt
-                and all(prm is not None and prm.grad is None for prm in params)):
-            layer.__dict__['_pk_arena_claimed'] = True  # (until the reducer has taken the bucket: ddp._finalize / _reset)
-            flat, o_wd, o_w2, o_vec = arena
-            wd = flat[o_wd: o_wd + sum(wrows) * d].view(sum(wrows), d)
-            w2 = flat[o_w2: o_w2 + d * f].view(d, f)
-            vec = flat[o_vec: o_vec + sum(vsz)]
-        else:
-            wd = torch.empty(sum(wrows), d, dtype=dt, device=dev)
-            w2 = torch.empty(d, f, dtype=dt, device=dev)
-            vec = torch.empty(sum(vsz), dtype=dt, device=dev)
-        ws_ = wd.split(wrows, 0)
-        vs_ = vec.split(vsz, 0)
+        wd, w2, vec, wrows, vsz = grad_buffers(layer, params, is_decoder, d, f, dt, dev)
         es = 2
         wp, vp = wd.data_ptr(), vec.data_ptr()
 
@@ -358,13 +375,7 @@ class NativeLayerFn(Function):
         lay.scratch, lay.scratch_bytes, lay.ws, lay.ws_bytes = scratch.data_ptr(), scratch.numel(), ws.data_ptr(), ws.numel()
         lay.stream = lib.stream_ptr()
         check(L.pk_layer_bwd(ctypes.byref(lay)), 'pk_layer_bwd')
-        grads = []
-        for k in range(nblk):  # q.w k.w v.w q.b k.b v.b out.w out.b ln.w ln.b
-            grads += [ws_[4 * k], ws_[4 * k + 1], ws_[4 * k + 2], vs_[6 * k], vs_[6 * k + 1], vs_[6 * k + 2], ws_[4 * k + 3],
-                      vs_[6 * k + 3], vs_[6 * k + 4], vs_[6 * k + 5]]
-        v0 = 6 * nblk
-        grads += [ws_[4 * nblk], vs_[v0], w2, vs_[v0 + 1], vs_[v0 + 2], vs_[v0 + 3]]
-        grads = [g if prm is not None else None for g, prm in zip(grads, params)]  # (a projection without bias)
+        grads = grads_in_param_order(wd, w2, vec, wrows, vsz, nblk, params)
         return (dx, denc_ret, None, None, None, None, *grads)
 
 

@@ -341,3 +341,102 @@ def test_direct_all_reduce_layout_replayed_on_the_host(n):
     arr = (ctypes.c_longlong * n)()
     assert L.pk_comm_direct_plan(count + 8, n, 0, ctypes.byref(one), ctypes.byref(one), arr, arr) != 0
     assert b'multiple' in L.pk_last_error()
+
+
+# ---- the gradient-arena layout of natively run layers (ddp._build_buckets + native_layer.grad_buffers) at world 4 and 8 ----
+def _worker_arena(rank, world, port, ret):
+    """The real model classes (bf16 parameters, on CPU) under the reducer with the arena layout on: each layer's backward is
+    stood in for by a Function that takes its gradient buffers from native_layer.grad_buffers — exactly what
+    NativeLayerFn.backward does — and fills them with values that depend on (rank, parameter).  After the backward every
+    gradient must be the mean over the ranks AND be the bucket view itself; only parameters outside the layers are packed."""
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['PASERO_NO_NATIVE_LAYER'] = '0'
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pasero_amd import ddp as D, native_layer as NL
+    from pasero_amd.config import TransformerConfig, DistributedConfig, SyntheticTask
+    from pasero_amd.transformer import Transformer
+    D._ARENA_ON_ANY_DEVICE = True
+    torch.manual_seed(5 + rank)
+    cfg = TransformerConfig(embed_dim=64, encoder_ffn_dim=128, decoder_ffn_dim=128, encoder_attention_heads=1,
+                            decoder_attention_heads=1, encoder_layers=2, decoder_layers=2, dropout=0.0)
+    model = Transformer(cfg, DistributedConfig(dp_size=world, dp_rank=rank), SyntheticTask(40)).to(torch.bfloat16)
+    ddp = D.DistributedDataParallel(model, bucket_cap_mb=0.01)
+    layers = [(l, False) for l in model.encoder.layers] + [(l, True) for l in model.decoder.layers]
+    out = {'arena_layers': len(ddp._arena_layers) == 4, 'buckets': len(ddp._buckets) > 2}
+
+    def value(r, k, p):  # the "gradient" rank r produces for the k-th parameter of a layer: exact in bf16
+        return float((r + 1) * (k % 7 + 1)) / 8.0
+
+    class StandIn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, layer, is_dec, *params):
+            ctx.layer, ctx.is_dec, ctx.params = layer, is_dec, params
+            return x + 1.0
+
+        @staticmethod
+        def backward(ctx, dy):
+            layer, is_dec, params = ctx.layer, ctx.is_dec, ctx.params
+            d, f = 64, 128
+            wd, w2, vec, wrows, vsz = NL.grad_buffers(layer, params, is_dec, d, f, torch.bfloat16, dy.device)
+            grads = NL.grads_in_param_order(wd, w2, vec, wrows, vsz, 2 if is_dec else 1, params)
+            for k, g in enumerate(grads):
+                g.fill_(value(rank, k, params[k]))
+            return (dy, None, None, *grads)
+
+    emb = model.encoder.embed_tokens.weight
+
+    def loss_of():
+        x = emb[:4].float().sum() * torch.ones(3)            # (a parameter outside the layers: packed by the reducer)
+        for layer, is_dec in layers:
+            x = StandIn.apply(x, layer, is_dec, *NL.layer_params(layer, is_dec))
+        return x.sum()
+
+    def check(tag, factor):
+        ok, views = True, True
+        for layer, is_dec in layers:
+            for k, p in enumerate(NL.layer_params(layer, is_dec)):
+                want = factor * sum(value(r, k, p) for r in range(world)) / world
+                ok &= p.grad is not None and bool(torch.allclose(p.grad.float(), torch.full_like(p.grad.float(), want),
+                                                                  rtol=1e-2, atol=0))
+                b, i = ddp._where[p]
+                views &= p.grad.data_ptr() == b.view(i).data_ptr()
+        out[tag + ':mean'], out[tag + ':views'] = ok, views
+
+    ddp.module.zero_grad(set_to_none=True)
+    loss = loss_of()
+    ddp._release_arenas()   # (what ddp.forward does; the stand-in graph is not built through it)
+    loss.backward()
+    check('step1', 1.0)
+    in_layers = sum(len(NL.layer_params(l, d_)) for l, d_ in layers)
+    out['only_outside_params_packed'] = ddp.packed_copies == 1        # the embedding
+    out['embedding_mean'] = bool(torch.allclose(emb.grad[:4].float(), torch.full((4, 64), 3.0), rtol=1e-2))
+    # a second step, and a no_sync micro-batch followed by a reducing one (the second finds `.grad` set: fresh tensors,
+    # accumulated by autograd INTO the bucket views)
+    ddp.module.zero_grad(set_to_none=True)
+    ddp._release_arenas()
+    loss_of().backward()
+    check('step2', 1.0)
+    ddp.module.zero_grad(set_to_none=True)
+    with ddp.no_sync():
+        ddp._release_arenas()
+        loss_of().backward()
+    ddp._release_arenas()
+    loss_of().backward()
+    check('accum', 2.0)
+    out['in_layers'] = in_layers == 2 * 16 + 2 * 26
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_ddp_gradient_arena_layout_world_4_and_8(world):
+    """the bucket-view gradients of natively run layers had only ever met one or two ranks"""
+    _run(_worker_arena, world=world, timeout=240)
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_ddp_bucket_order_world_4_and_8(world):
+    _run(_worker_order, world=world, timeout=240)

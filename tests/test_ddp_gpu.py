@@ -166,6 +166,41 @@ def test_two_forwards_back_propagated_together_under_the_reducer(monkeypatch):
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(300)
+def test_c2_step_under_every_all_reduce_schedule_is_bitwise_the_plain_step(monkeypatch):
+    """the C2-width step through the reducer with each of the three native schedules pinned
+    (ncclAllReduce, reduce-scatter + all-gather, the direct exchange with its fixed-order shard mean) — on one rank the mean
+    over the ranks is the identity, so every gradient must equal the plain step's BIT FOR BIT (dropout 0.1 is on: the reducer must not disturb the order the offsets are drawn in).  What an
+    8-GPU node then adds is bandwidth, not arithmetic."""
+    from pasero_amd import rng
+    from pasero_amd.ddp import DistributedDataParallel
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', str(_free_port()))
+    monkeypatch.setenv('PASERO_DDP_FORCE_REDUCE', '1')
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        model, batch = _base_width_model(torch.bfloat16)
+        model.train()
+        rng.manual_seed(5)
+        model(**batch)[0].backward()
+        plain = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        ddp = DistributedDataParallel(model, bucket_cap_mb=0.05)
+        assert ddp._native is not None
+        for sched in (0, 1, 2):
+            ddp._native.schedule = sched
+            for p in model.parameters():
+                p.grad = None
+            rng.manual_seed(5)
+            ddp(**batch)[0].backward()
+            torch.cuda.synchronize()
+            for n, p in model.named_parameters():
+                if n in plain:
+                    assert torch.equal(p.grad, plain[n]), (sched, n)
+    finally:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------------------------
 # two ranks, the real HIP model: both processes share the box's one card (gloo carries the CUDA buckets)
 # ------------------------------------------------------------------------------------------------------------
