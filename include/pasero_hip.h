@@ -53,6 +53,19 @@ int pk_gemm(const void* A, const void* B, void* C, const void* bias, const void*
             long long N, long long K, long long lda, long long ldb, long long ldc, long long ldaux, long long ldpre,
             int a_col, int b_col, int act, int mode, float alpha, int dtype, int splitk, void* workspace,
             size_t ws_bytes, void* asum_out, void* stream);
+/* pk_gemm with promises about padding (a vocabulary that is no multiple of 8 — NLLB's 256 206 — inside buffers whose rows
+ * are padded to one; without them such a GEMM only fits the 128-tile kernel: 715-770 instead of 1 150-1 300 TFLOP/s at C5):
+ *   PK_GEMM_PAD_N: C's rows have room for N rounded up to 8 (ldc >= that): whole 16-byte chunks may be stored, the pad
+ *     columns receive unspecified finite values.  Mode 0 without bias / activation / preact, no split-K.
+ *   PK_GEMM_PAD_K: row-form A, col-form B: A's rows extend to K rounded up to 8 (lda >= that) with ZEROS in the pad columns
+ *     (pk_ce_rows leaves them so in its gradient); B has exactly K rows.
+ * A promise that does not apply to the call (other layouts, fp32, N or K already a multiple of 8) is ignored. */
+#define PK_GEMM_PAD_N 1
+#define PK_GEMM_PAD_K 2
+int pk_gemm_ex(const void* A, const void* B, void* C, const void* bias, const void* aux, void* preact, long long M,
+               long long N, long long K, long long lda, long long ldb, long long ldc, long long ldaux, long long ldpre,
+               int a_col, int b_col, int act, int mode, float alpha, int dtype, int splitk, void* workspace,
+               size_t ws_bytes, void* asum_out, int pad_flags, void* stream);
 /* Launch timing for the roofline measurement (no reference counterpart; the analogue of wrapping the reference's
  * nn.Linear calls in torch.cuda.Event pairs).  After pk_gemm_timing_start(max_samples, stride) every `stride`-th pk_gemm
  * call records a HIP event pair around exactly its main GEMM kernel (not the split-K reduce), on the launching stream.

@@ -732,6 +732,9 @@ def _ce_chunk_rows(rows: int, V: int, itemsize: int, budget_bytes: int = _CE_BUD
     return min(rows, per)
 
 
+_NO_PAD_VOCAB = os.environ.get('PASERO_NO_PAD_VOCAB', '0') not in ('', '0')  # (A/B: V % 8 != 0 on the 128-tile kernel, as before round 4)
+
+
 class VocabCrossEntropyFn(Function):
     """Tied vocabulary projection + label-smoothed cross-entropy, chunked over rows so the (rows, V) logits never
     exist as a whole (pasero/models/modules.py:935-947 + pasero/models/transformer.py:354-380).
@@ -760,6 +763,7 @@ class VocabCrossEntropyFn(Function):
         if grad and step < rows:
             group = max(1, min(-(-4096 // step), (2 << 30) // (step * ldp * x.element_size())))
         logits = torch.empty(group * step, ldp, dtype=x.dtype, device=x.device)[:, :V]
+        padded = V % 8 != 0 and x.dtype in (torch.bfloat16, torch.float16) and not _NO_PAD_VOCAB
 
         def weight_grad_of(g0, g1, first):  # rows [g0, g1) of x2 <-> the first g1 - g0 rows of the group buffer
             lgs = logits[: g1 - g0]
@@ -773,12 +777,14 @@ class VocabCrossEntropyFn(Function):
             r1 = min(rows, r0 + step)
             slot = (i % group) * step
             lg = logits[slot: slot + r1 - r0]
-            F.gemm(x2[r0:r1], weight, out=lg)
+            # (a vocabulary that is no multiple of 8 — NLLB's 256 206: the buffer's rows are padded, pk_ce_rows leaves zeros
+            # in the pad columns of its gradient, and both GEMMs may then work in whole 16-byte chunks: the 256-tile kernel)
+            F.gemm(x2[r0:r1], weight, out=lg, pad_n=padded)
             F.ce_rows(lg, tgt[r0:r1], padding_idx, eps, row_loss[r0:r1], row_nll[r0:r1],
                       dlogits=lg if grad else None)
             if grad:
                 # dX chunk: few output tiles (chunk rows x d) but a vocabulary-long contraction -> split-K
-                F.gemm(lg, weight, b_col=True, out=dx[r0:r1], splitk=F.choose_splitk(r1 - r0, x2.size(1), V))
+                F.gemm(lg, weight, b_col=True, out=dx[r0:r1], splitk=F.choose_splitk(r1 - r0, x2.size(1), V), pad_k=padded)
                 if (i + 1) % group == 0 or r1 == rows:
                     dw = weight_grad_of(g0, r1, dw is None)
                     g0 = r1

@@ -16,6 +16,8 @@ struct PkLnParamGrad {
     void* dgamma;
     void* dbeta;
 };
+#define PK_GEMM_PAD_N 1 /* pk_gemm_ex promises (include/pasero_hip.h) */
+#define PK_GEMM_PAD_K 2
 #define PK_ACT_NONE 0
 #define PK_ACT_RELU 1
 #define PK_ACT_GELU 2       // erf

@@ -154,6 +154,10 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, l
         float g = active ? __expf(to_f32<T>(x[c]) - lse) - uni - (c == tgt ? 1.f - eps : 0.f) : 0.f;
         dx[c] = from_f32<T>(g);
     }
+    // a row pitch that leaves room for V rounded up to 8: the pad columns become ZERO, so that the gradient GEMM that
+    // contracts over the vocabulary may read whole 16-byte chunks (pk_gemm_ex, PK_GEMM_PAD_K)
+    const long long vpad = (V + 7) & ~7LL;
+    if (tid < vpad - V && ldd >= vpad) dx[V + tid] = from_f32<T>(0.f);
 }
 
 // sums[0] = sum(row_loss), sums[1] = sum(row_nll), sums[2] = #(target != pad); one workgroup, fp64 accumulation

@@ -753,10 +753,15 @@ inline void timing_end(GemmSample* sm, hipStream_t stream) {
 template <typename T>
 int launch_gemm(const void* A, const void* B, void* C, long long M, long long N, long long K, long long lda,
                 long long ldb, int a_col, int b_col, EpiParams ep, int splitk, void* workspace,
-                size_t ws_bytes, void* asum_out, hipStream_t stream) {
+                size_t ws_bytes, void* asum_out, hipStream_t stream, int pad_flags = 0) {
     using TR = Traits<T>;
     constexpr int EPV = TR::EPV;
     auto aligned = [&](const void* p, long long ld) { return ((uintptr_t)p % 16) == 0 && (ld % EPV) == 0; };
+    // pk_gemm_ex: a vocabulary-sized dimension that is no multiple of 8 inside buffers whose rows are padded to one.  The
+    // promises only matter to the 256-tile kernel (16-byte chunks everywhere); the 128-tile kernel below ignores them.
+    const bool pad_n = (pad_flags & PK_GEMM_PAD_N) && sizeof(T) == 2 && N % 8 && ep.mode == 0 && !ep.bias && !ep.preact &&
+                       ep.act == PK_ACT_NONE && splitk <= 1 && ep.ldc >= ((N + 7) & ~7LL);
+    const bool pad_k = (pad_flags & PK_GEMM_PAD_K) && sizeof(T) == 2 && K % 8 && !a_col && b_col && lda >= ((K + 7) & ~7LL);
     int flags = 0;
     if (aligned(A, lda)) flags |= 1;
     if (aligned(B, ldb)) flags |= 2;
@@ -796,16 +801,18 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         const bool lean_epi = !ep.preact && (ep.act == PK_ACT_NONE || ep.act == PK_ACT_RELU) && ep.mode < 3;
         const bool addr_ok = (flags & 1) && (flags & 2) && (!a_col || M % 8 == 0 || lda >= ((M + 7) & ~7LL)) &&
                              (!b_col || N % 8 == 0) &&
-                             N % 8 == 0 && K > 0;
+                             (N % 8 == 0 || pad_n) && K > 0;
         // gemm8p.hip zero-fills a partial last K-tile (K % 8 == 0: the vocabulary dX GEMMs, K = V); gemm256.hip needs
         // whole 64-deep tiles
-        const bool e8 = g_use_8p && pk_gemm8p_eligible(M, N, K, lda, ldb, a_col, b_col, asum_out != nullptr);
+        const long long K8 = pad_k ? ((K + 7) & ~7LL) : K;  // (what the phase-interleaved kernel contracts over)
+        const bool e8 = g_use_8p && pk_gemm8p_eligible(M, N, K8, lda, ldb, a_col, b_col, asum_out != nullptr);
         const bool k_ok = e8 || K % 64 == 0;
-        const bool simple = epi_ok && (lean_epi || (e8 && splitk <= 1));  // (the split-K reduce kernel has its own epilogue)
+        const bool simple = epi_ok && (lean_epi || (e8 && splitk <= 1)) &&  // (the split-K reduce kernel has its own epilogue)
+                            (e8 || (N % 8 == 0 && !pad_k));  // (only gemm8p.hip knows the padded forms)
         const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
         if (simple && addr_ok && k_ok && tile_pref != 128 && M >= 256 && N >= 256) {
             int sk = 1;
-            long long per = K;
+            long long per = K8;
             // split-K (weight-gradient) GEMMs: the 256 kernel re-derives its own split factor (~1 workgroup per CU).
             // Measured in the training step after the slab-major walk: C2 19.95 vs 20.16 ms, transformer_big 74.5 vs
             // 79.0 ms in favour of the 256 kernel.  PK_GEMM_SK256=2 keeps split-K on the 128 kernel, =1 caps the factor.
@@ -817,11 +824,11 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
             // vs 14.00 ms of GEMM time per step)
             if (splitk > 1 && (sk_mode == 2 || t256 < sk_min_tiles)) sk = 0;
             else if (splitk > 1) {  // the caller allows split-K: re-derive the factor for 256-tiles (~1 workgroup per CU)
-                sk = (int)std::max(1LL, std::min((long long)(256 / std::max(1LL, t256)), K / 512));
+                sk = (int)std::max(1LL, std::min((long long)(256 / std::max(1LL, t256)), K8 / 512));
                 sk = std::min(sk, 2 * splitk);  // the caller sized the workspace for twice its own factor
                 if (sk_mode == 1) sk = std::min(sk, splitk);
-                per = ((K + sk - 1) / sk + 63) / 64 * 64;
-                sk = (int)((K + per - 1) / per);
+                per = ((K8 + sk - 1) / sk + 63) / 64 * 64;
+                sk = (int)((K8 + per - 1) / per);
                 if ((size_t)sk * M * (N + (asum_out ? 1 : 0)) * sizeof(float) > ws_bytes) sk = 0;  // does not fit
             }
             const bool fills = t256 * std::max(sk, 1) >= 160;
@@ -832,10 +839,13 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
                 // operands beyond 4 GiB).  PK_GEMM_8P=0 switches it off (A/B inside one process: tools/gemm_bench.py)
                 // (sample tag of the gemm8p instantiation: 8 | 0x10 general epilogue | 0x20 partial last K-tile)
                 const bool any_epi = ep.preact || ep.mode == 3 || (ep.act != PK_ACT_NONE && ep.act != PK_ACT_RELU);
-                const int tag8 = 8 | (any_epi ? 0x10 : 0) | (K % 64 ? 0x20 : 0);
+                const int tag8 = 8 | (any_epi ? 0x10 : 0) | (K8 % 64 ? 0x20 : 0);
                 GemmSample* sm = timing_begin(e8 ? tag8 : 256, a_col, b_col, std::max(sk, 1), dtype16, M, N, K, stream);
-                int rc = (e8 ? pk_gemm8p_launch : pk_gemm256_launch)(A, B, C, w2, asw, asum_out, M, N, K, lda, ldb, a_col,
-                                                                    b_col, (int)per, std::max(sk, 1), ep, dtype16, stream);
+                EpiParams ep8 = ep;
+                if (e8 && pad_n) ep8.nstore = (N + 7) & ~7LL;
+                if (e8 && pad_k) ep8.kb_rows = K;
+                int rc = (e8 ? pk_gemm8p_launch : pk_gemm256_launch)(A, B, C, w2, asw, asum_out, M, N, e8 ? K8 : K, lda, ldb,
+                                                                    a_col, b_col, (int)per, std::max(sk, 1), ep8, dtype16, stream);
                 timing_end(sm, stream);
                 if (rc != 1) return rc;
                 if (w2) {
@@ -891,11 +901,27 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
 
 }  // namespace
 
+extern "C" int pk_gemm_ex(const void* A, const void* B, void* C, const void* bias, const void* aux, void* preact,
+                          long long M, long long N, long long K, long long lda, long long ldb, long long ldc,
+                          long long ldaux, long long ldpre, int a_col, int b_col, int act, int mode, float alpha,
+                          int dtype, int splitk, void* workspace, size_t ws_bytes, void* asum_out, int pad_flags,
+                          void* stream);
+
 extern "C" int pk_gemm(const void* A, const void* B, void* C, const void* bias, const void* aux, void* preact,
                        long long M, long long N, long long K, long long lda, long long ldb, long long ldc,
                        long long ldaux, long long ldpre, int a_col, int b_col, int act, int mode, float alpha,
                        int dtype, int splitk, void* workspace, size_t ws_bytes, void* asum_out, void* stream) {
+    return pk_gemm_ex(A, B, C, bias, aux, preact, M, N, K, lda, ldb, ldc, ldaux, ldpre, a_col, b_col, act, mode, alpha, dtype,
+                      splitk, workspace, ws_bytes, asum_out, 0, stream);
+}
+
+extern "C" int pk_gemm_ex(const void* A, const void* B, void* C, const void* bias, const void* aux, void* preact,
+                          long long M, long long N, long long K, long long lda, long long ldb, long long ldc,
+                          long long ldaux, long long ldpre, int a_col, int b_col, int act, int mode, float alpha,
+                          int dtype, int splitk, void* workspace, size_t ws_bytes, void* asum_out, int pad_flags,
+                          void* stream) {
     if (M == 0 || N == 0) return 0;  // an empty output: nothing to read, nothing to write (operands may be NULL)
+    PK_CHECK_ARG((pad_flags & ~(PK_GEMM_PAD_N | PK_GEMM_PAD_K)) == 0, "pk_gemm_ex: unknown flags %d", pad_flags);
     PK_CHECK_ARG(A && B && C, "pk_gemm: null operand");
     PK_CHECK_ARG(!asum_out || a_col, "pk_gemm: asum_out (fused bias gradient) needs A in col form");
     PK_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "pk_gemm: negative size");
@@ -910,9 +936,9 @@ extern "C" int pk_gemm(const void* A, const void* B, void* C, const void* bias, 
     ep.act = act; ep.mode = mode; ep.alpha = alpha;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PK_BF16)
-        return launch_gemm<bf16>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
+        return launch_gemm<bf16>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s, pad_flags);
     if (dtype == PK_F16)
-        return launch_gemm<f16>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
+        return launch_gemm<f16>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s, pad_flags);
     return launch_gemm<float>(A, B, C, M, N, K, lda, ldb, a_col, b_col, ep, splitk, workspace, ws_bytes, asum_out, s);
 }
 

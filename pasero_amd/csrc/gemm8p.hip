@@ -67,7 +67,7 @@ __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, T* _
                                               long long mh, long long n0, long long M, long long N, int tid) {
     const int col = (tid & 31) * 8, r0 = tid >> 5;
     const long long gn = n0 + col;
-    if (gn + 8 > N) return;
+    if (gn + 8 > (ep.nstore ? ep.nstore : N)) return;  // (nstore: the rows of C are padded, the last chunk is stored whole)
     float b[8];
     if (MODE != 2 && ep.bias) {
         Vec16<T> bv = load16<T>(reinterpret_cast<const T*>(ep.bias) + gn);
@@ -674,6 +674,10 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
     if (!pk_gemm8p_eligible(M, N, K, lda, ldb, a_col, b_col, asum_ws || asum_out)) return 0;
     long long a_bytes, b_bytes;
     operand_bytes(M, N, K, lda, ldb, a_col, b_col, &a_bytes, &b_bytes);
+    if (ep.kb_rows > 0 && b_col) {  // K was rounded up to 8 for a zero-padded row-form A: B ends where it really ends
+        long long unused;
+        operand_bytes(M, N, ep.kb_rows, lda, ldb, a_col, b_col, &unused, &b_bytes);
+    }
     const int total = (int)(((M + BM - 1) / BM) * ((N + BN - 1) / BN) * splitk);
     unsigned long long* stamps = nullptr;  // PK8P_STAMP_PTR: device buffer of the diagnostic build's time stamps
 #if defined(PK8P_STAMPS) || defined(PKBS_STAMPS)  /* (diagnostic builds only: the shipped library never reads the variable) */

@@ -8,6 +8,9 @@ struct EpiParams {
     int act;            // PK_ACT_*
     int mode;           // 0: act(v+bias)   1: act(v+bias) + aux   2: v * act'(aux)
     float alpha;
+    // a vocabulary that is no multiple of 8 in buffers whose rows are padded to one (pk_gemm_ex, include/pasero_hip.h):
+    long long nstore = 0;   // PK_GEMM_PAD_N: columns up to `nstore` = N rounded up to 8 may be STORED (0: N) — gemm8p's lean epilogue
+    long long kb_rows = 0;  // PK_GEMM_PAD_K: the rows a col-form B really has (the K passed on is rounded up to 8; 0: K)
 };
 
 // One weight-gradient problem of a grouped launch (include/pasero_hip.h: PkWgradProblem): C[M,N] = A^T B, both operands

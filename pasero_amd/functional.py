@@ -29,9 +29,10 @@ def _ld(t: Tensor) -> int:
 def gemm(a: Tensor, b: Tensor, *, a_col: bool = False, b_col: bool = False, bias: Optional[Tensor] = None,
          aux: Optional[Tensor] = None, act: str = 'none', mode: int = 0, alpha: float = 1.0,
          out: Optional[Tensor] = None, preact: Optional[Tensor] = None, splitk: int = 1,
-         asum_out: Optional[Tensor] = None) -> Tensor:
+         asum_out: Optional[Tensor] = None, pad_n: bool = False, pad_k: bool = False) -> Tensor:
     """C[m,n] = epi(alpha * sum_k A(m,k) B(n,k)).  `a` is [M,K] (or [K,M] if a_col), `b` is [N,K] (or [K,N] if b_col).
-    See include/pasero_hip.h:pk_gemm for the epilogue modes."""
+    See include/pasero_hip.h:pk_gemm for the epilogue modes; pad_n / pad_k: the promises of pk_gemm_ex (the rows of `out`
+    have room for N rounded up to 8 / the rows of a row-form `a` continue with zeros up to K rounded up to 8)."""
     require_gpu(a, b, bias, aux, out, preact)
     M, K = (a.size(1), a.size(0)) if a_col else (a.size(0), a.size(1))
     N, Kb = (b.size(1), b.size(0)) if b_col else (b.size(0), b.size(1))
@@ -53,6 +54,13 @@ def gemm(a: Tensor, b: Tensor, *, a_col: bool = False, b_col: bool = False, bias
         ws_bytes = 2 * splitk * M * (N + 1) * 4  # room for the 256-tile kernel's (up to 2x) larger split factor
         ws = lib.workspace(ws_bytes, a.device, 'splitk')
     L = lib.load()
+    if pad_n or pad_k:
+        flags = (lib.PK_GEMM_PAD_N if pad_n else 0) | (lib.PK_GEMM_PAD_K if pad_k else 0)
+        check(L.pk_gemm_ex(ptr(a), ptr(b), ptr(out), ptr(bias), ptr(aux), ptr(preact), M, N, K, _ld(a), _ld(b), _ld(out),
+                           _ld(aux) if aux is not None else 0, _ld(preact) if preact is not None else 0,
+                           int(a_col), int(b_col), ACT[act], mode, float(alpha), dtype_code(a), int(splitk),
+                           ptr(ws), ws_bytes, ptr(asum_out), flags, stream_ptr()), 'pk_gemm_ex')
+        return out
     check(L.pk_gemm(ptr(a), ptr(b), ptr(out), ptr(bias), ptr(aux), ptr(preact), M, N, K, _ld(a), _ld(b), _ld(out),
                     _ld(aux) if aux is not None else 0, _ld(preact) if preact is not None else 0,
                     int(a_col), int(b_col), ACT[act], mode, float(alpha), dtype_code(a), int(splitk),

@@ -22,6 +22,7 @@ SIGNATURES = {
     'pk_version': (I, []),
     'pk_last_error': (c_char_p, []),
     'pk_gemm': (I, [P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, SZ, P, P]),
+    'pk_gemm_ex': (I, [P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, SZ, P, I, P]),
     'pk_gemm_use_8p': (I, [I]),
     'pk_gemm_use_bs': (I, [I]),
     'pk_gemm_relu_bits_eligible': (I, [P, P, P, P, LL, LL, LL, LL, LL, LL, LL, I, I, I]),
@@ -84,6 +85,7 @@ SIGNATURES = {
 }
 
 PK_WGRAD_MAX = 8
+PK_GEMM_PAD_N, PK_GEMM_PAD_K = 1, 2  # pk_gemm_ex promises (include/pasero_hip.h)
 
 
 class PkWgradProblem(ctypes.Structure):

@@ -195,3 +195,55 @@ def test_gemm8p_is_bitwise_reproducible_under_load(F, a_col, b_col):
             torch.cuda.synchronize()
     finally:
         L.pk_gemm_use_8p(old)
+
+
+@pytest.mark.parametrize('rows,V,d', [(4096, 5006, 1024), (2048, 20486, 768), (2304, 41702, 768)])
+def test_vocabulary_that_is_no_multiple_of_8_runs_on_the_256_tile_kernel(rows, V, d):
+    """pk_gemm_ex: logits = x Eᵀ with V % 8 != 0 into rows padded to a multiple of 8 (PK_GEMM_PAD_N) and dX = dlogits E
+    contracting over that V with zeros in the pad columns (PK_GEMM_PAD_K) — NLLB's V = 256 206.  Both must run on the
+    phase-interleaved 256-tile kernel (launch sampling) and agree with fp64; the valid columns of the logits are bit for bit
+    those of the same GEMM through the 128-tile kernel's arithmetic only up to summation order, so: fp64 tolerance."""
+    import ctypes
+    from pasero_amd import functional as F, lib
+    torch.manual_seed(V)
+    x = (torch.randn(rows, d, device='cuda') * 0.5).bfloat16()
+    E = (torch.randn(V, d, device='cuda') * 0.05).bfloat16()
+    ldp = (V + 15) // 16 * 16
+    buf = torch.full((rows, ldp), float('nan'), dtype=torch.bfloat16, device='cuda')
+    lg = buf[:, :V]
+    L = lib.load()
+
+    def tags(fn):
+        lib.check(L.pk_gemm_timing_start(16, 1), 'start')
+        fn()
+        n = L.pk_gemm_timing_stop()
+        out = []
+        for i in range(n):
+            ints = [ctypes.c_int() for _ in range(5)]
+            fl, ms = ctypes.c_double(), ctypes.c_float()
+            lib.check(L.pk_gemm_timing_read(i, *[ctypes.byref(t) for t in ints], ctypes.byref(fl), ctypes.byref(ms)), 'read')
+            out.append(ints[0].value)
+        return out
+    t = tags(lambda: F.gemm(x, E, out=lg, pad_n=True))
+    assert t and all((k & 0xF) == 8 and k < 256 for k in t), t          # gemm8p
+    ref = x.double() @ E.double().t()
+    assert torch.isfinite(buf[:, : (V + 7) // 8 * 8]).all()              # (pad columns: unspecified but finite)
+    assert torch.isnan(buf[:, (V + 7) // 8 * 8:]).all()                  # nothing beyond the promised room is touched
+    err = (lg.double() - ref).abs().max().item()
+    assert err <= 2e-2 * ref.abs().max().item(), err
+    # the gradient side: dlogits with ZERO pad columns, contraction over V
+    g = torch.zeros(rows, ldp, dtype=torch.bfloat16, device='cuda')
+    g[:, :V] = (torch.randn(rows, V, device='cuda') * 0.1).bfloat16()
+    dx = torch.empty(rows, d, dtype=torch.bfloat16, device='cuda')
+    t = tags(lambda: F.gemm(g[:, :V], E, b_col=True, out=dx, splitk=F.choose_splitk(rows, d, V), pad_k=True))
+    assert t and all((k & 0xF) == 8 and k < 256 for k in t), t
+    ref = g[:, :V].double() @ E.double()
+    err = (dx.double() - ref).abs().max().item()
+    assert err <= 2e-2 * ref.abs().max().item(), err
+    # and the loss kernel really leaves zeros in the pad columns of its gradient
+    tgt = torch.randint(0, V, (rows,), device='cuda')
+    buf.fill_(float('nan'))
+    F.gemm(x, E, out=lg, pad_n=True)
+    rl, rn = torch.empty(rows, device='cuda'), torch.empty(rows, device='cuda')
+    F.ce_rows(lg, tgt, 1, 0.1, rl, rn, dlogits=lg)
+    assert (buf[:, V: (V + 7) // 8 * 8] == 0).all() and torch.isfinite(buf[:, :V]).all()
