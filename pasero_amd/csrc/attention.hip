@@ -653,22 +653,40 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
                 // two half-waves (keys +0..3 / +4..7) merge their nibbles into the byte of the stored bit mask
                 const long long mrow = ((long long)b * p.H + h) * p.T + t;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb) {
+                    unsigned word = 0;
+                    // One Philox4x32-10 draw covers 8 consecutive keys of a query row: words x, y serve keys +0..3 (lanes 0..31),
+                    // z, w keys +4..7 (lanes 32..63).  Each half-wave evaluates the draw of ONE of the two 8-key groups of a pair
+                    // and hands the partner the half it needs — half the evaluations (the forward kernel with dropout was bound
+                    // by them: 151 against 71 us at the IWSLT recipe's encoder shape); the bits are those of dropout_keep4.
+                    const unsigned thr16 = p.drop_thr >> 16;
+                    const bool hi = lane >= 32;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int key0 = s0 + kb * 32 + 8 * g + 4 * (lane >> 5);
-                        bool keep[4];
-                        dropout_keep4(p.seed, p.offset, ((unsigned long long)mrow * 8ull * p.mask_pitch + key0) >> 2,
-                                      p.drop_thr, keep);
-                        unsigned nib = 0;
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int g_own = 2 * gp + (hi ? 1 : 0);
+                        const unsigned long long ctr = ((unsigned long long)mrow * 8ull * p.mask_pitch + (s0 + kb * 32 + 8 * g_own)) >> 3;
+                        const Philox4 r = philox4x32_10(p.seed, p.offset, ctr);
+                        const unsigned got0 = __shfl_xor(hi ? r.x : r.z, 32, 64), got1 = __shfl_xor(hi ? r.y : r.w, 32, 64);
+                        const unsigned wv[2][2] = {{hi ? got0 : r.x, hi ? got1 : r.y},    // group 2 gp:     this lane's 4 keys
+                                                   {hi ? r.z : got0, hi ? r.w : got1}};   // group 2 gp + 1
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            nib |= (unsigned)keep[j] << j;
-                            if (!keep[j]) sc[kb][4 * g + j] = 0.f;
+                        for (int u = 0; u < 2; ++u) {
+                            const int g = 2 * gp + u;
+                            const bool keep[4] = {(wv[u][0] & 0xffffu) >= thr16, (wv[u][0] >> 16) >= thr16,
+                                                  (wv[u][1] & 0xffffu) >= thr16, (wv[u][1] >> 16) >= thr16};
+                            unsigned nib = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                nib |= (unsigned)keep[j] << j;
+                                if (!keep[j]) sc[kb][4 * g + j] = 0.f;
+                            }
+                            word |= nib << (8 * g + 4 * (lane >> 5));
                         }
-                        const unsigned other = __shfl_xor(nib, 32, 64);
-                        if (valid && lane < 32) p.drop_mask[mrow * p.mask_pitch + ((s0 + kb * 32) >> 3) + g] = (unsigned char)(nib | (other << 4));
                     }
+                    word |= __shfl_xor(word, 32, 64);  // (the two half-waves hold the low / high nibbles of the same bytes)
+                    if (valid && lane < 32)
+                        *reinterpret_cast<unsigned*>(p.drop_mask + mrow * p.mask_pitch + ((s0 + kb * 32) >> 3)) = word;
+                }
             }
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt)
@@ -698,9 +716,10 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
                                                                      dp[kb]);
                 if constexpr (DROP) {  // dP = M / (1 - p) * (dO . V): the stored keep bits of this query's keys
                     const long long mrow = ((long long)b * p.H + h) * p.T + t;
+                    const unsigned w4 = valid ? *reinterpret_cast<const unsigned*>(p.drop_mask + mrow * p.mask_pitch + ((s0 + kb * 32) >> 3)) : 0u;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        unsigned byte = valid ? p.drop_mask[mrow * p.mask_pitch + ((s0 + kb * 32) >> 3) + g] : 0u;
+                        unsigned byte = (w4 >> (8 * g)) & 0xffu;
                         byte >>= 4 * (lane >> 5);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -752,10 +771,21 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
     __shared__ __attribute__((aligned(16))) char q_lds[NI * KT * 128];   // dual-use images: read by rows and transposed
     __shared__ __attribute__((aligned(16))) char do_lds[NI * KT * 128];
     __shared__ __attribute__((aligned(16))) float l2_lds[KT], dl_lds[KT];
+    // attention-probability dropout: the stored keep bits of (this tile's 64 queries) x (this workgroup's 128 keys), one dword
+    // per (query, wave) — staged with the tile instead of one global byte load per score (the DROP instantiation ran 3.7x
+    // longer per (query, key) pair than the plain one: 201 us for the IWSLT recipe's encoder self-attention)
+    __shared__ unsigned m_lds[DROP ? KT * 4 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
     const int s = blockIdx.x * 128 + wave * 32 + (lane & 31);
     const bool kvalid = s < p.S && !(p.key_pad && p.key_pad[(long long)b * p.S + min(s, p.S - 1)]);
+    // thread tid brings dword tid & 3 (32 keys) of query row tid >> 2 of the tile; rows past T and dwords past the row: 0
+    auto mask_g2r = [&](int t0) -> unsigned {
+        const int t = t0 + (tid >> 2);
+        const long long byte0 = (long long)blockIdx.x * 16 + (tid & 3) * 4;
+        if (t >= p.T || byte0 + 4 > p.mask_pitch) return 0u;
+        return *reinterpret_cast<const unsigned*>(p.drop_mask + (((long long)b * p.H + h) * p.T + t) * p.mask_pitch + byte0);
+    };
     const float c = p.scale * LOG2E;
 
     bf16x8_t kf[NF], vf[NF];
@@ -777,15 +807,18 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
     const T* qbase = q + b * p.q_bs + h * HD;
     const T* dobase = d_o + b * p.do_bs + h * HD;
     uint4 qreg[2 * NI], doreg[2 * NI];
+    unsigned mreg = 0u;
     if (t_begin < p.T) {
         tile_g2r(qreg, qbase, p.q_rs, t_begin, p.T, tid);
         tile_g2r(doreg, dobase, p.do_rs, t_begin, p.T, tid);
         if (p.rope_cos) rope_tile<2 * NI, T>(qreg, p, p.rope_q0 + t_begin, tid);
+        if constexpr (DROP) mreg = mask_g2r(t_begin);
     }
     for (int t0 = t_begin; t0 < p.T; t0 += KT) {
         __syncthreads();
         tile_r2s<DUAL>(qreg, q_lds, tid);
         tile_r2s<DUAL>(doreg, do_lds, tid);
+        if constexpr (DROP) m_lds[tid] = mreg;
         if (tid < KT) {
             int t = t0 + tid;
             long long row = ((long long)b * p.H + h) * p.T + t;
@@ -796,6 +829,7 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
             tile_g2r(qreg, qbase, p.q_rs, t0 + KT, p.T, tid);
             tile_g2r(doreg, dobase, p.do_rs, t0 + KT, p.T, tid);
             if (p.rope_cos) rope_tile<2 * NI, T>(qreg, p, p.rope_q0 + t0 + KT, tid);
+            if constexpr (DROP) mreg = mask_g2r(t0 + KT);
         }
         __syncthreads();
         // causal classification of (this tile's 64 queries) x (this wave's 32 keys): wave-uniform
@@ -824,9 +858,9 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
                     if (check) x = s > t0 + tl + j + off ? -INFINITY : x;
                     const float pw = __builtin_amdgcn_exp2f(x);
                     float pv = pw, dpv = dp[4 * g + j];
-                    if constexpr (DROP) {  // keep bit of (query t0+tl+j, this lane's key)
-                        const int tq = t0 + tl + j;
-                        const bool keep = tq < p.T && s < p.S && drop_bit(p, ((long long)b * p.H + h) * p.T + tq, s);
+                    if constexpr (DROP) {  // keep bit of (query t0+tl+j, this lane's key): bit lane & 31 of the wave's dword
+                        const unsigned wd = m_lds[(tl + j) * 4 + wave];
+                        const bool keep = s < p.S && ((wd >> (lane & 31)) & 1u);  // (rows past T were staged as zeros)
                         pv = keep ? pw * p.drop_scale : 0.f;
                         dpv = keep ? dpv * p.drop_scale : 0.f;
                     }
@@ -862,7 +896,7 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
 // are computed once (the split dQ / dKdV kernels each recompute them).  Phase 1 (key on the lane, wave w owns keys
 // 32w..32w+31) produces dK, dV and leaves dSᵀ[key][query] in LDS; phase 2 (query on the lane, wave w owns queries
 // 32w..) contracts it with the K tile: dQᵀ[d][q] = Σ_key Kᵀ[d][key] · dSᵀ[key][q].
-constexpr int FUSED_LDS = 2 * (2 * KT * 128) + 128 * 256 + 2 * 128 * 4;  // Q | dO (K later) | dSᵀ | lse, delta
+constexpr int FUSED_LDS = 2 * (2 * KT * 128) + 128 * 256 + 2 * 128 * 4 + 128 * 16;  // Q | dO (K later) | dSᵀ | lse, delta | keep bits
 __device__ __forceinline__ int ds_off(int key, int qcol) {  // dSᵀ image: 256-B rows, 16-B chunk swizzled so that both
     // the 8-B row-segment writes of phase 1 and the transposed reads of phase 2 spread over the banks
     return key * 256 + ((((qcol >> 3) ^ ((key & 3) << 2) ^ ((key >> 2) & 3)) & 15) << 4) + (qcol & 7) * 2;
@@ -888,8 +922,19 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
     char* ds_lds = do_lds + 2 * KT * 128;       // dSᵀ [128 keys][128 queries]
     float* l2_lds = reinterpret_cast<float*>(ds_lds + 128 * 256);
     float* dl_lds = l2_lds + 128;
+    unsigned* m_lds = reinterpret_cast<unsigned*>(dl_lds + 128);  // DROP: keep bits [128 queries][4 dwords of 32 keys]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, h = blockIdx.x;
+    if constexpr (DROP) {  // (staged with the tiles; one dword per (query, wave) instead of a global byte load per score)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, t = idx >> 2, byte0 = (idx & 3) * 4;
+            unsigned w = 0u;
+            if (t < p.T && byte0 + 4 <= p.mask_pitch)
+                w = *reinterpret_cast<const unsigned*>(p.drop_mask + (((long long)b * p.H + h) * p.T + t) * p.mask_pitch + byte0);
+            m_lds[idx] = w;
+        }
+    }
     const float c = p.scale * LOG2E;
     const int off = p.S - p.T;
 
@@ -968,8 +1013,8 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
                 const float pw = __builtin_amdgcn_exp2f(x);
                 float pv = pw, dpv = dp[4 * g + j];
                 if constexpr (DROP) {
-                    const int tq = tl + j;
-                    const bool keep = tq < p.T && s < p.S && drop_bit(p, ((long long)b * p.H + h) * p.T + tq, s);
+                    const unsigned wd = m_lds[(tl + j) * 4 + wave];
+                    const bool keep = s < p.S && ((wd >> (lane & 31)) & 1u);  // (rows past T were staged as zeros)
                     pv = keep ? pw * p.drop_scale : 0.f;
                     dpv = keep ? dpv * p.drop_scale : 0.f;
                 }

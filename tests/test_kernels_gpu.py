@@ -351,7 +351,8 @@ def test_attention_head_dim_128(F, dtype, B, H, T, S, causal, ragged):
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,H,T,S,causal,ragged,hd', [(2, 2, 70, 90, False, True, 64), (2, 4, 128, 128, True, False, 64),
                                                         (3, 2, 100, 128, False, True, 64), (1, 2, 130, 257, False, True, 64),
-                                                        (2, 2, 64, 100, False, True, 128)])
+                                                        (2, 2, 64, 100, False, True, 128), (2, 4, 500, 500, False, True, 64),
+                                                        (1, 2, 200, 333, True, False, 64)])
 def test_attention_probability_dropout(F, dtype, B, H, T, S, causal, ragged, hd):
     """dropout_p of F.scaled_dot_product_attention (modules.py:707-720; attention_dropout 0.1 in the IWSLT2023 recipes):
     the forward kernel draws the keep bits and stores them; with THOSE bits the outputs and all three gradients must
