@@ -62,7 +62,7 @@ class FakeTask:
         self.decoder_num_embeddings = V
 
 
-def build_model(V, arch='transformer', **overrides):
+def build_model(V, arch='transformer', freeze_seed=None, **overrides):
     if arch == 'adapter_transformer':
         from pasero.models import adapters
         cfg_cls, model_cls = config.AdapterTransformerConfig, adapters.AdapterTransformer
@@ -74,7 +74,10 @@ def build_model(V, arch='transformer', **overrides):
         cfg.label_smoothing = 0.1
     cfg.model_type = cfg.model_type or 'encoder_decoder'
     cfg.decoder_max_len = cfg.decoder_max_len or 256
-    model = model_cls(cfg, config.DistributedConfig(), FakeTask(V))
+    task = FakeTask(V)
+    if freeze_seed is not None:  # pasero/tasks/translation.py:141-146 -> Embedding(freeze_mask=...), modules.py:900-947
+        task.freeze_encoder_embed_mask = torch.from_numpy(paramgen.make_freeze_mask(freeze_seed, V))
+    model = model_cls(cfg, config.DistributedConfig(), task)
     return cfg, model
 
 
@@ -136,9 +139,9 @@ def cfg_json(cfg):
 
 
 # ----------------------------------------------------------------------------------------------------------
-def gen_encdec(name, V, B, S, T, seed, store_grads='full', arch='transformer', prompt_cols=0, **overrides):
+def gen_encdec(name, V, B, S, T, seed, store_grads='full', arch='transformer', prompt_cols=0, freeze_seed=None, **overrides):
     """Whole Transformer.forward + backward (transformer.py:227-380), encoder (698-752), decoder (831-898)"""
-    cfg, model = build_model(V, arch=arch, **overrides)
+    cfg, model = build_model(V, arch=arch, freeze_seed=freeze_seed, **overrides)
     names_shapes = load_params(model, seed)
     model.train()  # dropout probabilities are 0 in every fixture config, so train() == eval() numerically
     batch = paramgen.make_text_batch(seed, B, S, T, V, prompt_cols=prompt_cols)
@@ -153,6 +156,8 @@ def gen_encdec(name, V, B, S, T, seed, store_grads='full', arch='transformer', p
     }
     if prompt_cols:
         out['prompt_cols'] = prompt_cols
+    if freeze_seed is not None:
+        out['freeze_seed'] = freeze_seed
     for k in ('prompt_nll_loss', 'num_prompt_tokens'):  # the two-part loss of cfg.prompt_loss != 1 (transformer.py:283-321)
         if k in logs:
             out['logs_' + k] = logs[k]
@@ -199,6 +204,14 @@ def gen_tiny_pre():
                encoder_positional_encoding='learned', decoder_positional_encoding='learned',
                positional_encoding_shift=0, scale_embed=False, encoder_embed_norm=True,
                decoder_embed_norm=True, label_smoothing=0.2, encoder_max_len=32, decoder_max_len=32)
+
+
+def gen_tiny_freeze():
+    """partially frozen source embeddings (`freeze_encoder_embed_regex`: Embedding(freeze_mask=...), modules.py:900-947): rows
+    of the mask come from a second table `frozen_embedding`, the others from `weight`; separate source / target embeddings"""
+    gen_encdec('tiny_freeze_embed', V=89, B=3, S=8, T=6, seed=17, freeze_seed=5,
+               embed_dim=128, encoder_ffn_dim=192, decoder_ffn_dim=192, encoder_attention_heads=2,
+               decoder_attention_heads=2, encoder_layers=1, decoder_layers=1, dropout=0.0, shared_embeddings=False)
 
 
 def gen_tiny_adapter():
@@ -703,6 +716,7 @@ GENERATORS = {
     'tiny_encdec_pre': gen_tiny_pre,
     'base_c1': gen_base_c1,
     'tiny_adapter': gen_tiny_adapter,
+    'tiny_freeze_embed': gen_tiny_freeze,
     'tiny_lora': gen_tiny_lora,
     'tiny_lora_rotary': gen_tiny_lora_rotary,
     'tiny_hd128': gen_tiny_hd128,

@@ -349,7 +349,11 @@ def encoder(P: dict, cfg, encoder_input: Tensor, encoder_input_length: Tensor):
     """models/transformer.py:698-752 -> (x (B,S,D), padding_mask (B,S))"""
     length = encoder_input_length
     if encoder_input.dim() == 2:
-        x = P['encoder.embed_tokens.weight'][encoder_input.clamp(min=0)]  # modules.py:916-933
+        ids = encoder_input.clamp(min=0)
+        x = P['encoder.embed_tokens.weight'][ids]  # modules.py:916-933
+        if 'encoder.embed_tokens.frozen_embedding.weight' in P:  # modules.py:929-933: masked tokens read the frozen table
+            mask = P['encoder.embed_tokens.freeze_mask'][ids][..., None]  # (not a parameter: the task's (V,) bool mask)
+            x = (~mask) * x + mask * P['encoder.embed_tokens.frozen_embedding.weight'][ids]
     else:  # speech features, transformer.py:731-737
         x = encoder_input
         if cfg.conv_kernel_sizes:

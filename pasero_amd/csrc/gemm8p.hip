@@ -62,9 +62,13 @@ constexpr int CP = BN + 4;  // floats, epilogue staging pitch
 #endif
 
 // one 64-row pass of the epilogue: thread t owns 16-byte chunk t % 32 of rows t / 32 + 16*it   (as in gemm256.hip)
+// (`av`: the pass's four aux chunks of this thread, loaded by the caller one pass AHEAD — loaded inside the pass, each of a
+// tile's four passes waited out a memory round trip of its own: the mode 1 / 2 GEMMs ran 4-5 us per tile and round behind
+// the same GEMM without aux)
 template <typename T, int ACT, int MODE>
 __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, T* __restrict__ C, const EpiParams& ep,
-                                              long long mh, long long n0, long long M, long long N, int tid) {
+                                              long long mh, long long n0, long long M, long long N, int tid,
+                                              const Vec16<T> (&av)[4]) {
     const int col = (tid & 31) * 8, r0 = tid >> 5;
     const long long gn = n0 + col;
     if (gn + 8 > (ep.nstore ? ep.nstore : N)) return;  // (nstore: the rows of C are padded, the last chunk is stored whole)
@@ -78,14 +82,6 @@ __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, T* _
         for (int e = 0; e < 8; ++e) b[e] = 0.f;
     }
     const float alpha = ep.alpha;
-    Vec16<T> av[4];
-    if (MODE != 0) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const long long gm = mh + r0 + 16 * it;
-            if (gm < M) av[it] = load16<T>(reinterpret_cast<const T*>(ep.aux) + gm * ep.ldaux + gn);
-        }
-    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const long long gm = mh + r0 + 16 * it;
@@ -475,6 +471,21 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
 
     // ---- epilogue: four 64-row passes of the accumulators through the fp32 staging buffer (all stages are free) ----
     float* cs = reinterpret_cast<float*>(smem);
+    // the aux operand of the lean mode 1 / 2 epilogues, one pass ahead of its use (aux may alias C: a chunk is read by the
+    // thread that stores it, and before that store)
+    const bool pre_aux = !ws && !ANY && ep.mode != 0;
+    Vec16<T> av_next[4];
+    auto aux_load = [&](int p) {
+        const int col = (tid & 31) * 8, r0 = tid >> 5;
+        const long long gn = n0 + col;
+        if (gn + 8 > N) return;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const long long gm = m0 + p * 64 + r0 + 16 * it;
+            if (gm < M) av_next[it] = load16<T>(reinterpret_cast<const T*>(ep.aux) + gm * ep.ldaux + gn);
+        }
+    };
+    if (pre_aux) aux_load(0);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         if (wr == (p & 1)) {  // tile rows [64p, 64p + 64) = row half p >> 1 of the waves with wr == p & 1
@@ -491,6 +502,12 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
         }
         __syncthreads();
         const long long mh = m0 + p * 64;
+        Vec16<T> av[4];
+        if (pre_aux) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) av[it] = av_next[it];
+            if (p < 3) aux_load(p + 1);
+        }
         if (ws) {  // split-K partial: raw fp32 slab [splitk][M][N]
             float* slab = ws + (long long)kslab * M * N;
             const int col = (tid & 31) * 8, r0 = tid >> 5;
@@ -509,14 +526,14 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
         } else if constexpr (ANY) {
             epilogue_pass_any<T>(cs, C, ep, mh, n0, M, N, tid);
         } else if (ep.mode == 0) {
-            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 0>(cs, C, ep, mh, n0, M, N, tid);
-            else epilogue_pass<T, PK_ACT_NONE, 0>(cs, C, ep, mh, n0, M, N, tid);
+            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 0>(cs, C, ep, mh, n0, M, N, tid, av);
+            else epilogue_pass<T, PK_ACT_NONE, 0>(cs, C, ep, mh, n0, M, N, tid, av);
         } else if (ep.mode == 1) {
-            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 1>(cs, C, ep, mh, n0, M, N, tid);
-            else epilogue_pass<T, PK_ACT_NONE, 1>(cs, C, ep, mh, n0, M, N, tid);
+            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 1>(cs, C, ep, mh, n0, M, N, tid, av);
+            else epilogue_pass<T, PK_ACT_NONE, 1>(cs, C, ep, mh, n0, M, N, tid, av);
         } else {
-            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 2>(cs, C, ep, mh, n0, M, N, tid);
-            else epilogue_pass<T, PK_ACT_NONE, 2>(cs, C, ep, mh, n0, M, N, tid);
+            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 2>(cs, C, ep, mh, n0, M, N, tid, av);
+            else epilogue_pass<T, PK_ACT_NONE, 2>(cs, C, ep, mh, n0, M, N, tid, av);
         }
         if (p < 3) __syncthreads();
     }

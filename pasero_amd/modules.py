@@ -417,28 +417,49 @@ class RotaryEmbedding(nn.Module):
 # embeddings
 # ------------------------------------------------------------------------------------------------------------
 class Embedding(nn.Embedding):
-    """Token embedding + tied output projection (modules.py:890-947).  Partially frozen embeddings are out of scope."""
+    """Token embedding + tied output projection (modules.py:890-947).
+
+    Partially frozen embeddings (`freeze_mask` (V,) bool, from `--freeze-encoder-embed-regex`, tasks/translation.py:141-146;
+    modules.py:909-913, 929-933, 942-946): rows of the mask come from a second table `frozen_embedding.weight`, the others from
+    `weight`.  The reference gathers from both tables and blends per token (and, for the projection, multiplies by both and
+    blends per column); here the two tables are merged ONCE per call into the effective table E = where(mask, frozen, weight)
+    — a (V, d) select, bytes of one table — and every kernel of the path (fused embed, tied projection, fused vocabulary loss)
+    runs on it unchanged; autograd routes dE back to the rows of either table.  As in the reference, `frozen_embedding.weight`
+    is an ordinary parameter (`self.frozen_embedding.requires_grad = False` at modules.py:911 sets an attribute of the MODULE
+    and freezes nothing: the table is frozen by the trainer's freeze regex, cli/train.py:235-238, or not at all)."""
 
     def __init__(self, num_embeddings: int, embedding_dim: int, padding_idx: int,
                  freeze_mask: Optional[BoolTensor] = None):
-        if freeze_mask is not None:
-            raise NotImplementedError('pasero_amd: partially frozen embeddings are not implemented')
         super().__init__(num_embeddings, embedding_dim, padding_idx)
         if not _fast_init:
             nn.init.normal_(self.weight, mean=0, std=embedding_dim ** -0.5)
             nn.init.constant_(self.weight[padding_idx], 0)
-        self.frozen_embedding = None
+        if freeze_mask is not None:
+            assert freeze_mask.dtype == torch.bool and freeze_mask.numel() == num_embeddings
+            self.freeze_mask = freeze_mask
+            self.frozen_embedding = nn.Embedding(num_embeddings, embedding_dim, padding_idx=padding_idx)
+            self.frozen_embedding.requires_grad = False  # (sic: modules.py:911)
+        else:
+            self.frozen_embedding = None
+
+    def effective_weight(self) -> Tensor:
+        """the table the kernels read: `weight`, or where(freeze_mask, frozen_embedding.weight, weight)"""
+        if self.frozen_embedding is None:
+            return self.weight
+        if self.freeze_mask.device != self.weight.device:
+            self.freeze_mask = self.freeze_mask.to(self.weight.device)
+        return torch.where(self.freeze_mask[:, None], self.frozen_embedding.weight.to(self.weight.dtype), self.weight)
 
     def forward(self, input: LongTensor) -> Tensor:
         # the reference asserts `input.max() < V` here (a host sync per call, modules.py:924-926); the kernel clamps
-        return EmbeddingFn.apply(input, self.weight, None, 1.0, 0, 0.0, self.padding_idx)
+        return EmbeddingFn.apply(input, self.effective_weight(), None, 1.0, 0, 0.0, self.padding_idx)
 
     def embed(self, input: LongTensor, pos_table: Optional[Tensor], scale: float, pos_start: int, p: float) -> Tensor:
         """fused  dropout(E[ids] * scale + positions)  (transformer.py:727-744, 866-878)"""
-        return EmbeddingFn.apply(input, self.weight, pos_table, scale, pos_start, p, self.padding_idx)
+        return EmbeddingFn.apply(input, self.effective_weight(), pos_table, scale, pos_start, p, self.padding_idx)
 
     def projection(self, input: Tensor) -> Tensor:
-        return LinearFn.apply(input, self.weight, None, 'none')
+        return LinearFn.apply(input, self.effective_weight(), None, 'none')
 
 
 # ------------------------------------------------------------------------------------------------------------

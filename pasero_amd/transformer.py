@@ -310,7 +310,7 @@ class Transformer(EncoderDecoder):
         """tied projection + label-smoothed CE without materialising the logits (:324-380 + modules.py:935-947); in the
         `--benchmark` log the reference's 'output_projection' and 'loss' entries are both inside this one 'loss'"""
         dec = self.decoder
-        weight = dec.embed_tokens.weight if dec.output_projection is None else dec.output_projection.weight
+        weight = dec.embed_tokens.effective_weight() if dec.output_projection is None else dec.output_projection.weight
         sums = VocabCrossEntropyFn.apply(features, weight, target, self.padding_idx, self.cfg.label_smoothing or 0.0)
         return sums[0], self._logs(sums.detach(), target.size(0))
 

@@ -98,3 +98,9 @@ def make_reverse_batch(seed: int, B: int, L: int, lo: int = 4, hi: int = 36, pad
 
 def make_array(seed: int, name: str, shape: tuple, scale: float = 1.0) -> np.ndarray:
     return (_rs(seed, name).standard_normal(tuple(shape)) * scale).astype(np.float32)
+
+
+def make_freeze_mask(seed: int, V: int, frac: float = 0.4) -> np.ndarray:
+    """(V,) bool: which source embeddings are frozen (pasero/tasks/translation.py:141-146 builds it from a regex over the
+    dictionary; here a seeded random subset)"""
+    return _rs(seed, 'freeze_encoder_embed_mask').rand(V) < frac

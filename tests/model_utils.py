@@ -21,7 +21,10 @@ def build_model(g, dtype=torch.float32, device='cpu'):
     from pasero_amd import transformer, adapters  # noqa: F401  (registers the architectures)
     cfg = build_cfg(g)
     V = int(g['V'])
-    model = get_architecture(cfg)(cfg, DistributedConfig(), SyntheticTask(V))
+    task = SyntheticTask(V)
+    if 'freeze_seed' in getattr(g, 'files', g):  # partially frozen source embeddings (tasks/translation.py:141-146)
+        task.freeze_encoder_embed_mask = torch.from_numpy(paramgen.make_freeze_mask(int(g['freeze_seed']), V))
+    model = get_architecture(cfg)(cfg, DistributedConfig(), task)
     load_paramgen(model, int(g['seed']))
     return cfg, model.to(dtype).to(device)
 
@@ -41,6 +44,8 @@ def oracle_state(g, cfg):
     P = O.to_torch_state(paramgen.make_state_dict(int(g['seed']), golden_names_shapes(g)))
     if cfg.shared_embeddings and 'encoder.embed_tokens.weight' in P:
         P['decoder.embed_tokens.weight'] = P['encoder.embed_tokens.weight']
+    if 'freeze_seed' in getattr(g, 'files', g):
+        P['encoder.embed_tokens.freeze_mask'] = torch.from_numpy(paramgen.make_freeze_mask(int(g['freeze_seed']), int(g['V'])))
     return P
 
 

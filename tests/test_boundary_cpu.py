@@ -30,7 +30,7 @@ def test_library_exports_every_header_symbol():
 
 
 @pytest.mark.parametrize('name', ['tiny_encdec_post', 'tiny_encdec_pre', 'tiny_encdec_rotary', 'tiny_encdec_swiglu', 'speech_whisper',
-                                  'speech_iwslt', 'base_c1', 'tiny_adapter', 'tiny_lora', 'tiny_hd128', 'tiny_encdec_rms', 'tiny_opts_a', 'tiny_opts_b', 'tiny_hd128_rotary', 'tiny_lora_rotary'])
+                                  'speech_iwslt', 'base_c1', 'tiny_adapter', 'tiny_lora', 'tiny_hd128', 'tiny_encdec_rms', 'tiny_opts_a', 'tiny_opts_b', 'tiny_hd128_rotary', 'tiny_lora_rotary', 'tiny_freeze_embed'])
 def test_parameter_names_and_shapes_match_reference(name):
     g = load_golden(name)
     _, model = build_model(g)

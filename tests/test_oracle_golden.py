@@ -31,6 +31,8 @@ def _run_encdec(name, full=True):
     P = {k: v.requires_grad_() for k, v in _state(g, seed).items()}
     if cfg.shared_embeddings:  # one tensor under two names (transformer.py:151-153)
         P['decoder.embed_tokens.weight'] = P['encoder.embed_tokens.weight']
+    if 'freeze_seed' in g.files:  # the task's (V,) bool mask of frozen source embeddings: an input, not a parameter
+        P['encoder.embed_tokens.freeze_mask'] = torch.from_numpy(paramgen.make_freeze_mask(int(g['freeze_seed']), int(g['V'])))
     prompt_cols = int(g['prompt_cols']) if 'prompt_cols' in g.files else 0
     batch = paramgen.make_text_batch(seed, int(g['B']), int(g['S']), int(g['T']), int(g['V']), prompt_cols=prompt_cols)
     tb = {k: torch.from_numpy(v) for k, v in batch.items()}
@@ -90,6 +92,11 @@ def test_tiny_encdec_swiglu_prenorm():
 
 def test_tiny_encdec_rmsnorm_rotary_swiglu_no_bias():
     _run_encdec('tiny_encdec_rms')
+
+
+def test_tiny_partially_frozen_source_embeddings():
+    """Embedding(freeze_mask=...) (modules.py:900-947): rows of the mask read `frozen_embedding.weight`"""
+    _run_encdec('tiny_freeze_embed')
 
 
 def test_tiny_heads_of_128_rotary():
