@@ -177,8 +177,9 @@ class GemmTimer:
             return 'gemm8p_group_kernel<%s>' % t
         if kernel == (8 | 0x80):  # Linear + residual + dropout + LayerNorm (pk_gemm_ln_fwd)
             return 'gemm8p_ln_kernel<%s>' % t
-        if kernel & 0xF == 8 and kernel < 256:  # gemm8p instantiation: <T, A_COL, B_COL, ANY epilogue, TAIL K-tile>
-            return 'gemm8p_kernel<%s, %s, %s, %s, %s>' % (t, tf[a_col], tf[b_col], tf[(kernel >> 4) & 1], tf[(kernel >> 5) & 1])
+        if kernel & 0xF == 8 and (kernel & ~0x400) < 256:  # gemm8p instantiation: <T, A_COL, B_COL, ANY epilogue, TAIL K-tile, half-M tile>
+            return 'gemm8p_kernel<%s, %s, %s, %s, %s, %s>' % (t, tf[a_col], tf[b_col], tf[(kernel >> 4) & 1], tf[(kernel >> 5) & 1],
+                                                              tf[(kernel >> 10) & 1])
         if kernel & 0x200:  # the B-stationary kernel (gemmbs.hip): <T, B_COL, K-tiles, activation, act'-mask, mask as bits, preact>
             return 'gemmbs_kernel<%s, %s, %d, %d, %s, %s, %s>' % (t, tf[b_col], kernel & 0xF, (kernel >> 4) & 3, tf[(kernel >> 6) & 1],
                                                                 tf[(kernel >> 7) & 1], tf[(kernel >> 8) & 1])

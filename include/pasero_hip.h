@@ -71,7 +71,7 @@ int pk_gemm_ex(const void* A, const void* B, void* C, const void* bias, const vo
  * call records a HIP event pair around exactly its main GEMM kernel (not the split-K reduce), on the launching stream.
  * pk_gemm_timing_stop() ends sampling and returns the number of samples; pk_gemm_timing_read(i, ...) synchronises on
  * sample i and returns the kernel that ran (128 = gemm_kernel 128x128 tiles, 256 = gemm256_kernel, 8 | flags = a
- * gemm8p instantiation: 0x10 general epilogue, 0x20 partial last K-tile, 0x40 the grouped weight-gradient launch of
+ * gemm8p instantiation: 0x10 general epilogue, 0x20 partial last K-tile, 0x400 the 128 x 256 tile, 0x40 the grouped weight-gradient launch of
  * pk_gemm_wgrad_group [flops = the sum over the group, splitk = the number of problems], 0x80 pk_gemm_ln_fwd), its
  * operand layouts, split-K factor, dtype, 2*M*N*K and the elapsed milliseconds. */
 int pk_gemm_timing_start(int max_samples, int stride);

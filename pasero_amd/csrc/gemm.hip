@@ -832,18 +832,25 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
                 if ((size_t)sk * M * (N + (asum_out ? 1 : 0)) * sizeof(float) > ws_bytes) sk = 0;  // does not fit
             }
             const bool fills = t256 * std::max(sk, 1) >= 160;
-            if (sk > 0 && (tile_pref == 256 || fills || (g_use_8p == 2 && e8))) {
+            // an output of 80..159 256-tiles (8192 x 1024: NLLB-1.3B's out-proj / cross-q / fc2 and their dX at C5) fills half
+            // the chip with 256-tiles and runs as one or two low-rate rounds of 128-tiles (560-950 TFLOP/s): gemm8p's half-M
+            // form (128 x 256 tiles) gives every CU one.  Lean epilogues, row-form A, no split-K.  PK_GEMM_HALFM=0: off (A/B).
+            static const bool halfm_on = [] { const char* e = getenv("PK_GEMM_HALFM"); return !e || atoi(e) != 0; }();
+            const long long t_half = ((M + 127) / 128) * ((N + 255) / 256);
+            const bool half_m = halfm_on && e8 && !fills && sk == 1 && !a_col && !asum_out && lean_epi && t_half >= 160 && tile_pref != 256 && g_use_8p != 2;
+            if (sk > 0 && (tile_pref == 256 || fills || half_m || (g_use_8p == 2 && e8))) {
                 float* w2 = sk > 1 ? (float*)workspace : nullptr;
                 float* asw = (sk > 1 && asum_out) ? w2 + (size_t)sk * M * N : nullptr;
                 // the phase-interleaved kernel (gemm8p.hip) takes what it can; gemm256.hip the rest (fused bias gradient,
                 // operands beyond 4 GiB).  PK_GEMM_8P=0 switches it off (A/B inside one process: tools/gemm_bench.py)
                 // (sample tag of the gemm8p instantiation: 8 | 0x10 general epilogue | 0x20 partial last K-tile)
                 const bool any_epi = ep.preact || ep.mode == 3 || (ep.act != PK_ACT_NONE && ep.act != PK_ACT_RELU);
-                const int tag8 = 8 | (any_epi ? 0x10 : 0) | (K8 % 64 ? 0x20 : 0);
+                const int tag8 = 8 | (any_epi ? 0x10 : 0) | (K8 % 64 ? 0x20 : 0) | (half_m ? 0x400 : 0);
                 GemmSample* sm = timing_begin(e8 ? tag8 : 256, a_col, b_col, std::max(sk, 1), dtype16, M, N, K, stream);
                 EpiParams ep8 = ep;
                 if (e8 && pad_n) ep8.nstore = (N + 7) & ~7LL;
                 if (e8 && pad_k) ep8.kb_rows = K;
+                ep8.half_m = half_m ? 1 : 0;
                 int rc = (e8 ? pk_gemm8p_launch : pk_gemm256_launch)(A, B, C, w2, asw, asum_out, M, N, e8 ? K8 : K, lda, ldb,
                                                                     a_col, b_col, (int)per, std::max(sk, 1), ep8, dtype16, stream);
                 timing_end(sm, stream);

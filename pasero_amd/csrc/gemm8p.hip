@@ -172,7 +172,12 @@ __device__ __noinline__ void epilogue_pass_any(const float* __restrict__ cs, T* 
 // per-lane masking in its DMA issue (VALU work in a load section is taken out of the partner wave's MFMA issue slots)
 // `lin`: this workgroup's position in the slab-major (K-slab, tile) walk of ONE problem (the kernels below derive it from
 // blockIdx through the XCD-contiguous remap; the grouped kernel subtracts the first workgroup of the problem)
-template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL>
+// HM ("half M"): a 128 x 256 tile for outputs whose 256 x 256 tiles would fill half the chip (8192 x 1024: NLLB-1.3B's
+// out-proj / cross-q / fc2 at C5).  The SAME eight-phase schedule with the second row half switched off: its DMA pieces are
+// issued against an empty descriptor (so every counted wait still counts the same instructions), its fragment reads, its
+// two quadrant MFMA sections and its two epilogue passes are compiled out.  Not the schedule one would design for this tile
+// (two of four phases only synchronise), but every hazard distance of the full schedule holds a fortiori.
+template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL, bool HM = false>
 __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
                                             float* __restrict__ ws, float* __restrict__ asum_ws,
                                             T* __restrict__ asum_out, long long M, long long N, long long K,
@@ -186,7 +191,9 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    const int nt_m = (int)((M + BM - 1) / BM), nt_n = (int)((N + BN - 1) / BN);
+    static_assert(!HM || !A_COL, "the half-M tile serves the row-form GEMMs (forward, dX)");
+    constexpr int TM = HM ? BM / 2 : BM;  // rows of the tile
+    const int nt_m = (int)((M + TM - 1) / TM), nt_n = (int)((N + BN - 1) / BN);
     // diagnostic build (-DPK8P_STAMPS, tools/gemm_phase_stamps.py): s_memrealtime at the seams of the tile, into a buffer
     // of their own (never into an output); the shipped build has no stamp
 #ifdef PK8P_STAMPS
@@ -203,7 +210,7 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     int group_size = GROUP_M * nt_n, gid = t / group_size, first_m = gid * GROUP_M;
     int gsz = min(nt_m - first_m, GROUP_M);
     int tile_m = first_m + (t % group_size) % gsz, tile_n = (t % group_size) / gsz;
-    const long long m0 = (long long)tile_m * BM, n0 = (long long)tile_n * BN;
+    const long long m0 = (long long)tile_m * TM, n0 = (long long)tile_n * BN;
     const long long kbeg = (long long)kslab * kchunk;
     const long long kend = min(K, kbeg + (long long)kchunk);
     // K-tiles of this slab; the last one may be partial (K % 8 == 0): col-form rows k >= K lie past the end of their
@@ -246,7 +253,8 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
 #endif
         const bool tail = TAIL && kt == nk - 1 && kvalid < BK;
         if (slot < 2) {
-            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, live ? (int)a_bytes : 0, 0x00020000);
+            const bool live_a = live && !(HM && slot == SLOT_A1);  // (half-M: the second row half is never fetched)
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, live_a ? (int)a_bytes : 0, 0x00020000);
             const unsigned so = kbase_a + (unsigned)kt * kstep_a;
             unsigned v0 = offa[slot][0], v1 = offa[slot][1];
             if (TAIL && !A_COL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
@@ -399,7 +407,7 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
         using SN = std::integral_constant<int, S ^ 1>;
         if constexpr (P == 0) load_a(s_c, I0{});                  // A0 of this K-tile
         if constexpr (P == 1) load_b(s_c, I3{}, fb1);             // B1
-        if constexpr (P == 2) load_a(s_c, I1{});                  // A1
+        if constexpr (P == 2 && !HM) load_a(s_c, I1{});           // A1
         if constexpr (P == 3) load_b(SN{}, I2{}, fb0[S ^ 1]);     // B0 of the NEXT K-tile (other stage)
         PK_WAIT(6);  // all but the three youngest half-tiles have landed (what the NEXT phase reads is among them)
         dma(dma_kt, dma_slot);
@@ -409,8 +417,8 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (P == 0) mma(0, 0, fb0[S]);
         if constexpr (P == 1) mma(0, 1, fb1);
-        if constexpr (P == 2) mma(1, 1, fb1);
-        if constexpr (P == 3) mma(1, 0, fb0[S]);
+        if constexpr (P == 2 && !HM) mma(1, 1, fb1);
+        if constexpr (P == 3 && !HM) mma(1, 0, fb0[S]);
         if constexpr (A_COL) {
             if (do_asum) {
                 constexpr int MH = P >> 1, KK = P & 1;
@@ -486,8 +494,9 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
         }
     };
     if (pre_aux) aux_load(0);
+    constexpr int NPASS = HM ? 2 : 4;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NPASS; ++p) {
         if (wr == (p & 1)) {  // tile rows [64p, 64p + 64) = row half p >> 1 of the waves with wr == p & 1
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -506,7 +515,7 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
         if (pre_aux) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) av[it] = av_next[it];
-            if (p < 3) aux_load(p + 1);
+            if (p + 1 < NPASS) aux_load(p + 1);
         }
         if (ws) {  // split-K partial: raw fp32 slab [splitk][M][N]
             float* slab = ws + (long long)kslab * M * N;
@@ -535,7 +544,7 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
             if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 2>(cs, C, ep, mh, n0, M, N, tid, av);
             else epilogue_pass<T, PK_ACT_NONE, 2>(cs, C, ep, mh, n0, M, N, tid, av);
         }
-        if (p < 3) __syncthreads();
+        if (p + 1 < NPASS) __syncthreads();
     }
 #ifdef PK8P_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -544,7 +553,7 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
 #undef PK_STAMP
 }
 
-template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL>
+template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL, bool HM = false>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A, const T* __restrict__ B,
                                                        T* __restrict__ C, float* __restrict__ ws,
                                                        float* __restrict__ asum_ws, T* __restrict__ asum_out,
@@ -552,8 +561,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
                                                        long long ldb, int kchunk, unsigned a_bytes, unsigned b_bytes,
                                                        int total, unsigned long long* stamps, EpiParams ep) {
     // slab-major (K-slab, tile) walk over the XCD-contiguous remap: an XCD owns whole K-slabs
-    gemm8p_tile<T, A_COL, B_COL, ANY, TAIL>(A, B, C, ws, asum_ws, asum_out, M, N, K, lda, ldb, kchunk, a_bytes, b_bytes,
-                                            xcd_remap(blockIdx.x, gridDim.x), stamps, ep);
+    gemm8p_tile<T, A_COL, B_COL, ANY, TAIL, HM>(A, B, C, ws, asum_ws, asum_out, M, N, K, lda, ldb, kchunk, a_bytes, b_bytes,
+                                                xcd_remap(blockIdx.x, gridDim.x), stamps, ep);
 }
 
 // ---- grouped weight gradients: up to PK_WGRAD_MAX (col,col) problems C_p = A_p^T B_p in ONE launch ----
@@ -695,7 +704,9 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
         long long unused;
         operand_bytes(M, N, ep.kb_rows, lda, ldb, a_col, b_col, &unused, &b_bytes);
     }
-    const int total = (int)(((M + BM - 1) / BM) * ((N + BN - 1) / BN) * splitk);
+    const bool hm = ep.half_m && !a_col && !(ep.preact || ep.mode == 3 || (ep.act != PK_ACT_NONE && ep.act != PK_ACT_RELU));
+    const int tm = hm ? BM / 2 : BM;
+    const int total = (int)(((M + tm - 1) / tm) * ((N + BN - 1) / BN) * splitk);
     unsigned long long* stamps = nullptr;  // PK8P_STAMP_PTR: device buffer of the diagnostic build's time stamps
 #if defined(PK8P_STAMPS) || defined(PKBS_STAMPS)  /* (diagnostic builds only: the shipped library never reads the variable) */
     static unsigned long long* const stamp_buf = [] { const char* e = getenv("PK8P_STAMP_PTR"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
@@ -721,9 +732,25 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
         if (dtype == PK_F16) PK_D(f16, AC, BC);        \
         else PK_D(bf16, AC, BC);                       \
     } while (0)
-    if (!a_col && !b_col) PK_L(false, false);
+    // the half-M tile: lean epilogues, row-form A (what pk_gemm sends it: see launch_gemm in gemm.hip)
+#define PK_H(TT, BC)                                                                                                     \
+    do {                                                                                                                 \
+        if (tail)                                                                                                        \
+            hipLaunchKernelGGL((gemm8p_kernel<TT, false, BC, false, true, true>), grid, block, 0, s, (const TT*)A, (const TT*)B, \
+                               (TT*)C, ws, asum_ws, (TT*)asum_out, M, N, K, lda, ldb, kchunk, (unsigned)a_bytes,         \
+                               (unsigned)b_bytes, total, stamps, ep);                                                    \
+        else                                                                                                             \
+            hipLaunchKernelGGL((gemm8p_kernel<TT, false, BC, false, false, true>), grid, block, 0, s, (const TT*)A, (const TT*)B, \
+                               (TT*)C, ws, asum_ws, (TT*)asum_out, M, N, K, lda, ldb, kchunk, (unsigned)a_bytes,         \
+                               (unsigned)b_bytes, total, stamps, ep);                                                    \
+    } while (0)
+    if (hm) {
+        if (dtype == PK_F16) { if (b_col) PK_H(f16, true); else PK_H(f16, false); }
+        else { if (b_col) PK_H(bf16, true); else PK_H(bf16, false); }
+    } else if (!a_col && !b_col) PK_L(false, false);
     else if (!a_col && b_col) PK_L(false, true);
     else PK_L(true, true);
+#undef PK_H
 #undef PK_L
 #undef PK_D
 #undef PK_K

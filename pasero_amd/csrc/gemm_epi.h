@@ -10,6 +10,7 @@ struct EpiParams {
     float alpha;
     // a vocabulary that is no multiple of 8 in buffers whose rows are padded to one (pk_gemm_ex, include/pasero_hip.h):
     long long nstore = 0;   // PK_GEMM_PAD_N: columns up to `nstore` = N rounded up to 8 may be STORED (0: N) — gemm8p's lean epilogue
+    int half_m = 0;         // gemm8p.hip: 128 x 256 tiles (an output of 256 x 256 tiles would fill half the chip)
     long long kb_rows = 0;  // PK_GEMM_PAD_K: the rows a col-form B really has (the K passed on is rounded up to 8; 0: K)
 };
 

@@ -247,3 +247,41 @@ def test_vocabulary_that_is_no_multiple_of_8_runs_on_the_256_tile_kernel(rows, V
     rl, rn = torch.empty(rows, device='cuda'), torch.empty(rows, device='cuda')
     F.ce_rows(lg, tgt, 1, 0.1, rl, rn, dlogits=lg)
     assert (buf[:, V: (V + 7) // 8 * 8] == 0).all() and torch.isfinite(buf[:, :V]).all()
+
+
+@pytest.mark.parametrize('M,N,K,b_col,mode,act,bias', [
+    (8192, 1024, 1024, False, 0, 'none', True), (8192, 1024, 8192, False, 0, 'relu', True),
+    (8192, 1024, 1024, True, 1, 'none', False), (8192, 1024, 3072, True, 0, 'none', False),
+    (8000, 1024, 1088, True, 2, 'relu', False), (4000, 2048, 1024, False, 1, 'none', True),
+    (8192, 1024, 1000, True, 0, 'none', False)])
+def test_half_m_tiles_for_outputs_that_fill_half_the_chip(M, N, K, b_col, mode, act, bias):
+    """Outputs of 80..159 256-tiles (NLLB-1.3B's 8192 x 1024 projections at C5) run on gemm8p's 128 x 256 tile form (launch
+    sampling: tag bit 0x400): forward with bias / ReLU, dX with the residual-branch gradient as aux, the ReLU-masked dH form,
+    ragged M (a partial last tile), K with a partial last K-tile — against fp64."""
+    import ctypes
+    from pasero_amd import functional as F, lib
+    torch.manual_seed(M + N + K)
+    a = (torch.randn(M, K, device='cuda') * 0.5).bfloat16()
+    b = (torch.randn(K, N, device='cuda') * 0.05).bfloat16() if b_col else (torch.randn(N, K, device='cuda') * 0.05).bfloat16()
+    bv = torch.randn(N, device='cuda').bfloat16() if bias else None
+    aux = torch.randn(M, N, device='cuda').bfloat16() if mode else None
+    L = lib.load()
+    lib.check(L.pk_gemm_timing_start(4, 1), 'start')
+    out = F.gemm(a, b, b_col=b_col, bias=bv, aux=aux, act=act, mode=mode)
+    n = L.pk_gemm_timing_stop()
+    ints = [ctypes.c_int() for _ in range(5)]
+    fl, ms = ctypes.c_double(), ctypes.c_float()
+    lib.check(L.pk_gemm_timing_read(0, *[ctypes.byref(t) for t in ints], ctypes.byref(fl), ctypes.byref(ms)), 'read')
+    assert n == 1 and (ints[0].value & 0x40F) == 0x408, hex(ints[0].value)      # gemm8p, half-M tile
+    ref = a.double() @ (b.double() if b_col else b.double().t())
+    if mode == 2:
+        ref = ref * (aux.double() > 0)
+    else:
+        if bv is not None:
+            ref = ref + bv.double()
+        if act == 'relu':
+            ref = ref.clamp_min(0)
+        if mode == 1:
+            ref = ref + aux.double()
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 1e-2 * ref.abs().max().item(), err
