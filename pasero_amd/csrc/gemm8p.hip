@@ -565,6 +565,261 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
                                                 xcd_remap(blockIdx.x, gridDim.x), stamps, ep);
 }
 
+// ---- 128 x 256 tiles with a schedule of their own (round 4) ----
+// Outputs of 80..159 256-tiles (8192 x 1024: NLLB-1.3B's out-proj / cross-q / fc2 and their dX at C5) fill half the chip as
+// 256 x 256 tiles.  The half-M switch of gemm8p_tile (HM) gives every CU a 128 x 256 tile but keeps four phases per K-tile, two
+// of which only synchronise (1.0 us per K-tile).  This is the schedule made for that tile: row-form A only (forward, dX).
+//   * 8 waves = 2 (M) x 4 (N) as above; wave (wr, wc) owns rows 64 wr + [0, 64) and columns 128 h + 32 wc + [0, 32), h = 0, 1:
+//     TWO 64 x 32 quadrants, 64 fp32 accumulators per lane;
+//   * a K-tile is THREE half-tile images — A0 (128 rows), B0, B1 — in a ring of THREE stages (144 KiB) and TWO phases of 16
+//     MFMAs per wave; waves 4..7 run one barrier behind waves 0..3 as above;
+//   * per-image rings, every DMA three phases (1.5 K-tiles) ahead of the wait that retires it, every wait `vmcnt(6)`:
+//       phase   fragment reads                    MFMA quadrant   DMA issued (after the wait)          last read of the slot
+//       A(t)    A0(t)                      [8]    (0, 0)          A0(t+2)                             A(t-1)
+//       B(t)    B1(t), B0(t+1)             [8]    (0, 1)          B1(t+2), B0(t+3)                    B(t-1), B(t-1)
+//     RAW: the wait at the end of a phase's load section leaves the three youngest half-tiles in flight; what the NEXT
+//     phase reads is older (A(t): in flight A0(t+1) B1(t+1) B0(t+2), B(t) reads B1(t) B0(t+1); B(t): in flight B1(t+1)
+//     B0(t+2) A0(t+2), A(t+1) reads A0(t+1)).  WAR: every slot is overwritten two phases after its last read.
+//   * tails as above: past the last K-tile the same DMA instructions go against an empty descriptor.
+namespace hm2 {
+constexpr int HSTAGE = 3 * HALF, HSMEM = 3 * HSTAGE;
+constexpr int S_A = 0, S_B0 = 1, S_B1 = 2;
+}  // namespace hm2
+
+template <typename T, bool B_COL, bool TAIL>
+__device__ __forceinline__ void gemm8p_hm2_tile(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
+                                                long long M, long long N, long long K, long long lda, long long ldb,
+                                                unsigned a_bytes, unsigned b_bytes, int lin, const EpiParams& ep) {
+    using namespace hm2;
+    typedef typename M16<T>::vec V;
+    typedef __attribute__((address_space(3))) void lds_void;
+    __shared__ __attribute__((aligned(16))) char smem[HSMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    constexpr int TM = BM / 2;
+    const int nt_m = (int)((M + TM - 1) / TM), nt_n = (int)((N + BN - 1) / BN);
+    const int GROUP_M = nt_n <= 2 ? 8 : 4;
+    const int group_size = GROUP_M * nt_n, gid = lin / group_size, first_m = gid * GROUP_M;
+    const int gsz = min(nt_m - first_m, GROUP_M);
+    const int tile_m = first_m + (lin % group_size) % gsz, tile_n = (lin % group_size) / gsz;
+    const long long m0 = (long long)tile_m * TM, n0 = (long long)tile_n * BN;
+    const int nk = (int)((K + BK - 1) / BK);
+    const int kvalid = (int)K - (nk - 1) * BK;  // depth of the last K-tile, 8..64
+
+    unsigned offa[2], offb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offa[i] = src_offset<false>(wave * 2 + i, lane, lda, m0, M);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) offb[h][i] = src_offset<B_COL>(wave * 2 + i, lane, ldb, n0 + 128 * h, N);
+    }
+    bool tail_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) tail_ok[i] = (((lane & 7) ^ ((4 * i + (lane >> 4)) & 7)) * 8) < kvalid;
+    constexpr unsigned DEAD_OFF = 0x80000000u;
+    const unsigned kstep_b = B_COL ? (unsigned)(BK * ldb * 2) : (unsigned)(BK * 2);
+
+    auto dma = [&](int kt, auto slot_c, auto stage_c) {
+        constexpr int SLOT = decltype(slot_c)::value, ST = decltype(stage_c)::value;
+        char* dst = smem + ST * HSTAGE + SLOT * HALF + wave * 2048;
+        const bool live = kt < nk;
+        const bool tail = TAIL && kt == nk - 1 && kvalid < BK;
+        if constexpr (SLOT == S_A) {
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, live ? (int)a_bytes : 0, 0x00020000);
+            const unsigned so = (unsigned)kt * (unsigned)(BK * 2);
+            unsigned v0 = offa[0], v1 = offa[1];
+            if (TAIL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, v0, so, 0, PK8P_AUX_A);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, v1, so, 0, PK8P_AUX_A);
+        } else {
+            __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, live ? (int)b_bytes : 0, 0x00020000);
+            const unsigned so = (unsigned)kt * kstep_b;
+            unsigned v0 = offb[SLOT - 1][0], v1 = offb[SLOT - 1][1];
+            if (TAIL && !B_COL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, v0, so, 0, PK8P_AUX_B);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, v1, so, 0, PK8P_AUX_B);
+        }
+    };
+
+    f32x4 acc[4][2][2];  // [m-tile][nh][n-tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    V fa[4][2], fb0[2][2], fb1[2][2];
+
+    unsigned cb[3][2];  // col-form B: per-lane LDS address of n-tile j at k-step 0, slot 0, per stage
+    {
+        typedef __attribute__((address_space(3))) char lds_char;
+        const unsigned base = (unsigned)(unsigned long)(lds_char*)smem;
+        const int q = (lane & 15) >> 2, p = lane & 3, krow = 8 * (lane >> 4) + q;
+#pragma unroll
+        for (int st = 0; st < 3; ++st)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = wc * 32 + 16 * j + 4 * p;
+                cb[st][j] = base + st * HSTAGE + HT<true>::offset(krow, col >> 3) + (col & 7) * 2;
+            }
+    }
+#define PK_TR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
+    auto col_frag = [&](unsigned addr, auto off_c) -> V {
+        constexpr int OFF = decltype(off_c)::value;
+        static_assert(OFF >= 0 && OFF + 4 * HT<true>::ROWB < 65536, "ds offset field");
+        s16x4 lo, hi;
+        PK_TR(lo, addr, OFF);
+        PK_TR(hi, addr, OFF + 4 * HT<true>::ROWB);
+        s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(V, f);
+    };
+#define PK_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+    auto load_a = [&](auto st_c) {
+        constexpr int ST = decltype(st_c)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = frag<T, false>(smem + ST * HSTAGE + S_A * HALF, wr * 64 + 16 * i, kk, lane);
+    };
+    auto load_b = [&](auto st_c, auto slot_c, V (&dst)[2][2]) {
+        constexpr int ST = decltype(st_c)::value, SLOT = decltype(slot_c)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (B_COL) {
+                dst[j][0] = col_frag(cb[ST][j], std::integral_constant<int, SLOT * HALF>{});
+                dst[j][1] = col_frag(cb[ST][j], std::integral_constant<int, SLOT * HALF + 32 * HT<true>::ROWB>{});
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    dst[j][kk] = frag<T, false>(smem + ST * HSTAGE + SLOT * HALF, wc * 32 + 16 * j, kk, lane);
+            }
+        }
+    };
+    auto mma = [&](int nh, V (&b)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][nh][j] = M16<T>::mfma(b[j][kk], fa[i][kk], acc[i][nh][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using IA = std::integral_constant<int, S_A>; using IB0 = std::integral_constant<int, S_B0>;
+    using IB1 = std::integral_constant<int, S_B1>;
+    auto tile = [&](auto st_c, int kt) {
+        constexpr int ST = decltype(st_c)::value;
+        using S1 = std::integral_constant<int, (ST + 1) % 3>; using S2 = std::integral_constant<int, (ST + 2) % 3>;
+        // ---- phase A: quadrant (0, 0) ----
+        load_a(st_c);
+        PK_WAIT(6);
+        dma(kt + 2, IA{}, S2{});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase B: quadrant (0, 1); the B0 fragments of the NEXT K-tile ----
+        load_b(st_c, IB1{}, fb1);
+        load_b(S1{}, IB0{}, fb0);
+        PK_WAIT(6);
+        dma(kt + 2, IB1{}, S2{});
+        dma(kt + 3, IB0{}, st_c);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if (nk > 0) {
+        dma(0, IB0{}, I0{}); dma(0, IA{}, I0{}); dma(0, IB1{}, I0{});
+        dma(1, IB0{}, I1{}); dma(1, IA{}, I1{}); dma(1, IB1{}, I1{});
+        dma(2, IB0{}, I2{});
+        PK_WAIT(10);  // B0, A0 of tile 0
+        asm volatile("; PK8P_LOOP_BEGIN" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_b(I0{}, IB0{}, fb0);
+        if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave of every SIMD runs one barrier behind the first
+        for (int kt = 0; kt < nk; kt += 3) {
+            tile(I0{}, kt);
+            if (kt + 1 >= nk) break;
+            tile(I1{}, kt + 1);
+            if (kt + 2 >= nk) break;
+            tile(I2{}, kt + 2);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("; PK8P_LOOP_END" ::: "memory");
+        PK_WAIT(0);
+    }
+#undef PK_WAIT
+#undef PK_TR
+    __syncthreads();
+
+    // ---- epilogue: two 64-row passes through the fp32 staging buffer, the aux operand one pass ahead (as gemm8p_tile) ----
+    float* cs = reinterpret_cast<float*>(smem);
+    const bool pre_aux = ep.mode != 0;
+    Vec16<T> av_next[4];
+    auto aux_load = [&](int p) {
+        const int col = (tid & 31) * 8, r0 = tid >> 5;
+        const long long gn = n0 + col;
+        if (gn + 8 > N) return;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const long long gm = m0 + p * 64 + r0 + 16 * it;
+            if (gm < M) av_next[it] = load16<T>(reinterpret_cast<const T*>(ep.aux) + gm * ep.ldaux + gn);
+        }
+    };
+    if (pre_aux) aux_load(0);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (wr == p) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 v = acc[i][nh][j];
+                        float* d = cs + (16 * i + (lane & 15)) * CP + 128 * nh + 32 * wc + 16 * j + 4 * (lane >> 4);
+                        *reinterpret_cast<float4*>(d) = float4{v[0], v[1], v[2], v[3]};
+                    }
+        }
+        __syncthreads();
+        const long long mh = m0 + p * 64;
+        Vec16<T> av[4];
+        if (pre_aux) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) av[it] = av_next[it];
+            if (p == 0) aux_load(1);
+        }
+        if (ep.mode == 0) {
+            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 0>(cs, C, ep, mh, n0, M, N, tid, av);
+            else epilogue_pass<T, PK_ACT_NONE, 0>(cs, C, ep, mh, n0, M, N, tid, av);
+        } else if (ep.mode == 1) {
+            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 1>(cs, C, ep, mh, n0, M, N, tid, av);
+            else epilogue_pass<T, PK_ACT_NONE, 1>(cs, C, ep, mh, n0, M, N, tid, av);
+        } else {
+            if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 2>(cs, C, ep, mh, n0, M, N, tid, av);
+            else epilogue_pass<T, PK_ACT_NONE, 2>(cs, C, ep, mh, n0, M, N, tid, av);
+        }
+        if (p == 0) __syncthreads();
+    }
+}
+
+template <typename T, bool B_COL, bool TAIL>
+__global__ __launch_bounds__(512, 2) void gemm8p_hm2_kernel(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
+                                                           long long M, long long N, long long K, long long lda,
+                                                           long long ldb, unsigned a_bytes, unsigned b_bytes, EpiParams ep) {
+    gemm8p_hm2_tile<T, B_COL, TAIL>(A, B, C, M, N, K, lda, ldb, a_bytes, b_bytes, xcd_remap(blockIdx.x, gridDim.x), ep);
+}
+
 // ---- grouped weight gradients: up to PK_WGRAD_MAX (col,col) problems C_p = A_p^T B_p in ONE launch ----
 // The weight-gradient GEMMs of a layer (q|k|v, out-proj, fc1, fc2, ...: outputs of 4..16 tiles, contraction over all
 // B*T rows) each need split-K to fill 256 CUs on their own — 16..64 fp32 slabs per output and a reduction launch per
@@ -744,7 +999,20 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
                                (TT*)C, ws, asum_ws, (TT*)asum_out, M, N, K, lda, ldb, kchunk, (unsigned)a_bytes,         \
                                (unsigned)b_bytes, total, stamps, ep);                                                    \
     } while (0)
-    if (hm) {
+    static const bool hm2_on = [] { const char* e = getenv("PK_GEMM_HM2"); return !e || atoi(e) != 0; }();  // (A/B: 0 = the switched-off form)
+    if (hm && hm2_on && splitk == 1 && !ws) {  // the 128 x 256 tile with its own two-phase schedule
+#define PK_H2(TT, BC, TL)                                                                                               \
+    hipLaunchKernelGGL((gemm8p_hm2_kernel<TT, BC, TL>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, M, N, K, lda, \
+                       ldb, (unsigned)a_bytes, (unsigned)b_bytes, ep)
+        if (dtype == PK_F16) {
+            if (b_col) { if (tail) PK_H2(f16, true, true); else PK_H2(f16, true, false); }
+            else { if (tail) PK_H2(f16, false, true); else PK_H2(f16, false, false); }
+        } else {
+            if (b_col) { if (tail) PK_H2(bf16, true, true); else PK_H2(bf16, true, false); }
+            else { if (tail) PK_H2(bf16, false, true); else PK_H2(bf16, false, false); }
+        }
+#undef PK_H2
+    } else if (hm) {
         if (dtype == PK_F16) { if (b_col) PK_H(f16, true); else PK_H(f16, false); }
         else { if (b_col) PK_H(bf16, true); else PK_H(bf16, false); }
     } else if (!a_col && !b_col) PK_L(false, false);

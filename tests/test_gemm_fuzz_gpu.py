@@ -261,10 +261,11 @@ def test_half_m_tiles_for_outputs_that_fill_half_the_chip(M, N, K, b_col, mode, 
     import ctypes
     from pasero_amd import functional as F, lib
     torch.manual_seed(M + N + K)
-    a = (torch.randn(M, K, device='cuda') * 0.5).bfloat16()
-    b = (torch.randn(K, N, device='cuda') * 0.05).bfloat16() if b_col else (torch.randn(N, K, device='cuda') * 0.05).bfloat16()
-    bv = torch.randn(N, device='cuda').bfloat16() if bias else None
-    aux = torch.randn(M, N, device='cuda').bfloat16() if mode else None
+    dt = torch.float16 if K == 3072 else torch.bfloat16   # (one of the shapes in the reference's default 16-bit type)
+    a = (torch.randn(M, K, device='cuda') * 0.5).to(dt)
+    b = (torch.randn(K, N, device='cuda') * 0.05).to(dt) if b_col else (torch.randn(N, K, device='cuda') * 0.05).to(dt)
+    bv = torch.randn(N, device='cuda').to(dt) if bias else None
+    aux = torch.randn(M, N, device='cuda').to(dt) if mode else None
     L = lib.load()
     lib.check(L.pk_gemm_timing_start(4, 1), 'start')
     out = F.gemm(a, b, b_col=b_col, bias=bv, aux=aux, act=act, mode=mode)
