@@ -1,0 +1,100 @@
+"""The long-key-sequence forward kernel (heads of 64, no causal mask, S >= 256: `attn_fwd_long_kernel`, lagging maximum,
+K / V tiles by LDS-DMA) against the oracle's explicit softmax attention on the cases its shortcuts could get wrong:
+rows whose maximum keeps growing from tile to tile (every tile re-anchors) or grows once by a large step; key-padding
+masks that are no suffix (whole tiles masked in front of, between and behind visible keys; rows with no visible key);
+query / key counts off the tile sizes; packed-projection strides; both 16-bit types.  Reference: modules.py:654-677, 707-771."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def F():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from pasero_amd import functional
+    return functional
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(0.05)).item()
+
+
+def run(F, q, k, v, H, key_pad, scale):
+    B, T, D = q.shape
+    S, hd = k.size(1), D // H
+    out, _ = O.attention_core(q.float().view(B, T, H, hd), k.float().view(B, S, H, hd), v.float().view(B, S, H, hd),
+                              key_pad, False, scale)
+    sc = torch.einsum('bthd,bshd->bhts', q.float().view(B, T, H, hd), k.float().view(B, S, H, hd)) * scale
+    if key_pad is not None:
+        sc = sc.masked_fill(key_pad[:, None, None, :], float('-inf'))
+    lse_ref = torch.logsumexp(sc, -1)
+    o, lse = F.attn_fwd(q.cuda(), k.cuda(), v.cuda(), H, key_pad.cuda() if key_pad is not None else None, False, scale)
+    return o.cpu(), lse.cpu(), out.reshape(B, T, D), lse_ref
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,H,T,S', [(2, 2, 130, 256), (1, 3, 257, 500), (2, 1, 64, 1500), (1, 2, 1500, 1500)])
+@pytest.mark.parametrize('growth', ['flat', 'ramp', 'step'])
+def test_long_forward_growing_maximum(F, dtype, B, H, T, S, growth):
+    """flat: unit-variance scores (the maximum settles in the first tiles); ramp: key norms grow along the sequence so the
+    row maximum rises in (nearly) every tile and each tile re-anchors; step: one key far down the sequence beats everything
+    before it by ~40 in the exp2 domain (the accumulator is rescaled by 2^-40 once, late)."""
+    g = torch.Generator().manual_seed(S * 7 + T)
+    D = H * 64
+    q, k, v = (torch.randn(B, n, D, generator=g) for n in (T, S, S))
+    if growth == 'ramp':
+        k = k * torch.linspace(0.5, 6.0, S)[None, :, None]
+    elif growth == 'step':
+        q = q + 1.0
+        k[:, (3 * S) // 4] = 3.0   # score ~ 3 * 64 * 0.125 = 24 (35 in the exp2 domain) against a spread of ~1.4
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    o, lse, ref, lse_ref = run(F, q, k, v, H, None, 0.125)
+    assert torch.isfinite(o.float()).all()
+    assert rel_err(o, ref) < (2.5e-2 if dtype == torch.bfloat16 else 4e-3), rel_err(o, ref)
+    assert (lse - lse_ref).abs().max().item() < 2e-3 * max(1.0, lse_ref.abs().max().item())
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_long_forward_masks_that_are_no_suffix(F, dtype):
+    """batch row 0: keys 0..199 masked (three whole tiles before the first visible key: the row stays unanchored through
+    them); row 1: visible keys only in [70, 90) and [400, 410) (masked tiles between and behind); row 2: nothing visible
+    (output 0, lse 0: the reference's nan_to_num); row 3: every second key masked; row 4: no mask."""
+    B, H, T, S, D = 5, 2, 200, 453, 128
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B, S, 3 * D, generator=g).to(dtype)
+    q, k, v = qkv[:, :T, :D], qkv[..., D:2 * D], qkv[..., 2 * D:]   # strided views of one packed buffer
+    pad = torch.zeros(B, S, dtype=torch.bool)
+    pad[0, :200] = True
+    pad[1] = True
+    pad[1, 70:90] = False
+    pad[1, 400:410] = False
+    pad[2] = True
+    pad[3, ::2] = True
+    B_, T_, D_ = q.shape
+    qc = qkv.cuda()
+    o, lse = F.attn_fwd(qc[:, :T, :D], qc[..., D:2 * D], qc[..., 2 * D:], H, pad.cuda(), False, 0.125)
+    out, _ = O.attention_core(q.float().reshape(B, T, H, 64), k.float().reshape(B, S, H, 64), v.float().reshape(B, S, H, 64),
+                              pad, False, 0.125)
+    out = out.reshape(B, T, D)
+    assert torch.isfinite(o.float()).all()
+    assert (o[2] == 0).all() and (lse[2] == 0).all()
+    assert rel_err(o.cpu(), out) < (2.5e-2 if dtype == torch.bfloat16 else 4e-3)
+
+
+def test_long_forward_is_row_local(F):
+    """a row's output does not depend on which other rows share its wave / workgroup / batch: the same (b, h) rows computed
+    inside a larger batch and on their own are bitwise equal (the re-anchoring decision is per row)."""
+    g = torch.Generator().manual_seed(11)
+    B, H, T, S, D = 3, 2, 300, 700, 128
+    q, k, v = (torch.randn(B, n, D, generator=g) for n in (T, S, S))
+    k = k * torch.linspace(0.5, 5.0, S)[None, :, None]
+    q, k, v = (t.bfloat16().cuda() for t in (q, k, v))
+    o, lse = F.attn_fwd(q, k, v, H, None, False, 0.125)
+    o1, lse1 = F.attn_fwd(q[1:2, 37:200].contiguous(), k[1:2].contiguous(), v[1:2].contiguous(), H, None, False, 0.125)
+    assert torch.equal(o[1:2, 37:200], o1) and torch.equal(lse[1:2, :, 37:200], lse1)
