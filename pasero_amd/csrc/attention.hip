@@ -15,131 +15,9 @@
 //   bwd_dkv      : one wave owns 32 keys, the KEY sits on the lane (S = Q·Kᵀ, dP = dO·Vᵀ), so P and dS feed
 //                  dVᵀ += dOᵀ·P and dKᵀ += Qᵀ·dS from registers and dK/dV need no cross-workgroup sum (no atomics).
 // fp32 path: one thread per query (or key) row with broadcast LDS reads — exact fp32 arithmetic for parity runs.
-#include "common.h"
-
-// Register budgets: the minimum number of waves per SIMD the compiler must leave room for (512 / n registers per lane).
-// Left to itself it takes 176-316 registers for these kernels and halves the occupancy for nothing: at these budgets
-// none of them spills.  Measured (bf16, B = 256, H = 8, T = S = 128): forward 41.5 -> 33.6 us; Whisper encoder shape
-// (T = S = 1500): forward 181 -> 148 us, backward (dQ + dK/dV kernels) 546 -> 407 us.  The fused backward spills 27
-// registers at three waves and stays at two; the dQ kernel for heads of 128 spills at two and stays at one.
-#ifndef PK_ATTN_FWD_WAVES
-#define PK_ATTN_FWD_WAVES 3
-#endif
-#ifndef PK_ATTN_FUSED_WAVES
-#define PK_ATTN_FUSED_WAVES 2
-#endif
-constexpr int q_min_waves(int mode, int hd) { return mode == 0 ? (hd == 64 ? PK_ATTN_FWD_WAVES : 2) : (hd == 64 ? 2 : 1); }
-constexpr int dkv_min_waves(int hd) { return hd == 64 ? 2 : 1; }
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-// 16-byte global loads / stores of the attention kernels; PKATT_NT (diagnostic builds): 1 = the fused backward's tile loads
-// streaming, 2 = fragment / tile loads of every kernel, 4 = the row stores (o, dq, dk, dv)
-#ifndef PKATT_NT
-#define PKATT_NT 0
-#endif
-template <int BIT, typename T> __device__ __forceinline__ uint4 att_ld(const T* p) {
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    if constexpr ((PKATT_NT & BIT) != 0) return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
-    else return *reinterpret_cast<const uint4*>(p);
-}
-template <typename T> __device__ __forceinline__ void att_st(T* p, uint4 v) {
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    if constexpr ((PKATT_NT & 4) != 0) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
-    else *reinterpret_cast<uint4*>(p) = v;
-}
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(8))) short s16x8;
-typedef __attribute__((address_space(3))) s16x4 lds_s4;
+#include "attention_common.h"
 
 namespace {
-
-constexpr int HD64 = 64;  // the single-workgroup fused backward is built for this head dimension only
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
-
-struct AttnParams {
-    int B, H, T, S;
-    long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;  // batch / row strides in elements (head stride = 64)
-    long long do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
-    const unsigned char* key_pad;  // [B][S] or null
-    int causal;
-    float scale;
-    // attention-probability dropout (F.scaled_dot_product_attention(dropout_p=...), modules.py:707-720): the forward pass
-    // draws keep bits from Philox (element index = row * 8 * mask_pitch + key) and stores them, one bit per (query, key),
-    // rows of `mask_pitch` = 8 * ceil(S / 64) bytes; the backward kernels read the bits back
-    unsigned drop_thr;             // 0: no dropout
-    float drop_scale;              // 1 / (1 - p)
-    unsigned long long seed, offset;
-    unsigned char* drop_mask;      // [B][H][T][mask_pitch]
-    long long mask_pitch;
-    // rotary positions folded into the kernels (RotaryEmbedding.forward, pasero/models/modules.py:982-1025, applied to q and
-    // k at modules.py:617-623): q and k arrive UNROTATED, every kernel rotates the rows it loads (query t by the angle of
-    // position rope_q0 + t, key s by rope_k0 + s) and the backward kernels rotate dQ / dK back as they leave — the gradients
-    // are those of the unrotated projection.  cos / sin: fp32 [rope_max][head_dim / 2]; rope_cos == NULL: no rotation.
-    const float* rope_cos;
-    const float* rope_sin;
-    int rope_max, rope_q0, rope_k0;
-};
-
-__device__ __forceinline__ bool drop_keep1(const AttnParams& p, long long row, int s) {
-    const unsigned long long idx = (unsigned long long)row * 8ull * p.mask_pitch + s;
-    return dropout_keep1(p.seed, p.offset, idx, p.drop_thr);
-}
-__device__ __forceinline__ bool drop_bit(const AttnParams& p, long long row, int s) {
-    return (p.drop_mask[row * p.mask_pitch + (s >> 3)] >> (s & 7)) & 1;
-}
-
-__device__ __forceinline__ bool key_masked(const AttnParams& p, int b, int t, int s) {
-    if (s >= p.S) return true;
-    if (p.key_pad && p.key_pad[(long long)b * p.S + s]) return true;
-    if (p.causal && s > t + (p.S - p.T)) return true;
-    return false;
-}
-
-// ---- rotary helpers (GPT-J halves: y[i] = x[i] c_i - x[i + hd/2] s_i ; y[i + hd/2] = x[i + hd/2] c_i + x[i] s_i) ----
-__device__ __forceinline__ int rope_row(const AttnParams& p, int pos) { return min(max(pos, 0), p.rope_max - 1); }
-// a whole fp32 row in registers, in place; INV: the transposed rotation (gradients)
-template <int HD, bool INV>
-__device__ __forceinline__ void rope_row_f32(float (&x)[HD], const AttnParams& p, int pos) {
-    const float* cs = p.rope_cos + (long long)rope_row(p, pos) * (HD / 2);
-    const float* sn = p.rope_sin + (long long)rope_row(p, pos) * (HD / 2);
-#pragma unroll
-    for (int i = 0; i < HD / 2; ++i) {
-        const float c = cs[i], s = INV ? -sn[i] : sn[i];
-        const float a = x[i], b = x[i + HD / 2];
-        x[i] = a * c - b * s;
-        x[i + HD / 2] = b * c + a * s;
-    }
-}
-// one element of a row read from memory: element d of head row `base` at position pos
-template <int HD>
-__device__ __forceinline__ float rope_elem_f32(const float* __restrict__ base, int d, const AttnParams& p, int pos) {
-    const int i = d & (HD / 2 - 1);
-    const long long r = (long long)rope_row(p, pos) * (HD / 2) + i;
-    const float c = p.rope_cos[r], s = p.rope_sin[r];
-    return d < HD / 2 ? base[d] * c - base[d + HD / 2] * s : base[d] * c + base[d - HD / 2] * s;
-}
-// 8 consecutive 16-bit elements of a head row (`own`) and the 8 of the other half (`oth`): own, rotated.  cs / sn point at
-// the 8 angles; upper: own is the second half; inverse: rotate back.  fp32 arithmetic, rounded once (as pk_rope does).
-template <typename T>
-__device__ __forceinline__ uint4 rope8(uint4 own, uint4 oth, const float* __restrict__ cs, const float* __restrict__ sn,
-                                        bool upper, bool inverse) {
-    const float4 c0 = *reinterpret_cast<const float4*>(cs), c1 = *reinterpret_cast<const float4*>(cs + 4);
-    const float4 s0 = *reinterpret_cast<const float4*>(sn), s1 = *reinterpret_cast<const float4*>(sn + 4);
-    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float sg = (upper != inverse) ? 1.f : -1.f;  // forward: lower a c - b s, upper a c + b s
-    const unsigned ow[4] = {own.x, own.y, own.z, own.w}, ot[4] = {oth.x, oth.y, oth.z, oth.w};
-    unsigned out[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const float a0 = H16<T>::val((unsigned short)(ow[w] & 0xffff)), a1 = H16<T>::val((unsigned short)(ow[w] >> 16));
-        const float b0 = H16<T>::val((unsigned short)(ot[w] & 0xffff)), b1 = H16<T>::val((unsigned short)(ot[w] >> 16));
-        const float y0 = a0 * c[2 * w] + sg * b0 * sv[2 * w], y1 = a1 * c[2 * w + 1] + sg * b1 * sv[2 * w + 1];
-        out[w] = (unsigned)H16<T>::bits(y0) | ((unsigned)H16<T>::bits(y1) << 16);
-    }
-    return make_uint4(out[0], out[1], out[2], out[3]);
-}
 
 // =====================================================================================================
 // fp32 path
@@ -331,204 +209,6 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_f32_kernel(const float* __re
     }
 }
 
-// =====================================================================================================
-// bf16 MFMA path
-// =====================================================================================================
-// LDS images of a [64 rows][64 x bf16] tile.  `P` > 0: plain rows of P bytes.
-constexpr int PITCH = 144;   // +16 B pad: ds_read_b128 row reads conflict-free (tiles that are only read by rows)
-constexpr int VPITCH = 192;  // V tile of the forward pass: only transposed reads (4 key rows on distinct bank quarters)
-constexpr int DUAL = 0;      // tiles read BOTH by rows (ds_read_b128) and transposed (ds_read_b64_tr_b16): 8-row x 32-col
-                             // subtiles of 512 B with the 16-B chunk XOR-swizzled by (row>>2)&3 — both kinds of read are
-                             // conflict-free (cdna guide T10 image (a), cut down to 128-B rows)
-template <int P> __device__ __forceinline__ int lds_off(int row, int ch) {
-    if constexpr (P == DUAL)
-        return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
-    else
-        return row * P + ch * 16;
-}
-constexpr int KT = 64;       // rows (keys or queries) staged per LDS tile
-// T = bf16 or f16: fragments travel as raw 8 x 16-bit vectors; only the MFMA instruction and the conversions differ
-template <typename T>
-__device__ __forceinline__ f32x16 mm(bf16x8_t a, bf16x8_t b, f32x16 c) {
-    typedef typename H16<T>::vec V;
-    return H16<T>::mfma(__builtin_bit_cast(V, a), __builtin_bit_cast(V, b), c);
-}
-// A [64 rows][head_dim] tile is head_dim / 64 images side by side (each 64 columns wide, laid out as above)
-template <int P> constexpr int img_bytes() { return KT * (P == DUAL ? 128 : P); }
-
-// stage a [64 rows][64 cols] bf16 tile (rows r0.., row limit `lim`, zero fill) into LDS with the given pitch
-template <typename T>
-__device__ __forceinline__ void stage_tile(char* lds, int pitch, const T* __restrict__ base, long long rs, int r0,
-                                           int lim, int tid) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int c = tid + i * 256;  // 512 chunks of 16 B
-        int r = c >> 3, cc = (c & 7) * 8;
-        uint4 val = {0, 0, 0, 0};
-        if (r0 + r < lim) val = *reinterpret_cast<const uint4*>(base + (long long)(r0 + r) * rs + cc);
-        *reinterpret_cast<uint4*>(lds + r * pitch + cc * 2) = val;
-    }
-}
-
-// the same in two halves, so the next tile's global loads fly under the current tile's MFMAs
-template <int NR, typename T>  // NR = 2 * head_dim / 64 chunks of 16 B per thread
-__device__ __forceinline__ void tile_g2r(uint4 (&regs)[NR], const T* __restrict__ base, long long rs, int r0, int lim,
-                                         int tid) {
-    constexpr int CPR = 4 * NR;  // 16-B chunks per row
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        int c = tid + i * 256;
-        int r = c / CPR, cc = (c % CPR) * 8;
-        regs[i] = make_uint4(0, 0, 0, 0);
-        if (r0 + r < lim) regs[i] = att_ld<2>(base + (long long)(r0 + r) * rs + cc);
-    }
-}
-template <int P, int NR>
-__device__ __forceinline__ void tile_r2s(const uint4 (&regs)[NR], char* lds, int tid) {
-    constexpr int CPR = 4 * NR;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        int c = tid + i * 256, ch = c % CPR;
-        *reinterpret_cast<uint4*>(lds + (ch >> 3) * img_bytes<P>() + lds_off<P>(c / CPR, ch & 7)) = regs[i];
-    }
-}
-
-// row fragment: lane (r = l&31, h = l>>5) gets row row0 + r, elements d = 16*kk + 8*h .. +7
-template <int P>
-__device__ __forceinline__ bf16x8_t row_frag(const char* lds, int row0, int kk, int lane) {
-    return *reinterpret_cast<const bf16x8_t*>(lds + (kk >> 2) * img_bytes<P>() +
-                                              lds_off<P>(row0 + (lane & 31), (kk & 3) * 2 + (lane >> 5)));
-}
-// transposed fragment for "accumulator tile as next operand" products (cdna guide §3): lane (r, h) gets column
-// c0 + r of rows  row0 + 16*s + 8*(j>>2) + 4*h + (j&3),  j = 0..7
-template <int P>
-__device__ __forceinline__ bf16x8_t tr_frag(const char* lds, int row0, int s, int c0, int lane) {
-    int q = (lane & 15) >> 2, p4 = lane & 3;
-    int col = (c0 & 63) + 16 * ((lane >> 4) & 1) + 4 * p4;
-    int row = row0 + 16 * s + 4 * (lane >> 5) + q;
-    lds += (c0 >> 6) * img_bytes<P>();  // the 64-column image this d-tile lives in
-    const char* ptr = lds + lds_off<P>(row, col >> 3) + (col & 7) * 2;
-    const char* ptr8 = lds + lds_off<P>(row + 8, col >> 3) + (col & 7) * 2;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)ptr);
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)ptr8);
-    s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8_t, f);
-}
-// accumulator registers 8s..8s+7 of a 32x32 tile -> bf16 B/A operand of k-step s
-template <typename T>
-__device__ __forceinline__ bf16x8_t acc_frag(const f32x16& a, int s) {
-    s16x8 f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (short)H16<T>::bits(a[8 * s + j]);
-    return __builtin_bit_cast(bf16x8_t, f);
-}
-__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
-
-// global row fragment (rows beyond `lim` read as zero): lane (r, h) row row0 + r, d = 16kk + 8h .. +7
-template <int NF, typename T>
-__device__ __forceinline__ void load_row_frags(bf16x8_t (&f)[NF], const T* __restrict__ base, long long rs, int row,
-                                               bool valid, int lane) {
-#pragma unroll
-    for (int kk = 0; kk < NF; ++kk) {
-        uint4 val = {0, 0, 0, 0};
-        if (valid) val = att_ld<2>(base + (long long)row * rs + kk * 16 + 8 * (lane >> 5));
-        f[kk] = __builtin_bit_cast(bf16x8_t, val);
-    }
-}
-
-// ---- rotary positions on the operands as they are loaded (AttnParams::rope_cos) ----
-// row fragments (load_row_frags): lane (r, h) holds chunk 2 kk + h of its row for every kk; the partner chunk hd/2
-// elements away is fragment kk + NF/2 of the SAME lane
-template <int NF, typename T>
-__device__ __forceinline__ void rope_frags(bf16x8_t (&f)[NF], const AttnParams& p, int pos, int lane) {
-    constexpr int HALF = NF * 8;  // head_dim / 2
-    const float* cs = p.rope_cos + (long long)rope_row(p, pos) * HALF + 8 * (lane >> 5);
-    const float* sn = p.rope_sin + (long long)rope_row(p, pos) * HALF + 8 * (lane >> 5);
-#pragma unroll
-    for (int kk = 0; kk < NF / 2; ++kk) {
-        const uint4 lo = __builtin_bit_cast(uint4, f[kk]), hi = __builtin_bit_cast(uint4, f[kk + NF / 2]);
-        f[kk] = __builtin_bit_cast(bf16x8_t, rope8<T>(lo, hi, cs + 16 * kk, sn + 16 * kk, false, false));
-        f[kk + NF / 2] = __builtin_bit_cast(bf16x8_t, rope8<T>(hi, lo, cs + 16 * kk, sn + 16 * kk, true, false));
-    }
-}
-// one 16-byte chunk `ch` (of CPR per row) of row `row` held by this lane: the partner chunk CPR / 2 away sits CPR / 2 lanes
-// away (tile_g2r and the fused backward's loads walk a row with consecutive lanes)
-template <int CPR, typename T>
-__device__ __forceinline__ uint4 rope_chunk(uint4 v, int ch, const AttnParams& p, int pos) {
-    constexpr int HC = CPR / 2;
-    uint4 o;
-    o.x = __shfl_xor(v.x, HC, 64); o.y = __shfl_xor(v.y, HC, 64); o.z = __shfl_xor(v.z, HC, 64); o.w = __shfl_xor(v.w, HC, 64);
-    const long long r = (long long)rope_row(p, pos) * (CPR * 4) + 8 * (ch & (HC - 1));
-    return rope8<T>(v, o, p.rope_cos + r, p.rope_sin + r, ch >= HC, false);
-}
-template <int NR, typename T>
-__device__ __forceinline__ void rope_tile(uint4 (&regs)[NR], const AttnParams& p, int pos0, int tid) {
-    constexpr int CPR = 4 * NR;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int c = tid + i * 256;
-        regs[i] = rope_chunk<CPR, T>(regs[i], c % CPR, p, pos0 + c / CPR);
-    }
-}
-// accumulators dQᵀ / dKᵀ [d-tile][d rows] x row-on-lane, rotated BACK in place (register 4g + j of d-tile dt is element
-// d = 32 dt + 8 g + 4 (l >> 5) + j of the lane's row; its partner is the same register of d-tile dt + ND / 2)
-template <int ND>
-__device__ __forceinline__ void rope_acc_inverse(f32x16 (&acc)[ND], const AttnParams& p, int pos, int lane) {
-    constexpr int HALF = ND * 16;  // head_dim / 2
-    const float* cs = p.rope_cos + (long long)rope_row(p, pos) * HALF + 4 * (lane >> 5);
-    const float* sn = p.rope_sin + (long long)rope_row(p, pos) * HALF + 4 * (lane >> 5);
-#pragma unroll
-    for (int dt = 0; dt < ND / 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 c4 = *reinterpret_cast<const float4*>(cs + 32 * dt + 8 * g);
-            const float4 s4 = *reinterpret_cast<const float4*>(sn + 32 * dt + 8 * g);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float c = (&c4.x)[j], sv = (&s4.x)[j];
-                const float a = acc[dt][4 * g + j], b = acc[dt + ND / 2][4 * g + j];
-                acc[dt][4 * g + j] = a * c + b * sv;
-                acc[dt + ND / 2][4 * g + j] = b * c - a * sv;
-            }
-        }
-}
-
-template <typename T>
-__device__ __forceinline__ float frag_dot(const bf16x8_t& a, const bf16x8_t& b) {
-    s16x8 x = __builtin_bit_cast(s16x8, a), y = __builtin_bit_cast(s16x8, b);
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += H16<T>::val((unsigned short)x[j]) * H16<T>::val((unsigned short)y[j]);
-    return s;
-}
-
-// write a transposed accumulator pair Xᵀ[d][row-on-lane] (2 d-tiles) as bf16 rows: lane (r, h) owns row `row`
-template <int ND, typename T>
-__device__ __forceinline__ void store_rowT(T* __restrict__ base, long long rs, int row, bool valid,
-                                           const f32x16 (&acc)[ND], float mul, int lane) {
-    // lanes l and l + 32 own the same row: columns [8g, 8g+4) and [8g+4, 8g+8) of every group g.  They swap one piece
-    // per pair of groups so that each writes 16 contiguous bytes (lane l: group 2j whole, lane l + 32: group 2j + 1)
-    const int h = lane >> 5;
-#pragma unroll
-    for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            unsigned lo[2], hi[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int g = 2 * j + q;
-                lo[q] = (unsigned)H16<T>::bits(acc[dt][4 * g] * mul) | ((unsigned)H16<T>::bits(acc[dt][4 * g + 1] * mul) << 16);
-                hi[q] = (unsigned)H16<T>::bits(acc[dt][4 * g + 2] * mul) | ((unsigned)H16<T>::bits(acc[dt][4 * g + 3] * mul) << 16);
-            }
-            const unsigned send_lo = h ? lo[0] : lo[1], send_hi = h ? hi[0] : hi[1];
-            const unsigned recv_lo = __shfl_xor(send_lo, 32), recv_hi = __shfl_xor(send_hi, 32);
-            // h = 0: group 2j = {own cols 0-3, partner's cols 4-7};  h = 1: group 2j + 1 = {partner's cols 0-3, own cols 4-7}
-            const uint4 v = h ? make_uint4(recv_lo, recv_hi, lo[1], hi[1]) : make_uint4(lo[0], hi[0], recv_lo, recv_hi);
-            const int d = dt * 32 + 8 * (2 * j + h);
-            if (valid) att_st(base + (long long)row * rs + d, v);
-        }
-}
-
 // ---- forward (MODE 0) and dQ backward (MODE 1): query on the lane ----
 template <typename T, int MODE, int HD, bool DROP>
 __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(const T* __restrict__ q, const T* __restrict__ k,
@@ -540,7 +220,7 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
     constexpr int NF = HD / 16, ND = HD / 32, NI = HD / 64;  // k-steps per row, 32-row d-tiles, 64-column LDS images
     __shared__ __attribute__((aligned(16))) char k_lds[NI * img_bytes<KP>()];
     __shared__ __attribute__((aligned(16))) char v_lds[NI * img_bytes<VP>()];
-    __shared__ __attribute__((aligned(16))) float kbias_lds[KT];
+    __shared__ unsigned long long dead_lds;  // bit i: key i of the staged tile is past S or a padding key
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
     const int t = blockIdx.x * 128 + wave * 32 + (lane & 31);
@@ -550,6 +230,10 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
     bf16x8_t qf[NF], dof[NF];
     load_row_frags(qf, q + b * p.q_bs + h * HD, p.q_rs, t, valid, lane);
     if (p.rope_cos) rope_frags<NF, T>(qf, p, p.rope_q0 + t, lane);
+    // Q carries c = scale log2(e) (scale_frags): the score MFMAs leave the exp2-domain score.  In the dQ pass they start from the
+    // accumulator -lse log2(e), dP = V dOᵀ from -delta: p = exp2(x), dS = p dP' with no other vector instruction per score;
+    // masked keys and the causal boundary cost selects only in the tiles that hold them (wave-uniform branches).
+    scale_frags<NF, T>(qf, c);
     float m = -INFINITY, l = 0.f, L2 = 0.f, dl = 0.f;
     f32x16 acc[ND];  // Oᵀ (MODE 0) or dQᵀ (MODE 1): [d-tile][d rows] x query lane
 #pragma unroll
@@ -588,10 +272,11 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
         __syncthreads();  // previous tile fully consumed
         tile_r2s<KP>(kreg, k_lds, tid);
         tile_r2s<VP>(vreg, v_lds, tid);
-        if (tid < KT) {  // additive key bias: 0, or -inf for keys past S / padding keys (modules.py:654-677)
+        if (tid < KT) {  // keys past S / padding keys (modules.py:654-677): wave 0 is exactly the tile's 64 keys
             const int sk = s0 + tid;
             const bool dead = sk >= p.S || (p.key_pad && p.key_pad[(long long)b * p.S + sk]);
-            kbias_lds[tid] = dead ? -INFINITY : 0.f;
+            const unsigned long long dm = __ballot(dead);
+            if (tid == 0) dead_lds = dm;
         }
         if (s0 + KT < s_end) {  // prefetch the next tile into registers
             tile_g2r(kreg, kbase, p.k_rs, s0 + KT, p.S, tid);
@@ -605,33 +290,42 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
         const bool check = p.causal && s0 + KT - 1 > wt0 + off;   // some (query, key) pairs are masked
 
         f32x16 sc[2];  // Sᵀ[key][query] for the two 32-key blocks of the tile
+        const unsigned long long dead = dead_lds;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) sc[kb][r] = MODE == 1 ? -L2 : 0.f;
 #pragma unroll
             for (int kk = 0; kk < NF; ++kk)
                 sc[kb] = mm<T>(row_frag<KP>(k_lds, kb * 32, kk, lane), qf[kk],
                                                                  sc[kb]);
         }
-        // scale + key bias (exp2 domain): registers 4g..4g+3 of a block are 4 consecutive keys -> one 16-B bias read
-        float tmax = -INFINITY;
+        if (dead) {  // wave-uniform: this tile holds masked keys
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
+                unsigned dm = (unsigned)(dead >> (32 * kb)) >> (4 * (lane >> 5));
+                asm volatile("; masked keys" : "+v"(dm));  // (a real branch: if-converted, the selects cost 3 instructions per score in every tile)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 kb4 = *reinterpret_cast<const float4*>(kbias_lds + kb * 32 + 8 * g + 4 * (lane >> 5));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float x = fmaf(sc[kb][4 * g + j], c, (&kb4.x)[j]);
-                    if (check) {
-                        const int sk = s0 + kb * 32 + 8 * g + 4 * (lane >> 5) + j;
-                        x = sk > t + off ? -INFINITY : x;
-                    }
-                    sc[kb][4 * g + j] = x;
-                    tmax = fmaxf(tmax, x);
-                }
+                for (int r = 0; r < 16; ++r)
+                    if ((dm >> ((r & 3) + 8 * (r >> 2))) & 1u) sc[kb][r] = -INFINITY;
             }
+        }
+        if (check) {  // wave-uniform: the causal boundary crosses this (wave, tile) block
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                int kq = t + off - s0 - kb * 32 - 4 * (lane >> 5);  // key index (in the block) > kq is in this query's future
+                asm volatile("; causal block" : "+v"(kq));
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) > kq) sc[kb][r] = -INFINITY;
+            }
+        }
+        float tmax = -INFINITY;
+        if constexpr (MODE == 0) {
+            tmax = fmaxf(sc[0][0], sc[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sc[0][r]), sc[1][r]);
+        }
         if constexpr (MODE == 0) {
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float mn = fmaxf(m, tmax);
@@ -709,7 +403,7 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dp[kb][r] = 0.f;
+                for (int r = 0; r < 16; ++r) dp[kb][r] = DROP ? 0.f : -dl;  // (with dropout dP is scaled before delta comes off)
 #pragma unroll
                 for (int kk = 0; kk < NF; ++kk)
                     dp[kb] = mm<T>(row_frag<VP>(v_lds, kb * 32, kk, lane), dof[kk],
@@ -728,8 +422,8 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float pw = __builtin_amdgcn_exp2f(sc[kb][r] - L2);  // masked: exp2(-inf) = 0
-                    sc[kb][r] = pw * (dp[kb][r] - dl);                   // dSᵀ
+                    const float pw = __builtin_amdgcn_exp2f(sc[kb][r]);         // masked: exp2(-inf) = 0
+                    sc[kb][r] = DROP ? pw * (dp[kb][r] - dl) : pw * dp[kb][r];  // dSᵀ
                 }
             }
             // dQᵀ[d][query] += Kᵀ[d][key] · dSᵀ[key][query]
@@ -755,240 +449,6 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
         if (p.rope_cos) rope_acc_inverse<ND>(acc, p, p.rope_q0 + t, lane);  // (the gradient of the UNROTATED query)
         store_rowT(dq + b * p.dq_bs + h * HD, p.dq_rs, t, valid, acc, p.scale, lane);
     }
-}
-
-// ---- forward for long key sequences (round 4): head_dim 64, no causal mask, no rotation ----
-// The kernel above spends ~10 vector instructions per (query, key) score (scale + bias, the causal select, running maximum,
-// subtraction, exp, sum, accumulator rescale, conversion) against 16 MFMAs per 2048 scores: at S >= 500 it is paced by its
-// VALU work, not by the matrix pipe (0.5 ps per pair whatever the shape).  This form keeps 4 per score:
-//   * the maximum LAGS: a query's scores are taken relative to the maximum m its row was last anchored at, x = s c - m (ONE
-//     fma), and m moves only when a tile's maximum exceeds it by more than LAG_THR (exp2 domain: p <= 2^LAG_THR, in range for
-//     both 16-bit types, relative precision unchanged) — the accumulator rescale, the exp of the correction and the
-//     subtraction leave the loop body for a wave-uniform branch that is rare after the first tile;
-//   * keys past S / padding keys are found per tile by one ballot; only tiles that hold one pay for the selects;
-//   * K and V tiles arrive by LDS-DMA (buffer_load ... lds, 16 B per lane, rows past S read as zeros through the buffer
-//     bound) into a two-deep ring of dual-use images (lds_off<DUAL>: a 1-KiB DMA piece is one 8-row group, the lane picks the
-//     global chunk that belongs at its LDS position), one barrier per tile, nothing staged through registers;
-//   * workgroups of one (batch, head) pair sit on one XCD (their K / V stay in that L2).
-// Same accumulator layouts, Q fragments and row stores as the kernel above.  A row's arithmetic depends on its own data only
-// (a lane re-anchors only when ITS maximum says so).
-constexpr float LAG_THR = 8.f;
-
-template <typename T, bool DROP>
-__global__ __launch_bounds__(256, 3) void attn_fwd_long_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                               const T* __restrict__ v, T* __restrict__ o,
-                                                               float* __restrict__ lse, AttnParams p, int nqb, int npairs) {
-    constexpr int HD = 64, NF = 4, ND = 2;
-    constexpr int IMG = img_bytes<DUAL>();  // 8 KiB: [64 rows][64 x 16 bit]
-    typedef __attribute__((address_space(3))) void lds_void;
-    __shared__ __attribute__((aligned(1024))) char ring[2 * 2 * IMG];  // stage st: K image at 2 st IMG, V image behind it
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lin = blockIdx.x, grp = (lin >> 3) / nqb, qb = (lin >> 3) % nqb;
-    const int pair = grp * 8 + (lin & 7);
-    if (pair >= npairs) return;
-    const int b = pair / p.H, h = pair % p.H;
-    const int t = qb * 128 + wave * 32 + (lane & 31);
-    const bool valid = t < p.T;
-    const float c = p.scale * LOG2E;
-
-    bf16x8_t qf[NF];
-    load_row_frags(qf, q + b * p.q_bs + h * HD, p.q_rs, t, valid, lane);
-    f32x16 acc[ND];
-#pragma unroll
-    for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
-    float negm = 0.f, l = 0.f;  // -m (exp2 domain) once the row is anchored, 0 before
-    bool anch = false;
-
-    // LDS-DMA: wave w brings the 8-row pieces w and w + 4 of the K and of the V tile; lane L lands at byte 16 L of its piece
-    const T* kbase = k + b * p.k_bs + h * HD;
-    const T* vbase = v + b * p.v_bs + h * HD;
-    const unsigned k_rsb = (unsigned)(p.k_rs * 2), v_rsb = (unsigned)(p.v_rs * 2);
-    const int kbytes = (int)(((long long)(p.S - 1) * p.k_rs + HD) * 2), vbytes = (int)(((long long)(p.S - 1) * p.v_rs + HD) * 2);
-    unsigned koff[2], voff[2];
-    {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = 8 * (wave + 4 * i) + ((lane >> 2) & 7);
-            const int ch = 4 * (lane >> 5) + ((lane & 3) ^ ((row >> 2) & 3));  // (the inverse of lds_off<DUAL>)
-            koff[i] = (unsigned)row * k_rsb + 16 * ch;
-            voff[i] = (unsigned)row * v_rsb + 16 * ch;
-        }
-    }
-    // transposed reads of the V image (tr_frag<DUAL>): lane addresses of rows 4 h + q and 4 h + q + 8 of d-tile 0; key block kb and
-    // k-step s add 1024 (4 kb + 2 s) bytes (16 keys = two 8-row groups of 1 KiB, the swizzle class of a row does not change),
-    // d-tile 1 adds 512 (chunks 4..7 of a row)
-    unsigned vaddr[2];
-    {
-        typedef __attribute__((address_space(3))) char lds_char;
-        const int qd = (lane & 15) >> 2, p4 = lane & 3;
-        const int col = 16 * ((lane >> 4) & 1) + 4 * p4, row = 4 * (lane >> 5) + qd;
-        const unsigned base = (unsigned)(unsigned long)(lds_char*)ring + (col & 7) * 2;
-        vaddr[0] = base + lds_off<DUAL>(row, col >> 3);
-        vaddr[1] = base + lds_off<DUAL>(row + 8, col >> 3);
-    }
-    const int ntiles = (p.S + KT - 1) / KT;
-    auto dma = [&](int tile, int st) {
-        __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, kbytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, vbytes, 0x00020000);
-        char* kd = ring + st * 2 * IMG + wave * 1024;
-        const unsigned ks = (unsigned)(tile * KT) * k_rsb, vs = (unsigned)(tile * KT) * v_rsb;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)(kd + 4096 * i), 16, koff[i], ks, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(kd + IMG + 4096 * i), 16, voff[i], vs, 0, 0);
-        }
-    };
-    // one byte per (tile, lane): is key 64 tile + lane past S or a padding key
-    const unsigned char* padrow = p.key_pad ? p.key_pad + (long long)b * p.S : nullptr;
-    auto pad_of = [&](int tile) -> unsigned {
-        const int sk = tile * KT + lane;
-        if (sk >= p.S) return 1u;
-        return padrow ? (unsigned)padrow[sk] : 0u;
-    };
-    const long long mrow = ((long long)b * p.H + h) * p.T + t;
-
-    auto body = [&](int tile, const char* k_lds, const char* v_lds, unsigned padb) {
-        const int s0 = tile * KT;
-        const unsigned long long dead = __ballot(padb != 0);
-        f32x16 sc[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < NF; ++kk) sc[kb] = mm<T>(row_frag<DUAL>(k_lds, kb * 32, kk, lane), qf[kk], sc[kb]);
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[kb][r] = fmaf(sc[kb][r], c, negm);
-        if (dead) {  // wave-uniform: this tile holds masked keys
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                unsigned dm = (unsigned)(dead >> (32 * kb)) >> (4 * (lane >> 5));
-                asm volatile("; masked keys" : "+v"(dm));  // (keeps this a real branch: if-converted, the selects cost 3 instructions per score in every tile)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if ((dm >> ((r & 3) + 8 * (r >> 2))) & 1u) sc[kb][r] = -INFINITY;
-            }
-        }
-        float tmax = fmaxf(sc[0][0], sc[1][0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sc[0][r]), sc[1][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const bool move = anch ? tmax > LAG_THR : tmax > -INFINITY;
-        if (__any(move)) {  // (re-)anchor the rows that ask for it: everything held at the old maximum is scaled exactly once
-            const float delta = move ? tmax : 0.f;
-            const float alpha = (move && anch) ? __builtin_amdgcn_exp2f(-delta) : 1.f;  // unanchored rows hold zeros
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sc[kb][r] -= delta;
-#pragma unroll
-            for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
-            l *= alpha;
-            negm -= delta;
-            anch = anch || move;
-        }
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pw = __builtin_amdgcn_exp2f(sc[kb][r]);
-                sc[kb][r] = pw;
-                psum += pw;
-            }
-        l += psum;  // the softmax denominator does not see the dropout
-        if constexpr (DROP) {  // the bits of the kernel above: one Philox draw per 8 keys of a row, a dword of keep bits per 32 keys
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                unsigned word = 0;
-                const unsigned thr16 = p.drop_thr >> 16;
-                const bool hi = lane >= 32;
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    const int g_own = 2 * gp + (hi ? 1 : 0);
-                    const unsigned long long ctr = ((unsigned long long)mrow * 8ull * p.mask_pitch + (s0 + kb * 32 + 8 * g_own)) >> 3;
-                    const Philox4 rr = philox4x32_10(p.seed, p.offset, ctr);
-                    const unsigned got0 = __shfl_xor(hi ? rr.x : rr.z, 32, 64), got1 = __shfl_xor(hi ? rr.y : rr.w, 32, 64);
-                    const unsigned wv[2][2] = {{hi ? got0 : rr.x, hi ? got1 : rr.y}, {hi ? rr.z : got0, hi ? rr.w : got1}};
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int g = 2 * gp + u;
-                        const bool keep[4] = {(wv[u][0] & 0xffffu) >= thr16, (wv[u][0] >> 16) >= thr16,
-                                              (wv[u][1] & 0xffffu) >= thr16, (wv[u][1] >> 16) >= thr16};
-                        unsigned nib = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            nib |= (unsigned)keep[j] << j;
-                            if (!keep[j]) sc[kb][4 * g + j] = 0.f;
-                        }
-                        word |= nib << (8 * g + 4 * (lane >> 5));
-                    }
-                }
-                word |= __shfl_xor(word, 32, 64);
-                if (valid && lane < 32)
-                    *reinterpret_cast<unsigned*>(p.drop_mask + mrow * p.mask_pitch + ((s0 + kb * 32) >> 3)) = word;
-            }
-        }
-        // Oᵀ[d][query] += Vᵀ[d][key] · P[key][query].  The transposed reads are inline asm: behind the builtin the compiler drains
-        // vmcnt before every LDS read that might alias the DMA in flight (the next tile's), which would put the whole flight
-        // time in front of these MFMAs.  The wait that covers them names the fragments, so no MFMA can be scheduled above it.
-        s16x4 vt[2][2][ND][2];  // [key block][k-step][d-tile][rows +0 / +8]
-        const unsigned va0 = vaddr[0] + (unsigned)(v_lds - ring), va8 = vaddr[1] + (unsigned)(v_lds - ring);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int dt = 0; dt < ND; ++dt) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[kb][s][dt][0]) : "v"(va0), "i"(1024 * (4 * kb + 2 * s) + 512 * dt));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[kb][s][dt][1]) : "v"(va8), "i"(1024 * (4 * kb + 2 * s) + 512 * dt));
-                }
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(vt[0][0][0][0]), "+v"(vt[0][0][0][1]), "+v"(vt[0][0][1][0]), "+v"(vt[0][0][1][1]),
-                       "+v"(vt[0][1][0][0]), "+v"(vt[0][1][0][1]), "+v"(vt[0][1][1][0]), "+v"(vt[0][1][1][1]),
-                       "+v"(vt[1][0][0][0]), "+v"(vt[1][0][0][1]), "+v"(vt[1][0][1][0]), "+v"(vt[1][0][1][1]),
-                       "+v"(vt[1][1][0][0]), "+v"(vt[1][1][0][1]), "+v"(vt[1][1][1][0]), "+v"(vt[1][1][1][1]));
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8_t pf = acc_frag<T>(sc[kb], s);
-#pragma unroll
-                for (int dt = 0; dt < ND; ++dt) {
-                    const s16x4 lo = vt[kb][s][dt][0], hi = vt[kb][s][dt][1];
-                    const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc[dt] = mm<T>(__builtin_bit_cast(bf16x8_t, f), pf, acc[dt]);
-                }
-            }
-    };
-
-    if (ntiles > 0) dma(0, 0);
-    unsigned padb = ntiles > 0 ? pad_of(0) : 0u;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the tile (and its stores of the tile before)
-        __syncthreads();                                   // everyone's pieces; the other stage is free
-        unsigned padn = 0;
-        if (tile + 1 < ntiles) {
-            dma(tile + 1, (tile + 1) & 1);
-            padn = pad_of(tile + 1);
-        }
-        const char* st = ring + (tile & 1) * 2 * IMG;
-        body(tile, st, st + IMG, padb);
-        padb = padn;
-    }
-    l += __shfl_xor(l, 32, 64);
-    float inv = l > 0.f ? 1.f / l : 0.f;
-    if constexpr (DROP) inv *= p.drop_scale;
-    store_rowT(o + b * p.o_bs + h * HD, p.o_rs, t, valid, acc, inv, lane);
-    if (valid && lane < 32) lse[mrow] = l > 0.f ? (log2f(l) - negm) * LN2 : 0.f;
 }
 
 // ---- dK / dV backward: key on the lane ----
@@ -1026,6 +486,11 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
     load_row_frags(kf, k + b * p.k_bs + h * HD, p.k_rs, s, s < p.S, lane);
     load_row_frags(vf, v + b * p.v_bs + h * HD, p.v_rs, s, s < p.S, lane);
     if (p.rope_cos) rope_frags<NF, T>(kf, p, p.rope_k0 + s, lane);
+    // K carries c = scale log2(e): S = Q (c K)ᵀ starts from the accumulator -lse log2(e) (rows of the staged tile) and leaves
+    // x = s c - lse, dP = dO Vᵀ starts from -delta: p = exp2(x), dS = p dP' — two vector instructions per score besides the
+    // conversions (was ~10).  A padding key / key past S is a whole lane here: its dK, dV rows are zeroed at the end instead of
+    // a -inf bias in every score.  (With dropout dP is scaled before delta comes off: explicit form, zero accumulators.)
+    scale_frags<NF, T>(kf, c);
     f32x16 dka[ND], dva[ND];  // dKᵀ, dVᵀ: [d-tile][d rows] x key lane
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt)
@@ -1037,7 +502,6 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
     int t_begin = 0;
     if (p.causal) t_begin = max(0, (int)(blockIdx.x * 128) - off) / KT * KT;
     const int ws0 = blockIdx.x * 128 + wave * 32;          // first key of this wave
-    const float lane_bias = kvalid ? 0.f : -INFINITY;      // padding keys / keys past S: p = exp2(-inf) = 0
     const T* qbase = q + b * p.q_bs + h * HD;
     const T* dobase = d_o + b * p.do_bs + h * HD;
     uint4 qreg[2 * NI], doreg[2 * NI];
@@ -1056,8 +520,8 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
         if (tid < KT) {
             int t = t0 + tid;
             long long row = ((long long)b * p.H + h) * p.T + t;
-            l2_lds[tid] = t < p.T ? lse[row] * LOG2E : INFINITY;  // +inf -> p = 0 for rows past T
-            dl_lds[tid] = t < p.T ? delta[row] : 0.f;
+            l2_lds[tid] = t < p.T ? -lse[row] * LOG2E : -INFINITY;  // (negated: initial accumulators) -inf -> p = 0 for rows past T
+            dl_lds[tid] = t < p.T ? -delta[row] : 0.f;
         }
         if (t0 + KT < p.T) {  // prefetch the next query tile into registers
             tile_g2r(qreg, qbase, p.q_rs, t0 + KT, p.T, tid);
@@ -1072,36 +536,49 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 sc, dp;  // S[query][key], dP[query][key]
+            float4 d4[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
+            for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are 4 consecutive queries: one 16-B read each of -lse, -delta
+                const int tl = qb * 32 + 8 * g + 4 * (lane >> 5);
+                const float4 l4 = *reinterpret_cast<const float4*>(l2_lds + tl);
+                d4[g] = *reinterpret_cast<const float4*>(dl_lds + tl);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sc[4 * g + j] = (&l4.x)[j];
+                    dp[4 * g + j] = DROP ? 0.f : (&d4[g].x)[j];
+                }
+            }
 #pragma unroll
             for (int kk = 0; kk < NF; ++kk) {
                 sc = mm<T>(row_frag<DUAL>(q_lds, qb * 32, kk, lane), kf[kk], sc);
                 if constexpr (DO_K)
                     dp = mm<T>(row_frag<DUAL>(do_lds, qb * 32, kk, lane), vf[kk], dp);
             }
+            if (check) {  // wave-uniform: the causal boundary crosses this (tile, wave) block
+                int sq = s - off - t0 - qb * 32 - 4 * (lane >> 5);  // key s is visible to query index (in the block) >= sq
+                asm volatile("; causal block" : "+v"(sq));          // (a real branch: if-converted, the selects cost 4 instructions per score in every tile)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) < sq) sc[r] = -INFINITY;
+            }
             f32x16 ds;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are 4 consecutive queries: one 16-B read each of lse, delta
-                const int tl = qb * 32 + 8 * g + 4 * (lane >> 5);
-                const float4 l4 = *reinterpret_cast<const float4*>(l2_lds + tl);
-                const float4 d4 = *reinterpret_cast<const float4*>(dl_lds + tl);
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float x = fmaf(sc[4 * g + j], c, lane_bias) - (&l4.x)[j];
-                    if (check) x = s > t0 + tl + j + off ? -INFINITY : x;
-                    const float pw = __builtin_amdgcn_exp2f(x);
-                    float pv = pw, dpv = dp[4 * g + j];
+                    const float pw = __builtin_amdgcn_exp2f(sc[4 * g + j]);
                     if constexpr (DROP) {  // keep bit of (query t0+tl+j, this lane's key): bit lane & 31 of the wave's dword
+                        const int tl = qb * 32 + 8 * g + 4 * (lane >> 5);
                         const unsigned wd = m_lds[(tl + j) * 4 + wave];
                         const bool keep = s < p.S && ((wd >> (lane & 31)) & 1u);  // (rows past T were staged as zeros)
-                        pv = keep ? pw * p.drop_scale : 0.f;
-                        dpv = keep ? dpv * p.drop_scale : 0.f;
+                        sc[4 * g + j] = keep ? pw * p.drop_scale : 0.f;
+                        const float dpv = keep ? dp[4 * g + j] * p.drop_scale : 0.f;
+                        ds[4 * g + j] = pw * (dpv + (&d4[g].x)[j]);
+                    } else {
+                        sc[4 * g + j] = pw;
+                        ds[4 * g + j] = pw * dp[4 * g + j];
                     }
-                    sc[4 * g + j] = pv;
-                    ds[4 * g + j] = pw * (dpv - (&d4.x)[j]);
                 }
-            }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 bf16x8_t pf = acc_frag<T>(sc, st), dsf = acc_frag<T>(ds, st);
@@ -1117,6 +594,12 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
                 }
             }
         }
+    }
+    if (!kvalid) {  // padding keys: zero rows (a select, not a product: their probabilities are unbounded)
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dka[dt][r] = dva[dt][r] = 0.f;
     }
     if constexpr (DO_K) {
         if (p.rope_cos) rope_acc_inverse<ND>(dka, p, p.rope_k0 + s, lane);
@@ -1200,18 +683,21 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
         part += __shfl_xor(part, 2);
         part += __shfl_xor(part, 4);  // the 8 lanes of a row
         if (ch == 0) {
-            dl_lds[r] = part;
+            dl_lds[r] = DROP ? part : -part;  // (negated without dropout: the initial accumulator of dP)
             if (r < p.T) delta[((long long)b * p.H + h) * p.T + r] = part;
         }
     }
-    if (tid < 128) l2_lds[tid] = tid < p.T ? lse[((long long)b * p.H + h) * p.T + tid] * LOG2E : INFINITY;
+    // negated: the initial accumulator of S (rows past T: -inf -> p = 0)
+    if (tid < 128) l2_lds[tid] = tid < p.T ? -lse[((long long)b * p.H + h) * p.T + tid] * LOG2E : -INFINITY;
     const int s = wave * 32 + (lane & 31);
     const bool kvalid = s < p.S && !(p.key_pad && p.key_pad[(long long)b * p.S + min(s, p.S - 1)]);
-    const float lane_bias = kvalid ? 0.f : -INFINITY;
     bf16x8_t kf[4], vf[4];
     load_row_frags(kf, kbase, p.k_rs, s, s < p.S, lane);
     load_row_frags(vf, v + b * p.v_bs + h * HD64, p.v_rs, s, s < p.S, lane);
     if (p.rope_cos) rope_frags<4, T>(kf, p, p.rope_k0 + s, lane);
+    // K carries c = scale log2(e); S starts from the accumulator -lse log2(e) (-inf on the lane of a padding key / key past S),
+    // dP from -delta: p = exp2(x), dS = p dP' (as in the dK / dV kernel above)
+    scale_frags<4, T>(kf, c);
     f32x16 dka[2], dva[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -1227,33 +713,47 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
         if (p.causal && ws0 > t0 + 31 + off) continue;       // every key of this wave is in the future of these queries
         const bool check = p.causal && ws0 + 31 > t0 + off;
         f32x16 sc, dp;
+        float4 d4[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
+        for (int g = 0; g < 4; ++g) {
+            const int tl = t0 + 8 * g + 4 * (lane >> 5);
+            const float4 l4 = *reinterpret_cast<const float4*>(l2_lds + tl);
+            d4[g] = *reinterpret_cast<const float4*>(dl_lds + tl);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sc[4 * g + j] = kvalid ? (&l4.x)[j] : -INFINITY;
+                dp[4 * g + j] = DROP ? 0.f : (&d4[g].x)[j];
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             sc = mm<T>(row_frag<DUAL>(q_lds, t0, kk, lane), kf[kk], sc);
             dp = mm<T>(row_frag<DUAL>(do_lds, t0, kk, lane), vf[kk], dp);
         }
+        if (check) {  // wave-uniform: the causal boundary crosses this (queries, keys) block
+            int sq = s - off - t0 - 4 * (lane >> 5);  // key s is visible to query index (in the block) >= sq
+            asm volatile("; causal block" : "+v"(sq));  // (a real branch: if-converted, the selects cost 4 instructions per score in every block)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((r & 3) + 8 * (r >> 2) < sq) sc[r] = -INFINITY;
+        }
         f32x16 ds;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int tl = t0 + 8 * g + 4 * (lane >> 5);
-            const float4 l4 = *reinterpret_cast<const float4*>(l2_lds + tl);
-            const float4 d4 = *reinterpret_cast<const float4*>(dl_lds + tl);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float x = fmaf(sc[4 * g + j], c, lane_bias) - (&l4.x)[j];
-                if (check) x = s > tl + j + off ? -INFINITY : x;
-                const float pw = __builtin_amdgcn_exp2f(x);
-                float pv = pw, dpv = dp[4 * g + j];
+                const float pw = __builtin_amdgcn_exp2f(sc[4 * g + j]);
                 if constexpr (DROP) {
                     const unsigned wd = m_lds[(tl + j) * 4 + wave];
                     const bool keep = s < p.S && ((wd >> (lane & 31)) & 1u);  // (rows past T were staged as zeros)
-                    pv = keep ? pw * p.drop_scale : 0.f;
-                    dpv = keep ? dpv * p.drop_scale : 0.f;
+                    sc[4 * g + j] = keep ? pw * p.drop_scale : 0.f;
+                    const float dpv = keep ? dp[4 * g + j] * p.drop_scale : 0.f;
+                    ds[4 * g + j] = pw * (dpv - (&d4[g].x)[j]);
+                } else {
+                    sc[4 * g + j] = pw;
+                    ds[4 * g + j] = pw * dp[4 * g + j];
                 }
-                sc[4 * g + j] = pv;
-                ds[4 * g + j] = pw * (dpv - (&d4.x)[j]);
             }
             unsigned lo = (unsigned)H16<T>::bits(ds[4 * g]) | ((unsigned)H16<T>::bits(ds[4 * g + 1]) << 16);
             unsigned hi = (unsigned)H16<T>::bits(ds[4 * g + 2]) | ((unsigned)H16<T>::bits(ds[4 * g + 3]) << 16);
@@ -1411,13 +911,7 @@ int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* l
     static const int long_min_s = [] { const char* e = getenv("PK_ATTN_LONG_MIN_S"); return e ? atoi(e) : 256; }();
     if (dtype != PK_F32 && hd == 64 && !causal && !p.rope_cos && S >= long_min_s &&
         (long long)S * std::max(k_rs, v_rs) * 2 < (1LL << 31)) {
-        const int nqb = (T + 127) / 128, npairs = B * H;
-        const dim3 lg((unsigned)((npairs + 7) / 8 * 8) * nqb);
-#define PK_LONG(TT, DR) hipLaunchKernelGGL((attn_fwd_long_kernel<TT, DR>), lg, dim3(256), 0, s, (const TT*)q, (const TT*)k, \
-                                           (const TT*)v, (TT*)o, lse, p, nqb, npairs)
-        if (dtype == PK_BF16) { if (p.drop_thr) PK_LONG(bf16, true); else PK_LONG(bf16, false); }
-        else { if (p.drop_thr) PK_LONG(f16, true); else PK_LONG(f16, false); }
-#undef PK_LONG
+        PK_CHECK_ARG(pk_attn_fwd_long_launch(q, k, v, o, lse, p, dtype, s) == 0, "pk_attn_fwd: launch of the long-sequence kernel failed");
         PK_LAUNCH_CHECK();
         return 0;
     }

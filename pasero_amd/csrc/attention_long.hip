@@ -1,0 +1,272 @@
+// Forward attention for long key sequences (round 4).  A file of its own because it is built with -fno-slp-vectorize: its loop
+// body places four scalar vector instructions behind every MFMA by hand, and the SLP vectoriser would gather them into packed
+// instructions behind the last MFMA (packed f32 instructions beside MFMAs are slower than the scalar pairs anyway:
+// MI355X_MICROARCH.md, cycle constants).
+#include "attention_common.h"
+
+namespace {
+
+// ---- forward for long key sequences (round 4): head_dim 64, no causal mask, no rotation ----
+// The kernel above spends ~10 vector instructions per (query, key) score (scale + bias, the causal select, running maximum,
+// subtraction, exp, sum, accumulator rescale, conversion) against 16 MFMAs per 2048 scores: at S >= 500 it is paced by its
+// VALU work, not by the matrix pipe (0.5 ps per pair whatever the shape).  This form keeps 4 per score:
+//   * the maximum LAGS: a query's scores are taken relative to the maximum m its row was last anchored at, x = s c - m (no
+//     instruction: Q is scaled by c when it is loaded and the MFMA chain starts from -m), and m moves only when a tile's maximum exceeds it by more than LAG_THR (exp2 domain: p <= 2^LAG_THR, in range for
+//     both 16-bit types, relative precision unchanged) — the accumulator rescale, the exp of the correction and the
+//     subtraction leave the loop body for a wave-uniform branch that is rare after the first tile;
+//   * keys past S / padding keys are found per tile by one ballot; only tiles that hold one pay for the selects;
+//   * K and V tiles arrive by LDS-DMA (buffer_load ... lds, 16 B per lane, rows past S read as zeros through the buffer
+//     bound) into a two-deep ring of dual-use images (lds_off<DUAL>: a 1-KiB DMA piece is one 8-row group, the lane picks the
+//     global chunk that belongs at its LDS position), one barrier per tile, nothing staged through registers;
+//   * workgroups of one (batch, head) pair sit on one XCD (their K / V stay in that L2).
+// Same accumulator layouts, Q fragments and row stores as the kernel above.  A row's arithmetic depends on its own data only
+// (a lane re-anchors only when ITS maximum says so).
+constexpr float LAG_THR = 8.f;
+#ifndef PKL_WAVES
+#define PKL_WAVES 3  // waves per SIMD the register budget leaves room for
+#endif
+
+template <typename T, bool DROP>
+__global__ __launch_bounds__(256, PKL_WAVES) void attn_fwd_long_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                               const T* __restrict__ v, T* __restrict__ o,
+                                                               float* __restrict__ lse, AttnParams p, int nqb, int npairs) {
+    constexpr int HD = 64, NF = 4, ND = 2;
+    constexpr int IMG = img_bytes<DUAL>();  // 8 KiB: [64 rows][64 x 16 bit]
+    typedef __attribute__((address_space(3))) void lds_void;
+#ifndef PKL_LDS_PAD
+#define PKL_LDS_PAD 0  // diagnostic builds: extra LDS per workgroup (fewer workgroups per CU)
+#endif
+    __shared__ __attribute__((aligned(1024))) char ring[2 * 2 * IMG + PKL_LDS_PAD];  // stage st: K image at 2 st IMG, V image behind it
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lin = blockIdx.x, grp = (lin >> 3) / nqb, qb = (lin >> 3) % nqb;
+    const int pair = grp * 8 + (lin & 7);
+    if (pair >= npairs) return;
+    const int b = pair / p.H, h = pair % p.H;
+    const int t = qb * 128 + wave * 32 + (lane & 31);
+    const bool valid = t < p.T;
+    const float c = p.scale * LOG2E;
+
+    // Q arrives scaled by c = scale log2(e) (rounded to the 16-bit type once more, as the reference's own q * scaling is): the
+    // MFMA chain then starts from the accumulator -m and leaves x = s c - m with no vector instruction at all
+    bf16x8_t qf[NF];
+    load_row_frags(qf, q + b * p.q_bs + h * HD, p.q_rs, t, valid, lane);
+#pragma unroll
+    for (int kk = 0; kk < NF; ++kk) {
+        s16x8 raw = __builtin_bit_cast(s16x8, qf[kk]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[j] = (short)H16<T>::bits(H16<T>::val((unsigned short)raw[j]) * c);
+        qf[kk] = __builtin_bit_cast(bf16x8_t, raw);
+    }
+    f32x16 acc[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    float negm = 0.f, l = 0.f;  // -m (exp2 domain) once the row is anchored, 0 before
+    f32x16 negm16;              // the same in every register: the initial accumulator of the score MFMAs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm16[r] = 0.f;
+    bool anch = false;
+
+    // LDS-DMA: wave w brings the 8-row pieces w and w + 4 of the K and of the V tile; lane L lands at byte 16 L of its piece
+    const T* kbase = k + b * p.k_bs + h * HD;
+    const T* vbase = v + b * p.v_bs + h * HD;
+    const unsigned k_rsb = (unsigned)(p.k_rs * 2), v_rsb = (unsigned)(p.v_rs * 2);
+    const int kbytes = (int)(((long long)(p.S - 1) * p.k_rs + HD) * 2), vbytes = (int)(((long long)(p.S - 1) * p.v_rs + HD) * 2);
+    unsigned koff[2], voff[2];
+    {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 8 * (wave + 4 * i) + ((lane >> 2) & 7);
+            const int ch = 4 * (lane >> 5) + ((lane & 3) ^ ((row >> 2) & 3));  // (the inverse of lds_off<DUAL>)
+            koff[i] = (unsigned)row * k_rsb + 16 * ch;
+            voff[i] = (unsigned)row * v_rsb + 16 * ch;
+        }
+    }
+    // transposed reads of the V image (tr_frag<DUAL>): lane addresses of rows 4 h + q and 4 h + q + 8 of d-tile 0; key block kb and
+    // k-step s add 1024 (4 kb + 2 s) bytes (16 keys = two 8-row groups of 1 KiB, the swizzle class of a row does not change),
+    // d-tile 1 adds 512 (chunks 4..7 of a row)
+    unsigned vaddr[2];
+    {
+        typedef __attribute__((address_space(3))) char lds_char;
+        const int qd = (lane & 15) >> 2, p4 = lane & 3;
+        const int col = 16 * ((lane >> 4) & 1) + 4 * p4, row = 4 * (lane >> 5) + qd;
+        const unsigned base = (unsigned)(unsigned long)(lds_char*)ring + (col & 7) * 2;
+        vaddr[0] = base + lds_off<DUAL>(row, col >> 3);
+        vaddr[1] = base + lds_off<DUAL>(row + 8, col >> 3);
+    }
+    const int ntiles = (p.S + KT - 1) / KT;
+    auto dma = [&](int tile, int st) {
+        __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, kbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, vbytes, 0x00020000);
+        char* kd = ring + st * 2 * IMG + wave * 1024;
+        const unsigned ks = (unsigned)(tile * KT) * k_rsb, vs = (unsigned)(tile * KT) * v_rsb;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)(kd + 4096 * i), 16, koff[i], ks, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(kd + IMG + 4096 * i), 16, voff[i], vs, 0, 0);
+        }
+    };
+    // one byte per (tile, lane): is key 64 tile + lane past S or a padding key
+    const unsigned char* padrow = p.key_pad ? p.key_pad + (long long)b * p.S : nullptr;
+    auto pad_of = [&](int tile) -> unsigned {
+        const int sk = tile * KT + lane;
+        if (sk >= p.S) return 1u;
+        return padrow ? (unsigned)padrow[sk] : 0u;
+    };
+    const long long mrow = ((long long)b * p.H + h) * p.T + t;
+
+    auto body = [&](int tile, const char* k_lds, const char* v_lds, unsigned padb) {
+        const int s0 = tile * KT;
+        const unsigned long long dead = __ballot(padb != 0);
+        f32x16 sc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            sc[kb] = mm<T>(row_frag<DUAL>(k_lds, kb * 32, 0, lane), qf[0], negm16);
+#pragma unroll
+            for (int kk = 1; kk < NF; ++kk) sc[kb] = mm<T>(row_frag<DUAL>(k_lds, kb * 32, kk, lane), qf[kk], sc[kb]);
+        }
+        if (dead) {  // wave-uniform: this tile holds masked keys
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                unsigned dm = (unsigned)(dead >> (32 * kb)) >> (4 * (lane >> 5));
+                asm volatile("; masked keys" : "+v"(dm));  // (keeps this a real branch: if-converted, the selects cost 3 instructions per score in every tile)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((dm >> ((r & 3) + 8 * (r >> 2))) & 1u) sc[kb][r] = -INFINITY;
+            }
+        }
+        float tmax = fmaxf(sc[0][0], sc[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sc[0][r]), sc[1][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const bool move = anch ? tmax > LAG_THR : tmax > -INFINITY;
+        if (__any(move)) {  // (re-)anchor the rows that ask for it: everything held at the old maximum is scaled exactly once
+            const float delta = move ? tmax : 0.f;
+            const float alpha = (move && anch) ? __builtin_amdgcn_exp2f(-delta) : 1.f;  // unanchored rows hold zeros
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[kb][r] -= delta;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+            l *= alpha;
+            negm -= delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm16[r] = negm;
+            anch = anch || move;
+        }
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        f32x2 ps2[2] = {{0.f, 0.f}, {0.f, 0.f}};  // packed adds: half the instructions of the row sum
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(sc[kb][r]), p1 = __builtin_amdgcn_exp2f(sc[kb][r + 1]);
+                sc[kb][r] = p0;
+                sc[kb][r + 1] = p1;
+                ps2[kb] += f32x2{p0, p1};
+            }
+        l += (ps2[0].x + ps2[1].x) + (ps2[0].y + ps2[1].y);  // the softmax denominator does not see the dropout
+        if constexpr (DROP) {  // the bits of the kernel above: one Philox draw per 8 keys of a row, a dword of keep bits per 32 keys
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                unsigned word = 0;
+                const unsigned thr16 = p.drop_thr >> 16;
+                const bool hi = lane >= 32;
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const int g_own = 2 * gp + (hi ? 1 : 0);
+                    const unsigned long long ctr = ((unsigned long long)mrow * 8ull * p.mask_pitch + (s0 + kb * 32 + 8 * g_own)) >> 3;
+                    const Philox4 rr = philox4x32_10(p.seed, p.offset, ctr);
+                    const unsigned got0 = __shfl_xor(hi ? rr.x : rr.z, 32, 64), got1 = __shfl_xor(hi ? rr.y : rr.w, 32, 64);
+                    const unsigned wv[2][2] = {{hi ? got0 : rr.x, hi ? got1 : rr.y}, {hi ? rr.z : got0, hi ? rr.w : got1}};
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int g = 2 * gp + u;
+                        const bool keep[4] = {(wv[u][0] & 0xffffu) >= thr16, (wv[u][0] >> 16) >= thr16,
+                                              (wv[u][1] & 0xffffu) >= thr16, (wv[u][1] >> 16) >= thr16};
+                        unsigned nib = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            nib |= (unsigned)keep[j] << j;
+                            if (!keep[j]) sc[kb][4 * g + j] = 0.f;
+                        }
+                        word |= nib << (8 * g + 4 * (lane >> 5));
+                    }
+                }
+                word |= __shfl_xor(word, 32, 64);
+                if (valid && lane < 32)
+                    *reinterpret_cast<unsigned*>(p.drop_mask + mrow * p.mask_pitch + ((s0 + kb * 32) >> 3)) = word;
+            }
+        }
+        // Oᵀ[d][query] += Vᵀ[d][key] · P[key][query].  The transposed reads are inline asm: behind the builtin the compiler drains
+        // vmcnt before every LDS read that might alias the DMA in flight (the next tile's), which would put the whole flight
+        // time in front of these MFMAs.  The wait that covers them names the fragments, so no MFMA can be scheduled above it.
+        s16x4 vt[2][2][ND][2];  // [key block][k-step][d-tile][rows +0 / +8]
+        const unsigned va0 = vaddr[0] + (unsigned)(v_lds - ring), va8 = vaddr[1] + (unsigned)(v_lds - ring);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[kb][s][dt][0]) : "v"(va0), "i"(1024 * (4 * kb + 2 * s) + 512 * dt));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[kb][s][dt][1]) : "v"(va8), "i"(1024 * (4 * kb + 2 * s) + 512 * dt));
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(vt[0][0][0][0]), "+v"(vt[0][0][0][1]), "+v"(vt[0][0][1][0]), "+v"(vt[0][0][1][1]),
+                       "+v"(vt[0][1][0][0]), "+v"(vt[0][1][0][1]), "+v"(vt[0][1][1][0]), "+v"(vt[0][1][1][1]),
+                       "+v"(vt[1][0][0][0]), "+v"(vt[1][0][0][1]), "+v"(vt[1][0][1][0]), "+v"(vt[1][0][1][1]),
+                       "+v"(vt[1][1][0][0]), "+v"(vt[1][1][0][1]), "+v"(vt[1][1][1][0]), "+v"(vt[1][1][1][1]));
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8_t pf = acc_frag<T>(sc[kb], s);
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) {
+                    const s16x4 lo = vt[kb][s][dt][0], hi = vt[kb][s][dt][1];
+                    const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc[dt] = mm<T>(__builtin_bit_cast(bf16x8_t, f), pf, acc[dt]);
+                }
+            }
+    };
+
+    if (ntiles > 0) dma(0, 0);
+    unsigned padb = ntiles > 0 ? pad_of(0) : 0u;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the tile (and its stores of the tile before)
+        __syncthreads();                                   // everyone's pieces; the other stage is free
+        unsigned padn = 0;
+        if (tile + 1 < ntiles) {
+            dma(tile + 1, (tile + 1) & 1);
+            padn = pad_of(tile + 1);
+        }
+        const char* st = ring + (tile & 1) * 2 * IMG;
+        body(tile, st, st + IMG, padb);
+        padb = padn;
+    }
+    l += __shfl_xor(l, 32, 64);
+    float inv = l > 0.f ? 1.f / l : 0.f;
+    if constexpr (DROP) inv *= p.drop_scale;
+    store_rowT(o + b * p.o_bs + h * HD, p.o_rs, t, valid, acc, inv, lane);
+    if (valid && lane < 32) lse[mrow] = l > 0.f ? (log2f(l) - negm) * LN2 : 0.f;
+}
+
+}  // namespace
+
+int pk_attn_fwd_long_launch(const void* q, const void* k, const void* v, void* o, float* lse, const pkattn::AttnParams& p, int dtype,
+                            hipStream_t s) {
+    const int nqb = (p.T + 127) / 128, npairs = p.B * p.H;
+    const dim3 lg((unsigned)((npairs + 7) / 8 * 8) * nqb);
+#define PK_LONG(TT, DR) hipLaunchKernelGGL((attn_fwd_long_kernel<TT, DR>), lg, dim3(256), 0, s, (const TT*)q, (const TT*)k, \
+                                           (const TT*)v, (TT*)o, lse, p, nqb, npairs)
+    if (dtype == PK_BF16) { if (p.drop_thr) PK_LONG(bf16, true); else PK_LONG(bf16, false); }
+    else { if (p.drop_thr) PK_LONG(f16, true); else PK_LONG(f16, false); }
+#undef PK_LONG
+    return (int)hipGetLastError();
+}
