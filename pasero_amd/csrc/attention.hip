@@ -502,6 +502,7 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
     int t_begin = 0;
     if (p.causal) t_begin = max(0, (int)(blockIdx.x * 128) - off) / KT * KT;
     const int ws0 = blockIdx.x * 128 + wave * 32;          // first key of this wave
+    const unsigned keep_bit = s < p.S ? 1u << (lane & 31) : 0u;  // (dropout) this lane's bit of a stored keep dword
     const T* qbase = q + b * p.q_bs + h * HD;
     const T* dobase = d_o + b * p.do_bs + h * HD;
     uint4 qreg[2 * NI], doreg[2 * NI];
@@ -570,10 +571,9 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
                     if constexpr (DROP) {  // keep bit of (query t0+tl+j, this lane's key): bit lane & 31 of the wave's dword
                         const int tl = qb * 32 + 8 * g + 4 * (lane >> 5);
                         const unsigned wd = m_lds[(tl + j) * 4 + wave];
-                        const bool keep = s < p.S && ((wd >> (lane & 31)) & 1u);  // (rows past T were staged as zeros)
-                        sc[4 * g + j] = keep ? pw * p.drop_scale : 0.f;
-                        const float dpv = keep ? dp[4 * g + j] * p.drop_scale : 0.f;
-                        ds[4 * g + j] = pw * (dpv + (&d4[g].x)[j]);
+                        const float km = (wd & keep_bit) ? p.drop_scale : 0.f;  // (rows past T were staged as zeros)
+                        sc[4 * g + j] = pw * km;
+                        ds[4 * g + j] = pw * fmaf(dp[4 * g + j], km, (&d4[g].x)[j]);
                     } else {
                         sc[4 * g + j] = pw;
                         ds[4 * g + j] = pw * dp[4 * g + j];
@@ -707,6 +707,7 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
 
     // ---- phase 1: key on the lane ----
     const int ws0 = wave * 32;
+    const unsigned keep_bit = s < p.S ? 1u << (lane & 31) : 0u;  // (dropout) this lane's bit of a stored keep dword
     for (int qb = 0; qb < 4; ++qb) {
         const int t0 = qb * 32;
         if (t0 >= p.T) break;
@@ -746,10 +747,9 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
                 const float pw = __builtin_amdgcn_exp2f(sc[4 * g + j]);
                 if constexpr (DROP) {
                     const unsigned wd = m_lds[(tl + j) * 4 + wave];
-                    const bool keep = s < p.S && ((wd >> (lane & 31)) & 1u);  // (rows past T were staged as zeros)
-                    sc[4 * g + j] = keep ? pw * p.drop_scale : 0.f;
-                    const float dpv = keep ? dp[4 * g + j] * p.drop_scale : 0.f;
-                    ds[4 * g + j] = pw * (dpv - (&d4[g].x)[j]);
+                    const float km = (wd & keep_bit) ? p.drop_scale : 0.f;  // (rows past T were staged as zeros)
+                    sc[4 * g + j] = pw * km;
+                    ds[4 * g + j] = pw * fmaf(dp[4 * g + j], km, -(&d4[g].x)[j]);
                 } else {
                     sc[4 * g + j] = pw;
                     ds[4 * g + j] = pw * dp[4 * g + j];
