@@ -85,20 +85,30 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, l
     if (active || row_lse) {
         float m = -INFINITY, s = 0.f, tot = 0.f;
         const long long nvec = vec_ok ? V / EPV : 0;
-        for (long long ch = tid; ch < nvec; ch += 256) {
-            Vec16<T> v = load16<T>(x + ch * EPV);
+        // four 16-byte loads in flight per thread (one per iteration left the pass latency-bound: 3.7 TB/s at V = 70 376)
+        auto take = [&](const Vec16<T>& v) {
             float cm = v.get(0);
 #pragma unroll
             for (int e = 1; e < EPV; ++e) cm = fmaxf(cm, v.get(e));
+            const float mn = fmaxf(m, cm);  // one rescale of the running sum per chunk, the chunk's terms against the new maximum
+            const float ms = mn == -INFINITY ? 0.f : mn;  // (nothing but -inf so far: every term is exp(-inf) = 0)
             float cs = 0.f;
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
                 float a = v.get(e);
-                cs += __expf(a - cm);
+                cs += __expf(a - ms);
                 tot += a;
             }
-            online_merge(m, s, cm, cs);
+            s = s * __expf(m - ms) + cs;
+            m = mn;
+        };
+        long long ch = tid;
+        for (; ch + 768 < nvec; ch += 1024) {
+            const Vec16<T> v0 = load16<T>(x + ch * EPV), v1 = load16<T>(x + (ch + 256) * EPV);
+            const Vec16<T> v2 = load16<T>(x + (ch + 512) * EPV), v3 = load16<T>(x + (ch + 768) * EPV);
+            take(v0); take(v1); take(v2); take(v3);
         }
+        for (; ch < nvec; ch += 256) take(load16<T>(x + ch * EPV));
         for (long long c = nvec * EPV + tid; c < V; c += 256) {
             float a = to_f32<T>(x[c]);
             tot += a;
@@ -135,20 +145,32 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, l
     T* dx = dlogits + row * ldd;
     const float uni = eps / (float)V;
     const long long nvec = vec_ok ? V / EPV : 0;
-    for (long long ch = tid; ch < nvec; ch += 256) {
+    const long long tch = (active && tgt >= 0) ? tgt / EPV : -1;  // the one chunk that holds the target column
+    const int te = (int)(tgt >= 0 ? tgt % EPV : 0);
+    const float onehot = 1.f - eps;
+    auto grad = [&](const Vec16<T>& v, long long ch) {
         Vec16<T> o;
-        if (active) {
-            Vec16<T> v = load16<T>(x + ch * EPV);
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                long long c = ch * EPV + e;
-                float g = __expf(v.get(e) - lse) - uni - (c == tgt ? 1.f - eps : 0.f);
-                o.set(e, g);
-            }
-        } else {
-            o.raw = {0, 0, 0, 0};
+        for (int e = 0; e < EPV; ++e) o.set(e, __expf(v.get(e) - lse) - uni);
+        if (ch == tch) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e)
+                if (e == te) o.set(e, __expf(v.get(e) - lse) - uni - onehot);
         }
         store16<T>(dx + ch * EPV, o);
+    };
+    if (active) {
+        long long ch = tid;
+        for (; ch + 768 < nvec; ch += 1024) {
+            const Vec16<T> v0 = load16<T>(x + ch * EPV), v1 = load16<T>(x + (ch + 256) * EPV);
+            const Vec16<T> v2 = load16<T>(x + (ch + 512) * EPV), v3 = load16<T>(x + (ch + 768) * EPV);
+            grad(v0, ch); grad(v1, ch + 256); grad(v2, ch + 512); grad(v3, ch + 768);
+        }
+        for (; ch < nvec; ch += 256) grad(load16<T>(x + ch * EPV), ch);
+    } else {
+        Vec16<T> o;
+        o.raw = {0, 0, 0, 0};
+        for (long long ch = tid; ch < nvec; ch += 256) store16<T>(dx + ch * EPV, o);
     }
     for (long long c = nvec * EPV + tid; c < V; c += 256) {
         float g = active ? __expf(to_f32<T>(x[c]) - lse) - uni - (c == tgt ? 1.f - eps : 0.f) : 0.f;
@@ -311,6 +333,157 @@ extern "C" int pk_embed_fwd(const long long* ids, const void* E, const void* pos
 
 // Label-smoothed CE of `rows` logit rows.  row_loss/row_nll [rows] fp32 outputs (0 for pad rows); row_lse optional;
 // dlogits optional (may alias logits): d(loss_sum)/dlogits.
+// The same with the row held in registers between the two passes (NV 16-byte vectors per thread): the logits cross the
+// fabric once each way.  The two-pass kernel above re-reads the row for the gradient, and at vocabulary widths of 70 k - 256 k
+// the rows in flight on an XCD (8 workgroups x 32 CUs x 140 - 512 KB) are far beyond its 4 MiB of L2, so the second read came
+// from memory again: 3 transfers per element at ~5.9 TB/s instead of 2.  Everything is loaded before the first store, so
+// dlogits may alias logits here as well.
+template <typename T, int NV, int THREADS>
+__global__ __launch_bounds__(THREADS) void ce_reg_kernel(const T* __restrict__ logits, long long ld,
+                                                         const long long* __restrict__ target, T* __restrict__ dlogits,
+                                                         long long ldd, float* __restrict__ row_loss,
+                                                         float* __restrict__ row_nll, float* __restrict__ row_lse, long long V,
+                                                         long long pad_idx, float eps) {
+    constexpr int EPV = 16 / sizeof(T), NW = THREADS / 64;
+    __shared__ float red_m[NW], red_s[NW], red_t[NW];
+    __shared__ float bc[2];
+    const long long row = blockIdx.x;
+    const T* x = logits + row * ld;
+    const long long tgt = target[row];
+    const bool active = tgt != pad_idx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nvec = (int)(V / EPV);
+    float x_tgt = 0.f;
+    if (active && tid == 0) {
+        long long tc = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
+        x_tgt = to_f32<T>(x[tc]);
+    }
+    if (!active && !row_lse) {  // padding position: zero gradient, nothing to read
+        if (tid == 0) { row_loss[row] = 0.f; row_nll[row] = 0.f; }
+        if (dlogits) {
+            T* dx = dlogits + row * ldd;
+            Vec16<T> o;
+            o.raw = {0, 0, 0, 0};
+            for (int ch = tid; ch < nvec; ch += THREADS) store16<T>(dx + (long long)ch * EPV, o);
+            for (long long c = (long long)nvec * EPV + tid; c < V; c += THREADS) dx[c] = from_f32<T>(0.f);
+            const long long vpad = (V + 7) & ~7LL;
+            if (tid < vpad - V && ldd >= vpad) dx[V + tid] = from_f32<T>(0.f);
+        }
+        return;
+    }
+    Vec16<T> v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int ch = tid + i * THREADS;
+        if (ch < nvec) v[i] = load16<T>(x + (long long)ch * EPV);
+    }
+    float m = -INFINITY, s = 0.f, tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (tid + i * THREADS < nvec) {
+            float cm = v[i].get(0);
+#pragma unroll
+            for (int e = 1; e < EPV; ++e) cm = fmaxf(cm, v[i].get(e));
+            const float mn = fmaxf(m, cm);
+            const float ms = mn == -INFINITY ? 0.f : mn;
+            float cs = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const float a = v[i].get(e);
+                cs += __expf(a - ms);
+                tot += a;
+            }
+            s = s * __expf(m - ms) + cs;
+            m = mn;
+        }
+    }
+    for (long long c = (long long)nvec * EPV + tid; c < V; c += THREADS) {
+        const float a = to_f32<T>(x[c]);
+        tot += a;
+        online_merge(m, s, a, 1.f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        online_merge(m, s, m2, s2);
+        tot += __shfl_xor(tot, o, 64);
+    }
+    if (lane == 0) { red_m[wave] = m; red_s[wave] = s; red_t[wave] = tot; }
+    // the tail columns (V not a multiple of the vector width) are re-read for the gradient: fetch them before anyone stores
+    float tail_a = 0.f;
+    const long long tail_c = (long long)nvec * EPV + tid;
+    if (tail_c < V) tail_a = to_f32<T>(x[tail_c]);
+    __syncthreads();
+    if (tid == 0) {
+        float M = red_m[0], S = red_s[0], Tt = red_t[0];
+        for (int w = 1; w < NW; ++w) { online_merge(M, S, red_m[w], red_s[w]); Tt += red_t[w]; }
+        bc[0] = M + __logf(S);
+        bc[1] = Tt;
+    }
+    __syncthreads();
+    const float lse = bc[0];
+    if (tid == 0) {
+        if (row_lse) row_lse[row] = lse;
+        if (active) {
+            const float nll = lse - x_tgt;
+            const float smooth = lse - bc[1] / (float)V;
+            row_nll[row] = nll;
+            row_loss[row] = eps > 0.f ? (1.f - eps) * nll + eps * smooth : nll;
+        } else {
+            row_loss[row] = 0.f;
+            row_nll[row] = 0.f;
+        }
+    }
+    if (!dlogits) return;
+    T* dx = dlogits + row * ldd;
+    const float uni = eps / (float)V, onehot = 1.f - eps;
+    const long long tch = (active && tgt >= 0) ? tgt / EPV : -1;
+    const int te = (int)(tgt >= 0 ? tgt % EPV : 0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int ch = tid + i * THREADS;
+        if (ch < nvec) {
+            Vec16<T> o;
+            if (active) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o.set(e, __expf(v[i].get(e) - lse) - uni);
+                if (ch == tch) {
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e)
+                        if (e == te) o.set(e, __expf(v[i].get(e) - lse) - uni - onehot);
+                }
+            } else {
+                o.raw = {0, 0, 0, 0};
+            }
+            store16<T>(dx + (long long)ch * EPV, o);
+        }
+    }
+    if (tail_c < V) dx[tail_c] = from_f32<T>(active ? __expf(tail_a - lse) - uni - (tail_c == tgt ? onehot : 0.f) : 0.f);
+    const long long vpad = (V + 7) & ~7LL;
+    if (tid < vpad - V && ldd >= vpad) dx[V + tid] = from_f32<T>(0.f);
+}
+
+// the register-resident form where the row fits (true: launched)
+template <typename T>
+static bool launch_ce_reg(const T* logits, long long ld, const long long* target, T* dlogits, long long ldd, float* row_loss,
+                          float* row_nll, float* row_lse, long long V, long long pad_idx, float eps, long long rows, bool vec_ok,
+                          hipStream_t stream) {
+    constexpr int EPV = 16 / sizeof(T);
+    const long long nvec = V / EPV;
+    static const bool no_reg = getenv("PK_CE_NO_REG") != nullptr;  // (diagnostic: the two-pass kernel)
+    // (rows wider than 12 vectors x 1024 threads — NLLB's 256 206 — would need 128 data registers per thread at 4 waves per SIMD:
+    // measured 853 us against the two-pass kernel's 651 at 2048 rows; they stay there)
+    if (!vec_ok || no_reg || nvec == 0 || nvec > 12 * 1024) return false;
+#define PK_CE_REG(NV, TH)                                                                                                  \
+    hipLaunchKernelGGL((ce_reg_kernel<T, NV, TH>), dim3((unsigned)rows), dim3(TH), 0, stream, logits, ld, target, dlogits, ldd, \
+                       row_loss, row_nll, row_lse, V, pad_idx, eps)
+    if (nvec <= 4 * 256) PK_CE_REG(4, 256);
+    else if (nvec <= 4 * 1024) PK_CE_REG(4, 1024);
+    else PK_CE_REG(12, 1024);
+#undef PK_CE_REG
+    return true;
+}
+
 extern "C" int pk_ce_rows(const void* logits, long long ld, const long long* target, void* dlogits, long long ldd,
                           float* row_loss, float* row_nll, float* row_lse, long long rows, long long V,
                           long long pad_idx, float eps, int dtype, void* stream) {
@@ -322,8 +495,10 @@ extern "C" int pk_ce_rows(const void* logits, long long ld, const long long* tar
     PK_DTYPE_SWITCH(dtype, "pk_ce_rows", {
         constexpr int EPV = 16 / sizeof(T);
         bool vec_ok = is_aligned16(logits) && ld % EPV == 0 && (!dlogits || (is_aligned16(dlogits) && ldd % EPV == 0));
-        hipLaunchKernelGGL((ce_kernel<T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const T*)logits,
-                           ld, target, (T*)dlogits, ldd, row_loss, row_nll, row_lse, V, pad_idx, eps, vec_ok);
+        if (!launch_ce_reg<T>((const T*)logits, ld, target, (T*)dlogits, ldd, row_loss, row_nll, row_lse, V, pad_idx, eps, rows,
+                              vec_ok, (hipStream_t)stream))
+            hipLaunchKernelGGL((ce_kernel<T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const T*)logits,
+                               ld, target, (T*)dlogits, ldd, row_loss, row_nll, row_lse, V, pad_idx, eps, vec_ok);
     })
     PK_LAUNCH_CHECK();
     return 0;
