@@ -443,6 +443,11 @@ typedef struct {
     void* stream;
 } PkLayer;
 int pk_layer_fwd(const PkLayer* layer);
+/* bytes of workspace pk_layer_fwd can use through layer->ws / ws_bytes (0: none): a pre-norm layer whose fc2 has a long
+ * contraction at a few thousand rows (NLLB-1.3B's 8192 -> 1024 at the IWSLT recipe's 2048-row decoder batch) runs that GEMM
+ * as K-slabs + reduction, like its dX GEMM in pk_layer_bwd; without the workspace every forward GEMM runs unsplit.
+ * Replaces: nothing in the reference (nn.Linear, pasero/models/modules.py:92-96, leaves the split to the BLAS library). */
+size_t pk_layer_fwd_ws(const PkLayer* layer);
 int pk_layer_bwd_sizes(const PkLayer* layer, size_t* scratch_bytes, size_t* ws_bytes);
 int pk_layer_bwd(const PkLayer* layer);
 

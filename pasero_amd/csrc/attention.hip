@@ -225,15 +225,15 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
     const int b = blockIdx.z, h = blockIdx.y;
     const int t = blockIdx.x * 128 + wave * 32 + (lane & 31);
     const bool valid = t < p.T;
-    const float c = p.scale * LOG2E;
+    const float c = p.scale * LOG2E, inv_c = 1.f / c;
 
     bf16x8_t qf[NF], dof[NF];
     load_row_frags(qf, q + b * p.q_bs + h * HD, p.q_rs, t, valid, lane);
     if (p.rope_cos) rope_frags<NF, T>(qf, p, p.rope_q0 + t, lane);
-    // Q carries c = scale log2(e) (scale_frags): the score MFMAs leave the exp2-domain score.  In the dQ pass they start from the
-    // accumulator -lse log2(e), dP = V dOᵀ from -delta: p = exp2(x), dS = p dP' with no other vector instruction per score;
-    // masked keys and the causal boundary cost selects only in the tiles that hold them (wave-uniform branches).
-    scale_frags<NF, T>(qf, c);
+    // In the dQ pass the score MFMAs start from the accumulator -lse / scale and leave s - lse / scale, dP = V dOᵀ starts from
+    // -delta: p = exp2(c acc), dS = p dP' — a multiply, the exp and a multiply per score; masked keys and the causal boundary
+    // cost selects only in the tiles that hold them (wave-uniform branches).  (Q itself stays unscaled: folding c into its
+    // 16-bit fragments saves the multiply and costs 1.7e-3 on lse — tests/test_fullsize_gpu.py holds 1e-3.)
     float m = -INFINITY, l = 0.f, L2 = 0.f, dl = 0.f;
     f32x16 acc[ND];  // Oᵀ (MODE 0) or dQᵀ (MODE 1): [d-tile][d rows] x query lane
 #pragma unroll
@@ -294,11 +294,13 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[kb][r] = MODE == 1 ? -L2 : 0.f;
+            for (int r = 0; r < 16; ++r) sc[kb][r] = MODE == 1 ? -L2 * inv_c : 0.f;
 #pragma unroll
             for (int kk = 0; kk < NF; ++kk)
                 sc[kb] = mm<T>(row_frag<KP>(k_lds, kb * 32, kk, lane), qf[kk],
                                                                  sc[kb]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kb][r] *= c;
         }
         if (dead) {  // wave-uniform: this tile holds masked keys
 #pragma unroll
@@ -480,17 +482,16 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
         if (t >= p.T || byte0 + 4 > p.mask_pitch) return 0u;
         return *reinterpret_cast<const unsigned*>(p.drop_mask + (((long long)b * p.H + h) * p.T + t) * p.mask_pitch + byte0);
     };
-    const float c = p.scale * LOG2E;
+    const float c = p.scale * LOG2E, inv_scale = 1.f / p.scale;
 
     bf16x8_t kf[NF], vf[NF];
     load_row_frags(kf, k + b * p.k_bs + h * HD, p.k_rs, s, s < p.S, lane);
     load_row_frags(vf, v + b * p.v_bs + h * HD, p.v_rs, s, s < p.S, lane);
     if (p.rope_cos) rope_frags<NF, T>(kf, p, p.rope_k0 + s, lane);
-    // K carries c = scale log2(e): S = Q (c K)ᵀ starts from the accumulator -lse log2(e) (rows of the staged tile) and leaves
-    // x = s c - lse, dP = dO Vᵀ starts from -delta: p = exp2(x), dS = p dP' — two vector instructions per score besides the
-    // conversions (was ~10).  A padding key / key past S is a whole lane here: its dK, dV rows are zeroed at the end instead of
-    // a -inf bias in every score.  (With dropout dP is scaled before delta comes off: explicit form, zero accumulators.)
-    scale_frags<NF, T>(kf, c);
+    // S = Q Kᵀ starts from the accumulator -lse / scale (rows of the staged tile) and leaves s - lse / scale, dP = dO Vᵀ starts
+    // from -delta: p = exp2(c acc), dS = p dP' — three vector instructions per score besides the conversions (was ~10).  A
+    // padding key / key past S is a whole lane here: its dK, dV rows are zeroed at the end instead of a -inf bias in every
+    // score.  (With dropout dP is scaled before delta comes off: explicit form, zero accumulators.)
     f32x16 dka[ND], dva[ND];  // dKᵀ, dVᵀ: [d-tile][d rows] x key lane
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt)
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
         if (tid < KT) {
             int t = t0 + tid;
             long long row = ((long long)b * p.H + h) * p.T + t;
-            l2_lds[tid] = t < p.T ? -lse[row] * LOG2E : -INFINITY;  // (negated: initial accumulators) -inf -> p = 0 for rows past T
+            l2_lds[tid] = t < p.T ? -lse[row] * inv_scale : -INFINITY;  // (initial accumulators, in units of the raw score) -inf -> p = 0 for rows past T
             dl_lds[tid] = t < p.T ? -delta[row] : 0.f;
         }
         if (t0 + KT < p.T) {  // prefetch the next query tile into registers
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float pw = __builtin_amdgcn_exp2f(sc[4 * g + j]);
+                    const float pw = __builtin_amdgcn_exp2f(sc[4 * g + j] * c);
                     if constexpr (DROP) {  // keep bit of (query t0+tl+j, this lane's key): bit lane & 31 of the wave's dword
                         const int tl = qb * 32 + 8 * g + 4 * (lane >> 5);
                         const unsigned wd = m_lds[(tl + j) * 4 + wave];
@@ -687,17 +688,16 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
             if (r < p.T) delta[((long long)b * p.H + h) * p.T + r] = part;
         }
     }
-    // negated: the initial accumulator of S (rows past T: -inf -> p = 0)
-    if (tid < 128) l2_lds[tid] = tid < p.T ? -lse[((long long)b * p.H + h) * p.T + tid] * LOG2E : -INFINITY;
+    // the initial accumulator of S, in units of the raw score (rows past T: -inf -> p = 0)
+    if (tid < 128) l2_lds[tid] = tid < p.T ? -lse[((long long)b * p.H + h) * p.T + tid] / p.scale : -INFINITY;
     const int s = wave * 32 + (lane & 31);
     const bool kvalid = s < p.S && !(p.key_pad && p.key_pad[(long long)b * p.S + min(s, p.S - 1)]);
     bf16x8_t kf[4], vf[4];
     load_row_frags(kf, kbase, p.k_rs, s, s < p.S, lane);
     load_row_frags(vf, v + b * p.v_bs + h * HD64, p.v_rs, s, s < p.S, lane);
     if (p.rope_cos) rope_frags<4, T>(kf, p, p.rope_k0 + s, lane);
-    // K carries c = scale log2(e); S starts from the accumulator -lse log2(e) (-inf on the lane of a padding key / key past S),
-    // dP from -delta: p = exp2(x), dS = p dP' (as in the dK / dV kernel above)
-    scale_frags<4, T>(kf, c);
+    // S starts from the accumulator -lse / scale (-inf on the lane of a padding key / key past S), dP from -delta:
+    // p = exp2(c acc), dS = p dP' (as in the dK / dV kernel above)
     f32x16 dka[2], dva[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
             const int tl = t0 + 8 * g + 4 * (lane >> 5);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float pw = __builtin_amdgcn_exp2f(sc[4 * g + j]);
+                const float pw = __builtin_amdgcn_exp2f(sc[4 * g + j] * c);
                 if constexpr (DROP) {
                     const unsigned wd = m_lds[(tl + j) * 4 + wave];
                     const float km = (wd & keep_bit) ? p.drop_scale : 0.f;  // (rows past T were staged as zeros)

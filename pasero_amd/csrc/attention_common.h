@@ -293,20 +293,6 @@ __device__ __forceinline__ void rope_acc_inverse(f32x16 (&acc)[ND], const AttnPa
         }
 }
 
-// fragments of a row operand scaled by a constant, rounded to the 16-bit type once more (what the reference's own `q * scaling`
-// does): with the query (or key) side of S = Q Kᵀ carrying c = scale log2(e), the MFMA chain leaves the exp2-domain score and
-// its initial accumulator can carry the row constant (-m, -lse) — no vector instruction per score for either
-template <int NF, typename T>
-__device__ __forceinline__ void scale_frags(bf16x8_t (&f)[NF], float c) {
-#pragma unroll
-    for (int kk = 0; kk < NF; ++kk) {
-        s16x8 raw = __builtin_bit_cast(s16x8, f[kk]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = (short)H16<T>::bits(H16<T>::val((unsigned short)raw[j]) * c);
-        f[kk] = __builtin_bit_cast(bf16x8_t, raw);
-    }
-}
-
 template <typename T>
 __device__ __forceinline__ float frag_dot(const bf16x8_t& a, const bf16x8_t& b) {
     s16x8 x = __builtin_bit_cast(s16x8, a), y = __builtin_bit_cast(s16x8, b);

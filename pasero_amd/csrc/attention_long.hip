@@ -11,7 +11,7 @@ namespace {
 // subtraction, exp, sum, accumulator rescale, conversion) against 16 MFMAs per 2048 scores: at S >= 500 it is paced by its
 // VALU work, not by the matrix pipe (0.5 ps per pair whatever the shape).  This form keeps 4 per score:
 //   * the maximum LAGS: a query's scores are taken relative to the maximum m its row was last anchored at, x = s c - m (no
-//     instruction: Q is scaled by c when it is loaded and the MFMA chain starts from -m), and m moves only when a tile's maximum exceeds it by more than LAG_THR (exp2 domain: p <= 2^LAG_THR, in range for
+//     multiply: the MFMA chain starts from the accumulator -m / c), and m moves only when a tile's maximum exceeds it by more than LAG_THR (exp2 domain: p <= 2^LAG_THR, in range for
 //     both 16-bit types, relative precision unchanged) — the accumulator rescale, the exp of the correction and the
 //     subtraction leave the loop body for a wave-uniform branch that is rare after the first tile;
 //   * keys past S / padding keys are found per tile by one ballot; only tiles that hold one pay for the selects;
@@ -45,26 +45,17 @@ __global__ __launch_bounds__(256, PKL_WAVES) void attn_fwd_long_kernel(const T* 
     const int b = pair / p.H, h = pair % p.H;
     const int t = qb * 128 + wave * 32 + (lane & 31);
     const bool valid = t < p.T;
-    const float c = p.scale * LOG2E;
+    const float c = p.scale * LOG2E, inv_c = 1.f / c;
 
-    // Q arrives scaled by c = scale log2(e) (rounded to the 16-bit type once more, as the reference's own q * scaling is): the
-    // MFMA chain then starts from the accumulator -m and leaves x = s c - m with no vector instruction at all
     bf16x8_t qf[NF];
     load_row_frags(qf, q + b * p.q_bs + h * HD, p.q_rs, t, valid, lane);
-#pragma unroll
-    for (int kk = 0; kk < NF; ++kk) {
-        s16x8 raw = __builtin_bit_cast(s16x8, qf[kk]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = (short)H16<T>::bits(H16<T>::val((unsigned short)raw[j]) * c);
-        qf[kk] = __builtin_bit_cast(bf16x8_t, raw);
-    }
     f32x16 acc[ND];
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     float negm = 0.f, l = 0.f;  // -m (exp2 domain) once the row is anchored, 0 before
-    f32x16 negm16;              // the same in every register: the initial accumulator of the score MFMAs
+    f32x16 negm16;              // -m / c in every register: the initial accumulator of the score MFMAs (units of the raw score)
 #pragma unroll
     for (int r = 0; r < 16; ++r) negm16[r] = 0.f;
     bool anch = false;
@@ -126,6 +117,8 @@ __global__ __launch_bounds__(256, PKL_WAVES) void attn_fwd_long_kernel(const T* 
             sc[kb] = mm<T>(row_frag<DUAL>(k_lds, kb * 32, 0, lane), qf[0], negm16);
 #pragma unroll
             for (int kk = 1; kk < NF; ++kk) sc[kb] = mm<T>(row_frag<DUAL>(k_lds, kb * 32, kk, lane), qf[kk], sc[kb]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kb][r] *= c;  // x = s c - m
         }
         if (dead) {  // wave-uniform: this tile holds masked keys
 #pragma unroll
@@ -156,7 +149,7 @@ __global__ __launch_bounds__(256, PKL_WAVES) void attn_fwd_long_kernel(const T* 
             l *= alpha;
             negm -= delta;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) negm16[r] = negm;
+            for (int r = 0; r < 16; ++r) negm16[r] = negm * inv_c;
             anch = anch || move;
         }
         typedef __attribute__((ext_vector_type(2))) float f32x2;

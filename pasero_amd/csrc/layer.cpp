@@ -39,6 +39,15 @@ int choose_splitk(long long M, long long N, long long K) {
     return (int)std::max(1LL, std::min(512 / tiles, K / 512));
 }
 inline size_t splitk_ws(int sk, long long M, long long N) { return sk > 1 ? (size_t)2 * sk * M * (N + 1) * 4 : 0; }
+// Forward GEMMs are not split as a rule (their outputs fill the chip).  The exception: a projection back to d from a long
+// contraction at a few thousand rows — NLLB-1.3B's fc2 (8192 -> 1024) at the IWSLT recipe's 2048-row decoder batch is 32 tiles
+// of 256 x 256: 123 us on the 128-tile kernel, ~40 as 8 K-slabs of the 256-tile kernel + reduction (what its dX GEMM already
+// does).  4 here = 8 slabs there (pk_gemm re-derives the factor for its 256-tiles, capped at twice the caller's).
+inline int fwd_split(long long M, long long N, long long K) {
+    // (M <= 2048 only: from 4096 rows up the 128 x 256-tile form takes these GEMMs, and a batch and its halves must not fall on
+    // two sides of a split rule — tests/test_configs_fullsize_gpu.py compares them)
+    return (K >= 4096 && K % 512 == 0 && N <= 1024 && N % 256 == 0 && M >= 512 && M <= 2048 && M % 256 == 0) ? 4 : 1;
+}
 
 struct Bump {  // the backward's gradient temporaries: one region of `scratch` each (256-byte aligned)
     char* base;
@@ -151,7 +160,12 @@ int layer_fwd_prenorm(const PkLayer& L) {
     const long long rows = (long long)L.B * L.T, rows_kv = (long long)L.B * L.S, d = L.d, f = L.f;
     const int hd = L.d / L.heads, dt = L.dtype;
     auto linear = [&](const void* a, const void* w, const void* bias, void* out, long long M, long long N, long long K, int act, void* pre) {
-        return pk_gemm(a, w, out, bias, nullptr, pre, M, N, K, K, K, N, 0, pre ? N : 0, 0, 0, act, 0, 1.f, dt, 1, nullptr, 0, nullptr, L.stream);
+        // (forward split-K: fwd_split; the slab count depends on N and K only, so a row computes the same in a batch of any size)
+        int sk = pre ? 1 : fwd_split(M, N, K);
+        const size_t need = splitk_ws(sk, M, N);
+        if (sk > 1 && (!L.ws || L.ws_bytes < need)) sk = 1;
+        return pk_gemm(a, w, out, bias, nullptr, pre, M, N, K, K, K, N, 0, pre ? N : 0, 0, 0, act, 0, 1.f, dt, sk, sk > 1 ? L.ws : nullptr,
+                       sk > 1 ? need : 0, nullptr, L.stream);
     };
     PK_REQ(L.self.ln_out && L.ffn.ln_out && (!L.is_decoder || L.cross.ln_out), "pk_layer_fwd: pre-norm layer without ln_out buffers");
     // the end of a block (z = in + dropout(o)) and the LayerNorm that starts the NEXT block of the layer in one pass: the
@@ -238,6 +252,13 @@ extern "C" int pk_layer_fwd(const PkLayer* lp) {
                        0, nullptr, L.stream));
     return block_end(L, L.ffn.h, f, L.ffn.w2, L.ffn.b2, y, L.ffn.ln_g, L.ffn.ln_b, L.ffn.z, L.ffn.y, L.ffn.mean, L.ffn.rstd,
                      L.ffn.drop_offset);
+}
+
+// bytes of workspace pk_layer_fwd can use (PkLayer::ws / ws_bytes; without it the forward GEMMs run unsplit): 0 = none
+extern "C" size_t pk_layer_fwd_ws(const PkLayer* lp) {
+    if (!lp || !lp->prenorm) return 0;
+    const long long rows = (long long)lp->B * lp->T;
+    return splitk_ws(fwd_split(rows, lp->d, lp->f), rows, lp->d);
 }
 
 extern "C" int pk_layer_bwd_sizes(const PkLayer* lp, size_t* scratch_bytes, size_t* ws_bytes) {

@@ -78,6 +78,7 @@ SIGNATURES = {
     'pk_comm_all_reduce_mean': (I, [P, LL, I, I, P, P]),
     'pk_comm_direct_plan': (I, [LL, I, I, P, P, P, P]),
     'pk_layer_fwd': (I, [P]),
+    'pk_layer_fwd_ws': (SZ, [P]),
     'pk_layer_bwd_sizes': (I, [P, P, P]),
     'pk_layer_bwd': (I, [P]),
     'pk_logmel_workspace': (SZ, [I]),

@@ -304,6 +304,12 @@ class NativeLayerFn(Function):
             seed, fb.drop_offset = rng.next_offset()
         lay.seed = seed
         lay.stream = lib.stream_ptr()
+        # a few-rows fc2 with a long contraction (NLLB's 8192 -> 1024 at a 2048-row decoder batch: 32 of 256 CUs as it stands)
+        # runs split-K in the forward pass too when the layer brings a workspace (pk_layer_fwd_ws: 0 when no GEMM asks)
+        fws = L.pk_layer_fwd_ws(ctypes.byref(lay))
+        if fws:
+            wsf = lib.workspace(fws, x.device, 'layer_ws')
+            lay.ws, lay.ws_bytes = wsf.data_ptr(), wsf.numel()
         check(L.pk_layer_fwd(ctypes.byref(lay)), 'pk_layer_fwd')
         ctx.lay, ctx.layer, ctx.is_decoder = lay, layer, is_decoder
         chain = None
