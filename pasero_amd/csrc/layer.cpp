@@ -161,7 +161,7 @@ int layer_fwd_prenorm(const PkLayer& L) {
     const int hd = L.d / L.heads, dt = L.dtype;
     auto linear = [&](const void* a, const void* w, const void* bias, void* out, long long M, long long N, long long K, int act, void* pre) {
         // (forward split-K: fwd_split; the slab count depends on N and K only, so a row computes the same in a batch of any size)
-        int sk = pre ? 1 : fwd_split(M, N, K);
+        int sk = (pre || dt == PK_F32) ? 1 : fwd_split(M, N, K);
         const size_t need = splitk_ws(sk, M, N);
         if (sk > 1 && (!L.ws || L.ws_bytes < need)) sk = 1;
         return pk_gemm(a, w, out, bias, nullptr, pre, M, N, K, K, K, N, 0, pre ? N : 0, 0, 0, act, 0, 1.f, dt, sk, sk > 1 ? L.ws : nullptr,
@@ -256,7 +256,7 @@ extern "C" int pk_layer_fwd(const PkLayer* lp) {
 
 // bytes of workspace pk_layer_fwd can use (PkLayer::ws / ws_bytes; without it the forward GEMMs run unsplit): 0 = none
 extern "C" size_t pk_layer_fwd_ws(const PkLayer* lp) {
-    if (!lp || !lp->prenorm) return 0;
+    if (!lp || !lp->prenorm || lp->dtype == PK_F32) return 0;
     const long long rows = (long long)lp->B * lp->T;
     return splitk_ws(fwd_split(rows, lp->d, lp->f), rows, lp->d);
 }

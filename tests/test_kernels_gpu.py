@@ -557,6 +557,39 @@ def test_cross_entropy_rows(F, dtype, eps, V):
     assert torch.equal(lg, dl)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('V,ld', [(1000, 1000), (8192, 8192), (32000, 32000), (50004, 50008), (98304, 98304), (98312, 98312),
+                                   (256206, 256208)])
+def test_cross_entropy_rows_register_resident(F, dtype, V, ld):
+    """16-bit rows of up to 98 304 columns stay in registers between the statistics and the gradient pass (`ce_reg_kernel`:
+    4 vectors x 256 threads, 4 / 12 vectors x 1024 threads); wider rows (NLLB's 256 206) and fp32 take the two-pass kernel.
+    Every instantiation and both sides of each boundary, a row pitch padded to 8 with a scalar tail (50 004 in rows of 50 008,
+    256 206 in 256 208: the pad columns must come back as zeros), padding targets, the gradient written over the logits —
+    against the oracle's label-smoothed cross-entropy in fp32 (transformer.py:324-380)."""
+    rows, eps = 9, 0.1
+    g = torch.Generator().manual_seed(V)
+    buf = torch.full((rows, ld), float('nan'), dtype=dtype)
+    buf[:, :V] = (torch.randn(rows, V, generator=g) * 2.0).to(dtype)
+    target = torch.randint(4, V, (rows,), generator=g)
+    target[2] = 1           # padding position: zero loss, zero gradient row
+    target[3] = V - 1       # the last column (inside the scalar tail where there is one)
+    target[4] = 0
+    x = buf[:, :V].float().requires_grad_()
+    loss, nll, ntok = O.label_smoothed_ce(x, target, 1, eps)
+    loss.backward()
+    lg = buf.cuda()
+    row_loss, row_nll = torch.empty(rows, device='cuda'), torch.empty(rows, device='cuda')
+    F.ce_rows(lg[:, :V], target.cuda(), 1, eps, row_loss, row_nll, dlogits=lg[:, :V])
+    sums = F.ce_finalize(row_loss, row_nll, target.cuda(), 1).cpu()
+    assert abs(sums[0].item() - loss.item()) <= 2e-6 * abs(loss.item())
+    assert abs(sums[1].item() - nll.item()) <= 2e-6 * abs(nll.item())
+    assert int(sums[2].item()) == int(ntok)
+    assert rel_err(lg[:, :V], x.grad) < (8e-3 if dtype == torch.bfloat16 else 1e-3)
+    assert lg[2, :V].abs().max().item() == 0
+    if ld > V:
+        assert (lg[:, V:(V + 7) // 8 * 8] == 0).all()
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('M,N', [(1000, 512), (7, 2048), (33000, 1536), (50, 100), (3, 9)])
 def test_colsum(F, dtype, M, N):
