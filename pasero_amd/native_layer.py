@@ -154,9 +154,11 @@ def takes(layer, x, enc, state, return_layers, is_decoder: bool, pad=None) -> bo
     f = layer.fc1.weight.size(0)
     rows = B * T
     # the grouped weight-gradient launch takes outputs of >= 256 x 256 and whole 16-byte rows (pk_gemm_wgrad_group_eligible)
-    if rows < 256 or d < 256 or f < 256 or d % 8 or f % 8:
+    # (and a contraction — the rows of the batch — of whole 16-byte columns: 1500 rows, one 30 s clip, are not)
+    if rows < 256 or d < 256 or f < 256 or d % 8 or f % 8 or rows % 8:
         return False
-    if is_decoder and (enc is None or enc.dtype != x.dtype or enc.dim() != 3 or enc.size(0) != B or enc.size(0) * enc.size(1) < 64):
+    if is_decoder and (enc is None or enc.dtype != x.dtype or enc.dim() != 3 or enc.size(0) != B or enc.size(0) * enc.size(1) < 64
+                       or (enc.size(0) * enc.size(1)) % 8):
         return False
     if not _pad_ok(pad, B, enc.size(1) if is_decoder else T):
         return False

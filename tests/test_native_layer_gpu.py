@@ -107,6 +107,11 @@ def test_what_is_not_the_stock_layer_stays_on_the_per_op_path():
                                       None, [], False)
     tiny = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(4, 2, 8, 8, V).items()}
     assert _step(model, tiny, native=True)[3] == 0  # too few rows for the grouped weight-gradient launch
+    # a row count that is no multiple of 8 (the weight gradients contract over the rows: no whole 16-byte columns) — one 30 s
+    # Whisper clip is 1500 rows; it used to pass `takes` and fail inside pk_layer_bwd
+    odd = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(4, 3, 100, 100, V, ragged=False).items()}
+    loss, _, _, calls = _step(model, odd, native=True)
+    assert calls == 0 and torch.isfinite(torch.as_tensor(loss))
 
 
 def test_second_backward_over_a_retained_graph_and_a_gradient_towards_the_input():
