@@ -91,8 +91,8 @@ def test_gemm_asymmetric_identity(F, dtype):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('act', ['none', 'relu', 'gelu', 'gelu_tanh', 'silu'])
-def test_gemm_epilogues(F, dtype, act):
-    M, N, K = 200, 264, 96
+@pytest.mark.parametrize('M,N,K', [(200, 264, 96), (384, 512, 128)])  # ragged edge tiles; whole tiles only (the lean epilogues)
+def test_gemm_epilogues(F, dtype, act, M, N, K):
     x = rnd((M, K), 3, dtype)
     w = rnd((N, K), 4, dtype, K ** -0.5)
     bias = rnd((N,), 5, dtype)
