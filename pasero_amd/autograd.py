@@ -214,7 +214,8 @@ class LinearFn(Function):
         x2 = _2d(_contig(x))
         need_pre = act not in ('none', 'relu') and any(wants_grad(ctx))
         pre = torch.empty(x2.size(0), weight.size(0), dtype=x.dtype, device=x.device) if need_pre else None
-        y = F.gemm(x2, weight, bias=bias, act=act, preact=pre)
+        y = F.gemm(x2, weight, bias=bias, act=act, preact=pre,
+                   splitk=1 if pre is not None else F.fwd_split(x2.size(0), weight.size(0), weight.size(1), x.dtype))
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x2, weight, pre if need_pre else (y if act == 'relu' else None))
@@ -258,7 +259,7 @@ class FFNFn(Function):
             h, bits = F.gemm_relu_bits(x2, w1, b1)
         else:
             h = F.gemm(x2, w1, bias=b1, act=act, preact=pre)
-        y = F.gemm(h, w2, bias=b2)
+        y = F.gemm(h, w2, bias=b2, splitk=F.fwd_split(h.size(0), w2.size(0), w2.size(1), x.dtype))
         ctx.act = act
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
         ctx.save_for_backward(x2, w1, w2, h, pre, bits)

@@ -152,6 +152,17 @@ def wgrad_group(entries):
     return out
 
 
+def fwd_split(M: int, N: int, K: int, dtype) -> int:
+    """csrc/layer.cpp: fwd_split — forward GEMMs are not split as a rule; the exception is a projection back to d from a long
+    contraction at a few thousand rows (NLLB-1.3B's fc2, 8192 -> 1024, at the IWSLT recipe's 2048-row decoder batch: 32 tiles of
+    256 x 256, 123 us on the 128-tile kernel, ~40 as K-slabs + reduction).  16-bit types only (fp32 is the parity path); the
+    slab count depends on N and K alone, so a row computes the same in a batch of any size.  The native layer applies the
+    same rule (the two paths stay bit for bit equal)."""
+    if dtype == torch.float32:
+        return 1
+    return 4 if (K >= 4096 and K % 512 == 0 and N <= 1024 and N % 256 == 0 and 512 <= M <= 2048 and M % 256 == 0) else 1
+
+
 def choose_splitk(M: int, N: int, K: int, target_blocks: int = 512) -> int:
     """Split the contraction when the output has too few 128x128 tiles to fill 256 CUs (weight-gradient GEMMs)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
