@@ -222,8 +222,10 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
     __shared__ __attribute__((aligned(16))) char v_lds[NI * img_bytes<VP>()];
     __shared__ unsigned long long dead_lds;  // bit i: key i of the staged tile is past S or a padding key
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int t = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    // 1-D grid, the blocks of one (batch, head) pair on ONE XCD (pair_block): they re-read the pair's K / V from its L2
+    int b, h, blk;
+    if (!pair_block(p, p.nqb, b, h, blk)) return;
+    const int t = blk * 128 + wave * 32 + (lane & 31);
     const bool valid = t < p.T;
     const float c = p.scale * LOG2E, inv_c = 1.f / c;
 
@@ -258,8 +260,8 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
     // causal: keys beyond the last query of this workgroup are never visible
     const int off = p.S - p.T;
     int s_end = p.S;
-    if (p.causal) s_end = min(p.S, blockIdx.x * 128 + 128 + off);
-    const int wt0 = blockIdx.x * 128 + wave * 32;  // first query of this wave
+    if (p.causal) s_end = min(p.S, blk * 128 + 128 + off);
+    const int wt0 = blk * 128 + wave * 32;  // first query of this wave
     const T* kbase = k + b * p.k_bs + h * HD;
     const T* vbase = v + b * p.v_bs + h * HD;
     uint4 kreg[2 * NI], vreg[2 * NI];
@@ -472,13 +474,14 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
     // longer per (query, key) pair than the plain one: 201 us for the IWSLT recipe's encoder self-attention)
     __shared__ unsigned m_lds[DROP ? KT * 4 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int s = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    int b, h, blk;  // (the key blocks of a (batch, head) pair on one XCD: they re-read the pair's Q / dO from its L2)
+    if (!pair_block(p, p.nkb, b, h, blk)) return;
+    const int s = blk * 128 + wave * 32 + (lane & 31);
     const bool kvalid = s < p.S && !(p.key_pad && p.key_pad[(long long)b * p.S + min(s, p.S - 1)]);
     // thread tid brings dword tid & 3 (32 keys) of query row tid >> 2 of the tile; rows past T and dwords past the row: 0
     auto mask_g2r = [&](int t0) -> unsigned {
         const int t = t0 + (tid >> 2);
-        const long long byte0 = (long long)blockIdx.x * 16 + (tid & 3) * 4;
+        const long long byte0 = (long long)blk * 16 + (tid & 3) * 4;
         if (t >= p.T || byte0 + 4 > p.mask_pitch) return 0u;
         return *reinterpret_cast<const unsigned*>(p.drop_mask + (((long long)b * p.H + h) * p.T + t) * p.mask_pitch + byte0);
     };
@@ -501,8 +504,8 @@ __global__ __launch_bounds__(256, dkv_min_waves(HD)) void attn_bwd_dkv_kernel(co
     // causal: queries before the first key of this workgroup (minus the offset) never see it
     const int off = p.S - p.T;
     int t_begin = 0;
-    if (p.causal) t_begin = max(0, (int)(blockIdx.x * 128) - off) / KT * KT;
-    const int ws0 = blockIdx.x * 128 + wave * 32;          // first key of this wave
+    if (p.causal) t_begin = max(0, (int)(blk * 128) - off) / KT * KT;
+    const int ws0 = blk * 128 + wave * 32;          // first key of this wave
     const unsigned keep_bit = s < p.S ? 1u << (lane & 31) : 0u;  // (dropout) this lane's bit of a stored keep dword
     const T* qbase = q + b * p.q_bs + h * HD;
     const T* dobase = d_o + b * p.do_bs + h * HD;
@@ -906,6 +909,8 @@ int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* l
     PK_CHECK_ARG(q && k && v && o && lse, "pk_attn_fwd: null tensor");
     if (B == 0 || T == 0) return 0;
     dim3 grid((T + 127) / 128, H, B);
+    p.nqb = (T + 127) / 128;
+    const dim3 grid16((unsigned)((B * H + 7) / 8 * 8) * p.nqb);  // (16-bit kernels: 1-D, pair_block)
     hipStream_t s = (hipStream_t)stream;
     // long key sequences, heads of 64, no causal mask, no rotation: the lagging-maximum kernel (PK_ATTN_LONG_MIN_S: diagnostic)
     static const int long_min_s = [] { const char* e = getenv("PK_ATTN_LONG_MIN_S"); return e ? atoi(e) : 256; }();
@@ -918,10 +923,10 @@ int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* l
 #define PK_FWD16(TT, D)                                                                                              \
     do {                                                                                                             \
         if (p.drop_thr)                                                                                              \
-            hipLaunchKernelGGL((attn_q_kernel<TT, 0, D, true>), grid, dim3(256), 0, s, (const TT*)q, (const TT*)k,   \
+            hipLaunchKernelGGL((attn_q_kernel<TT, 0, D, true>), grid16, dim3(256), 0, s, (const TT*)q, (const TT*)k,   \
                                (const TT*)v, (TT*)o, (const TT*)nullptr, lse, (float*)nullptr, (TT*)nullptr, p);     \
         else                                                                                                         \
-            hipLaunchKernelGGL((attn_q_kernel<TT, 0, D, false>), grid, dim3(256), 0, s, (const TT*)q, (const TT*)k,  \
+            hipLaunchKernelGGL((attn_q_kernel<TT, 0, D, false>), grid16, dim3(256), 0, s, (const TT*)q, (const TT*)k,  \
                                (const TT*)v, (TT*)o, (const TT*)nullptr, lse, (float*)nullptr, (TT*)nullptr, p);     \
     } while (0)
 #define PK_FWD(D)                                                                                                    \
@@ -972,7 +977,10 @@ int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, co
                      "pk_attn_bwd: bf16 strides must be multiples of 8 elements");
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    dim3 gq((T + 127) / 128, H, B), gk((S + 127) / 128, H, B);
+    p.nqb = (T + 127) / 128; p.nkb = (S + 127) / 128;
+    const unsigned np8 = (unsigned)((B * H + 7) / 8 * 8);
+    dim3 gq(np8 * p.nqb), gk(np8 * p.nkb);  // (1-D: pair_block)
+    const dim3 gq3((T + 127) / 128, H, B), gk3((S + 127) / 128, H, B);  // (the fp32 kernels: one thread per row, 3-D)
     static const bool no_fused = getenv("PK_ATTN_NO_FUSED_BWD") != nullptr;
     const bool half = dtype != PK_F32;
 #define PK_T16(...) do { if (dtype == PK_F16) { using TT = f16; __VA_ARGS__; } else { using TT = bf16; __VA_ARGS__; } } while (0)
@@ -1027,10 +1035,10 @@ int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, co
 #define PK_BWD32(D)                                                                                                  \
     do {                                                                                                             \
         if (T > 0)                                                                                                   \
-            hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<D>), gq, dim3(128), 0, s, (const float*)q, (const float*)k,   \
+            hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<D>), gq3, dim3(128), 0, s, (const float*)q, (const float*)k,   \
                                (const float*)v, (const float*)o, (const float*)d_o, lse, delta, (float*)dq, p);      \
         if (S > 0)                                                                                                   \
-            hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<D>), gk, dim3(128), 0, s, (const float*)q, (const float*)k,  \
+            hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<D>), gk3, dim3(128), 0, s, (const float*)q, (const float*)k,  \
                                (const float*)v, (const float*)d_o, lse, (const float*)delta, (float*)dk, (float*)dv, \
                                p);                                                                                   \
     } while (0)

@@ -60,6 +60,7 @@ struct AttnParams {
     const float* rope_cos;
     const float* rope_sin;
     int rope_max, rope_q0, rope_k0;
+    int nqb, nkb;  // 128-row query / key blocks per (batch, head) pair: the 1-D grids of the 16-bit kernels (pair_block)
 };
 }  // namespace pkattn
 using pkattn::AttnParams;
@@ -70,6 +71,18 @@ constexpr int HD64 = 64;  // the single-workgroup fused backward is built for th
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
+
+// 1-D grid of the tiled 16-bit kernels: workgroup `lin` -> (batch b, head h, block blk of nblk); the hardware deals workgroups
+// to the eight XCDs round-robin, so lin % 8 is the XCD and all nblk blocks of a pair sit on one (pairs beyond B H: false)
+__device__ __forceinline__ bool pair_block(const AttnParams& p, int nblk, int& b, int& h, int& blk) {
+    const int lin = blockIdx.x, j = lin >> 3;
+    const int pair = (j / nblk) * 8 + (lin & 7);
+    blk = j % nblk;
+    if (pair >= p.B * p.H) return false;
+    b = pair / p.H;
+    h = pair % p.H;
+    return true;
+}
 
 __device__ __forceinline__ bool drop_keep1(const AttnParams& p, long long row, int s) {
     const unsigned long long idx = (unsigned long long)row * 8ull * p.mask_pitch + s;
