@@ -291,12 +291,69 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
         if (skip) continue;
         const bool check = p.causal && s0 + KT - 1 > wt0 + off;   // some (query, key) pairs are masked
 
-        f32x16 sc[2];  // Sᵀ[key][query] for the two 32-key blocks of the tile
         const unsigned long long dead = dead_lds;
+        if constexpr (MODE == 1) {
+            // dQ pass: one 32-key block at a time — scores, dP, dS and the dQ product of a block before the next one starts (the
+            // live set is one block's S and dP: the kernel fits three waves per SIMD; both blocks at once took 232 registers)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16 s1, d1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s1[r] = -L2 * inv_c;
+#pragma unroll
+                for (int kk = 0; kk < NF; ++kk) s1 = mm<T>(row_frag<KP>(k_lds, kb * 32, kk, lane), qf[kk], s1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s1[r] *= c;
+                if (dead) {  // wave-uniform: this tile holds masked keys
+                    unsigned dm = (unsigned)(dead >> (32 * kb)) >> (4 * (lane >> 5));
+                    asm volatile("; masked keys" : "+v"(dm));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((dm >> ((r & 3) + 8 * (r >> 2))) & 1u) s1[r] = -INFINITY;
+                }
+                if (check) {  // wave-uniform: the causal boundary crosses this (wave, tile) block
+                    int kq = t + off - s0 - kb * 32 - 4 * (lane >> 5);
+                    asm volatile("; causal block" : "+v"(kq));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((r & 3) + 8 * (r >> 2) > kq) s1[r] = -INFINITY;
+                }
+                // dPᵀ[key][query] = V[key][:] · dO[query][:]
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d1[r] = DROP ? 0.f : -dl;  // (with dropout dP is scaled before delta comes off)
+#pragma unroll
+                for (int kk = 0; kk < NF; ++kk) d1 = mm<T>(row_frag<VP>(v_lds, kb * 32, kk, lane), dof[kk], d1);
+                if constexpr (DROP) {  // dP = M / (1 - p) * (dO . V): the stored keep bits of this query's keys
+                    const long long mrow = ((long long)b * p.H + h) * p.T + t;
+                    const unsigned w4 = valid ? *reinterpret_cast<const unsigned*>(p.drop_mask + mrow * p.mask_pitch + ((s0 + kb * 32) >> 3)) : 0u;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        unsigned byte = (w4 >> (8 * g)) & 0xffu;
+                        byte >>= 4 * (lane >> 5);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) d1[4 * g + j] = ((byte >> j) & 1) ? d1[4 * g + j] * p.drop_scale : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pw = __builtin_amdgcn_exp2f(s1[r]);          // masked: exp2(-inf) = 0
+                    s1[r] = DROP ? pw * (d1[r] - dl) : pw * d1[r];           // dSᵀ
+                }
+                // dQᵀ[d][query] += Kᵀ[d][key] · dSᵀ[key][query]
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8_t pf = acc_frag<T>(s1, s);
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt) acc[dt] = mm<T>(tr_frag<KP>(k_lds, kb * 32, s, dt * 32, lane), pf, acc[dt]);
+                }
+            }
+            continue;
+        }
+        f32x16 sc[2];  // Sᵀ[key][query] for the two 32-key blocks of the tile
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[kb][r] = MODE == 1 ? -L2 * inv_c : 0.f;
+            for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < NF; ++kk)
                 sc[kb] = mm<T>(row_frag<KP>(k_lds, kb * 32, kk, lane), qf[kk],

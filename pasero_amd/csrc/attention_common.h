@@ -11,10 +11,13 @@
 #ifndef PK_ATTN_FWD_WAVES
 #define PK_ATTN_FWD_WAVES 3
 #endif
+#ifndef PK_ATTN_DQ_WAVES
+#define PK_ATTN_DQ_WAVES 2
+#endif
 #ifndef PK_ATTN_FUSED_WAVES
 #define PK_ATTN_FUSED_WAVES 2
 #endif
-constexpr int q_min_waves(int mode, int hd) { return mode == 0 ? (hd == 64 ? PK_ATTN_FWD_WAVES : 2) : (hd == 64 ? 2 : 1); }
+constexpr int q_min_waves(int mode, int hd) { return mode == 0 ? (hd == 64 ? PK_ATTN_FWD_WAVES : 2) : (hd == 64 ? PK_ATTN_DQ_WAVES : 1); }
 constexpr int dkv_min_waves(int hd) { return hd == 64 ? 2 : 1; }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
