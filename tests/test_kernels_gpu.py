@@ -529,6 +529,31 @@ def test_embedding_backward_runs_across_workgroup_ranges(F, counts):
     assert a[pad].abs().max().item() == 0
 
 
+@pytest.mark.parametrize('ntok,V', [(1, 50), (2, 8032), (1000, 8032), (4097, 600), (32768, 8032), (32768, 70376), (8192, 256206),
+                                    (32767, 131072), (40000, 8032)])
+def test_embedding_backward_sort_sizes(F, ntok, V):
+    """token counts from 1 to 40 000 over vocabularies of 50 to 256 206 rows (the key widths of the position sort), one hot row,
+    the first and the last id present — against index_add in fp64, twice for the bits.  (Written for a single-workgroup
+    bitonic sort that was measured and dropped: 120 stages over 128 KiB of LDS are bound by one CU's LDS bandwidth, 270-350 us
+    against the radix sort's 45.)"""
+    g = torch.Generator().manual_seed(ntok + V)
+    d = 64
+    ids = torch.randint(0, V, (ntok,), generator=g)
+    ids[: ntok // 3] = int(ids[0])  # one hot row
+    if ntok > 2:
+        ids[-1], ids[-2] = V - 1, 0
+    dout = torch.randn(ntok, d, generator=g).bfloat16()
+    a = F.embed_bwd(ids.cuda(), dout.cuda(), V, -1, 1.0)
+    b = F.embed_bwd(ids.cuda(), dout.cuda(), V, -1, 1.0)
+    assert torch.equal(a, b)
+    ref = torch.zeros(V, d, dtype=torch.float64)
+    ref.index_add_(0, ids, dout.double())
+    assert rel_err(a, ref.float()) < 6e-3
+    touched = torch.zeros(V, dtype=torch.bool)
+    touched[ids] = True
+    assert a[~touched.cuda()].abs().max().item() == 0 if (~touched).any() else True
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('eps', [0.0, 0.1])
 @pytest.mark.parametrize('V', [8032, 101, 70376])
