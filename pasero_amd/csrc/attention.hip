@@ -1070,7 +1070,14 @@ int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, co
     PK_T16(hipLaunchKernelGGL((attn_bwd_dkv_kernel<TT, D, W, DR>), gk, dim3(256), 0, s, (const TT*)q, (const TT*)k,  \
                               (const TT*)v, (const TT*)d_o, lse, (const float*)delta, (TT*)dk, (TT*)dv, p))
 #define PK_DKV(D, W) do { if (p.drop_thr) PK_DKV_(D, W, true); else PK_DKV_(D, W, false); } while (0)
-        if (T > 0) {
+        // long key sequences, heads of 64, no causal mask, no rotation: the dQ kernel with the forward's frame (attention_long.hip)
+        static const int long_min_s = [] { const char* ev = getenv("PK_ATTN_LONG_MIN_S"); return ev ? atoi(ev) : 256; }();
+        static const bool long_dq = [] { const char* ev = getenv("PK_ATTN_LONG_DQ"); return !ev || atoi(ev) != 0; }();  // (A/B)
+        if (T > 0 && long_dq && hd == 64 && !causal && !p.rope_cos && S >= long_min_s &&
+            (long long)S * std::max(k_rs, v_rs) * 2 < (1LL << 31)) {
+            PK_CHECK_ARG(pk_attn_dq_long_launch(q, k, v, o, d_o, lse, delta, dq, p, dtype, s) == 0,
+                         "pk_attn_bwd: launch of the long-sequence dQ kernel failed");
+        } else if (T > 0) {
             if (hd == 64) PK_DQ(64);
             else PK_DQ(128);
         }

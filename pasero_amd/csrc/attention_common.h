@@ -350,3 +350,6 @@ __device__ __forceinline__ void store_rowT(T* __restrict__ base, long long rs, i
 // attention_long.hip: the long-key-sequence forward (heads of 64, 16-bit types, no causal mask, no rotation); returns a HIP error code
 int pk_attn_fwd_long_launch(const void* q, const void* k, const void* v, void* o, float* lse, const pkattn::AttnParams& p, int dtype,
                             hipStream_t stream);
+// the dQ pass of the same shapes (also writes delta for the dK / dV kernel that follows)
+int pk_attn_dq_long_launch(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                           float* delta, void* dq, const pkattn::AttnParams& p, int dtype, hipStream_t stream);

@@ -22,6 +22,9 @@ namespace {
 // Same accumulator layouts, Q fragments and row stores as the kernel above.  A row's arithmetic depends on its own data only
 // (a lane re-anchors only when ITS maximum says so).
 constexpr float LAG_THR = 8.f;
+#ifndef PKL_DQ_WAVES
+#define PKL_DQ_WAVES 3  // (the dQ kernel below: 174 registers left alone, 168 under this budget without a spill)
+#endif
 #ifndef PKL_WAVES
 #define PKL_WAVES 3  // waves per SIMD the register budget leaves room for
 #endif
@@ -250,6 +253,187 @@ __global__ __launch_bounds__(256, PKL_WAVES) void attn_fwd_long_kernel(const T* 
     if (valid && lane < 32) lse[mrow] = l > 0.f ? (log2f(l) - negm) * LN2 : 0.f;
 }
 
+
+// ---- dQ for long key sequences: the frame of the forward kernel above around the dQ arithmetic of attention.hip ----
+// (query on the lane; K and V tiles by LDS-DMA into the two-deep ring, one barrier per tile, masked keys per tile by one
+// ballot, one 32-key block at a time: S starts from the accumulator -lse / scale, dP from -delta, p = exp2(c acc),
+// dS = p dP', dQᵀ += Kᵀ dSᵀ with the transposed K reads in inline asm — see the forward kernel for why.)  Also writes
+// delta = rowsum(dO o) for the dK / dV kernel that follows.  Heads of 64, no causal mask, no rotation.
+template <typename T, bool DROP>
+__global__ __launch_bounds__(256, PKL_DQ_WAVES) void attn_dq_long_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                              const T* __restrict__ v, const T* __restrict__ o,
+                                                              const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, T* __restrict__ dq, AttnParams p,
+                                                              int nqb, int npairs) {
+    constexpr int HD = 64, NF = 4, ND = 2;
+    constexpr int IMG = img_bytes<DUAL>();
+    typedef __attribute__((address_space(3))) void lds_void;
+    __shared__ __attribute__((aligned(1024))) char ring[2 * 2 * IMG];  // stage st: K image at 2 st IMG, V image behind it
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lin = blockIdx.x, grp = (lin >> 3) / nqb, qb = (lin >> 3) % nqb;
+    const int pair = grp * 8 + (lin & 7);
+    if (pair >= npairs) return;
+    const int b = pair / p.H, h = pair % p.H;
+    const int t = qb * 128 + wave * 32 + (lane & 31);
+    const bool valid = t < p.T;
+    const float c = p.scale * LOG2E;
+    const long long mrow = ((long long)b * p.H + h) * p.T + t;
+
+    bf16x8_t qf[NF], dof[NF];
+    load_row_frags(qf, q + b * p.q_bs + h * HD, p.q_rs, t, valid, lane);
+    load_row_frags(dof, d_o + b * p.do_bs + h * HD, p.do_rs, t, valid, lane);
+    float dl = 0.f, s_init = -INFINITY;  // rows past T: exp2(c (s - inf)) = 0
+    {
+        bf16x8_t of[NF];
+        load_row_frags(of, o + b * p.o_bs + h * HD, p.o_rs, t, valid, lane);
+#pragma unroll
+        for (int kk = 0; kk < NF; ++kk) dl += frag_dot<T>(dof[kk], of[kk]);
+        dl += __shfl_xor(dl, 32, 64);
+        if (valid) {
+            s_init = -lse[mrow] / p.scale;
+            if (lane < 32) delta[mrow] = dl;
+        }
+    }
+    f32x16 acc[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+
+    const T* kbase = k + b * p.k_bs + h * HD;
+    const T* vbase = v + b * p.v_bs + h * HD;
+    const unsigned k_rsb = (unsigned)(p.k_rs * 2), v_rsb = (unsigned)(p.v_rs * 2);
+    const int kbytes = (int)(((long long)(p.S - 1) * p.k_rs + HD) * 2), vbytes = (int)(((long long)(p.S - 1) * p.v_rs + HD) * 2);
+    unsigned koff[2], voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (wave + 4 * i) + ((lane >> 2) & 7);
+        const int ch = 4 * (lane >> 5) + ((lane & 3) ^ ((row >> 2) & 3));  // (the inverse of lds_off<DUAL>)
+        koff[i] = (unsigned)row * k_rsb + 16 * ch;
+        voff[i] = (unsigned)row * v_rsb + 16 * ch;
+    }
+    unsigned kaddr[2];  // transposed reads of the K image: rows 4 h + q and + 8 of d-tile 0 (see the forward kernel)
+    {
+        typedef __attribute__((address_space(3))) char lds_char;
+        const int qd = (lane & 15) >> 2, p4 = lane & 3;
+        const int col = 16 * ((lane >> 4) & 1) + 4 * p4, row = 4 * (lane >> 5) + qd;
+        const unsigned base = (unsigned)(unsigned long)(lds_char*)ring + (col & 7) * 2;
+        kaddr[0] = base + lds_off<DUAL>(row, col >> 3);
+        kaddr[1] = base + lds_off<DUAL>(row + 8, col >> 3);
+    }
+    const int ntiles = (p.S + KT - 1) / KT;
+    auto dma = [&](int tile, int st) {
+        __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, kbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, vbytes, 0x00020000);
+        char* kd = ring + st * 2 * IMG + wave * 1024;
+        const unsigned ks = (unsigned)(tile * KT) * k_rsb, vs = (unsigned)(tile * KT) * v_rsb;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)(kd + 4096 * i), 16, koff[i], ks, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(kd + IMG + 4096 * i), 16, voff[i], vs, 0, 0);
+        }
+    };
+    const unsigned char* padrow = p.key_pad ? p.key_pad + (long long)b * p.S : nullptr;
+    auto pad_of = [&](int tile) -> unsigned {
+        const int sk = tile * KT + lane;
+        if (sk >= p.S) return 1u;
+        return padrow ? (unsigned)padrow[sk] : 0u;
+    };
+    // the stored keep bits of this query's keys: a dword per 32 keys (rows past T: zeros)
+    auto bits_of = [&](int tile, int kb) -> unsigned {
+        if (!DROP || !valid) return 0u;
+        return *reinterpret_cast<const unsigned*>(p.drop_mask + mrow * p.mask_pitch + ((tile * KT + kb * 32) >> 3));
+    };
+
+    auto body = [&](const char* k_lds, const char* v_lds, unsigned padb, unsigned w0, unsigned w1) {
+        const unsigned long long dead = __ballot(padb != 0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s1, d1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s1[r] = s_init;
+#pragma unroll
+            for (int kk = 0; kk < NF; ++kk) s1 = mm<T>(row_frag<DUAL>(k_lds, kb * 32, kk, lane), qf[kk], s1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d1[r] = DROP ? 0.f : -dl;  // (with dropout dP is scaled before delta comes off)
+#pragma unroll
+            for (int kk = 0; kk < NF; ++kk) d1 = mm<T>(row_frag<DUAL>(v_lds, kb * 32, kk, lane), dof[kk], d1);
+            // Kᵀ fragments of this block for the dQ product (asm: no vmcnt drain in front of them)
+            s16x4 kt[2][ND][2];
+            const unsigned ka0 = kaddr[0] + (unsigned)(k_lds - ring), ka8 = kaddr[1] + (unsigned)(k_lds - ring);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) {
+                    if (kb == 0) {
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(kt[s][dt][0]) : "v"(ka0), "i"(1024 * (2 * s) + 512 * dt));
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(kt[s][dt][1]) : "v"(ka8), "i"(1024 * (2 * s) + 512 * dt));
+                    } else {
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(kt[s][dt][0]) : "v"(ka0), "i"(1024 * (4 + 2 * s) + 512 * dt));
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(kt[s][dt][1]) : "v"(ka8), "i"(1024 * (4 + 2 * s) + 512 * dt));
+                    }
+                }
+            if (dead) {  // wave-uniform: this tile holds masked keys
+                unsigned dm = (unsigned)(dead >> (32 * kb)) >> (4 * (lane >> 5));
+                asm volatile("; masked keys" : "+v"(dm));
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((dm >> ((r & 3) + 8 * (r >> 2))) & 1u) s1[r] = -INFINITY;
+            }
+            if constexpr (DROP) {
+                const unsigned w4 = kb ? w1 : w0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned byte = (w4 >> (8 * g)) & 0xffu;
+                    byte >>= 4 * (lane >> 5);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d1[4 * g + j] = ((byte >> j) & 1) ? d1[4 * g + j] * p.drop_scale : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pw = __builtin_amdgcn_exp2f(s1[r] * c);  // masked: exp2(-inf) = 0
+                s1[r] = DROP ? pw * (d1[r] - dl) : pw * d1[r];        // dSᵀ
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(kt[0][0][0]), "+v"(kt[0][0][1]), "+v"(kt[0][1][0]), "+v"(kt[0][1][1]),
+                           "+v"(kt[1][0][0]), "+v"(kt[1][0][1]), "+v"(kt[1][1][0]), "+v"(kt[1][1][1]));
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8_t pf = acc_frag<T>(s1, s);
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) {
+                    const s16x4 lo = kt[s][dt][0], hi = kt[s][dt][1];
+                    const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc[dt] = mm<T>(__builtin_bit_cast(bf16x8_t, f), pf, acc[dt]);
+                }
+            }
+        }
+    };
+
+    unsigned padb = 0, w0 = 0, w1 = 0;
+    if (ntiles > 0) {
+        w0 = bits_of(0, 0); w1 = bits_of(0, 1);
+        padb = pad_of(0);
+        dma(0, 0);
+    }
+    for (int tile = 0; tile < ntiles; ++tile) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the tile (and the bits / pad byte behind them)
+        __syncthreads();                                   // everyone's pieces; the other stage is free
+        unsigned padn = 0, n0 = 0, n1 = 0;
+        if (tile + 1 < ntiles) {
+            n0 = bits_of(tile + 1, 0); n1 = bits_of(tile + 1, 1);
+            padn = pad_of(tile + 1);
+            dma(tile + 1, (tile + 1) & 1);
+        }
+        const char* st = ring + (tile & 1) * 2 * IMG;
+        body(st, st + IMG, padb, w0, w1);
+        padb = padn; w0 = n0; w1 = n1;
+    }
+    store_rowT(dq + b * p.dq_bs + h * HD, p.dq_rs, t, valid, acc, p.scale, lane);
+}
+
 }  // namespace
 
 int pk_attn_fwd_long_launch(const void* q, const void* k, const void* v, void* o, float* lse, const pkattn::AttnParams& p, int dtype,
@@ -258,6 +442,18 @@ int pk_attn_fwd_long_launch(const void* q, const void* k, const void* v, void* o
     const dim3 lg((unsigned)((npairs + 7) / 8 * 8) * nqb);
 #define PK_LONG(TT, DR) hipLaunchKernelGGL((attn_fwd_long_kernel<TT, DR>), lg, dim3(256), 0, s, (const TT*)q, (const TT*)k, \
                                            (const TT*)v, (TT*)o, lse, p, nqb, npairs)
+    if (dtype == PK_BF16) { if (p.drop_thr) PK_LONG(bf16, true); else PK_LONG(bf16, false); }
+    else { if (p.drop_thr) PK_LONG(f16, true); else PK_LONG(f16, false); }
+#undef PK_LONG
+    return (int)hipGetLastError();
+}
+
+int pk_attn_dq_long_launch(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                           float* delta, void* dq, const pkattn::AttnParams& p, int dtype, hipStream_t s) {
+    const int nqb = (p.T + 127) / 128, npairs = p.B * p.H;
+    const dim3 lg((unsigned)((npairs + 7) / 8 * 8) * nqb);
+#define PK_LONG(TT, DR) hipLaunchKernelGGL((attn_dq_long_kernel<TT, DR>), lg, dim3(256), 0, s, (const TT*)q, (const TT*)k, \
+                                           (const TT*)v, (const TT*)o, (const TT*)d_o, lse, delta, (TT*)dq, p, nqb, npairs)
     if (dtype == PK_BF16) { if (p.drop_thr) PK_LONG(bf16, true); else PK_LONG(bf16, false); }
     else { if (p.drop_thr) PK_LONG(f16, true); else PK_LONG(f16, false); }
 #undef PK_LONG
