@@ -1082,7 +1082,12 @@ int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, co
             else PK_DQ(128);
         }
         PK_LAUNCH_CHECK();
-        if (S > 0) {
+        static const bool long_dkv = [] { const char* ev = getenv("PK_ATTN_LONG_DKV"); return !ev || atoi(ev) != 0; }();  // (A/B)
+        if (S > 0 && long_dkv && hd == 64 && !causal && !p.rope_cos && T >= long_min_s &&
+            (long long)T * std::max(q_rs, do_rs) * 2 < (1LL << 31)) {
+            PK_CHECK_ARG(pk_attn_dkv_long_launch(q, k, v, d_o, lse, delta, dk, dv, p, dtype, s) == 0,
+                         "pk_attn_bwd: launch of the long-sequence dK / dV kernel failed");
+        } else if (S > 0) {
             if (hd == 64) {
                 PK_DKV(64, 0);
             } else {  // head_dim 128: dV and dK in two launches (each recomputes S; both accumulators do not fit)

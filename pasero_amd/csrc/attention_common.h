@@ -353,3 +353,6 @@ int pk_attn_fwd_long_launch(const void* q, const void* k, const void* v, void* o
 // the dQ pass of the same shapes (also writes delta for the dK / dV kernel that follows)
 int pk_attn_dq_long_launch(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                            float* delta, void* dq, const pkattn::AttnParams& p, int dtype, hipStream_t stream);
+// the dK / dV pass for long QUERY sequences (T >= the same threshold)
+int pk_attn_dkv_long_launch(const void* q, const void* k, const void* v, const void* d_o, const float* lse, const float* delta,
+                            void* dk, void* dv, const pkattn::AttnParams& p, int dtype, hipStream_t stream);

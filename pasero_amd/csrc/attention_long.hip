@@ -434,6 +434,197 @@ __global__ __launch_bounds__(256, PKL_DQ_WAVES) void attn_dq_long_kernel(const T
     store_rowT(dq + b * p.dq_bs + h * HD, p.dq_rs, t, valid, acc, p.scale, lane);
 }
 
+
+// ---- dK / dV for long query sequences: the same frame, key on the lane ----
+// One workgroup = 128 keys of a (batch, head) pair (wave w: keys 32 w .. on its lanes, K / V fragments in registers), the
+// pair's queries stream by in tiles of 64: Q and dO tiles by LDS-DMA into the two-deep ring of dual-use images (read by rows
+// for S = Q Kᵀ and dP = dO Vᵀ, transposed — inline asm, see the forward kernel — for dVᵀ += dOᵀ P and dKᵀ += Qᵀ dS), the
+// tile's -lse / scale and -delta rows (the initial accumulators) and, with dropout, its keep dwords through registers into a
+// two-deep LDS row next to them; one barrier per tile.  Arithmetic and results of attn_bwd_dkv_kernel (attention.hip); heads of
+// 64, no causal mask, no rotation.
+template <typename T, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_dkv_long_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                               const T* __restrict__ v, const T* __restrict__ d_o,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               T* __restrict__ dk, T* __restrict__ dv, AttnParams p, int nkb,
+                                                               int npairs) {
+    constexpr int HD = 64, NF = 4, ND = 2;
+    constexpr int IMG = img_bytes<DUAL>();
+    typedef __attribute__((address_space(3))) void lds_void;
+    __shared__ __attribute__((aligned(1024))) char ring[2 * 2 * IMG];  // stage st: Q image at 2 st IMG, dO image behind it
+    __shared__ __attribute__((aligned(16))) float rowc[2][2][KT];      // stage st: -lse / scale, -delta of the tile's rows
+    __shared__ unsigned m_lds[DROP ? 2 * KT * 4 : 1];                  // stage st: keep dwords [row][wave]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lin = blockIdx.x, grp = (lin >> 3) / nkb, blk = (lin >> 3) % nkb;
+    const int pair = grp * 8 + (lin & 7);
+    if (pair >= npairs) return;
+    const int b = pair / p.H, h = pair % p.H;
+    const int s = blk * 128 + wave * 32 + (lane & 31);
+    const bool kvalid = s < p.S && !(p.key_pad && p.key_pad[(long long)b * p.S + min(s, p.S - 1)]);
+    const float c = p.scale * LOG2E, inv_scale = 1.f / p.scale;
+    const unsigned keep_bit = s < p.S ? 1u << (lane & 31) : 0u;
+    const long long row0 = ((long long)b * p.H + h) * p.T;
+
+    bf16x8_t kf[NF], vf[NF];
+    load_row_frags(kf, k + b * p.k_bs + h * HD, p.k_rs, s, s < p.S, lane);
+    load_row_frags(vf, v + b * p.v_bs + h * HD, p.v_rs, s, s < p.S, lane);
+    f32x16 dka[ND], dva[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dka[dt][r] = dva[dt][r] = 0.f;
+
+    const T* qbase = q + b * p.q_bs + h * HD;
+    const T* dobase = d_o + b * p.do_bs + h * HD;
+    const unsigned q_rsb = (unsigned)(p.q_rs * 2), do_rsb = (unsigned)(p.do_rs * 2);
+    const int qbytes = (int)(((long long)(p.T - 1) * p.q_rs + HD) * 2), dobytes = (int)(((long long)(p.T - 1) * p.do_rs + HD) * 2);
+    unsigned qoff[2], dooff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (wave + 4 * i) + ((lane >> 2) & 7);
+        const int ch = 4 * (lane >> 5) + ((lane & 3) ^ ((row >> 2) & 3));  // (the inverse of lds_off<DUAL>)
+        qoff[i] = (unsigned)row * q_rsb + 16 * ch;
+        dooff[i] = (unsigned)row * do_rsb + 16 * ch;
+    }
+    unsigned taddr[2];  // transposed reads of an image: rows 4 h + q and + 8 of d-tile 0 (see the forward kernel)
+    {
+        typedef __attribute__((address_space(3))) char lds_char;
+        const int qd = (lane & 15) >> 2, p4 = lane & 3;
+        const int col = 16 * ((lane >> 4) & 1) + 4 * p4, row = 4 * (lane >> 5) + qd;
+        const unsigned base = (unsigned)(unsigned long)(lds_char*)ring + (col & 7) * 2;
+        taddr[0] = base + lds_off<DUAL>(row, col >> 3);
+        taddr[1] = base + lds_off<DUAL>(row + 8, col >> 3);
+    }
+    const int ntiles = (p.T + KT - 1) / KT;
+    auto dma = [&](int tile, int st) {
+        __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, qbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, dobytes, 0x00020000);
+        char* qd = ring + st * 2 * IMG + wave * 1024;
+        const unsigned qs = (unsigned)(tile * KT) * q_rsb, ds = (unsigned)(tile * KT) * do_rsb;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void*)(qd + 4096 * i), 16, qoff[i], qs, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void*)(qd + IMG + 4096 * i), 16, dooff[i], ds, 0, 0);
+        }
+    };
+    // thread tid < 64: the row constants of row tid of a tile; every thread: dword tid & 3 of the keep bits of row tid >> 2
+    float l_n = 0.f, d_n = 0.f;
+    unsigned m_n = 0u;
+    auto rows_g2r = [&](int tile) {
+        const int t0 = tile * KT;
+        if (tid < KT) {
+            const int t = t0 + tid;
+            l_n = t < p.T ? -lse[row0 + t] * inv_scale : -INFINITY;  // -inf -> p = 0 for rows past T
+            d_n = t < p.T ? -delta[row0 + t] : 0.f;
+        }
+        if constexpr (DROP) {
+            const int t = t0 + (tid >> 2);
+            const long long byte0 = (long long)blk * 16 + (tid & 3) * 4;
+            m_n = (t >= p.T || byte0 + 4 > p.mask_pitch) ? 0u
+                                                        : *reinterpret_cast<const unsigned*>(p.drop_mask + (row0 + t) * p.mask_pitch + byte0);
+        }
+    };
+
+    auto body = [&](int st) {
+        const char* q_lds = ring + st * 2 * IMG;
+        const char* do_lds = q_lds + IMG;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 sc, dp;
+            float4 d4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are 4 consecutive queries: one 16-B read each of -lse, -delta
+                const int tl = qb * 32 + 8 * g + 4 * (lane >> 5);
+                const float4 l4 = *reinterpret_cast<const float4*>(&rowc[st][0][tl]);
+                d4[g] = *reinterpret_cast<const float4*>(&rowc[st][1][tl]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sc[4 * g + j] = (&l4.x)[j];
+                    dp[4 * g + j] = DROP ? 0.f : (&d4[g].x)[j];
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < NF; ++kk) {
+                sc = mm<T>(row_frag<DUAL>(q_lds, qb * 32, kk, lane), kf[kk], sc);
+                dp = mm<T>(row_frag<DUAL>(do_lds, qb * 32, kk, lane), vf[kk], dp);
+            }
+            s16x4 tq[2][ND][2], td[2][ND][2];  // Qᵀ / dOᵀ fragments of this query block: [k-step][d-tile][rows +0 / +8]
+            const unsigned a0 = taddr[0] + (unsigned)(q_lds - ring), a8 = taddr[1] + (unsigned)(q_lds - ring);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(td[s2][dt][0]) : "v"(a0), "i"(8192 + 1024 * (4 * qb + 2 * s2) + 512 * dt));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(td[s2][dt][1]) : "v"(a8), "i"(8192 + 1024 * (4 * qb + 2 * s2) + 512 * dt));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(tq[s2][dt][0]) : "v"(a0), "i"(1024 * (4 * qb + 2 * s2) + 512 * dt));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(tq[s2][dt][1]) : "v"(a8), "i"(1024 * (4 * qb + 2 * s2) + 512 * dt));
+                }
+            f32x16 ds;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float pw = __builtin_amdgcn_exp2f(sc[4 * g + j] * c);
+                    if constexpr (DROP) {  // keep bit of (query tl + j, this lane's key): bit lane & 31 of the wave's dword
+                        const int tl = qb * 32 + 8 * g + 4 * (lane >> 5);
+                        const unsigned wd = m_lds[st * KT * 4 + (tl + j) * 4 + wave];
+                        const float km = (wd & keep_bit) ? p.drop_scale : 0.f;  // (rows past T were staged as zeros)
+                        sc[4 * g + j] = pw * km;
+                        ds[4 * g + j] = pw * fmaf(dp[4 * g + j], km, (&d4[g].x)[j]);
+                    } else {
+                        sc[4 * g + j] = pw;
+                        ds[4 * g + j] = pw * dp[4 * g + j];
+                    }
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(tq[0][0][0]), "+v"(tq[0][0][1]), "+v"(tq[0][1][0]), "+v"(tq[0][1][1]),
+                           "+v"(tq[1][0][0]), "+v"(tq[1][0][1]), "+v"(tq[1][1][0]), "+v"(tq[1][1][1]),
+                           "+v"(td[0][0][0]), "+v"(td[0][0][1]), "+v"(td[0][1][0]), "+v"(td[0][1][1]),
+                           "+v"(td[1][0][0]), "+v"(td[1][0][1]), "+v"(td[1][1][0]), "+v"(td[1][1][1]));
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8_t pf = acc_frag<T>(sc, s2), dsf = acc_frag<T>(ds, s2);
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) {
+                    // dVᵀ[d][key] += dOᵀ[d][query] · P[query][key] ;  dKᵀ[d][key] += Qᵀ[d][query] · dS[query][key]
+                    const s16x8 fd = {td[s2][dt][0][0], td[s2][dt][0][1], td[s2][dt][0][2], td[s2][dt][0][3],
+                                      td[s2][dt][1][0], td[s2][dt][1][1], td[s2][dt][1][2], td[s2][dt][1][3]};
+                    const s16x8 fq = {tq[s2][dt][0][0], tq[s2][dt][0][1], tq[s2][dt][0][2], tq[s2][dt][0][3],
+                                      tq[s2][dt][1][0], tq[s2][dt][1][1], tq[s2][dt][1][2], tq[s2][dt][1][3]};
+                    dva[dt] = mm<T>(__builtin_bit_cast(bf16x8_t, fd), pf, dva[dt]);
+                    dka[dt] = mm<T>(__builtin_bit_cast(bf16x8_t, fq), dsf, dka[dt]);
+                }
+            }
+        }
+    };
+
+    if (ntiles > 0) {
+        rows_g2r(0);
+        dma(0, 0);
+    }
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int st = tile & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the tile and the row constants behind them
+        if (tid < KT) { rowc[st][0][tid] = l_n; rowc[st][1][tid] = d_n; }
+        if constexpr (DROP) m_lds[st * KT * 4 + tid] = m_n;
+        __syncthreads();                                   // everyone's pieces and rows; the other stage is free
+        if (tile + 1 < ntiles) {
+            rows_g2r(tile + 1);
+            dma(tile + 1, st ^ 1);
+        }
+        body(st);
+    }
+    if (!kvalid) {  // padding keys: zero rows (a select, not a product: their probabilities are unbounded)
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dka[dt][r] = dva[dt][r] = 0.f;
+    }
+    store_rowT(dk + b * p.dk_bs + h * HD, p.dk_rs, s, s < p.S, dka, p.scale, lane);
+    store_rowT(dv + b * p.dv_bs + h * HD, p.dv_rs, s, s < p.S, dva, 1.f, lane);
+}
+
 }  // namespace
 
 int pk_attn_fwd_long_launch(const void* q, const void* k, const void* v, void* o, float* lse, const pkattn::AttnParams& p, int dtype,
@@ -454,6 +645,18 @@ int pk_attn_dq_long_launch(const void* q, const void* k, const void* v, const vo
     const dim3 lg((unsigned)((npairs + 7) / 8 * 8) * nqb);
 #define PK_LONG(TT, DR) hipLaunchKernelGGL((attn_dq_long_kernel<TT, DR>), lg, dim3(256), 0, s, (const TT*)q, (const TT*)k, \
                                            (const TT*)v, (const TT*)o, (const TT*)d_o, lse, delta, (TT*)dq, p, nqb, npairs)
+    if (dtype == PK_BF16) { if (p.drop_thr) PK_LONG(bf16, true); else PK_LONG(bf16, false); }
+    else { if (p.drop_thr) PK_LONG(f16, true); else PK_LONG(f16, false); }
+#undef PK_LONG
+    return (int)hipGetLastError();
+}
+
+int pk_attn_dkv_long_launch(const void* q, const void* k, const void* v, const void* d_o, const float* lse, const float* delta,
+                            void* dk, void* dv, const pkattn::AttnParams& p, int dtype, hipStream_t s) {
+    const int nkb = (p.S + 127) / 128, npairs = p.B * p.H;
+    const dim3 lg((unsigned)((npairs + 7) / 8 * 8) * nkb);
+#define PK_LONG(TT, DR) hipLaunchKernelGGL((attn_dkv_long_kernel<TT, DR>), lg, dim3(256), 0, s, (const TT*)q, (const TT*)k, \
+                                           (const TT*)v, (const TT*)d_o, lse, delta, (TT*)dk, (TT*)dv, p, nkb, npairs)
     if (dtype == PK_BF16) { if (p.drop_thr) PK_LONG(bf16, true); else PK_LONG(bf16, false); }
     else { if (p.drop_thr) PK_LONG(f16, true); else PK_LONG(f16, false); }
 #undef PK_LONG
