@@ -1,5 +1,6 @@
-"""The long-key-sequence forward kernel (heads of 64, no causal mask, S >= 256: `attn_fwd_long_kernel`, lagging maximum,
-K / V tiles by LDS-DMA) against the oracle's explicit softmax attention on the cases its shortcuts could get wrong:
+"""The long-sequence attention kernels of csrc/attention_long.hip (heads of 64, no causal mask: forward `attn_fwd_long_kernel`
+with its lagging maximum and dQ `attn_dq_long_kernel` at S >= 256, dK / dV `attn_dkv_long_kernel` at T >= 256; K / V resp.
+Q / dO tiles by LDS-DMA) against the oracle's explicit softmax attention on the cases their shortcuts could get wrong:
 rows whose maximum keeps growing from tile to tile (every tile re-anchors) or grows once by a large step; key-padding
 masks that are no suffix (whole tiles masked in front of, between and behind visible keys; rows with no visible key);
 query / key counts off the tile sizes; packed-projection strides; both 16-bit types.  Reference: modules.py:654-677, 707-771."""
@@ -98,3 +99,40 @@ def test_long_forward_is_row_local(F):
     o, lse = F.attn_fwd(q, k, v, H, None, False, 0.125)
     o1, lse1 = F.attn_fwd(q[1:2, 37:200].contiguous(), k[1:2].contiguous(), v[1:2].contiguous(), H, None, False, 0.125)
     assert torch.equal(o[1:2, 37:200], o1) and torch.equal(lse[1:2, :, 37:200], lse1)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,H,T,S,packed', [(2, 2, 300, 700, False), (1, 3, 500, 500, True), (2, 1, 257, 256, False),
+                                            (1, 2, 1500, 1500, True), (3, 2, 64, 1500, False), (2, 2, 700, 100, False)])
+def test_long_backward_against_the_oracle(F, dtype, B, H, T, S, packed):
+    """dQ (S >= 256) and dK / dV (T >= 256) through pk_attn_bwd with key-padding masks that are no suffix (row 0: the first
+    70 keys and every third key masked; the last batch row: nothing but keys 5..9 visible) — gradients of the oracle's
+    attention by autograd in fp32.  (T = 64 x S = 1500: the long dQ kernel beside the tiled dK / dV kernel; 700 x 100 the
+    other way round.)"""
+    g = torch.Generator().manual_seed(T * 3 + S)
+    D = H * 64
+    if packed:
+        qkv = torch.randn(B, T, 3 * D, generator=g).to(dtype)
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        qc = qkv.cuda()
+        qg, kg, vg = qc[..., :D], qc[..., D:2 * D], qc[..., 2 * D:]
+    else:
+        q, k, v = (torch.randn(B, n, D, generator=g).to(dtype) for n in (T, S, S))
+        qg, kg, vg = q.cuda(), k.cuda(), v.cuda()
+    dy = torch.randn(B, T, D, generator=g).to(dtype)
+    pad = torch.zeros(B, S, dtype=torch.bool)
+    pad[0, :min(70, S - 1)] = True
+    pad[0, ::3] = True
+    pad[0, S - 1] = False
+    pad[B - 1] = True
+    pad[B - 1, 5:10] = False
+    qf, kf, vf = (x.float().clone().requires_grad_() for x in (q, k, v))
+    out, _ = O.attention_core(qf.view(B, T, H, 64), kf.view(B, S, H, 64), vf.view(B, S, H, 64), pad, False, 0.125)
+    out.reshape(B, T, D).backward(dy.float())
+    o, lse = F.attn_fwd(qg, kg, vg, H, pad.cuda(), False, 0.125)
+    dq, dk, dv = F.attn_bwd(qg, kg, vg, o, dy.cuda(), lse, H, pad.cuda(), False, 0.125)
+    tol = 2.5e-2 if dtype == torch.bfloat16 else 4e-3
+    for name, got, want in (('o', o, out.detach().reshape(B, T, D)), ('dq', dq, qf.grad), ('dk', dk, kf.grad), ('dv', dv, vf.grad)):
+        assert torch.isfinite(got.float()).all(), name
+        assert rel_err(got, want) < tol, (name, rel_err(got, want))
+    assert (dk[0][pad[0].cuda()] == 0).all() and (dv[0][pad[0].cuda()] == 0).all()  # masked keys receive no gradient
