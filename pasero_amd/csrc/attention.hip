@@ -969,8 +969,11 @@ int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* l
     p.nqb = (T + 127) / 128;
     const dim3 grid16((unsigned)((B * H + 7) / 8 * 8) * p.nqb);  // (16-bit kernels: 1-D, pair_block)
     hipStream_t s = (hipStream_t)stream;
-    // long key sequences, heads of 64, no causal mask, no rotation: the lagging-maximum kernel (PK_ATTN_LONG_MIN_S: diagnostic)
-    static const int long_min_s = [] { const char* e = getenv("PK_ATTN_LONG_MIN_S"); return e ? atoi(e) : 256; }();
+    // heads of 64, no causal mask, no rotation, at least one whole key tile: the lagging-maximum kernel (attention_long.hip).  Built
+    // for long key sequences, it is also the faster one at the short ones (B 256, H 8, T 128: S = 64 / 96 / 128 / 192 25.3 / 31.0 /
+    // 32.2 / 38.7 -> 22.7 / 27.1 / 28.3 / 33.9 us), and with the threshold below every padded length of the training shapes a batch
+    // and its padded twin run on one kernel.  (PK_ATTN_LONG_MIN_S: diagnostic)
+    static const int long_min_s = [] { const char* e = getenv("PK_ATTN_LONG_MIN_S"); return e ? atoi(e) : 64; }();
     if (dtype != PK_F32 && hd == 64 && !causal && !p.rope_cos && S >= long_min_s &&
         (long long)S * std::max(k_rs, v_rs) * 2 < (1LL << 31)) {
         PK_CHECK_ARG(pk_attn_fwd_long_launch(q, k, v, o, lse, p, dtype, s) == 0, "pk_attn_fwd: launch of the long-sequence kernel failed");
@@ -1071,7 +1074,7 @@ int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, co
                               (const TT*)v, (const TT*)d_o, lse, (const float*)delta, (TT*)dk, (TT*)dv, p))
 #define PK_DKV(D, W) do { if (p.drop_thr) PK_DKV_(D, W, true); else PK_DKV_(D, W, false); } while (0)
         // long key sequences, heads of 64, no causal mask, no rotation: the dQ kernel with the forward's frame (attention_long.hip)
-        static const int long_min_s = [] { const char* ev = getenv("PK_ATTN_LONG_MIN_S"); return ev ? atoi(ev) : 256; }();
+        static const int long_min_s = [] { const char* ev = getenv("PK_ATTN_LONG_MIN_BWD"); return ev ? atoi(ev) : 256; }();  // (the streamed length)
         static const bool long_dq = [] { const char* ev = getenv("PK_ATTN_LONG_DQ"); return !ev || atoi(ev) != 0; }();  // (A/B)
         if (T > 0 && long_dq && hd == 64 && !causal && !p.rope_cos && S >= long_min_s &&
             (long long)S * std::max(k_rs, v_rs) * 2 < (1LL << 31)) {
