@@ -974,8 +974,7 @@ int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* l
     // 32.2 / 38.7 -> 22.7 / 27.1 / 28.3 / 33.9 us), and with the threshold below every padded length of the training shapes a batch
     // and its padded twin run on one kernel.  (PK_ATTN_LONG_MIN_S: diagnostic)
     static const int long_min_s = [] { const char* e = getenv("PK_ATTN_LONG_MIN_S"); return e ? atoi(e) : 64; }();
-    if (dtype != PK_F32 && hd == 64 && !causal && !p.rope_cos && S >= long_min_s &&
-        (long long)S * std::max(k_rs, v_rs) * 2 < (1LL << 31)) {
+    if (dtype != PK_F32 && hd == 64 && !p.rope_cos && S >= long_min_s && (long long)S * std::max(k_rs, v_rs) * 2 < (1LL << 31)) {
         PK_CHECK_ARG(pk_attn_fwd_long_launch(q, k, v, o, lse, p, dtype, s) == 0, "pk_attn_fwd: launch of the long-sequence kernel failed");
         PK_LAUNCH_CHECK();
         return 0;

@@ -6,10 +6,11 @@
 
 namespace {
 
-// ---- forward for long key sequences (round 4): head_dim 64, no causal mask, no rotation ----
+// ---- forward for key sequences of 64 and more (round 4): head_dim 64, no rotation ----
 // The kernel above spends ~10 vector instructions per (query, key) score (scale + bias, the causal select, running maximum,
 // subtraction, exp, sum, accumulator rescale, conversion) against 16 MFMAs per 2048 scores: at S >= 500 it is paced by its
-// VALU work, not by the matrix pipe (0.5 ps per pair whatever the shape).  This form keeps 4 per score:
+// VALU work, not by the matrix pipe (0.5 ps per pair whatever the shape).  This form keeps 4 per score (causal launches too:
+// whole tiles in a wave's future are skipped, the diagonal's are masked in a wave-uniform branch):
 //   * the maximum LAGS: a query's scores are taken relative to the maximum m its row was last anchored at, x = s c - m (no
 //     multiply: the MFMA chain starts from the accumulator -m / c), and m moves only when a tile's maximum exceeds it by more than LAG_THR (exp2 domain: p <= 2^LAG_THR, in range for
 //     both 16-bit types, relative precision unchanged) — the accumulator rescale, the exp of the correction and the
@@ -42,7 +43,9 @@ __global__ __launch_bounds__(256, PKL_WAVES) void attn_fwd_long_kernel(const T* 
     __shared__ __attribute__((aligned(1024))) char ring[2 * 2 * IMG + PKL_LDS_PAD];  // stage st: K image at 2 st IMG, V image behind it
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lin = blockIdx.x, grp = (lin >> 3) / nqb, qb = (lin >> 3) % nqb;
+    const int lin = blockIdx.x, grp = (lin >> 3) / nqb;
+    // (causal: the heaviest query blocks — the last ones see the most keys — are dealt first)
+    const int qb = p.causal ? nqb - 1 - (lin >> 3) % nqb : (lin >> 3) % nqb;
     const int pair = grp * 8 + (lin & 7);
     if (pair >= npairs) return;
     const int b = pair / p.H, h = pair % p.H;
@@ -90,7 +93,10 @@ __global__ __launch_bounds__(256, PKL_WAVES) void attn_fwd_long_kernel(const T* 
         vaddr[0] = base + lds_off<DUAL>(row, col >> 3);
         vaddr[1] = base + lds_off<DUAL>(row + 8, col >> 3);
     }
-    const int ntiles = (p.S + KT - 1) / KT;
+    // causal (query t sees keys <= t + S - T): tiles beyond the last query of the workgroup are never visible; a wave skips the
+    // tiles that lie in the future of all its queries and masks inside the ones its diagonal crosses (both wave-uniform)
+    const int off = p.S - p.T, wt0 = qb * 128 + wave * 32;
+    const int ntiles = p.causal ? max(0, min((p.S + KT - 1) / KT, (qb * 128 + 128 + off + KT - 1) / KT)) : (p.S + KT - 1) / KT;
     auto dma = [&](int tile, int st) {
         __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, kbytes, 0x00020000);
         __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, vbytes, 0x00020000);
@@ -113,6 +119,8 @@ __global__ __launch_bounds__(256, PKL_WAVES) void attn_fwd_long_kernel(const T* 
 
     auto body = [&](int tile, const char* k_lds, const char* v_lds, unsigned padb) {
         const int s0 = tile * KT;
+        if (p.causal && s0 > wt0 + 31 + off) return;               // every key is in the future of every query of this wave
+        const bool check = p.causal && s0 + KT - 1 > wt0 + off;    // some (query, key) pairs are masked
         const unsigned long long dead = __ballot(padb != 0);
         f32x16 sc[2];
 #pragma unroll
@@ -131,6 +139,16 @@ __global__ __launch_bounds__(256, PKL_WAVES) void attn_fwd_long_kernel(const T* 
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if ((dm >> ((r & 3) + 8 * (r >> 2))) & 1u) sc[kb][r] = -INFINITY;
+            }
+        }
+        if (check) {  // wave-uniform: the causal boundary crosses this (wave, tile) block
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                int kq = t + off - s0 - kb * 32 - 4 * (lane >> 5);  // key index (in the block) > kq is in this query's future
+                asm volatile("; causal block" : "+v"(kq));
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) > kq) sc[kb][r] = -INFINITY;
             }
         }
         float tmax = fmaxf(sc[0][0], sc[1][0]);

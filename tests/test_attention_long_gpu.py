@@ -136,3 +136,26 @@ def test_long_backward_against_the_oracle(F, dtype, B, H, T, S, packed):
         assert torch.isfinite(got.float()).all(), name
         assert rel_err(got, want) < tol, (name, rel_err(got, want))
     assert (dk[0][pad[0].cuda()] == 0).all() and (dv[0][pad[0].cuda()] == 0).all()  # masked keys receive no gradient
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,H,T,S', [(2, 2, 500, 500), (1, 2, 1500, 1500), (2, 1, 130, 700), (1, 3, 64, 64), (2, 2, 129, 129)])
+def test_long_forward_causal(F, dtype, B, H, T, S):
+    """the same kernel under the causal mask (query t sees keys <= t + S - T): tiles in a wave's future skipped, the
+    diagonal's masked, the heaviest query blocks dealt first — output, lse and (through the tiled backward kernels) the
+    gradients against the oracle"""
+    g = torch.Generator().manual_seed(T + 2 * S)
+    D = H * 64
+    q, k, v, dy = (torch.randn(B, n, D, generator=g).to(dtype) for n in (T, S, S, T))
+    qf, kf, vf = (x.float().clone().requires_grad_() for x in (q, k, v))
+    out, _ = O.attention_core(qf.view(B, T, H, 64), kf.view(B, S, H, 64), vf.view(B, S, H, 64), None, True, 0.125)
+    out.reshape(B, T, D).backward(dy.float())
+    sc = torch.einsum('bthd,bshd->bhts', q.float().view(B, T, H, 64), k.float().view(B, S, H, 64)) * 0.125
+    sc = sc.masked_fill(torch.ones(T, S, dtype=torch.bool).triu(1 + S - T), float('-inf'))
+    o, lse = F.attn_fwd(q.cuda(), k.cuda(), v.cuda(), H, None, True, 0.125)
+    dq, dk, dv = F.attn_bwd(q.cuda(), k.cuda(), v.cuda(), o, dy.cuda(), lse, H, None, True, 0.125)
+    tol = 2.5e-2 if dtype == torch.bfloat16 else 4e-3
+    assert (lse.cpu() - torch.logsumexp(sc, -1)).abs().max().item() < 2e-3 * max(1.0, torch.logsumexp(sc, -1).abs().max().item())
+    for name, got, want in (('o', o, out.detach().reshape(B, T, D)), ('dq', dq, qf.grad), ('dk', dk, kf.grad), ('dv', dv, vf.grad)):
+        assert torch.isfinite(got.float()).all(), name
+        assert rel_err(got, want) < tol, (name, rel_err(got, want))
