@@ -1075,7 +1075,7 @@ int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, co
         // long key sequences, heads of 64, no causal mask, no rotation: the dQ kernel with the forward's frame (attention_long.hip)
         static const int long_min_s = [] { const char* ev = getenv("PK_ATTN_LONG_MIN_BWD"); return ev ? atoi(ev) : 256; }();  // (the streamed length)
         static const bool long_dq = [] { const char* ev = getenv("PK_ATTN_LONG_DQ"); return !ev || atoi(ev) != 0; }();  // (A/B)
-        if (T > 0 && long_dq && hd == 64 && !causal && !p.rope_cos && S >= long_min_s &&
+        if (T > 0 && long_dq && hd == 64 && !p.rope_cos && S >= long_min_s &&
             (long long)S * std::max(k_rs, v_rs) * 2 < (1LL << 31)) {
             PK_CHECK_ARG(pk_attn_dq_long_launch(q, k, v, o, d_o, lse, delta, dq, p, dtype, s) == 0,
                          "pk_attn_bwd: launch of the long-sequence dQ kernel failed");
@@ -1085,7 +1085,7 @@ int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, co
         }
         PK_LAUNCH_CHECK();
         static const bool long_dkv = [] { const char* ev = getenv("PK_ATTN_LONG_DKV"); return !ev || atoi(ev) != 0; }();  // (A/B)
-        if (S > 0 && long_dkv && hd == 64 && !causal && !p.rope_cos && T >= long_min_s &&
+        if (S > 0 && long_dkv && hd == 64 && !p.rope_cos && T >= long_min_s &&
             (long long)T * std::max(q_rs, do_rs) * 2 < (1LL << 31)) {
             PK_CHECK_ARG(pk_attn_dkv_long_launch(q, k, v, d_o, lse, delta, dk, dv, p, dtype, s) == 0,
                          "pk_attn_bwd: launch of the long-sequence dK / dV kernel failed");

@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256, PKL_DQ_WAVES) void attn_dq_long_kernel(const T
     __shared__ __attribute__((aligned(1024))) char ring[2 * 2 * IMG];  // stage st: K image at 2 st IMG, V image behind it
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lin = blockIdx.x, grp = (lin >> 3) / nqb, qb = (lin >> 3) % nqb;
+    const int lin = blockIdx.x, grp = (lin >> 3) / nqb;
+    const int qb = p.causal ? nqb - 1 - (lin >> 3) % nqb : (lin >> 3) % nqb;  // (causal: heaviest query blocks first)
     const int pair = grp * 8 + (lin & 7);
     if (pair >= npairs) return;
     const int b = pair / p.H, h = pair % p.H;
@@ -340,7 +341,10 @@ __global__ __launch_bounds__(256, PKL_DQ_WAVES) void attn_dq_long_kernel(const T
         kaddr[0] = base + lds_off<DUAL>(row, col >> 3);
         kaddr[1] = base + lds_off<DUAL>(row + 8, col >> 3);
     }
-    const int ntiles = (p.S + KT - 1) / KT;
+    // causal: as in the forward kernel (tiles beyond the workgroup's last query never staged, a wave skips the tiles in the
+    // future of all its queries and masks inside the ones its diagonal crosses)
+    const int off = p.S - p.T, wt0 = qb * 128 + wave * 32;
+    const int ntiles = p.causal ? max(0, min((p.S + KT - 1) / KT, (qb * 128 + 128 + off + KT - 1) / KT)) : (p.S + KT - 1) / KT;
     auto dma = [&](int tile, int st) {
         __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, kbytes, 0x00020000);
         __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, vbytes, 0x00020000);
@@ -364,7 +368,10 @@ __global__ __launch_bounds__(256, PKL_DQ_WAVES) void attn_dq_long_kernel(const T
         return *reinterpret_cast<const unsigned*>(p.drop_mask + mrow * p.mask_pitch + ((tile * KT + kb * 32) >> 3));
     };
 
-    auto body = [&](const char* k_lds, const char* v_lds, unsigned padb, unsigned w0, unsigned w1) {
+    auto body = [&](int tile, const char* k_lds, const char* v_lds, unsigned padb, unsigned w0, unsigned w1) {
+        const int s0 = tile * KT;
+        if (p.causal && s0 > wt0 + 31 + off) return;
+        const bool check = p.causal && s0 + KT - 1 > wt0 + off;
         const unsigned long long dead = __ballot(padb != 0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -398,6 +405,13 @@ __global__ __launch_bounds__(256, PKL_DQ_WAVES) void attn_dq_long_kernel(const T
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if ((dm >> ((r & 3) + 8 * (r >> 2))) & 1u) s1[r] = -INFINITY;
+            }
+            if (check) {  // wave-uniform: the causal boundary crosses this (wave, tile) block
+                int kq = t + off - s0 - kb * 32 - 4 * (lane >> 5);  // key index (in the block) > kq is in this query's future
+                asm volatile("; causal block" : "+v"(kq));
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) > kq) s1[r] = -INFINITY;
             }
             if constexpr (DROP) {
                 const unsigned w4 = kb ? w1 : w0;
@@ -446,7 +460,7 @@ __global__ __launch_bounds__(256, PKL_DQ_WAVES) void attn_dq_long_kernel(const T
             dma(tile + 1, (tile + 1) & 1);
         }
         const char* st = ring + (tile & 1) * 2 * IMG;
-        body(st, st + IMG, padb, w0, w1);
+        body(tile, st, st + IMG, padb, w0, w1);
         padb = padn; w0 = n0; w1 = n1;
     }
     store_rowT(dq + b * p.dq_bs + h * HD, p.dq_rs, t, valid, acc, p.scale, lane);
@@ -514,7 +528,11 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_long_kernel(const T* __restri
         taddr[0] = base + lds_off<DUAL>(row, col >> 3);
         taddr[1] = base + lds_off<DUAL>(row + 8, col >> 3);
     }
+    // causal (query t sees keys <= t + S - T): the query tiles before the workgroup's first key are never staged; a wave skips
+    // the tiles whose queries all lie before its keys and masks inside the ones its diagonal crosses (both wave-uniform)
+    const int off = p.S - p.T, ws0 = blk * 128 + wave * 32;
     const int ntiles = (p.T + KT - 1) / KT;
+    const int tile0 = p.causal ? max(0, blk * 128 - off) / KT : 0;
     auto dma = [&](int tile, int st) {
         __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, qbytes, 0x00020000);
         __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, dobytes, 0x00020000);
@@ -544,9 +562,12 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_long_kernel(const T* __restri
         }
     };
 
-    auto body = [&](int st) {
+    auto body = [&](int tile, int st) {
         const char* q_lds = ring + st * 2 * IMG;
         const char* do_lds = q_lds + IMG;
+        const int t0 = tile * KT;
+        if (p.causal && ws0 > t0 + KT - 1 + off) return;       // every key of this wave is in the future of every query
+        const bool check = p.causal && ws0 + 31 > t0 + off;   // some pairs are masked
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 sc, dp;
@@ -566,6 +587,13 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_long_kernel(const T* __restri
             for (int kk = 0; kk < NF; ++kk) {
                 sc = mm<T>(row_frag<DUAL>(q_lds, qb * 32, kk, lane), kf[kk], sc);
                 dp = mm<T>(row_frag<DUAL>(do_lds, qb * 32, kk, lane), vf[kk], dp);
+            }
+            if (check) {  // wave-uniform: the causal boundary crosses this (tile, wave) block
+                int sq = s - off - t0 - qb * 32 - 4 * (lane >> 5);  // key s is visible to query index (in the block) >= sq
+                asm volatile("; causal block" : "+v"(sq));
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) < sq) sc[r] = -INFINITY;
             }
             s16x4 tq[2][ND][2], td[2][ND][2];  // Qᵀ / dOᵀ fragments of this query block: [k-step][d-tile][rows +0 / +8]
             const unsigned a0 = taddr[0] + (unsigned)(q_lds - ring), a8 = taddr[1] + (unsigned)(q_lds - ring);
@@ -617,11 +645,11 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_long_kernel(const T* __restri
         }
     };
 
-    if (ntiles > 0) {
-        rows_g2r(0);
-        dma(0, 0);
+    if (tile0 < ntiles) {
+        rows_g2r(tile0);
+        dma(tile0, tile0 & 1);
     }
-    for (int tile = 0; tile < ntiles; ++tile) {
+    for (int tile = tile0; tile < ntiles; ++tile) {
         const int st = tile & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the tile and the row constants behind them
         if (tid < KT) { rowc[st][0][tid] = l_n; rowc[st][1][tid] = d_n; }
@@ -631,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_long_kernel(const T* __restri
             rows_g2r(tile + 1);
             dma(tile + 1, st ^ 1);
         }
-        body(st);
+        body(tile, st);
     }
     if (!kvalid) {  // padding keys: zero rows (a select, not a product: their probabilities are unbounded)
 #pragma unroll
