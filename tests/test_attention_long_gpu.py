@@ -159,3 +159,25 @@ def test_long_forward_causal(F, dtype, B, H, T, S):
     for name, got, want in (('o', o, out.detach().reshape(B, T, D)), ('dq', dq, qf.grad), ('dk', dk, kf.grad), ('dv', dv, vf.grad)):
         assert torch.isfinite(got.float()).all(), name
         assert rel_err(got, want) < tol, (name, rel_err(got, want))
+
+
+@pytest.mark.parametrize('B,H,T,S', [(2, 2, 300, 300), (2, 1, 130, 700)])
+def test_long_kernels_causal_with_key_padding(F, B, H, T, S):
+    """both masks at once (the reference adds them, modules.py:654-677): padding keys inside the causal window, the last batch
+    row with its first 40 keys masked (its first queries see no key at all: zero rows, zero lse)"""
+    g = torch.Generator().manual_seed(T + S)
+    D = H * 64
+    q, k, v, dy = (torch.randn(B, n, D, generator=g).bfloat16() for n in (T, S, S, T))
+    pad = torch.zeros(B, S, dtype=torch.bool)
+    pad[0, 5::7] = True
+    pad[B - 1, :40] = True
+    qf, kf, vf = (x.float().clone().requires_grad_() for x in (q, k, v))
+    out, _ = O.attention_core(qf.view(B, T, H, 64), kf.view(B, S, H, 64), vf.view(B, S, H, 64), pad, True, 0.125)
+    out.reshape(B, T, D).backward(dy.float())
+    o, lse = F.attn_fwd(q.cuda(), k.cuda(), v.cuda(), H, pad.cuda(), True, 0.125)
+    dq, dk, dv = F.attn_bwd(q.cuda(), k.cuda(), v.cuda(), o, dy.cuda(), lse, H, pad.cuda(), True, 0.125)
+    for name, got, want in (('o', o, out.detach().reshape(B, T, D)), ('dq', dq, qf.grad), ('dk', dk, kf.grad), ('dv', dv, vf.grad)):
+        assert torch.isfinite(got.float()).all(), name
+        assert rel_err(got, want) < 2.5e-2, (name, rel_err(got, want))
+    if S == T:  # queries 0..39 of the last row see only masked keys
+        assert (o[B - 1, :40] == 0).all() and (lse[B - 1, :, :40] == 0).all()
