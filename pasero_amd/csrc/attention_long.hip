@@ -1,26 +1,28 @@
-// Forward attention for long key sequences (round 4).  A file of its own because it is built with -fno-slp-vectorize: its loop
-// body places four scalar vector instructions behind every MFMA by hand, and the SLP vectoriser would gather them into packed
-// instructions behind the last MFMA (packed f32 instructions beside MFMAs are slower than the scalar pairs anyway:
-// MI355X_MICROARCH.md, cycle constants).
+// Attention kernels on the LDS-DMA frame (round 4): forward (`attn_fwd_long_kernel`, 64 keys and more), dQ and dK / dV for long
+// streamed sequences (`attn_dq_long_kernel`, `attn_dkv_long_kernel`, 256 and more); heads of 64, no rotation.  The tiled kernels
+// of attention.hip keep everything else and remain the reference for the arithmetic.  Built with -fno-slp-vectorize: packed f32
+// instructions beside MFMAs are slower than the scalar pairs (MI355X_MICROARCH.md, cycle constants), and the measured-and-dropped
+// two-tiles-in-flight form of the forward needed its hand-placed instruction groups left where they were put.
 #include "attention_common.h"
 
 namespace {
 
 // ---- forward for key sequences of 64 and more (round 4): head_dim 64, no rotation ----
-// The kernel above spends ~10 vector instructions per (query, key) score (scale + bias, the causal select, running maximum,
+// attn_q_kernel (attention.hip) spent ~10 vector instructions per (query, key) score (scale + bias, the causal select, running maximum,
 // subtraction, exp, sum, accumulator rescale, conversion) against 16 MFMAs per 2048 scores: at S >= 500 it is paced by its
 // VALU work, not by the matrix pipe (0.5 ps per pair whatever the shape).  This form keeps 4 per score (causal launches too:
 // whole tiles in a wave's future are skipped, the diagonal's are masked in a wave-uniform branch):
 //   * the maximum LAGS: a query's scores are taken relative to the maximum m its row was last anchored at, x = s c - m (no
-//     multiply: the MFMA chain starts from the accumulator -m / c), and m moves only when a tile's maximum exceeds it by more than LAG_THR (exp2 domain: p <= 2^LAG_THR, in range for
-//     both 16-bit types, relative precision unchanged) — the accumulator rescale, the exp of the correction and the
+//     subtraction: the MFMA chain starts from the accumulator -m / c, one multiply by c follows), and m moves only when a tile's
+//     maximum exceeds it by more than LAG_THR (exp2 domain: p <= 2^LAG_THR, in range for both 16-bit types, relative precision
+//     unchanged) — the accumulator rescale, the exp of the correction and the
 //     subtraction leave the loop body for a wave-uniform branch that is rare after the first tile;
 //   * keys past S / padding keys are found per tile by one ballot; only tiles that hold one pay for the selects;
 //   * K and V tiles arrive by LDS-DMA (buffer_load ... lds, 16 B per lane, rows past S read as zeros through the buffer
 //     bound) into a two-deep ring of dual-use images (lds_off<DUAL>: a 1-KiB DMA piece is one 8-row group, the lane picks the
 //     global chunk that belongs at its LDS position), one barrier per tile, nothing staged through registers;
 //   * workgroups of one (batch, head) pair sit on one XCD (their K / V stay in that L2).
-// Same accumulator layouts, Q fragments and row stores as the kernel above.  A row's arithmetic depends on its own data only
+// Same accumulator layouts, Q fragments and row stores as attn_q_kernel.  A row's arithmetic depends on its own data only
 // (a lane re-anchors only when ITS maximum says so).
 constexpr float LAG_THR = 8.f;
 #ifndef PKL_DQ_WAVES
