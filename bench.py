@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
 PEAK_BF16_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+PEAK_HBM_GBPS = 8000.0     # same guide: 8 TB/s HBM3E peak (~6.3 TB/s achievable)
 
 WORKLOADS = {
     # name: (config class name, V, B, S, T)
@@ -586,6 +587,9 @@ def run(args):
                 traffic, how = committed_pmc_traffic(dom), f'committed profiles/ ({how})'
             out['roofline']['traffic'] = traffic
             out['roofline']['traffic_source'] = how
+            if traffic:  # the same kernel against the memory roof: L2 <-> fabric bytes per launch / its duration
+                gbps = traffic / (d['avg_us'] * 1e-6) / 1e9
+                out['roofline']['hbm'] = {'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBPS}
         if world == 1 and not args.no_extra_workloads and args.workload == 'c2_base_bf16':
             # the other BASELINE configurations that fit one GPU, timed by THIS run after the headline region (same
             # process, same protocol, a few steps each): d = 1024 is where north_star states its 40 % target
