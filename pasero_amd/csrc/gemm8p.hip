@@ -40,6 +40,10 @@
 // swizzle sits on the per-lane SOURCE offset and is undone on the read (row images: ds_read_b128, chunk ^ (row>>1)&7;
 // col images: ds_read_b64_tr_b16, chunk ^ 2*((k&3) | ((k>>3)&1)<<2)).
 #include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <queue>
+#include <vector>
 #include <type_traits>
 #include <vector>
 #include "common.h"
@@ -1041,7 +1045,25 @@ inline long long tiles256(const PkWgradProblem& q) { return ((q.M + BM - 1) / BM
 // ceil(K_p / L) slabs.  L minimises  rounds x (time of a workgroup) + the slab traffic:  rounds = ceil(workgroups / 256),
 // a workgroup = L / 64 K-tiles of ~1.45 us + ~6.5 us of prologue / epilogue (tools/gemm_phase_stamps.py), 512 KiB of
 // fp32 slab written and read back per split workgroup at ~5 TB/s.
-void plan_group(const PkWgradProblem* p, int n, GroupPlan* pl) {
+// Round 4: TWO lengths where one leaves the last round of the chip half empty — the problems with few tiles take L / 2 (twice
+// the slabs): NLLB-1.3B's encoder layer at 8192 rows is 320 tiles; two slabs each = 640 workgroups = 2.5 rounds of the long
+// kind (3 in practice), while fc1 / fc2 at two slabs (512 workgroups, two full rounds) + q|k|v and out-proj at four (256
+// workgroups of half the duration) is 2.5 rounds' worth of time.  The mixed plan is taken only when list scheduling (longest
+// first, 256 CUs) says it beats the best single length by 5 %; plans are cached by the group's shapes.
+inline double wg_us(long long L) { return (double)L / BK * 1.45 + 6.5; }
+double list_makespan(double dur_long, long long n_long, double dur_short, long long n_short) {
+    std::priority_queue<double, std::vector<double>, std::greater<double>> h;
+    for (int i = 0; i < 256; ++i) h.push(0.0);
+    double last = 0.0;
+    for (long long i = 0; i < n_long + n_short; ++i) {
+        const double t = h.top() + (i < n_long ? dur_long : dur_short);
+        h.pop();
+        h.push(t);
+        last = std::max(last, t);
+    }
+    return last;
+}
+void plan_group_uncached(const PkWgradProblem* p, int n, GroupPlan* pl) {
     long long kmax = 0;
     for (int i = 0; i < n; ++i) kmax = std::max(kmax, p[i].K);
     double best = 1e30;
@@ -1057,16 +1079,42 @@ void plan_group(const PkWgradProblem* p, int n, GroupPlan* pl) {
             if (sp > 1) split_wgs += tiles256(p[i]) * sp;
         }
         const double rounds = (double)((wgs + 255) / 256);
-        const double cost = rounds * ((double)L / BK * 1.45 + 6.5) + (double)split_wgs * 0.105 + (split_wgs ? 4.0 : 0.0);
+        const double cost = rounds * wg_us(L) + (double)split_wgs * 0.105 + (split_wgs ? 4.0 : 0.0);
         if (cost < best) { best = cost; bestL = L; }
         if (L <= 512) break;
+    }
+    // the mixed plans: problems of at most `cut` tiles at half the length (PK_WGRAD_MIXED=0: off, A/B)
+    static const bool mixed_on = [] { const char* e = getenv("PK_WGRAD_MIXED"); return !e || atoi(e) != 0; }();
+    long long mixL = 0, mixLs = 0, mixcut = -1;
+    double mixbest = 0.95 * best;
+    prevL = -1;
+    for (int s = 1; mixed_on && s <= 16; ++s) {
+        const long long L = ((kmax + s - 1) / s + BK - 1) / BK * BK, Ls = (L / 2 + BK - 1) / BK * BK;
+        if (L == prevL || Ls < 512) continue;
+        prevL = L;
+        for (int c = 0; c < n; ++c) {
+            const long long cut = tiles256(p[c]);
+            long long nl = 0, ns = 0, split_wgs = 0;
+            bool any_big = false;
+            for (int i = 0; i < n; ++i) {
+                const bool small = tiles256(p[i]) <= cut;
+                const long long sp = (p[i].K + (small ? Ls : L) - 1) / (small ? Ls : L);
+                (small ? ns : nl) += tiles256(p[i]) * sp;
+                if (sp > 1) split_wgs += tiles256(p[i]) * sp;
+                any_big |= !small;
+            }
+            if (!any_big || nl + ns > 4096) continue;
+            const double cost = list_makespan(wg_us(L), nl, wg_us(Ls), ns) + (double)split_wgs * 0.105 + (split_wgs ? 4.0 : 0.0);
+            if (cost < mixbest) { mixbest = cost; mixL = L; mixLs = Ls; mixcut = cut; }
+        }
     }
     int wg = 0, blk = 0;
     size_t off = 0;
     for (int i = 0; i < n; ++i) {
-        const int sp = (int)((p[i].K + bestL - 1) / bestL);
+        const long long Li = mixcut < 0 ? bestL : (tiles256(p[i]) <= mixcut ? mixLs : mixL);
+        const int sp = (int)((p[i].K + Li - 1) / Li);
         pl->nslab[i] = sp;
-        pl->kchunk[i] = (int)bestL;
+        pl->kchunk[i] = (int)Li;
         pl->wg_begin[i] = wg;
         wg += (int)tiles256(p[i]) * sp;
         pl->blk_begin[i] = blk;
@@ -1085,6 +1133,25 @@ void plan_group(const PkWgradProblem* p, int n, GroupPlan* pl) {
     pl->total_wgs = wg;
     pl->total_blks = blk;
     pl->ws_floats = off;
+}
+// (the plan depends on the shapes and on which problems carry a bias sum: cached — four calls per launch ask for it)
+void plan_group(const PkWgradProblem* p, int n, GroupPlan* pl) {
+    struct Key { long long v[PK_WGRAD_MAX][4]; int n; };
+    static std::mutex mu;
+    static std::vector<std::pair<Key, GroupPlan>> cache;
+    Key k;
+    memset(&k, 0, sizeof k);
+    k.n = n;
+    for (int i = 0; i < n; ++i) { k.v[i][0] = p[i].M; k.v[i][1] = p[i].N; k.v[i][2] = p[i].K; k.v[i][3] = p[i].asum_out != nullptr; }
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (const auto& e : cache)
+            if (memcmp(&e.first, &k, sizeof k) == 0) { *pl = e.second; return; }
+    }
+    plan_group_uncached(p, n, pl);
+    std::lock_guard<std::mutex> g(mu);
+    if (cache.size() >= 64) cache.erase(cache.begin());
+    cache.emplace_back(k, *pl);
 }
 
 // The launch map (GroupMap above).  Units = (problem, K-slab); a unit of more than 32 tiles is cut into runs of 32
@@ -1124,7 +1191,10 @@ int plan_map(const PkWgradProblem* p, int n, const GroupPlan& pl, GroupMap* mp) 
         // Largest runs first, each into the bin (of 8 x rounds bins of 32 workgroups) that has room and the LEAST panel
         // load so far: small, poorly sharing units (a d x d problem: 4 tiles, 4 panels) end up spread over the XCDs beside
         // the large ones instead of eight of them in one bin — an XCD's pace is set by what it fetches per K-step.
-        std::stable_sort(items.begin(), items.end(), [](const MapRun& a, const MapRun& b) { return a.cnt > b.cnt; });
+        // (a mixed plan: the long workgroups first, so that every XCD runs its share of them before the short ones)
+        std::stable_sort(items.begin(), items.end(), [&](const MapRun& a, const MapRun& b) {
+            return pl.kchunk[a.prob] != pl.kchunk[b.prob] ? pl.kchunk[a.prob] > pl.kchunk[b.prob] : a.cnt > b.cnt;
+        });
         const int nbins = 8 * ((pl.total_wgs + 255) / 256);
         std::vector<int> fill(nbins, 0), pload(nbins, 0);
         std::vector<std::vector<MapRun>> bins(nbins);

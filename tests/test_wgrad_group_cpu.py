@@ -170,3 +170,33 @@ def test_launch_map_keeps_a_slab_unit_on_one_xcd_at_base_width():
             tiles = math.ceil(M / 256) * math.ceil(N / 256)
             where.setdefault((p, lin // tiles), set()).add(b % 8)
         assert all(len(x) == 1 for x in where.values()), where
+
+
+def test_two_slab_lengths_where_one_leaves_the_last_round_half_empty():
+    """NLLB-1.3B's layers at 8192 rows: one K-chunk length for all problems gives 640 (encoder) / 768 (decoder) workgroups of
+    half the contraction — 2.5 / 3 rounds of the chip; the planner instead leaves fc1 / fc2 whole (256 workgroups: one round)
+    and cuts only the d x d problems in two (list scheduling on 256 CUs says 16 % less).  At base width (one round either
+    way) nothing changes.  And the map deals the LONG workgroups first: every XCD's list starts with its share of them."""
+    import math
+    enc, dec = _layers(1024, 8192, 8192)
+    for probs, want in ((enc, [2, 2, 1, 1]), (dec, [2, 2, 2, 2, 2, 1, 1])):
+        m = _map_of(probs)
+        per = {}
+        for pr, lin in m:
+            if pr >= 0:
+                per[pr] = per.get(pr, 0) + 1
+        slabs = [per[i] // (math.ceil(M / 256) * math.ceil(N / 256)) for i, (M, N, K) in enumerate(probs)]
+        assert slabs == want, slabs
+        long_probs = {i for i, s in enumerate(slabs) if s == 1}
+        for x in range(8):
+            mine = [e[0] for b, e in enumerate(m) if b % 8 == x and e[0] >= 0]
+            n_long = sum(1 for pr in mine if pr in long_probs)
+            assert n_long == 32 and all(pr in long_probs for pr in mine[:n_long]), (x, mine)
+    for probs in _layers(512, 2048, 32768):
+        m = _map_of(probs)
+        per = {}
+        for pr, lin in m:
+            if pr >= 0:
+                per[pr] = per.get(pr, 0) + 1
+        slabs = {per[i] // (math.ceil(M / 256) * math.ceil(N / 256)) for i, (M, N, K) in enumerate(probs)}
+        assert len(slabs) == 1, slabs
