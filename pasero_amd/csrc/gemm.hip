@@ -795,7 +795,9 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         // (up to 1024 rows for N <= 512 — the out / q / fc2 projections of a 1024-row decoder batch, C4: 256 workgroups
         // instead of the 32 of the 128-tile kernel: 22.5 -> 15.4 us at K = 2048, 8.3 -> 7.8 at K = 512; wider outputs re-read
         // too much of A: N = 1536 / 2048 at K = 512 8.8 -> 12.2 / 9.0 -> 15.4 us, they stay on the tiles.  C4 step -0.25 ms.)
-        if (!a_col && !b_col && (M <= 64 || (M <= 256 && N <= 8192) || (M <= 1024 && N <= 512)) && splitk <= 1 && !asum_out &&
+        // (round 4: any number of rows for outputs of <= 64 columns — an adapter's down-projection, 16 000 x 64 with K = 1024: the
+        // weight is 128 KB, re-reading it per 64-row block costs nothing, while the 128-tile kernel ran it at 1.2 TB/s: 28 -> 9 us)
+        if (!a_col && !b_col && (M <= 64 || (M <= 256 && N <= 8192) || (M <= 1024 && N <= 512) || N <= 64) && splitk <= 1 && !asum_out &&
             !no_skinny) {
             int rc = pk_gemm_skinny_launch(A, B, C, M, N, K, lda, ldb, ep, dtype16, stream);
             if (rc != 0) return rc == 1 ? 0 : rc;  // 1 = launched, 0 = not eligible, anything else = error

@@ -100,7 +100,7 @@ extern "C" int pk_gemm_skinny_launch(const void* A, const void* B, void* C, long
     const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) && lda % 8 == 0 &&
                          ldb % 8 == 0 && ep.ldc % 8 == 0 && (!ep.bias || (uintptr_t)ep.bias % 16 == 0) &&
                          (ep.mode != 1 || ((uintptr_t)ep.aux % 16 == 0 && ep.ldaux % 8 == 0));
-    if (!aligned || M > 1024 || K % 64 != 0 || K <= 0 || ep.preact || ep.mode > 1) return 0;
+    if (!aligned || (M > 1024 && N > 64) || M > 64LL * 65535 || K % 64 != 0 || K <= 0 || ep.preact || ep.mode > 1) return 0;
     dim3 grid((unsigned)((N + SK_BN - 1) / SK_BN), (unsigned)((M + SK_BM - 1) / SK_BM)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define SK_T(TT, ACT, MD) \

@@ -55,10 +55,11 @@ def test_gemm_layouts(F, dtype, a_col, b_col, M, N, K):
 
 @pytest.mark.parametrize('act', ['none', 'relu', 'gelu'])
 @pytest.mark.parametrize('M,N,K', [(1, 512, 512), (7, 1536, 512), (64, 512, 2048), (64, 8032, 512), (100, 520, 64),
-                                   (256, 2048, 512), (129, 36, 192), (1024, 512, 2048), (1000, 512, 512), (777, 264, 1024)])
+                                   (256, 2048, 512), (129, 36, 192), (1024, 512, 2048), (1000, 512, 512), (777, 264, 1024),
+                                   (16000, 64, 1024), (3001, 40, 128)])
 def test_gemm_few_rows_decoding_shapes(F, act, M, N, K):
-    """M <= 256 (<= 1024 for outputs of <= 512 columns), row-form bf16 operands, K % 64 == 0: the latency-shaped kernel of a
-    decoding step / a short decoder batch (gemm_skinny.hip);
+    """M <= 256 (<= 1024 for outputs of <= 512 columns; any M for outputs of <= 64 columns: an adapter's down-projection),
+    row-form bf16 operands, K % 64 == 0: the latency-shaped kernel of a decoding step / a short decoder batch (gemm_skinny.hip);
     bias + activation (+ residual) epilogues, ragged M and N tails, a strided input (q columns of a packed projection)"""
     x3 = rnd((M, 3 * K), 11, torch.bfloat16).cuda()
     x = x3[:, K:2 * K]  # row stride 3K, like q = qkv[:, :D]
