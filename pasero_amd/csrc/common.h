@@ -144,14 +144,39 @@ template <typename T> __device__ __forceinline__ void store16_nt(T* p, const Vec
     else { PK_CHECK_ARG(false, "%s: dtype %d not supported", who, dtype); }
 
 // ---- wave (64 lanes) reductions ----
-__device__ __forceinline__ float wave_sum(float v) {
+// A butterfly over the partners 32, 16, 8, 4, 2, 1 lanes away, in this order; every lane holds the result.  Written
+// with `__shfl_xor` each step compiles to ds_bpermute_b32 plus a compare / select for its width argument — 4
+// instructions and an LDS round trip, 12 dependent round trips for the mean and the variance of a LayerNorm row.
+// gfx950's v_permlane32_swap / v_permlane16_swap exchange the halves / the odd and even rows of two registers; within
+// a row of 16 lanes DPP rotations and quad permutes reach the partner (after the step "8" the values repeat with period
+// 8, so a rotation by 4 finds the lane ^ 4 partner's value).  10 VALU instructions per reduction and bit for bit the
+// `__shfl_xor` butterfly's result (tools/ln_bench.py's companion scratch test: 262 144 waves, no mismatch): the
+// LayerNorm backward of C2 37.0 -> 28.5 us together with its specialisation (layernorm.hip).  All 64 lanes must be
+// active.  (The swaps are inline asm: given the same register twice, the builtin's two results are folded into one by
+// hipcc 7.2.)
+template <int CTRL> __device__ __forceinline__ float dpp_mov_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+#define PK_WAVE_BUTTERFLY(OP)                                                         \
+    float a = v, b = v;                                                               \
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));       \
+    v = OP(a, b);                                                                     \
+    a = v; b = v;                                                                     \
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));       \
+    v = OP(a, b);                                                                     \
+    v = OP(v, dpp_mov_f32<0x128>(v)); /* row_ror:8 */                                 \
+    v = OP(v, dpp_mov_f32<0x124>(v)); /* row_ror:4 */                                 \
+    v = OP(v, dpp_mov_f32<0x4E>(v));  /* quad_perm:[2,3,0,1] */                       \
+    v = OP(v, dpp_mov_f32<0xB1>(v));  /* quad_perm:[1,0,3,2] */                       \
+    return v;
+__device__ __forceinline__ float pk_add_f32(float a, float b) { return a + b; }
+__device__ __forceinline__ float wave_sum(float v) { PK_WAVE_BUTTERFLY(pk_add_f32) }
+__device__ __forceinline__ float wave_max(float v) { PK_WAVE_BUTTERFLY(fmaxf) }
+#undef PK_WAVE_BUTTERFLY
+// (the LDS-pipe form, kept for the kernels' tests of the above)
+__device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 

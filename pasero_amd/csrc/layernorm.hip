@@ -338,6 +338,157 @@ __global__ __launch_bounds__(256, NCH == 4 ? 3 : NCH == 8 ? 2 : 1) void residual
     }
 }
 
+// ---- the backward kernel for the rows the models train on: 16-bit storage, d = 512 or 1024, LayerNorm with gamma ----
+// residual_ln_bwd_kernel above decides everything at run time (gamma? dz_extra? which outputs? RMSNorm? dropout?
+// a partial last chunk?) and hipcc turns those decisions into per-element selects and register copies: 480 vector
+// instructions per 8-element chunk, of which 80 are moves, 68 selects, 48 the shuffle reductions and 16 64-bit
+// address updates.  A wave64 instruction occupies its SIMD for four cycles, a SIMD owns 32 rows of a 32768-row
+// tensor: 32 x 480 x 4 cycles = 29 us of instruction issue for a kernel whose 128 MB take 20 us at the copy rate —
+// the kernel was bound by its own instruction stream (33 us measured).  Here the decisions are template flags, a row
+// is wave-uniform (scalar base address, mean / rstd by scalar loads), the next row's loads go into a second register
+// set (loop unrolled twice instead of copying), arithmetic is on float pairs (v_pk_*), and the two row sums are DPP
+// butterflies.  FL: 1 = dz_extra, 2 = dx_out with dropout (dres_out is always written).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <typename T> __device__ __forceinline__ f32x2 unpack2(unsigned w) {
+    f32x2 r;
+    if constexpr (sizeof(T) == 2 && !__is_same(T, f16)) {
+        r.x = __uint_as_float(w << 16);
+        r.y = __uint_as_float(w & 0xffff0000u);
+    } else {
+        r.x = H16<f16>::val((unsigned short)(w & 0xffffu));
+        r.y = H16<f16>::val((unsigned short)(w >> 16));
+    }
+    return r;
+}
+template <typename T> __device__ __forceinline__ unsigned pack2(f32x2 v) {
+    return (unsigned)H16<T>::bits(v.x) | ((unsigned)H16<T>::bits(v.y) << 16);
+}
+
+template <typename T, int NCH, int FL>
+__global__ __launch_bounds__(256) void residual_ln_bwd16_kernel(
+    const T* __restrict__ dy, const T* __restrict__ dz_extra, const T* __restrict__ z, const T* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dres_out, T* __restrict__ dx_out,
+    float* __restrict__ partials, long long rows, unsigned thr, float drop_scale, unsigned long long seed,
+    unsigned long long offset) {
+    constexpr int D = NCH * 512;
+    constexpr bool EXTRA = (FL & 1) != 0, DROPX = (FL & 2) != 0;
+    constexpr float inv_d = 1.f / (float)D;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    f32x2 gm[NCH][4], dg[NCH][4], db[NCH][4];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const uint4 gv = *(reinterpret_cast<const uint4*>(gamma) + lane + 64 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            gm[i][j] = unpack2<T>((&gv.x)[j]);
+            dg[i][j] = f32x2{0.f, 0.f};
+            db[i][j] = f32x2{0.f, 0.f};
+        }
+    }
+    const long long row_step = (long long)gridDim.x * ROWS_PER_BLOCK;
+    uint4 dA[NCH], zA[NCH], dB[NCH], zB[NCH];
+    float muA = 0.f, rsA = 0.f, muB = 0.f, rsB = 0.f;
+    auto fetch = [&](long long row, uint4(&dv)[NCH], uint4(&zv)[NCH], float& mu, float& rs) {
+        mu = mean[row];
+        rs = rstd[row];
+        const uint4* dp = reinterpret_cast<const uint4*>(dy + row * D) + lane;
+        const uint4* zp = reinterpret_cast<const uint4*>(z + row * D) + lane;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            dv[i] = dp[64 * i];
+            zv[i] = zp[64 * i];
+        }
+    };
+    auto work = [&](long long row, const uint4(&dv)[NCH], const uint4(&zv)[NCH], float mu, float rs) {
+        f32x2 g[NCH][4], xh[NCH][4];
+        f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+        uint4 ev[NCH];
+        if constexpr (EXTRA) {
+            const uint4* ep = reinterpret_cast<const uint4*>(dz_extra + row * D) + lane;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) ev[i] = ep[64 * i];
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 dyv = unpack2<T>((&dv[i].x)[j]);
+                const f32x2 x = (unpack2<T>((&zv[i].x)[j]) - mu) * rs;
+                const f32x2 gg = dyv * gm[i][j];
+                g[i][j] = gg;
+                xh[i][j] = x;
+                a1 += gg;
+                a2 += gg * x;
+                dg[i][j] += dyv * x;
+                db[i][j] += dyv;
+            }
+        const float s1 = wave_sum(a1.x + a1.y) * inv_d;
+        const float s2 = wave_sum(a2.x + a2.y) * inv_d;
+        uint4* rp = reinterpret_cast<uint4*>(dres_out + row * D) + lane;
+        uint4* xp = DROPX ? reinterpret_cast<uint4*>(dx_out + row * D) + lane : nullptr;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            f32x2 t[4];
+            uint4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
+                if constexpr (EXTRA) t[j] += unpack2<T>((&ev[i].x)[j]);
+                (&o.x)[j] = pack2<T>(t[j]);
+            }
+            // (streaming: the residual branch's gradient is read again several kernels later — see the kernel above)
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(rp + 64 * i));
+            if constexpr (DROPX) {
+                bool keep[8];
+                dropout_keep8(seed, offset, ((unsigned long long)row * D >> 3) + lane + 64 * i, thr, keep);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x2 m;
+                    m.x = keep[2 * j] ? t[j].x * drop_scale : 0.f;
+                    m.y = keep[2 * j + 1] ? t[j].y * drop_scale : 0.f;
+                    (&o.x)[j] = pack2<T>(m);
+                }
+                xp[64 * i] = o;
+            }
+        }
+    };
+    long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + wave;
+    // (the prefetch is unconditional — past the wave's last row it reads that row again: behind a branch the number of
+    // loads in flight is unknown at the join and hipcc waits for all of them, the prefetch included)
+    if (row < rows) fetch(row, dA, zA, muA, rsA);
+    while (row < rows) {
+        long long nx = row + row_step;
+        fetch(nx < rows ? nx : row, dB, zB, muB, rsB);
+        work(row, dA, zA, muA, rsA);
+        row = nx;
+        if (row >= rows) break;
+        nx = row + row_step;
+        fetch(nx < rows ? nx : row, dA, zA, muA, rsA);
+        work(row, dB, zB, muB, rsB);
+        row = nx;
+    }
+    if (!partials) return;
+    // one partial per workgroup, in the slab layout of the kernel above
+    __shared__ float red[ROWS_PER_BLOCK][2][512];
+    float* slab = partials + (long long)blockIdx.x * 2 * D;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<f32x2*>(&red[wave][0][lane * 8 + 2 * j]) = dg[i][j];
+            *reinterpret_cast<f32x2*>(&red[wave][1][lane * 8 + 2 * j]) = db[i][j];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * 512; c += 256) {
+            const int which = c >> 9, col = c & 511;
+            slab[which * D + i * 512 + col] = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+        }
+        __syncthreads();
+    }
+}
+
 // partials[nslabs][2][d] fp32 -> dgamma / dbeta in T.  Workgroup (x, y): 16 columns of gamma (y = 0) or beta (y = 1);
 // its 64 thread-rows each sum every 64th slab with all loads in flight at once, then a tree reduction through LDS
 // (blockIdx.z: one of up to PK_LN_GROUP_MAX LayerNorms whose backward passes left their slabs — pk_ln_param_grads)
@@ -428,6 +579,36 @@ int launch_bwd(const void* dy, const void* dz_extra, const void* z, const void* 
         PK_CHECK_ARG(ws && ws_bytes >= need, "pk_residual_ln_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
     }
     dim3 grid(nblocks), block(256);
+    if constexpr (sizeof(T) == 2) {
+        static const bool off16 = getenv("PK_LN_BWD16") && atoi(getenv("PK_LN_BWD16")) == 0;  // (experiments)
+        const bool dropx = dx && thr;
+        if (!off16 && (d == 512 || d == 1024) && gamma && mean && dres && (dropx || !dx)) {
+            const int fl = (dz_extra ? 1 : 0) | (dropx ? 2 : 0);
+#define PK_L16(N, F)                                                                                                   \
+    hipLaunchKernelGGL((residual_ln_bwd16_kernel<T, N, F>), grid, block, 0, s, (const T*)dy, (const T*)dz_extra,       \
+                       (const T*)z, (const T*)gamma, mean, rstd, (T*)dres, (T*)dx, want_pg ? ws : nullptr, rows, thr, \
+                       scale, seed, offset)
+#define PK_L16N(N)                      \
+    do {                                \
+        if (fl == 0) PK_L16(N, 0);      \
+        else if (fl == 1) PK_L16(N, 1); \
+        else if (fl == 2) PK_L16(N, 2); \
+        else PK_L16(N, 3);              \
+    } while (0)
+            if (d == 512) PK_L16N(1);
+            else PK_L16N(2);
+#undef PK_L16N
+#undef PK_L16
+            PK_LAUNCH_CHECK();
+            if (want_pg && !defer) {
+                LnReduceItems it = {};
+                it.partials[0] = ws; it.dgamma[0] = dgamma; it.dbeta[0] = dbeta;
+                hipLaunchKernelGGL((ln_param_grad_kernel<T>), dim3((d + 15) / 16, 2, 1), dim3(1024), 0, s, it, nblocks, d);
+                PK_LAUNCH_CHECK();
+            }
+            return 0;
+        }
+    }
 #define PK_L(N)                                                                                                  \
     hipLaunchKernelGGL((residual_ln_bwd_kernel<T, N>), grid, block, 0, s, (const T*)dy, (const T*)dz_extra,      \
                        (const T*)z, (const T*)gamma, mean, rstd, (T*)dres, (T*)dx, want_pg ? ws : nullptr, rows, \
