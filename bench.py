@@ -177,7 +177,7 @@ class GemmTimer:
         if kernel == (8 | 0x40):  # the grouped weight-gradient launch (pk_gemm_wgrad_group): flops = sum over the group
             return 'gemm8p_group_kernel<%s>' % t
         if kernel == (8 | 0x80):  # Linear + residual + dropout + LayerNorm (pk_gemm_ln_fwd)
-            return 'gemm8p_ln_kernel<%s>' % t
+            return 'gemm8p_ln_kernel<%s, %d>' % (t, a_col)  # (a_col: the epilogue specialisation, see pk_gemm_ln_fwd)
         if kernel & 0xF == 8 and (kernel & ~0x400) < 256:  # gemm8p instantiation: <T, A_COL, B_COL, ANY epilogue, TAIL K-tile, half-M tile>
             return 'gemm8p_kernel<%s, %s, %s, %s, %s, %s>' % (t, tf[a_col], tf[b_col], tf[(kernel >> 4) & 1], tf[(kernel >> 5) & 1],
                                                               tf[(kernel >> 10) & 1])

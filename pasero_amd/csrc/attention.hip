@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
             for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sc[0][r]), sc[1][r]);
         }
         if constexpr (MODE == 0) {
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = half_wave_max(tmax);
             const float mn = fmaxf(m, tmax);
             const float ms = mn == -INFINITY ? 0.f : mn;  // all keys masked so far: exp2(-inf - 0) = 0 everywhere
             const float alpha = __builtin_amdgcn_exp2f(m - ms);

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, PKL_WAVES) void attn_fwd_long_kernel(const T* 
         float tmax = fmaxf(sc[0][0], sc[1][0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sc[0][r]), sc[1][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = half_wave_max(tmax);
         const bool move = anch ? tmax > LAG_THR : tmax > -INFINITY;
         if (__any(move)) {  // (re-)anchor the rows that ask for it: everything held at the old maximum is scaled exactly once
             const float delta = move ? tmax : 0.f;

@@ -173,6 +173,13 @@ __device__ __forceinline__ float pk_add_f32(float a, float b) { return a + b; }
 __device__ __forceinline__ float wave_sum(float v) { PK_WAVE_BUTTERFLY(pk_add_f32) }
 __device__ __forceinline__ float wave_max(float v) { PK_WAVE_BUTTERFLY(fmaxf) }
 #undef PK_WAVE_BUTTERFLY
+// max over the lane and its partner 32 lanes away (the two half-waves of a 32 x 32 MFMA tile hold the same rows): one
+// swap instead of the LDS round trip of `__shfl_xor(v, 32)` — it sits on the serial chain of an attention tile
+__device__ __forceinline__ float half_wave_max(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
 // (the LDS-pipe form, kept for the kernels' tests of the above)
 __device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
@@ -294,9 +301,10 @@ __device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsign
     for (int r = 0; r < 10; ++r) {
         unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
         unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-        unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+        // (one v_bitop3_b32 each, truth table 0x96 = a ^ b ^ c: hipcc 7.2 emits two v_xor_b32 for the plain expression)
+        unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), c1, k0, 0x96);
         unsigned n1 = (unsigned)p1;
-        unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        unsigned n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), c3, k1, 0x96);
         unsigned n3 = (unsigned)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u;

@@ -1020,8 +1020,9 @@ extern "C" int pk_gemm_ln_fwd(const void* A, const void* W, const void* bias, co
                               void* stream) {
     if (M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    // (sample tag 8 | 0x80: the 128 x 512-tile instantiation with the LayerNorm epilogue)
-    GemmSample* sm = timing_begin(8 | 0x80, 0, 0, 1, dtype, M, N, K, s);
+    // (sample tag 8 | 0x80: the 128 x 512-tile instantiation with the LayerNorm epilogue; the sample's `a_col` field carries
+    // the epilogue specialisation gemmln.hip picks: 0 generic, 1 residual, 2 residual + dropout)
+    GemmSample* sm = timing_begin(8 | 0x80, !residual ? 0 : drop_p > 0.f ? 2 : 1, 0, 1, dtype, M, N, K, s);
     const int rc = pk_gemmln_launch(A, W, bias, residual, gamma, beta, z_out, y_out, mean, rstd, M, N, K, lda, ldb, ldr,
                                     eps, drop_p, seed, offset, dtype, stream);
     timing_end(sm, s);

@@ -56,7 +56,10 @@ struct LnArgs {
     unsigned long long seed, offset;
 };
 
-template <typename T>
+// SPEC: the epilogue's per-element decisions as template flags (decided at run time, "dropout?" and "residual?" become
+// two selects per element: the epilogue is bound by its instruction count — 8 waves per CU, 223 vector instructions per
+// row of 512): 0 = at run time, 1 = residual without dropout, 2 = residual and dropout.
+template <typename T, int SPEC>
 __global__ __launch_bounds__(512, 2) void gemm8p_ln_kernel(const T* __restrict__ A, const T* __restrict__ B, long long M,
                                                           long long K, long long lda, long long ldb, unsigned a_bytes,
                                                           unsigned b_bytes, LnArgs ln) {
@@ -208,12 +211,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_ln_kernel(const T* __restrict__
     T* zo = reinterpret_cast<T*>(ln.z_out);
     T* yo = reinterpret_cast<T*>(ln.y_out);
     const bool rms = ln.mean_out == nullptr;
+    const bool use_res = SPEC == 0 ? res != nullptr : true, use_thr = SPEC == 0 ? ln.thr != 0 : SPEC == 2;
     constexpr int RPW = EROWS / 8;  // rows per wave per pass
     // Every residual row this wave will need is requested NOW, before the first store: vmcnt retires loads and stores in
     // one in-order queue, so a load issued behind the z / y stores of an earlier row would not return before those
     // stores are acknowledged — with every CU of the chip writing at once that is microseconds per row.
     Vec16<T> rv[LBM / 8];
-    if (res) {
+    if (use_res) {
 #pragma unroll
         for (int p = 0; p < LBM / EROWS; ++p)
 #pragma unroll
@@ -248,14 +252,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_ln_kernel(const T* __restrict__
             float x[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
             const long long off = gm * LBN + col;
             bool keep[8];
-            if (ln.thr) {
+            if (use_thr) {
                 dropout_keep8(ln.seed, ln.offset, (unsigned long long)off >> 3, ln.thr, keep);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float a = x[e] + bia[e];
-                if (ln.thr) a = keep[e] ? a * ln.drop_scale : 0.f;
-                if (res) a += rv[p * RPW + rr].get(e);
+                if (use_thr) a = keep[e] ? a * ln.drop_scale : 0.f;
+                if (use_res) a += rv[p * RPW + rr].get(e);
                 x[e] = a;
             }
             // z is a tensor of the storage type in the reference (and what the backward pass re-reads): statistics on
@@ -335,12 +339,20 @@ extern "C" int pk_gemmln_launch(const void* A, const void* W, const void* bias, 
     const unsigned a_bytes = (unsigned)(((M - 1) * lda + K) * 2), b_bytes = (unsigned)(((N - 1) * ldb + K) * 2);
     dim3 grid((unsigned)((M + LBM - 1) / LBM)), block(512);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == PK_F16)
-        hipLaunchKernelGGL((gemm8p_ln_kernel<f16>), grid, block, 0, s, (const f16*)A, (const f16*)W, M, K, lda, ldb, a_bytes,
-                           b_bytes, ln);
-    else
-        hipLaunchKernelGGL((gemm8p_ln_kernel<bf16>), grid, block, 0, s, (const bf16*)A, (const bf16*)W, M, K, lda, ldb,
-                           a_bytes, b_bytes, ln);
+    const int spec = !residual ? 0 : ln.thr ? 2 : 1;
+#define PK_LN_LAUNCH(TT, SP)                                                                                              \
+    hipLaunchKernelGGL((gemm8p_ln_kernel<TT, SP>), grid, block, 0, s, (const TT*)A, (const TT*)W, M, K, lda, ldb, a_bytes, \
+                       b_bytes, ln)
+    if (dtype == PK_F16) {
+        if (spec == 2) PK_LN_LAUNCH(f16, 2);
+        else if (spec == 1) PK_LN_LAUNCH(f16, 1);
+        else PK_LN_LAUNCH(f16, 0);
+    } else {
+        if (spec == 2) PK_LN_LAUNCH(bf16, 2);
+        else if (spec == 1) PK_LN_LAUNCH(bf16, 1);
+        else PK_LN_LAUNCH(bf16, 0);
+    }
+#undef PK_LN_LAUNCH
     PK_LAUNCH_CHECK();
     return 0;
 }
