@@ -420,10 +420,12 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
                     for (int gp = 0; gp < 2; ++gp) {
                         const int g_own = 2 * gp + (hi ? 1 : 0);
                         const unsigned long long ctr = ((unsigned long long)mrow * 8ull * p.mask_pitch + (s0 + kb * 32 + 8 * g_own)) >> 3;
-                        const Philox4 r = philox4x32_10(p.seed, p.offset, ctr);
-                        const unsigned got0 = __shfl_xor(hi ? r.x : r.z, 32, 64), got1 = __shfl_xor(hi ? r.y : r.w, 32, 64);
-                        const unsigned wv[2][2] = {{hi ? got0 : r.x, hi ? got1 : r.y},    // group 2 gp:     this lane's 4 keys
-                                                   {hi ? r.z : got0, hi ? r.w : got1}};   // group 2 gp + 1
+                        Philox4 r = philox4x32_10(p.seed, p.offset, ctr);
+                        // the lower half-wave keeps (x, y) = its 4 keys of group 2 gp and needs the upper one's (x, y) for group 2 gp + 1; the
+                        // upper one keeps (z, w) and needs the lower one's: one swap per register pair
+                        half_wave_swap(r.x, r.z);
+                        half_wave_swap(r.y, r.w);
+                        const unsigned wv[2][2] = {{r.x, r.y}, {r.z, r.w}};
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const int g = 2 * gp + u;
@@ -438,7 +440,11 @@ __global__ __launch_bounds__(256, q_min_waves(MODE, HD)) void attn_q_kernel(cons
                             word |= nib << (8 * g + 4 * (lane >> 5));
                         }
                     }
-                    word |= __shfl_xor(word, 32, 64);  // (the two half-waves hold the low / high nibbles of the same bytes)
+                    {
+                        unsigned wa = word, wb = word;  // (the two half-waves hold the low / high nibbles of the same bytes)
+                        half_wave_swap(wa, wb);
+                        word = wa | wb;
+                    }
                     if (valid && lane < 32)
                         *reinterpret_cast<unsigned*>(p.drop_mask + mrow * p.mask_pitch + ((s0 + kb * 32) >> 3)) = word;
                 }
@@ -740,9 +746,7 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
         *reinterpret_cast<uint4*>(q_lds + lds_off<DUAL>(r, ch)) = qv;
         *reinterpret_cast<uint4*>(do_lds + lds_off<DUAL>(r, ch)) = dov;
         float part = frag_dot<T>(__builtin_bit_cast(bf16x8_t, dov), __builtin_bit_cast(bf16x8_t, ov));
-        part += __shfl_xor(part, 1);
-        part += __shfl_xor(part, 2);
-        part += __shfl_xor(part, 4);  // the 8 lanes of a row
+        part = lanes8_sum(part);  // the 8 lanes of a row
         if (ch == 0) {
             dl_lds[r] = DROP ? part : -part;  // (negated without dropout: the initial accumulator of dP)
             if (r < p.T) delta[((long long)b * p.H + h) * p.T + r] = part;

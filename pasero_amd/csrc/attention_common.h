@@ -336,10 +336,12 @@ __device__ __forceinline__ void store_rowT(T* __restrict__ base, long long rs, i
                 lo[q] = (unsigned)H16<T>::bits(acc[dt][4 * g] * mul) | ((unsigned)H16<T>::bits(acc[dt][4 * g + 1] * mul) << 16);
                 hi[q] = (unsigned)H16<T>::bits(acc[dt][4 * g + 2] * mul) | ((unsigned)H16<T>::bits(acc[dt][4 * g + 3] * mul) << 16);
             }
-            const unsigned send_lo = h ? lo[0] : lo[1], send_hi = h ? hi[0] : hi[1];
-            const unsigned recv_lo = __shfl_xor(send_lo, 32), recv_hi = __shfl_xor(send_hi, 32);
-            // h = 0: group 2j = {own cols 0-3, partner's cols 4-7};  h = 1: group 2j + 1 = {partner's cols 0-3, own cols 4-7}
-            const uint4 v = h ? make_uint4(recv_lo, recv_hi, lo[1], hi[1]) : make_uint4(lo[0], hi[0], recv_lo, recv_hi);
+            // h = 0: group 2j = {own cols 0-3, partner's cols 4-7};  h = 1: group 2j + 1 = {partner's cols 0-3, own cols 4-7}:
+            // the upper half-wave's [0] pieces change places with the lower half-wave's [1] pieces (one swap instruction per
+            // register; as two `__shfl_xor(.., 32)` this was 56 LDS round trips in the fused backward's epilogue)
+            half_wave_swap(lo[0], lo[1]);
+            half_wave_swap(hi[0], hi[1]);
+            const uint4 v = make_uint4(lo[0], hi[0], lo[1], hi[1]);
             const int d = dt * 32 + 8 * (2 * j + h);
             if (valid) att_st(base + (long long)row * rs + d, v);
         }

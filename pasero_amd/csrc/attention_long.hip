@@ -197,9 +197,12 @@ __global__ __launch_bounds__(256, PKL_WAVES) void attn_fwd_long_kernel(const T* 
                 for (int gp = 0; gp < 2; ++gp) {
                     const int g_own = 2 * gp + (hi ? 1 : 0);
                     const unsigned long long ctr = ((unsigned long long)mrow * 8ull * p.mask_pitch + (s0 + kb * 32 + 8 * g_own)) >> 3;
-                    const Philox4 rr = philox4x32_10(p.seed, p.offset, ctr);
-                    const unsigned got0 = __shfl_xor(hi ? rr.x : rr.z, 32, 64), got1 = __shfl_xor(hi ? rr.y : rr.w, 32, 64);
-                    const unsigned wv[2][2] = {{hi ? got0 : rr.x, hi ? got1 : rr.y}, {hi ? rr.z : got0, hi ? rr.w : got1}};
+                    Philox4 rr = philox4x32_10(p.seed, p.offset, ctr);
+                    // the lower half-wave keeps (x, y) = its 4 keys of group 2 gp and needs the upper one's (x, y) for group 2 gp + 1; the
+                    // upper one keeps (z, w) and needs the lower one's: one swap per register pair
+                    half_wave_swap(rr.x, rr.z);
+                    half_wave_swap(rr.y, rr.w);
+                    const unsigned wv[2][2] = {{rr.x, rr.y}, {rr.z, rr.w}};
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int g = 2 * gp + u;
@@ -214,7 +217,11 @@ __global__ __launch_bounds__(256, PKL_WAVES) void attn_fwd_long_kernel(const T* 
                         word |= nib << (8 * g + 4 * (lane >> 5));
                     }
                 }
-                word |= __shfl_xor(word, 32, 64);
+                {
+                    unsigned wa = word, wb = word;  // (the two half-waves hold the low / high nibbles of the same bytes)
+                    half_wave_swap(wa, wb);
+                    word = wa | wb;
+                }
                 if (valid && lane < 32)
                     *reinterpret_cast<unsigned*>(p.drop_mask + mrow * p.mask_pitch + ((s0 + kb * 32) >> 3)) = word;
             }

@@ -180,6 +180,19 @@ __device__ __forceinline__ float half_wave_max(float v) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return fmaxf(a, b);
 }
+// sum over the 8 consecutive lanes a lane belongs to (partners 1, 2, 4 away, in this order, as three `__shfl_xor` steps
+// would add them): quad permutes, then the half-row mirror (lane ^ 7 — its quad already holds the quad's sum)
+__device__ __forceinline__ float lanes8_sum(float v) {
+    v += dpp_mov_f32<0xB1>(v);   // quad_perm:[1,0,3,2]
+    v += dpp_mov_f32<0x4E>(v);   // quad_perm:[2,3,0,1]
+    v += dpp_mov_f32<0x141>(v);  // row_half_mirror
+    return v;
+}
+// exchange between the two half-waves: afterwards lanes 32..63 of `a` hold what lanes 0..31 of `b` held and vice versa
+// (v_permlane32_swap_b32; the other halves stay)
+__device__ __forceinline__ void half_wave_swap(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
 // (the LDS-pipe form, kept for the kernels' tests of the above)
 __device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
@@ -293,23 +306,29 @@ template <typename T> __device__ __forceinline__ float act_bwd_t(int act, float 
 struct Philox4 {
     unsigned x, y, z, w;
 };
+// one round (of ten); k0 / k1: the round's keys = seed halves + round * (0x9E3779B9, 0xBB67AE85)
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    // (one v_bitop3_b32 each, truth table 0x96 = a ^ b ^ c: hipcc 7.2 emits two v_xor_b32 for the plain expression)
+    const unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), c1, k0, 0x96);
+    const unsigned n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), c3, k1, 0x96);
+    c1 = (unsigned)p1;
+    c3 = (unsigned)p0;
+    c0 = n0;
+    c2 = n2;
+}
+// rounds [R0, R1) on a state kept by the caller (gemmln.hip spreads the ten rounds of a draw over two phases of its K loop)
+template <int R0, int R1>
+__device__ __forceinline__ void philox_rounds(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned long long seed) {
+#pragma unroll
+    for (int r = R0; r < R1; ++r)
+        philox_round(c0, c1, c2, c3, (unsigned)seed + (unsigned)r * 0x9E3779B9u, (unsigned)(seed >> 32) + (unsigned)r * 0xBB67AE85u);
+}
 __device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed, unsigned long long offset,
                                                  unsigned long long idx) {
     unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = (unsigned)offset, c3 = (unsigned)(offset >> 32);
-    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
-        unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-        // (one v_bitop3_b32 each, truth table 0x96 = a ^ b ^ c: hipcc 7.2 emits two v_xor_b32 for the plain expression)
-        unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), c1, k0, 0x96);
-        unsigned n1 = (unsigned)p1;
-        unsigned n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), c3, k1, 0x96);
-        unsigned n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
+    philox_rounds<0, 10>(c0, c1, c2, c3, seed);
     return Philox4{c0, c1, c2, c3};
 }
 // keep-threshold for drop probability p: element kept iff rnd >= thr

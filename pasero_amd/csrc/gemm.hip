@@ -43,6 +43,7 @@ extern "C" int pk_gemm8p_group_plan(const PkWgradProblem* p, int n, size_t* ws_b
 extern "C" int pk_gemm8p_group_map(const PkWgradProblem* p, int n, int* out, int cap);
 extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream);
 extern "C" int pk_gemm8p_group_reduce(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream);
+extern "C" int pk_gemmln_spec(int has_residual, float drop_p, long long K);
 extern "C" int pk_gemmln_launch(const void* A, const void* W, const void* bias, const void* residual, const void* gamma,
                                 const void* beta, void* z_out, void* y_out, float* mean, float* rstd, long long M,
                                 long long N, long long K, long long lda, long long ldb, long long ldr, float eps,
@@ -1022,7 +1023,7 @@ extern "C" int pk_gemm_ln_fwd(const void* A, const void* W, const void* bias, co
     hipStream_t s = (hipStream_t)stream;
     // (sample tag 8 | 0x80: the 128 x 512-tile instantiation with the LayerNorm epilogue; the sample's `a_col` field carries
     // the epilogue specialisation gemmln.hip picks: 0 generic, 1 residual, 2 residual + dropout)
-    GemmSample* sm = timing_begin(8 | 0x80, !residual ? 0 : drop_p > 0.f ? 2 : 1, 0, 1, dtype, M, N, K, s);
+    GemmSample* sm = timing_begin(8 | 0x80, pk_gemmln_spec(residual != nullptr, drop_p, K), 0, 1, dtype, M, N, K, s);
     const int rc = pk_gemmln_launch(A, W, bias, residual, gamma, beta, z_out, y_out, mean, rstd, M, N, K, lda, ldb, ldr,
                                     eps, drop_p, seed, offset, dtype, stream);
     timing_end(sm, s);

@@ -8,7 +8,8 @@ by __graft_entry__.build() and the CPU tests:
   2. the transposed LDS reads are inline asm, so the compiler neither waits for them nor knows when their destination
      registers become valid: from each `ds_read_b64_tr_b16` to the next `s_waitcnt lgkmcnt(0)` nothing else may read or
      write those registers (a compiler copy there would move stale data);
-  3. no scratch (spill) traffic inside the K loop (spills in the prologue / epilogue are reported, not refused).
+  3. no scratch (spill) traffic inside the K loop's blocks (spills in the prologue / epilogue, or between the markers
+     but outside every loop block — executed once — are reported, not refused).
 The smallest counted wait a kernel places in its loop is 6 unless the kernel says otherwise with a `; PK8P_MIN_VMCNT n`
 marker; rule 2 also covers a `PKBS_BFRAG_BEGIN / _END` region (gemmbs.hip's one-time transposed reads of the B panel).
 
@@ -74,6 +75,7 @@ def audit(path: str):
         except StopIteration:
             pass
         pending = {}  # register -> line of the asm tr read that wrote it
+        looping = False  # inside a block LLVM marks as part of a loop
         for k, in_loop in [(k, lp) for (s0, s1, lp) in spans for k in range(s0, s1)]:
             ln = body[k]
             if not in_loop:  # the B-fragment region: only rule 2
@@ -90,8 +92,14 @@ def audit(path: str):
                         problems.append(f'{name}: line {k}: `{ln.strip()}` touches v{sorted(bad)} before the lgkmcnt(0) '
                                         f'that covers the asm read at line {pending[sorted(bad)[0]]}')
                 continue
+            mlab = re.match(r'^\.LBB\d+_\d+:(.*)$', ln)
+            if mlab:  # LLVM annotates the labels of blocks that belong to a loop ("Loop Header" / "in Loop:")
+                looping = 'Loop' in mlab.group(1)
             if 'scratch_' in ln:
-                problems.append(f'{name}: line {k}: spill traffic inside the K loop: `{ln.strip()}`')
+                if looping:
+                    problems.append(f'{name}: line {k}: spill traffic inside the K loop: `{ln.strip()}`')
+                else:  # between the markers but executed once: ahead of the first iteration or behind the last
+                    notes.append(f'{name}: line {k}: spill outside the loop blocks (runs once): `{ln.strip()}`')
                 n_scratch -= 1
             op, ops = operands(ln)
             if op in ('s_branch', 's_endpgm', 's_setpc_b64'):
