@@ -709,6 +709,37 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
     unsigned* m_lds = reinterpret_cast<unsigned*>(dl_lds + 128);  // DROP: keep bits [128 queries][4 dwords of 32 keys]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, h = blockIdx.x;
+    const float c = p.scale * LOG2E;
+    const int off = p.S - p.T;
+
+    // ---- loads: Q, dO (+O for delta) tiles, the K tile (kept in registers until phase 2), own-key K/V fragments ----
+    // EVERY global load of the prologue is requested before the first wait, without a branch in between: rows past T / S
+    // read the last row and are zeroed afterwards.  (Behind `if (r < p.T)` each of the four row groups was a block of its
+    // own, and at a block join hipcc waits for every load in flight — the prologue was four tile round trips, then the
+    // statistics, the padding byte and the K / V fragments one after the other: seven serial trips to memory out of the
+    // ~19 us a workgroup lives.)
+    const T* qbase = q + b * p.q_bs + h * HD64;
+    const T* dobase = d_o + b * p.do_bs + h * HD64;
+    const T* obase = o + b * p.o_bs + h * HD64;
+    const T* kbase = k + b * p.k_bs + h * HD64;
+    uint4 kreg[4], qreg[4], doreg[4], oreg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cidx = tid + i * 256, r = cidx >> 3, ch = cidx & 7;
+        const int rq = min(r, p.T - 1), rk = min(r, p.S - 1);
+        qreg[i] = att_ld<1>(qbase + (long long)rq * p.q_rs + ch * 8);
+        doreg[i] = att_ld<1>(dobase + (long long)rq * p.do_rs + ch * 8);
+        oreg[i] = att_ld<1>(obase + (long long)rq * p.o_rs + ch * 8);
+        kreg[i] = att_ld<1>(kbase + (long long)rk * p.k_rs + ch * 8);
+    }
+    const int s = wave * 32 + (lane & 31);
+    bf16x8_t kf[4], vf[4];
+    load_row_frags(kf, kbase, p.k_rs, s, s < p.S, lane);
+    load_row_frags(vf, v + b * p.v_bs + h * HD64, p.v_rs, s, s < p.S, lane);
+    const float lse_t = lse[((long long)b * p.H + h) * p.T + min(tid & 127, p.T - 1)];
+    // (no padding mask: any readable byte — the select below ignores it)
+    const unsigned char* padp = p.key_pad ? p.key_pad + (long long)b * p.S + min(s, p.S - 1) : reinterpret_cast<const unsigned char*>(lse);
+    const unsigned char padv = *padp;
     if constexpr (DROP) {  // (staged with the tiles; one dword per (query, wave) instead of a global byte load per score)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -719,26 +750,12 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
             m_lds[idx] = w;
         }
     }
-    const float c = p.scale * LOG2E;
-    const int off = p.S - p.T;
-
-    // ---- loads: Q, dO (+O for delta) tiles, the K tile (kept in registers until phase 2), own-key K/V fragments ----
-    const T* qbase = q + b * p.q_bs + h * HD64;
-    const T* dobase = d_o + b * p.do_bs + h * HD64;
-    const T* obase = o + b * p.o_bs + h * HD64;
-    const T* kbase = k + b * p.k_bs + h * HD64;
-    uint4 kreg[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int cidx = tid + i * 256, r = cidx >> 3, ch = cidx & 7;
-        uint4 qv = {0, 0, 0, 0}, dov = {0, 0, 0, 0}, ov = {0, 0, 0, 0};
-        kreg[i] = make_uint4(0, 0, 0, 0);
-        if (r < p.T) {
-            qv = att_ld<1>(qbase + (long long)r * p.q_rs + ch * 8);
-            dov = att_ld<1>(dobase + (long long)r * p.do_rs + ch * 8);
-            ov = att_ld<1>(obase + (long long)r * p.o_rs + ch * 8);
-        }
-        if (r < p.S) kreg[i] = att_ld<1>(kbase + (long long)r * p.k_rs + ch * 8);
+        uint4 qv = sel4(r < p.T, qreg[i]);
+        const uint4 dov = sel4(r < p.T, doreg[i]), ov = sel4(r < p.T, oreg[i]);
+        kreg[i] = sel4(r < p.S, kreg[i]);
         if (p.rope_cos) {
             qv = rope_chunk<8, T>(qv, ch, p, p.rope_q0 + r);
             kreg[i] = rope_chunk<8, T>(kreg[i], ch, p, p.rope_k0 + r);
@@ -753,12 +770,8 @@ __global__ __launch_bounds__(256, PK_ATTN_FUSED_WAVES) void attn_bwd_fused128_ke
         }
     }
     // the initial accumulator of S, in units of the raw score (rows past T: -inf -> p = 0)
-    if (tid < 128) l2_lds[tid] = tid < p.T ? -lse[((long long)b * p.H + h) * p.T + tid] / p.scale : -INFINITY;
-    const int s = wave * 32 + (lane & 31);
-    const bool kvalid = s < p.S && !(p.key_pad && p.key_pad[(long long)b * p.S + min(s, p.S - 1)]);
-    bf16x8_t kf[4], vf[4];
-    load_row_frags(kf, kbase, p.k_rs, s, s < p.S, lane);
-    load_row_frags(vf, v + b * p.v_bs + h * HD64, p.v_rs, s, s < p.S, lane);
+    if (tid < 128) l2_lds[tid] = tid < p.T ? -lse_t / p.scale : -INFINITY;
+    const bool kvalid = s < p.S && !(p.key_pad && padv);
     if (p.rope_cos) rope_frags<4, T>(kf, p, p.rope_k0 + s, lane);
     // S starts from the accumulator -lse / scale (-inf on the lane of a padding key / key past S), dP from -delta:
     // p = exp2(c acc), dS = p dP' (as in the dK / dV kernel above)

@@ -31,6 +31,9 @@ template <int BIT, typename T> __device__ __forceinline__ uint4 att_ld(const T* 
     if constexpr ((PKATT_NT & BIT) != 0) return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
     else return *reinterpret_cast<const uint4*>(p);
 }
+// v or zeros (component by component: a `c ? a : b` on whole uint4 objects selects between their ADDRESSES and parks the
+// operands in scratch memory)
+__device__ __forceinline__ uint4 sel4(bool c, const uint4 v) { return make_uint4(c ? v.x : 0u, c ? v.y : 0u, c ? v.z : 0u, c ? v.w : 0u); }
 template <typename T> __device__ __forceinline__ void att_st(T* p, uint4 v) {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     if constexpr ((PKATT_NT & 4) != 0) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
@@ -195,8 +198,10 @@ __device__ __forceinline__ void tile_g2r(uint4 (&regs)[NR], const T* __restrict_
     for (int i = 0; i < NR; ++i) {
         int c = tid + i * 256;
         int r = c / CPR, cc = (c % CPR) * 8;
-        regs[i] = make_uint4(0, 0, 0, 0);
-        if (r0 + r < lim) regs[i] = att_ld<2>(base + (long long)(r0 + r) * rs + cc);
+        // (no branch around the load — rows past `lim` read the last row and are zeroed: at the join behind a branch hipcc
+        // waits for EVERY load in flight, the caller's prefetches included)
+        const uint4 got = att_ld<2>(base + (long long)min(r0 + r, lim - 1) * rs + cc);
+        regs[i] = sel4(r0 + r < lim, got);
     }
 }
 template <int P, int NR>
@@ -246,8 +251,8 @@ __device__ __forceinline__ void load_row_frags(bf16x8_t (&f)[NF], const T* __res
                                                bool valid, int lane) {
 #pragma unroll
     for (int kk = 0; kk < NF; ++kk) {
-        uint4 val = {0, 0, 0, 0};
-        if (valid) val = att_ld<2>(base + (long long)row * rs + kk * 16 + 8 * (lane >> 5));
+        const uint4 got = att_ld<2>(base + (long long)(valid ? row : 0) * rs + kk * 16 + 8 * (lane >> 5));  // (branch-free, as above)
+        const uint4 val = sel4(valid, got);
         f[kk] = __builtin_bit_cast(bf16x8_t, val);
     }
 }
