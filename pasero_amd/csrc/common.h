@@ -120,6 +120,19 @@ template <> struct Vec16<f16> {
         w = (i & 1) ? ((w & 0x0000ffffu) | (b << 16)) : ((w & 0xffff0000u) | b);
     }
 };
+// a 16-byte chunk from its elements as floats.  (Vec16::set inserts ONE element: a conversion, a shift and a masked merge
+// each — three instructions per element where v_cvt_pk_bf16_f32 converts and packs two; the cross-entropy gradient spent
+// 390 instructions per 96 elements on it.)
+template <typename T> __device__ __forceinline__ Vec16<T> vec16_pack(const float (&f)[16 / sizeof(T)]) {
+    Vec16<T> o;
+    if constexpr (sizeof(T) == 4) {
+        o.raw = float4{f[0], f[1], f[2], f[3]};
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) (&o.raw.x)[j] = (unsigned)H16<T>::bits(f[2 * j]) | ((unsigned)H16<T>::bits(f[2 * j + 1]) << 16);
+    }
+    return o;
+}
 template <typename T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
     Vec16<T> v;
     v.raw = *reinterpret_cast<const decltype(v.raw)*>(p);

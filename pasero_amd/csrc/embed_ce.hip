@@ -51,6 +51,14 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
 // ------------------------------------------------------------------------------------------------------
 // label-smoothed cross entropy: one workgroup per row
 // ------------------------------------------------------------------------------------------------------
+// e^(a - m).  16-bit kernels: one fma and v_exp_f32, `nml` = -m log2(e) computed once per chunk / row (as `__expf(a - m)` it
+// is a subtraction, a multiplication and the exponential: the kernels below are bound by their instruction count — 17
+// issue slots per logit over the two passes against 366 us of memory time at 8192 x 70 376).  The fp32 kernel (the
+// parity path) keeps the plain expression.
+template <typename T> __device__ __forceinline__ float exp_sub(float a, float m, float nml) {
+    if constexpr (sizeof(T) == 2) return __builtin_amdgcn_exp2f(fmaf(a, 1.4426950408889634f, nml));
+    else return __expf(a - m);
+}
 __device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
     float mn = fmaxf(m, m2);
     if (mn == -INFINITY) { m = mn; s = 0.f; return; }
@@ -93,10 +101,11 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, l
             const float mn = fmaxf(m, cm);  // one rescale of the running sum per chunk, the chunk's terms against the new maximum
             const float ms = mn == -INFINITY ? 0.f : mn;  // (nothing but -inf so far: every term is exp(-inf) = 0)
             float cs = 0.f;
+            const float nml = -ms * 1.4426950408889634f;
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
                 float a = v.get(e);
-                cs += __expf(a - ms);
+                cs += exp_sub<T>(a, ms, nml);
                 tot += a;
             }
             s = s * __expf(m - ms) + cs;
@@ -148,16 +157,19 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, l
     const long long tch = (active && tgt >= 0) ? tgt / EPV : -1;  // the one chunk that holds the target column
     const int te = (int)(tgt >= 0 ? tgt % EPV : 0);
     const float onehot = 1.f - eps;
+    const float nlse = -lse * 1.4426950408889634f;
     auto grad = [&](const Vec16<T>& v, long long ch) {
-        Vec16<T> o;
+        float g[EPV];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) o.set(e, __expf(v.get(e) - lse) - uni);
-        if (ch == tch) {
+        for (int e = 0; e < EPV; ++e) g[e] = exp_sub<T>(v.get(e), lse, nlse) - uni;
+        if (ch == tch) {  // (one chunk of the row — a real branch: if-converted it is EPV selects in every chunk)
+            int te_v = te;
+            asm volatile("; target chunk" : "+v"(te_v));
 #pragma unroll
             for (int e = 0; e < EPV; ++e)
-                if (e == te) o.set(e, __expf(v.get(e) - lse) - uni - onehot);
+                if (e == te_v) g[e] -= onehot;
         }
-        store16<T>(dx + ch * EPV, o);
+        store16<T>(dx + ch * EPV, vec16_pack<T>(g));
     };
     if (active) {
         long long ch = tid;
@@ -387,10 +399,11 @@ __global__ __launch_bounds__(THREADS) void ce_reg_kernel(const T* __restrict__ l
             const float mn = fmaxf(m, cm);
             const float ms = mn == -INFINITY ? 0.f : mn;
             float cs = 0.f;
+            const float nml = -ms * 1.4426950408889634f;
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
                 const float a = v[i].get(e);
-                cs += __expf(a - ms);
+                cs += exp_sub<T>(a, ms, nml);
                 tot += a;
             }
             s = s * __expf(m - ms) + cs;
@@ -439,19 +452,24 @@ __global__ __launch_bounds__(THREADS) void ce_reg_kernel(const T* __restrict__ l
     const float uni = eps / (float)V, onehot = 1.f - eps;
     const long long tch = (active && tgt >= 0) ? tgt / EPV : -1;
     const int te = (int)(tgt >= 0 ? tgt % EPV : 0);
+    const float nlse = -lse * 1.4426950408889634f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int ch = tid + i * THREADS;
         if (ch < nvec) {
             Vec16<T> o;
             if (active) {
+                float g[EPV];
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) o.set(e, __expf(v[i].get(e) - lse) - uni);
-                if (ch == tch) {
+                for (int e = 0; e < EPV; ++e) g[e] = exp_sub<T>(v[i].get(e), lse, nlse) - uni;
+                if (ch == tch) {  // (a real branch, as in ce_kernel)
+                    int te_v = te;
+                    asm volatile("; target chunk" : "+v"(te_v));
 #pragma unroll
                     for (int e = 0; e < EPV; ++e)
-                        if (e == te) o.set(e, __expf(v[i].get(e) - lse) - uni - onehot);
+                        if (e == te_v) g[e] -= onehot;
                 }
+                o = vec16_pack<T>(g);
             } else {
                 o.raw = {0, 0, 0, 0};
             }

@@ -49,12 +49,7 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
                     v[i][e] = a;
                     sum += a;
                 }
-                if (z_out) {
-                    Vec16<T> zv;
-#pragma unroll
-                    for (int e = 0; e < EPV; ++e) zv.set(e, v[i][e]);
-                    store16<T>(z_out + off, zv);
-                }
+                if (z_out) store16<T>(z_out + off, vec16_pack<T>(v[i]));
             } else {
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) v[i][e] = 0.f;
@@ -96,15 +91,16 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
         for (int i = 0; i < NCH; ++i) {
             int ch = lane + 64 * i;
             if (ch < nchunks) {
-                Vec16<T> gv = load16<T>(gamma + ch * EPV), bv, yv;
+                Vec16<T> gv = load16<T>(gamma + ch * EPV), bv;
                 if (beta) bv = load16<T>(beta + ch * EPV);
+                float yf[EPV];
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) {
                     float y = (v[i][e] - mu) * rstd * gv.get(e);
                     if (beta) y += bv.get(e);
-                    yv.set(e, y);
+                    yf[e] = y;
                 }
-                store16<T>(y_out + row * d + (long long)ch * EPV, yv);
+                store16<T>(y_out + row * d + (long long)ch * EPV, vec16_pack<T>(yf));
             }
         }
     }
