@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
         const T* erow = E + id * d;
         const T* prow = pos ? pos + (long long)(pos_start + (int)(tok % Tlen)) * d : nullptr;
         for (int ch = lane; ch < nchunks; ch += 64) {
-            Vec16<T> ev = load16<T>(erow + ch * EPV), pv, ov;
+            Vec16<T> ev = load16<T>(erow + ch * EPV), pv;
+            float of[EPV];
             if (prow) pv = load16<T>(prow + ch * EPV);
             long long off = tok * d + (long long)ch * EPV;
             bool keep[EPV];
@@ -41,9 +42,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
                 float x = ev.get(e) * scale;
                 if (prow) x += pv.get(e);
                 if (thr) x = keep[e] ? x * drop_scale : 0.f;
-                ov.set(e, x);
+                of[e] = x;
             }
-            store16<T>(out + off, ov);
+            store16<T>(out + off, vec16_pack<T>(of));
         }
     }
 }
@@ -281,12 +282,13 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
     constexpr int EPV = 16 / sizeof(T);
     const long long nvec = n / EPV;
     for (long long ch = (long long)blockIdx.x * 256 + threadIdx.x; ch < nvec; ch += (long long)gridDim.x * 256) {
-        Vec16<T> v = load16<T>(x + ch * EPV), o;
+        Vec16<T> v = load16<T>(x + ch * EPV);
         bool keep[EPV];
         dropout_keep_chunk<EPV>(seed, offset, (unsigned long long)(ch * EPV), thr, keep);
+        float of[EPV];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) o.set(e, keep[e] ? v.get(e) * drop_scale : 0.f);
-        store16<T>(out + ch * EPV, o);
+        for (int e = 0; e < EPV; ++e) of[e] = keep[e] ? v.get(e) * drop_scale : 0.f;
+        store16<T>(out + ch * EPV, vec16_pack<T>(of));
     }
     if (blockIdx.x == 0) {
         for (long long i = nvec * EPV + threadIdx.x; i < n; i += 256) {
@@ -303,10 +305,11 @@ __global__ __launch_bounds__(256) void scale_kernel(const T* __restrict__ x, T* 
     const float a = (dev_scalar ? *dev_scalar : 1.f) * host_scalar;
     const long long nvec = n / EPV;
     for (long long ch = (long long)blockIdx.x * 256 + threadIdx.x; ch < nvec; ch += (long long)gridDim.x * 256) {
-        Vec16<T> v = load16<T>(x + ch * EPV), o;
+        Vec16<T> v = load16<T>(x + ch * EPV);
+        float of[EPV];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) o.set(e, v.get(e) * a);
-        store16<T>(out + ch * EPV, o);
+        for (int e = 0; e < EPV; ++e) of[e] = v.get(e) * a;
+        store16<T>(out + ch * EPV, vec16_pack<T>(of));
     }
     if (blockIdx.x == 0)
         for (long long i = nvec * EPV + threadIdx.x; i < n; i += 256) out[i] = from_f32<T>(to_f32<T>(x[i]) * a);

@@ -318,10 +318,7 @@ __device__ __forceinline__ void fast_epilogue(const float* __restrict__ cs, T* _
             x[e] = y;
         }
         if constexpr (PRE) {
-            Vec16<T> pv;
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) pv.set(e, pre[e]);
-            store16<T>(reinterpret_cast<T*>(ep.preact) + (m0 + r0 + (long long)i * RPT) * ep.ldpre + n0 + col, pv);
+            store16<T>(reinterpret_cast<T*>(ep.preact) + (m0 + r0 + (long long)i * RPT) * ep.ldpre + n0 + col, vec16_pack<T>(pre));
         }
         if constexpr (sizeof(T) == 2) {
             typedef __attribute__((ext_vector_type(8))) float f32x8;
@@ -696,16 +693,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict
                     v[e] += t4.x; v[e + 1] += t4.y; v[e + 2] += t4.z; v[e + 3] += t4.w;
                 }
             }
-            Vec16<T> o;
             if (ep.mode == 1) {
                 Vec16<T> a = load16<T>(reinterpret_cast<const T*>(ep.aux) + gm * ep.ldaux + gn);
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) o.set(e, v[e] * ep.alpha + a.get(e));
+                for (int e = 0; e < EPV; ++e) v[e] = v[e] * ep.alpha + a.get(e);
             } else {
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) o.set(e, v[e] * ep.alpha);
+                for (int e = 0; e < EPV; ++e) v[e] = v[e] * ep.alpha;
             }
-            store16_nt<T>(C + gm * ep.ldc + gn, o);
+            store16_nt<T>(C + gm * ep.ldc + gn, vec16_pack<T>(v));
         }
         return;
     }

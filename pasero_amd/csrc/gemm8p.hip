@@ -150,23 +150,24 @@ __device__ __noinline__ void epilogue_pass_any(const float* __restrict__ cs, T* 
         const float* src = cs + (r0 + 16 * it) * CP + col;
         const float4 a4 = *reinterpret_cast<const float4*>(src), b4 = *reinterpret_cast<const float4*>(src + 4);
         float x[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
-        Vec16<T> pre, o;
+        float pre[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float y = x[e] * alpha;
+            pre[e] = 0.f;
             if (mode == 2) {
                 y *= act_bwd_fast(act, av.get(e));
             } else {
                 y += b[e];
-                pre.set(e, y);
+                pre[e] = y;
                 y = act_fwd_fast(act, y);
                 if (mode == 1) y += av.get(e);
                 else if (mode == 3) y *= av.get(e);
             }
-            o.set(e, y);
+            x[e] = y;
         }
-        store16_nt<T>(C + gm * ep.ldc + gn, o);
-        if (ep.preact && mode != 2) store16_nt<T>(reinterpret_cast<T*>(ep.preact) + gm * ep.ldpre + gn, pre);
+        store16_nt<T>(C + gm * ep.ldc + gn, vec16_pack<T>(x));
+        if (ep.preact && mode != 2) store16_nt<T>(reinterpret_cast<T*>(ep.preact) + gm * ep.ldpre + gn, vec16_pack<T>(pre));
     }
 }
 
@@ -919,10 +920,7 @@ __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(GroupArgs g, in
             v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
             v[4] += b4.x; v[5] += b4.y; v[6] += b4.z; v[7] += b4.w;
         }
-        Vec16<T> o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o.set(e, v[e]);
-        store16_nt<T>(C + gm * q.ldc + gn, o);
+        store16_nt<T>(C + gm * q.ldc + gn, vec16_pack<T>(v));
     }
 }
 

@@ -83,8 +83,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
         if (ep.bias) y += full ? bv.get(e) : (gn + e < N ? to_f32(reinterpret_cast<const T*>(ep.bias)[gn + e]) : 0.f);
         y = act_fwd_t<T>(ACT, y);
         if (MODE == 1) y += full ? av.get(e) : (gn + e < N ? to_f32(reinterpret_cast<const T*>(ep.aux)[gm * ep.ldaux + gn + e]) : 0.f);
-        o.set(e, y);
+        v[e] = y;
     }
+    o = vec16_pack<T>(v);
     if (full) {
         store16<T>(C + gm * ep.ldc + gn, o);
     } else {
