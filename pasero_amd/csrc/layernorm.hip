@@ -9,6 +9,7 @@
 // RMSNorm (pasero/models/modules.py:192-202: y = x * rsqrt(mean(x^2) + eps) * weight, computed in fp32) is the same
 // kernels with the mean fixed at 0: the C ABI selects it with mean == NULL (then beta must be NULL too).
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
             for (int i = 0; i < NCH; ++i)
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) {
-                    v[i][e] = bf2f(f2bf(v[i][e]));
+                    v[i][e] = H16<std::conditional_t<sizeof(T) == 2, T, bf16>>::val(H16<std::conditional_t<sizeof(T) == 2, T, bf16>>::bits(v[i][e]));
                     sum += v[i][e];
                 }
         }
@@ -360,6 +361,114 @@ template <typename T> __device__ __forceinline__ unsigned pack2(f32x2 v) {
     return (unsigned)H16<T>::bits(v.x) | ((unsigned)H16<T>::bits(v.y) << 16);
 }
 
+// ---- the forward kernel for the same rows (16-bit storage, d = 512 or 1024) ----
+// residual_ln_fwd_kernel above spends 353 (d = 512) / 628 (d = 1024, with scalar registers spilled to lanes) vector
+// instructions per row on run-time decisions, per-element selects and one-at-a-time conversions: at 8192 rows x 1024 that
+// is 8 rows x 628 x 4 cycles = 9.6 us of issue per SIMD in a 13.6 us kernel whose 33.5 MB take 6 us.  The combinations
+// the models use as template flags (FL: 1 = residual, 2 = dropout on x, 4 = LayerNorm — without it the residual-only
+// pass of the pre-norm blocks; z is written exactly when 1 or 2 is set; beta is required with 4), a wave-uniform row,
+// the next row in a second register set, float pairs, packed conversions.
+template <typename T, int NCH, int FL>
+__global__ __launch_bounds__(256) void residual_ln_fwd16_kernel(
+    const T* __restrict__ x, const T* __restrict__ residual, const T* __restrict__ gamma, const T* __restrict__ beta,
+    T* __restrict__ z_out, T* __restrict__ y_out, float* __restrict__ mean_out, float* __restrict__ rstd_out, long long rows,
+    float eps, unsigned thr, float drop_scale, unsigned long long seed, unsigned long long offset) {
+    constexpr int D = NCH * 512;
+    constexpr bool RES = (FL & 1) != 0, DROP = (FL & 2) != 0, LN = (FL & 4) != 0, ZOUT = RES || DROP;
+    constexpr float inv_d = 1.f / (float)D;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    f32x2 gm[NCH][4], bt[NCH][4];
+    if constexpr (LN) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const uint4 gv = *(reinterpret_cast<const uint4*>(gamma) + lane + 64 * i);
+            const uint4 bv = *(reinterpret_cast<const uint4*>(beta) + lane + 64 * i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gm[i][j] = unpack2<T>((&gv.x)[j]);
+                bt[i][j] = unpack2<T>((&bv.x)[j]);
+            }
+        }
+    }
+    const long long row_step = (long long)gridDim.x * ROWS_PER_BLOCK;
+    uint4 xA[NCH], rA[NCH], xB[NCH], rB[NCH];
+    auto fetch = [&](long long row, uint4(&xv)[NCH], uint4(&rv)[NCH]) {
+        const uint4* xp = reinterpret_cast<const uint4*>(x + row * D) + lane;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) xv[i] = xp[64 * i];
+        if constexpr (RES) {
+            const uint4* rp = reinterpret_cast<const uint4*>(residual + row * D) + lane;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) rv[i] = rp[64 * i];
+        }
+    };
+    auto work = [&](long long row, const uint4(&xv)[NCH], const uint4(&rv)[NCH]) {
+        f32x2 v[NCH][4];
+        f32x2 a1 = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            bool keep[8];
+            if constexpr (DROP) dropout_keep8(seed, offset, ((unsigned long long)row * D >> 3) + lane + 64 * i, thr, keep);
+            uint4 zw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x2 a = unpack2<T>((&xv[i].x)[j]);
+                if constexpr (DROP) {
+                    a.x = keep[2 * j] ? a.x * drop_scale : 0.f;
+                    a.y = keep[2 * j + 1] ? a.y * drop_scale : 0.f;
+                }
+                if constexpr (RES) a += unpack2<T>((&rv[i].x)[j]);
+                if constexpr (ZOUT) {
+                    // z is a tensor of the storage type in the reference (and what the backward pass re-reads): statistics on
+                    // the rounded values
+                    (&zw.x)[j] = pack2<T>(a);
+                    a = unpack2<T>((&zw.x)[j]);
+                }
+                v[i][j] = a;
+                a1 += a;
+            }
+            if constexpr (ZOUT) *(reinterpret_cast<uint4*>(z_out + row * D) + lane + 64 * i) = zw;
+        }
+        if constexpr (LN) {
+            const float mu = wave_sum(a1.x + a1.y) * inv_d;
+            f32x2 a2 = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[i][j] -= mu;
+                    a2 += v[i][j] * v[i][j];
+                }
+            const float rstd = rsqrtf(wave_sum(a2.x + a2.y) * inv_d + eps);
+            if (lane == 0) {
+                mean_out[row] = mu;
+                rstd_out[row] = rstd;
+            }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                uint4 yw;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) (&yw.x)[j] = pack2<T>(v[i][j] * rstd * gm[i][j] + bt[i][j]);
+                *(reinterpret_cast<uint4*>(y_out + row * D) + lane + 64 * i) = yw;
+            }
+        }
+    };
+    long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + wave;
+    if (row < rows) fetch(row, xA, rA);
+    while (row < rows) {  // (unconditional prefetch, as in the backward kernel below)
+        long long nx = row + row_step;
+        fetch(nx < rows ? nx : row, xB, rB);
+        work(row, xA, rA);
+        row = nx;
+        if (row >= rows) break;
+        nx = row + row_step;
+        fetch(nx < rows ? nx : row, xA, rA);
+        work(row, xB, rB);
+        row = nx;
+    }
+}
+
 template <typename T, int NCH, int FL>
 __global__ __launch_bounds__(256) void residual_ln_bwd16_kernel(
     const T* __restrict__ dy, const T* __restrict__ dz_extra, const T* __restrict__ z, const T* __restrict__ gamma,
@@ -543,6 +652,35 @@ int launch_fwd(const void* x, const void* res, const void* gamma, const void* be
     float scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
     int nch = (d / EPV + 63) / 64;
     dim3 grid(ln_grid(rows)), block(256);
+    if constexpr (sizeof(T) == 2) {
+        static const bool off16 = getenv("PK_LN_FWD16") && atoi(getenv("PK_LN_FWD16")) == 0;  // (experiments)
+        const bool ln = gamma != nullptr, zout = res || thr;
+        if (!off16 && (d == 512 || d == 1024) && (!ln || (beta && mean && y && rstd)) && (ln || zout) && (zout == (z != nullptr)) &&
+            !(thr && !res && !ln)) {
+            const int fl = (res ? 1 : 0) | (thr ? 2 : 0) | (ln ? 4 : 0);
+#define PK_LFWD(N, F)                                                                                                \
+    hipLaunchKernelGGL((residual_ln_fwd16_kernel<T, N, F>), grid, block, 0, s, (const T*)x, (const T*)res,          \
+                       (const T*)gamma, (const T*)beta, (T*)z, (T*)y, mean, rstd, rows, eps, thr, scale, seed, offset)
+#define PK_LFWDN(N)                      \
+    do {                                \
+        if (fl == 4) PK_LFWD(N, 4);      \
+        else if (fl == 5) PK_LFWD(N, 5); \
+        else if (fl == 7) PK_LFWD(N, 7); \
+        else if (fl == 1) PK_LFWD(N, 1); \
+        else if (fl == 3) PK_LFWD(N, 3); \
+        else fl16_done = false;         \
+    } while (0)
+            bool fl16_done = true;
+            if (d == 512) PK_LFWDN(1);
+            else PK_LFWDN(2);
+#undef PK_LFWDN
+#undef PK_LFWD
+            if (fl16_done) {
+                PK_LAUNCH_CHECK();
+                return 0;
+            }
+        }
+    }
 #define PK_L(N)                                                                                                   \
     hipLaunchKernelGGL((residual_ln_fwd_kernel<T, N>), grid, block, 0, s, (const T*)x, (const T*)res,             \
                        (const T*)gamma, (const T*)beta, (T*)z, (T*)y, mean, rstd, rows, d, eps, thr, scale, seed, \

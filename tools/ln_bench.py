@@ -33,6 +33,22 @@ def run(rows, d, dtype, extra, p):
                              drop_p=p, seed=1234, offset=77)
 
 
+def run_fwd(rows, d, dtype, mode, p):
+    g = torch.Generator(device='cuda').manual_seed(rows * 3 + d)
+    r = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    x, res = r(rows, d).to(dtype), r(rows, d).to(dtype)
+    gamma, beta = (1 + 0.1 * r(d)).to(dtype), (0.1 * r(d)).to(dtype)
+    if mode == 'ln':       # LayerNorm alone (pre-norm blocks)
+        return F.residual_ln_fwd(x, None, gamma, beta, 1e-5, want_z=False)
+    if mode == 'block':    # post-norm block end
+        return F.residual_ln_fwd(x, res, gamma, beta, 1e-5, p, 1234, 77)
+    return F.residual_ln_fwd(x, res, None, None, 0.0, p, 1234, 77)  # residual + dropout only
+
+
+FWD_CASES = [(d, dt, mode, p) for d in (512, 1024) for dt in (torch.bfloat16, torch.float16)
+             for mode, p in (('ln', 0.0), ('block', 0.0), ('block', 0.1), ('res', 0.0), ('res', 0.1))]
+
+
 def timeit(fn, iters):
     for _ in range(10):
         fn()
@@ -59,11 +75,13 @@ def main():
         out = {}
         for d, dt, extra, p in cases:
             out[(d, str(dt), extra, p)] = [None if t is None else t.float().cpu() for t in run(4096 + 3, d, dt, extra, p)]
+        for d, dt, mode, p in FWD_CASES:
+            out[('fwd', d, str(dt), mode, p)] = [None if t is None else t.float().cpu() for t in run_fwd(4096 + 3, d, dt, mode, p)]
         torch.save(out, args.dump)
         return
     if args.compare:
         path = '/tmp/ln_bench_general.pt'
-        env = dict(os.environ, PK_LN_BWD16='0')
+        env = dict(os.environ, PK_LN_BWD16='0', PK_LN_FWD16='0')
         subprocess.run([sys.executable, os.path.abspath(__file__), '--dump', path], env=env, check=True)
         ref = torch.load(path)
         worst = 0.0
@@ -79,6 +97,17 @@ def main():
                 worst = max(worst, rel)
                 print(f'd={d} {str(dt)[6:]:8s} extra={int(extra)} p={p}: {name:6s} max|diff| {diff:.3e} (rel {rel:.2e}), '
                       f'{100 * nz:.3f} % of elements differ')
+        for d, dt, mode, p in FWD_CASES:
+            got = [None if t is None else t.float().cpu() for t in run_fwd(4096 + 3, d, dt, mode, p)]
+            for name, a, b in zip(('y', 'z', 'mean', 'rstd'), got, ref[('fwd', d, str(dt), mode, p)]):
+                if a is None:
+                    assert b is None, (d, dt, mode, p, name)
+                    continue
+                diff = (a - b).abs().max().item()
+                rel = diff / max(b.abs().max().item(), 1e-9)
+                worst = max(worst, rel)
+                print(f'fwd d={d} {str(dt)[6:]:8s} {mode:5s} p={p}: {name:5s} max|diff| {diff:.3e} (rel {rel:.2e}), '
+                      f'{100 * (a != b).float().mean().item():.3f} % of elements differ')
         print('worst relative difference', worst)
         return
     for d, dt, extra, p in cases:
@@ -92,6 +121,20 @@ def main():
         gb = streams * args.rows * d * 2 / 1e9
         print(f'bwd rows={args.rows} d={d} extra={int(extra)} p={p}: {us:7.1f} us  ({gb / us * 1e6 / 1e3:.2f} TB/s of {streams} streams; '
               f'incl. the parameter-gradient reduction launch)')
+    for rows in sorted({args.rows, 8192}):
+        for d in (512, 1024):
+            for mode, p in (('ln', 0.0), ('res', 0.1)):
+                g = torch.Generator(device='cuda').manual_seed(d)
+                x = torch.randn(rows, d, device='cuda', generator=g).bfloat16()
+                res = torch.randn(rows, d, device='cuda', generator=g).bfloat16()
+                gamma, beta = torch.ones(d, device='cuda').bfloat16(), torch.zeros(d, device='cuda').bfloat16()
+                if mode == 'ln':
+                    fn = lambda: F.residual_ln_fwd(x, None, gamma, beta, 1e-5, want_z=False)
+                else:
+                    fn = lambda: F.residual_ln_fwd(x, res, None, None, 0.0, p, 1234, 77)
+                us = timeit(fn, args.iters)
+                streams = 2 if mode == 'ln' else 3
+                print(f'fwd {mode:3s} rows={rows} d={d} p={p}: {us:7.1f} us  ({streams * rows * d * 2 / us / 1e6:.2f} TB/s of {streams} streams)')
     for d in (512, 1024):
         g = torch.Generator(device='cuda').manual_seed(d)
         x = torch.randn(args.rows, d, device='cuda', generator=g).bfloat16()
