@@ -386,11 +386,14 @@ __global__ __launch_bounds__(THREADS) void ce_reg_kernel(const T* __restrict__ l
         }
         return;
     }
+    // (no branch around a load: slots past the row read its last chunk and are skipped below — behind `if (ch < nvec)` every
+    // load is a block of its own and hipcc waits for ALL of them at the first use; now the first chunks are reduced while
+    // the later ones are still on their way)
     Vec16<T> v[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int ch = tid + i * THREADS;
-        if (ch < nvec) v[i] = load16<T>(x + (long long)ch * EPV);
+        const int ch = min(tid + i * THREADS, nvec - 1);
+        v[i] = load16<T>(x + (long long)ch * EPV);
     }
     float m = -INFINITY, s = 0.f, tot = 0.f;
 #pragma unroll

@@ -231,6 +231,45 @@ def test_layernorm_fwd_bwd(F, dtype, rows, d):
     assert rel_err(dres2, xz.grad + extra.float()) < tol
 
 
+def test_wave_reductions_match_their_shuffle_statements(tmp_path):
+    """wave_sum / wave_max / lanes8_sum / half_wave_max / half_wave_swap (common.h: permlane swaps + DPP instead of
+    ds_bpermute round trips) bit for bit against the `__shfl_xor` statements they replace — every LayerNorm, softmax and
+    attention-epilogue result depends on them.  tools/wave_reduce_check.hip includes the library's own header."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    exe = str(tmp_path / 'wave_reduce_check')
+    subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', os.path.join(root, 'tools', 'wave_reduce_check.hip'), '-o', exe],
+                   check=True, capture_output=True, timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(': 0 mismatches') == 5, out.stdout
+
+
+def test_specialised_layernorm_kernels_match_the_general_ones():
+    """residual_ln_fwd16_kernel / residual_ln_bwd16_kernel (16-bit rows of 512 / 1024: template flags, packed arithmetic, a
+    second register set for the next row) against the general kernels on the same inputs — bf16 and f16, every flag
+    combination the dispatch takes, ragged row count: tools/ln_bench.py --compare runs the general kernels in a child process
+    (PK_LN_FWD16=0 PK_LN_BWD16=0).  Parameter gradients and z are identical; the rest within one 16-bit ulp of a few elements."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'ln_bench.py'), '--compare'], capture_output=True, text=True,
+                         cwd=root, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count('max|diff|') >= 100, out.stdout[-2000:]
+    for line in out.stdout.splitlines():
+        m = re.search(r'(dgamma|dbeta| z  ) +max\|diff\| ([0-9.e+-]+)', line)
+        if m:
+            assert float(m.group(2)) == 0.0, line
+    worst = float(re.search(r'worst relative difference ([0-9.e+-]+)', out.stdout).group(1))
+    assert worst < 8e-3, out.stdout[-2000:]
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('rows,d', [(7, 128), (1000, 512), (5, 2048), (3, 520)])
 def test_rmsnorm_fwd_bwd(F, dtype, rows, d):

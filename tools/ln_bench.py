@@ -3,7 +3,7 @@
 (with --compare) the specialised 16-bit backward kernel against the general one on the same inputs (PK_LN_BWD16=0 in a
 child process): largest difference of every output.
 
-    python tools/ln_bench.py [--rows 32768] [--iters 200] [--compare]"""
+    python tools/ln_bench.py [--rows 32768] [--iters 200] [--compare | --widths]"""
 import argparse
 import os
 import subprocess
@@ -68,7 +68,25 @@ def main():
     ap.add_argument('--iters', type=int, default=200)
     ap.add_argument('--compare', action='store_true')
     ap.add_argument('--dump', default=None)
+    ap.add_argument('--widths', action='store_true',
+                    help='the round-2 sweep: forward and backward over the model widths of the presets (512 ... 4096, bf16)')
     args = ap.parse_args()
+    if args.widths:
+        for d in (512, 1024, 1280, 2048, 4096):
+            rows = (32768 * 512) // d
+            x = torch.randn(rows, d, device='cuda').bfloat16()
+            res = torch.randn(rows, d, device='cuda').bfloat16()
+            g = torch.ones(d, device='cuda').bfloat16()
+            b = torch.zeros(d, device='cuda').bfloat16()
+            dy = torch.randn(rows, d, device='cuda').bfloat16()
+            y, z, mean, rstd = F.residual_ln_fwd(x, res, g, b, 1e-5)
+            nbytes = rows * d * 2
+            t_f = timeit(lambda: F.residual_ln_fwd(x, res, g, b, 1e-5), args.iters)       # reads x, res; writes z, y
+            t_b = timeit(lambda: F.residual_ln_bwd(dy, None, z, g, mean, rstd, want_dres=True, want_dx=False,
+                                                   want_param_grads=True), args.iters)     # reads dy, z; writes dres
+            print(f'd={d:5d} rows={rows:6d}  fwd {t_f:6.1f} us ({4 * nbytes / t_f / 1e6:5.2f} TB/s)   '
+                  f'bwd {t_b:6.1f} us ({3 * nbytes / t_b / 1e6:5.2f} TB/s)', flush=True)
+        return
     cases = [(d, dt, extra, p) for d in (512, 1024) for dt in (torch.bfloat16, torch.float16)
              for extra, p in ((False, 0.1), (True, 0.0), (True, 0.1), (False, 0.0))]
     if args.dump:  # child of --compare: outputs of every case to a file
