@@ -163,7 +163,7 @@ template <typename T> __device__ __forceinline__ void store16_nt(T* p, const Vec
 // gfx950's v_permlane32_swap / v_permlane16_swap exchange the halves / the odd and even rows of two registers; within
 // a row of 16 lanes DPP rotations and quad permutes reach the partner (after the step "8" the values repeat with period
 // 8, so a rotation by 4 finds the lane ^ 4 partner's value).  10 VALU instructions per reduction and bit for bit the
-// `__shfl_xor` butterfly's result (tools/ln_bench.py's companion scratch test: 262 144 waves, no mismatch): the
+// `__shfl_xor` butterfly's result (tools/wave_reduce_check.hip, run by the GPU tests: 4096 random waves, no mismatch): the
 // LayerNorm backward of C2 37.0 -> 28.5 us together with its specialisation (layernorm.hip).  All 64 lanes must be
 // active.  (The swaps are inline asm: given the same register twice, the builtin's two results are folded into one by
 // hipcc 7.2.)
