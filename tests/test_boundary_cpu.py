@@ -121,3 +121,28 @@ def test_gemm8p_assembly_audit_is_part_of_the_build():
         last = report.strip().splitlines()[-1]
         assert last.endswith(', 0 problems') and int(last.split()[0]) >= at_least, (name, last)
         assert 'PROBLEM' not in report
+
+
+def test_assembly_audit_tells_loop_spills_from_spills_that_run_once(tmp_path):
+    """tools/check_asm_loads.py rule 3: scratch traffic in a block LLVM marks as part of a loop is refused; a spill between
+    the loop markers but outside every loop block (ahead of the first iteration / behind the last) is only reported"""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    tool = os.path.join(ROOT, 'tools', 'check_asm_loads.py')
+    head = ['_ZN12_GLOBAL__N_113gemm8p_kernelIfEEvv:', '\t; PK8P_LOOP_BEGIN']
+    tail = ['\t; PK8P_LOOP_END', '\ts_endpgm', '.Lfunc_end0:']
+    loop = ['.LBB0_1:                                ; =>This Inner Loop Header: Depth=1', '\ts_waitcnt vmcnt(6)',
+            '\tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]', '\ts_cbranch_scc1 .LBB0_1']
+    spill = '\tscratch_store_dword off, v230, off      ; 4-byte Folded Spill'
+
+    def run(lines):
+        f = tmp_path / 'k.s'
+        f.write_text('\n'.join(lines) + '\n')
+        return subprocess.run([sys.executable, tool, str(f)], capture_output=True, text=True)
+
+    once = run(head + [spill] + loop + ['.LBB0_2:', '\tscratch_load_dword v230, off, off'] + tail)
+    assert once.returncode == 0 and '0 problems' in once.stdout and 'runs once' in once.stdout, once.stdout
+    inside = run(head + loop[:2] + [spill] + loop[2:] + tail)
+    assert inside.returncode == 1 and 'spill traffic inside the K loop' in inside.stdout, inside.stdout
