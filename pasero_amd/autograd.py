@@ -452,6 +452,34 @@ class ResidualLayerNormFn(Function):
                 dbeta if ctx.has_beta else None, None, None, None, None)
 
 
+class LayerNormForkFn(Function):
+    """(LayerNorm(x), x) — a pre-norm sub-block reads its input twice: through the LayerNorm and, as the residual, around
+    the sub-block (pasero/models/transformer.py:1070-1075: `residual = x; x = self.self_attn_prenorm(x)`).  As two
+    consumers of one tensor, autograd adds their gradients in an elementwise pass of its own (141 launches per step of the
+    IWSLT recipe, 2.3 % of it); as ONE node the residual branch's gradient enters the LayerNorm backward kernel as
+    `dz_extra` — what the native layer call does (csrc/layer.cpp `ln_in_bwd`), with one rounding instead of two."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float):
+        xc = _contig(x)
+        y, _, mean, rstd = F.residual_ln_fwd(xc, None, gamma, beta, eps, want_z=False)
+        ctx.has_beta = beta is not None
+        ctx.save_for_backward(xc, gamma, mean, rstd)
+        return y, x  # (an input returned as it is: autograd hands out a view of it whose history is this node)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        want_pg = ctx.needs_input_grad[1] or (ctx.has_beta and ctx.needs_input_grad[2])
+        if dy is None:  # only the residual branch was used
+            return dres, None, None, None
+        extra = _contig(dres) if dres is not None else None
+        dx, _, dgamma, dbeta = F.residual_ln_bwd(_contig(dy), extra, x, gamma, mean, rstd, want_dres=True, want_dx=False,
+                                                 want_param_grads=want_pg, has_beta=ctx.has_beta)
+        return (dx if ctx.needs_input_grad[0] else None, dgamma if ctx.needs_input_grad[1] else None,
+                dbeta if (ctx.has_beta and ctx.needs_input_grad[2]) else None, None)
+
+
 class BlockTail:
     """What the LAST GEMM of a post-norm sub-block needs to finish the block itself (LinearResidualLnFn): handed by the
     layer to the module that runs that GEMM (MultiheadAttention.out_proj) for one call; `done` tells the layer that the

@@ -25,7 +25,7 @@ from .profiling import block as _bench_block, region as _bench_region
 from .modules import Embedding, Identity
 from .autograd import (FFNFn, GatedFFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn,
                        AddPositionsFn, LinearFn, ResidualLink, WGradGroup, WGradSinkFn, BlockTail, FFNResidualLnFn,
-                       block_tail_eligible)
+                       block_tail_eligible, LayerNormForkFn)
 
 from .config import register_model  # also enters the reference's registry when `pasero` is importable
 
@@ -34,6 +34,8 @@ logger = logging.getLogger('models')
 _NO_WGRAD_GROUP = bool(int(os.environ.get('PASERO_NO_WGRAD_GROUP', '0') or 0))
 # diagnostic: the post-norm block ends as stand-alone LayerNorm launches (A/B of the fused GEMM + LayerNorm kernel)
 _NO_FUSED_TAIL = bool(int(os.environ.get('PASERO_NO_FUSED_TAIL', '0') or 0))
+# diagnostic: pre-norm sub-blocks call their LayerNorm hook and leave the sum of the two input gradients to autograd
+_NO_LN_FORK = bool(int(os.environ.get('PASERO_NO_LN_FORK', '0') or 0))
 # diagnostic: read the step's sums at the end of the forward pass, as the reference does (A/B of the deferred read)
 _EAGER_LOGS = bool(int(os.environ.get('PASERO_EAGER_LOGS', '0') or 0))
 LN2 = math.log(2)
@@ -641,6 +643,18 @@ class _LayerBase(modules._PerCallAttrs, nn.Module):
         """`final_layer_norm` is a lambda when --shared-norm (:977-980)"""
         return norm if isinstance(norm, nn.Module) else self.self_attn_layer_norm
 
+    def _prenorm(self, x: Tensor, hook: str, norm):
+        """`residual = x; x = *_prenorm(x)` of a sub-block -> (x, residual).  Pre-norm layers with the stock hook and a
+        LayerNorm module: one autograd node for both uses of the input (autograd.LayerNormForkFn — the two gradients meet
+        inside the LayerNorm backward kernel instead of in an elementwise addition); the reference's hook call otherwise."""
+        m = self._norm_module(norm)
+        if (self.prenorm and not _NO_LN_FORK and torch.is_grad_enabled() and x.requires_grad and x.is_cuda
+                and isinstance(m, modules.LayerNorm) and getattr(m, 'weight', None) is not None
+                and self._hooks_are_base(hook) and not torch.is_autocast_enabled('cuda')):
+            y, residual = LayerNormForkFn.apply(x, m.weight, m.bias, m.eps)
+            return y, residual
+        return getattr(self, hook)(x), x
+
     def _hooks_are_base(self, *names) -> bool:
         cls = TransformerDecoderLayer if isinstance(self, TransformerDecoderLayer) else TransformerEncoderLayer
         return all(getattr(type(self), n) is getattr(cls, n) for n in names)
@@ -688,7 +702,10 @@ class _LayerBase(modules._PerCallAttrs, nn.Module):
             return FFNResidualLnFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
                                          self.activation_fn.name, norm.weight, norm.bias, norm.eps,
                                          self.dropout.p if self.training else 0.0, group)
-        x = self.ffn_prenorm(x)
+        if x is residual:
+            x, residual = self._prenorm(x, 'ffn_prenorm', self.final_layer_norm)
+        else:
+            x = self.ffn_prenorm(x)
         x = self.ffn(x, residual, padding_mask)
         return self._block_end(x, residual, self.final_layer_norm, 'ffn_residual', 'ffn_postnorm', link)
 
@@ -767,7 +784,7 @@ class TransformerEncoderLayer(_LayerBase):
                             self.self_attn_layer_norm, self.self_attn, '_residual_link')
         tail = self._tail_for(self.self_attn, ('self_attention', 'self_attn_prenorm'), 'self_attn_residual',
                               'self_attn_postnorm', self.self_attn_layer_norm, residual)
-        x = self.self_attn_prenorm(x)
+        x, residual = self._prenorm(x, 'self_attn_prenorm', self.self_attn_layer_norm)
         x = self.self_attention(x, residual, padding_mask)
         self.self_attn._tail = None
         x = self._block_end(x, residual, self.self_attn_layer_norm, 'self_attn_residual', 'self_attn_postnorm', link,
@@ -881,7 +898,7 @@ class TransformerDecoderLayer(_LayerBase):
         if state is None:
             tail = self._tail_for(self.self_attn, ('self_attention', 'self_attn_prenorm'), 'self_attn_residual',
                                   'self_attn_postnorm', self.self_attn_layer_norm, residual)
-        x = self.self_attn_prenorm(x)
+        x, residual = self._prenorm(x, 'self_attn_prenorm', self.self_attn_layer_norm)
         x = self.self_attention(x, residual, padding_mask, self_attn_mask=self_attn_mask, state=state)
         self.self_attn._tail = None
         x = self._block_end(x, residual, self.self_attn_layer_norm, 'self_attn_residual', 'self_attn_postnorm', link,
@@ -891,7 +908,7 @@ class TransformerDecoderLayer(_LayerBase):
                             self.encoder_attn_layer_norm, self.encoder_attn, '_residual_link')
         tail = self._tail_for(self.encoder_attn, ('cross_attention', 'cross_attn_prenorm'), 'cross_attn_residual',
                               'cross_attn_postnorm', self.encoder_attn_layer_norm, residual)
-        x = self.cross_attn_prenorm(x)
+        x, residual = self._prenorm(x, 'cross_attn_prenorm', self.encoder_attn_layer_norm)
         x = self.cross_attention(x, residual, encoder_out, encoder_mask)
         self.encoder_attn._tail = None
         x = self._block_end(x, residual, self.encoder_attn_layer_norm, 'cross_attn_residual', 'cross_attn_postnorm',

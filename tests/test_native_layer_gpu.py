@@ -161,6 +161,41 @@ def test_native_prenorm_layer_against_the_per_op_path(over, B, S, T):
     assert l2 == l1 and all(torch.equal(g2[k], g1[k]) for k in g1)
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-5), (torch.bfloat16, 2.5e-2)])
+def test_prenorm_input_fork_against_autograds_addition(dtype, tol):
+    """per-op path, pre-norm layers: `residual = x; x = *_prenorm(x)` as ONE autograd node (autograd.LayerNormForkFn — the
+    residual branch's gradient enters the LayerNorm backward kernel as `dz_extra`) against the reference's two uses of x whose
+    gradients autograd adds: same loss (the forward is untouched), gradients equal to round-off — fp32 2e-5, bf16 one rounding
+    less per sub-block; and the node really is in the graph (no elementwise addition kernel left for those sums)."""
+    from pasero_amd import transformer, autograd
+    V = 1000
+    over = dict(dropout=0.1, encoder_layers=2, decoder_layers=2, encoder_prenorm=True, decoder_prenorm=True)
+    model = _model(V, dtype=dtype, **over)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(4, 24, 40, 36, V, ragged=True).items()}
+    calls = {'n': 0}
+    orig = autograd.LayerNormForkFn.backward
+
+    def counted(*a, **k):
+        calls['n'] += 1
+        return orig(*a, **k)
+    autograd.LayerNormForkFn.backward = staticmethod(counted)
+    try:
+        l1, n1, g1, c1 = _step(model, batch, native=False)
+        forks = calls['n']
+        transformer._NO_LN_FORK = True
+        l0, n0, g0, c0 = _step(model, batch, native=False)
+    finally:
+        transformer._NO_LN_FORK = False
+        autograd.LayerNormForkFn.backward = staticmethod(orig)
+    assert c1 == 0 and c0 == 0 and forks == 2 * 2 + 2 * 3 and calls['n'] == forks, (c1, c0, forks, calls)
+    assert n1 == n0 and l1 == l0, (l1, l0)
+    assert set(g1) == set(g0)
+    for k in g0:
+        a, r = g1[k].float(), g0[k].float()
+        ref = g0[k.replace('bias', 'weight')].float().norm().item() if k.endswith('k_proj.bias') else r.norm().item()
+        assert (a - r).norm().item() <= tol * ref + 1e-7, (k, (a - r).norm().item(), ref)
+
+
 def test_encoder_gradient_chain_belongs_to_the_decoder_pass():
     """the tally of the chained encoder-output gradients lived on the encoder TENSOR — a decoder pass over it that
     was never back-propagated left a stale count behind and the next pass over the same tensor lost the encoder's gradient
