@@ -115,20 +115,7 @@ def names_shapes_arrays(names_shapes):
     }
 
 
-CFG_KEYS = [
-    'encoder_layers', 'decoder_layers', 'embed_dim', 'encoder_ffn_dim', 'decoder_ffn_dim',
-    'encoder_attention_heads', 'decoder_attention_heads', 'dropout', 'attention_dropout', 'activation_dropout',
-    'label_smoothing', 'activation_fn', 'encoder_prenorm', 'decoder_prenorm', 'encoder_embed_norm',
-    'decoder_embed_norm', 'encoder_positional_encoding', 'decoder_positional_encoding',
-    'positional_encoding_shift', 'scale_embed', 'encoder_max_len', 'decoder_max_len', 'shared_embeddings',
-    'tied_output_projection', 'rope_base', 'input_dim', 'conv_input_dim', 'conv_channels', 'conv_kernel_sizes',
-    'conv_strides', 'conv_activation', 'norm_eps', 'padding_idx', 'eos_idx', 'bos_idx', 'attention_key_bias',
-    'has_bias', 'rms_norm', 'norm_bias', 'scale_attn', 'prompt_loss', 'shared_norm',
-]
-
-
-EXTRA_KEYS = ['lora_rank', 'lora_alpha', 'encoder_adapter_dim', 'decoder_adapter_dim', 'adapter_zero_init',
-              'train_all_params']
+CFG_KEYS, EXTRA_KEYS = paramgen.CFG_KEYS, paramgen.EXTRA_KEYS  # the fixture schema: tests/test_oracle_golden.py checks every file against it
 
 
 def cfg_json(cfg):
@@ -212,6 +199,29 @@ def gen_tiny_freeze():
     gen_encdec('tiny_freeze_embed', V=89, B=3, S=8, T=6, seed=17, freeze_seed=5,
                embed_dim=128, encoder_ffn_dim=192, decoder_ffn_dim=192, encoder_attention_heads=2,
                decoder_attention_heads=2, encoder_layers=1, decoder_layers=1, dropout=0.0, shared_embeddings=False)
+
+
+def gen_tiny_freeze_shared():
+    """partially frozen embeddings SHARED by encoder and decoder (transformer.py:151-153: the decoder reuses the encoder's
+    Embedding object, so its lookup and its tied projection blend the two tables as well, modules.py:929-946) — plus the greedy
+    tokens of `decoding.sample_on_the_fly` on that model: the incremental-decoding path must read the blended table too"""
+    name = 'tiny_freeze_shared'
+    cfg, model, tb = gen_encdec(name, V=89, B=3, S=8, T=6, seed=19, freeze_seed=7,
+                                embed_dim=128, encoder_ffn_dim=192, decoder_ffn_dim=192, encoder_attention_heads=2,
+                                decoder_attention_heads=2, encoder_layers=1, decoder_layers=2, dropout=0.0,
+                                shared_embeddings=True)
+    assert model.decoder.embed_tokens is model.encoder.embed_tokens and model.decoder.embed_tokens.frozen_embedding is not None
+    model.eval()
+    with torch.no_grad():
+        enc_out, enc_mask, _ = model.encoder(tb['encoder_input'], tb['encoder_input_length'])
+        bos = torch.full((3, 1), cfg.bos_idx, dtype=torch.long)
+        steps = [npy(o['tokens']).copy() for o in decoding.sample_on_the_fly(
+            model.decoder, enc_out, enc_mask, 12, {}, decoder_input=bos, sampling_temperature=0)]
+    path = os.path.join(OUT, name + '.npz')
+    out = dict(np.load(path, allow_pickle=False))
+    out['greedy_tokens'] = np.concatenate(steps, axis=1)
+    out['max_output_len'] = 12
+    save(name, **out)
 
 
 def gen_tiny_adapter():
@@ -717,6 +727,7 @@ GENERATORS = {
     'base_c1': gen_base_c1,
     'tiny_adapter': gen_tiny_adapter,
     'tiny_freeze_embed': gen_tiny_freeze,
+    'tiny_freeze_shared': gen_tiny_freeze_shared,
     'tiny_lora': gen_tiny_lora,
     'tiny_lora_rotary': gen_tiny_lora_rotary,
     'tiny_hd128': gen_tiny_hd128,

@@ -379,8 +379,15 @@ def encoder(P: dict, cfg, encoder_input: Tensor, encoder_input_length: Tensor):
 
 
 def _dec_embed_weight(P, cfg):
-    # shared_embeddings: the decoder reuses the encoder's Embedding object (transformer.py:151-153)
-    return P['decoder.embed_tokens.weight'] if 'decoder.embed_tokens.weight' in P else P['encoder.embed_tokens.weight']
+    # shared_embeddings: the decoder reuses the encoder's Embedding object (transformer.py:151-153) — including its frozen
+    # table: lookup and tied projection blend `weight` and `frozen_embedding.weight` per token / per column
+    # (modules.py:929-933, 942-946), which is the table where(mask, frozen, weight) applied to either
+    pre = 'decoder' if 'decoder.embed_tokens.weight' in P else 'encoder'
+    E = P[pre + '.embed_tokens.weight']
+    if pre + '.embed_tokens.frozen_embedding.weight' in P:
+        mask = P['encoder.embed_tokens.freeze_mask'][:, None]
+        E = (~mask) * E + mask * P[pre + '.embed_tokens.frozen_embedding.weight']
+    return E
 
 
 def decoder(P: dict, cfg, enc_out: Tensor, enc_mask: Tensor, decoder_input: Tensor,

@@ -465,15 +465,17 @@ class LayerNormForkFn(Function):
         y, _, mean, rstd = F.residual_ln_fwd(xc, None, gamma, beta, eps, want_z=False)
         ctx.has_beta = beta is not None
         ctx.save_for_backward(xc, gamma, mean, rstd)
+        # an output nobody consumed arrives as None in backward, not as a tensor of zeros allocated for the occasion
+        ctx.set_materialize_grads(False)
         return y, x  # (an input returned as it is: autograd hands out a view of it whose history is this node)
 
     @staticmethod
     def backward(ctx, dy, dres):
         x, gamma, mean, rstd = ctx.saved_tensors
+        if dy is None:  # only the residual branch was used: the identity
+            return (dres if ctx.needs_input_grad[0] else None), None, None, None
         want_pg = ctx.needs_input_grad[1] or (ctx.has_beta and ctx.needs_input_grad[2])
-        if dy is None:  # only the residual branch was used
-            return dres, None, None, None
-        extra = _contig(dres) if dres is not None else None
+        extra = _contig(dres) if dres is not None else None  # None: only the LayerNorm branch was used
         dx, _, dgamma, dbeta = F.residual_ln_bwd(_contig(dy), extra, x, gamma, mean, rstd, want_dres=True, want_dx=False,
                                                  want_param_grads=want_pg, has_beta=ctx.has_beta)
         return (dx if ctx.needs_input_grad[0] else None, dgamma if ctx.needs_input_grad[1] else None,

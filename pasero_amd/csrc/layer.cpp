@@ -160,7 +160,8 @@ int layer_fwd_prenorm(const PkLayer& L) {
     const long long rows = (long long)L.B * L.T, rows_kv = (long long)L.B * L.S, d = L.d, f = L.f;
     const int hd = L.d / L.heads, dt = L.dtype;
     auto linear = [&](const void* a, const void* w, const void* bias, void* out, long long M, long long N, long long K, int act, void* pre) {
-        // (forward split-K: fwd_split; the slab count depends on N and K only, so a row computes the same in a batch of any size)
+        // (forward split-K: fwd_split gates on M — inside its row range the slab count depends on N and K only; across it the
+        // rows agree to fp32 round-off of the accumulation, functional.fwd_split)
         int sk = (pre || dt == PK_F32) ? 1 : fwd_split(M, N, K);
         const size_t need = splitk_ws(sk, M, N);
         if (sk > 1 && (!L.ws || L.ws_bytes < need)) sk = 1;

@@ -67,6 +67,11 @@ def build_plan(decoder) -> Optional[Plan]:
     if (decoder.training or not decoder.embed_tokens.weight.is_cuda
             or cfg.embed_dim != 64 * cfg.decoder_attention_heads):  # the native step is built for head_dim 64
         return None
+    if getattr(decoder.embed_tokens, 'frozen_embedding', None) is not None:
+        # a partially frozen table (modules.py:929-946: lookup and tied projection blend `weight` with
+        # `frozen_embedding.weight`; with shared embeddings the decoder carries the encoder's): the plan holds ONE raw
+        # table pointer, so these decoders stay on the per-op path, which reads `effective_weight()`
+        return None
     pos = decoder.embed_positions
     if not isinstance(pos, (modules.SinusoidalPositionalEmbedding, modules.LearnedPositionalEmbedding)):
         return None  # rotary: positions are applied inside attention — per-op path

@@ -155,9 +155,13 @@ def wgrad_group(entries):
 def fwd_split(M: int, N: int, K: int, dtype) -> int:
     """csrc/layer.cpp: fwd_split — forward GEMMs are not split as a rule; the exception is a projection back to d from a long
     contraction at a few thousand rows (NLLB-1.3B's fc2, 8192 -> 1024, at the IWSLT recipe's 2048-row decoder batch: 32 tiles of
-    256 x 256, 123 us on the 128-tile kernel, ~40 as K-slabs + reduction).  16-bit types only (fp32 is the parity path); the
-    slab count depends on N and K alone, so a row computes the same in a batch of any size.  The native layer applies the
-    same rule (the two paths stay bit for bit equal)."""
+    256 x 256, 123 us on the 128-tile kernel, ~40 as K-slabs + reduction).  16-bit types only (fp32 is the parity path).
+    The rule gates on M: within 512..2048 rows (multiples of 256) the slab count depends on N and K alone, so a batch and its
+    halves compute the same rows bit for bit THERE; across the boundary (a 4096-row batch against its 2048-row halves, an
+    evaluation batch against a training batch) fc2's summation order differs — 4 partial sums of K / 4 added in fp32 against
+    one chain over K — and the rows agree to fp32 round-off of the accumulation, not bitwise
+    (tests/test_native_layer_gpu.py::test_forward_split_boundary_moves_rows_by_round_off_only pins that deviation).  The
+    native layer applies the same rule (the two paths stay bit for bit equal)."""
     if dtype == torch.float32:
         return 1
     return 4 if (K >= 4096 and K % 512 == 0 and N <= 1024 and N % 256 == 0 and 512 <= M <= 2048 and M % 256 == 0) else 1

@@ -17,7 +17,7 @@ ACT = {'none': 0, None: 0, 'relu': 1, 'gelu': 2, 'gelu_tanh': 3, 'geglu': 3, 'sw
 
 P, I, F, LL, SZ, ULL = c_void_p, c_int, c_float, c_longlong, c_size_t, c_ulonglong
 
-# name -> (restype, argtypes); must stay in sync with include/pasero_hip.h (tests/test_abi.py checks the symbols)
+# name -> (restype, argtypes); must stay in sync with include/pasero_hip.h (tests/test_boundary_cpu.py checks the symbols)
 SIGNATURES = {
     'pk_version': (I, []),
     'pk_last_error': (c_char_p, []),

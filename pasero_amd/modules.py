@@ -8,6 +8,7 @@ import contextlib
 import functools
 import math
 import os
+import weakref
 from typing import Optional, Union
 
 import torch
@@ -416,6 +417,27 @@ class RotaryEmbedding(nn.Module):
 # ------------------------------------------------------------------------------------------------------------
 # embeddings
 # ------------------------------------------------------------------------------------------------------------
+_merged_tables = weakref.WeakKeyDictionary()  # Embedding -> (key, merged table): Embedding.effective_weight
+
+
+class MergeTablesFn(torch.autograd.Function):
+    """E = where(mask[:, None], frozen, weight) with a backward that keeps nothing the engine frees (the mask rides on the
+    context as a plain attribute), so the node may serve several graphs: see `Embedding.effective_weight`."""
+
+    @staticmethod
+    def forward(ctx, weight: Tensor, frozen: Tensor, mask: Tensor) -> Tensor:
+        ctx.mask = mask
+        ctx.frozen_dtype = frozen.dtype
+        return torch.where(mask[:, None], frozen.to(weight.dtype), weight)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        m = ctx.mask[:, None]
+        dw = g.masked_fill(m, 0) if ctx.needs_input_grad[0] else None
+        df = g.masked_fill(~m, 0).to(ctx.frozen_dtype) if ctx.needs_input_grad[1] else None
+        return dw, df, None
+
+
 class Embedding(nn.Embedding):
     """Token embedding + tied output projection (modules.py:890-947).
 
@@ -443,12 +465,24 @@ class Embedding(nn.Embedding):
             self.frozen_embedding = None
 
     def effective_weight(self) -> Tensor:
-        """the table the kernels read: `weight`, or where(freeze_mask, frozen_embedding.weight, weight)"""
+        """the table the kernels read: `weight`, or where(freeze_mask, frozen_embedding.weight, weight).
+
+        Merged once per parameter state, not once per caller: with shared embeddings and a tied projection one training step
+        reads the table three times (encoder lookup, decoder lookup, vocabulary loss) — they share ONE merge node, whose
+        backward splits the summed (V, d) gradient between the two tables once.  The merged table is kept until either
+        table changes (`_version`: an optimizer step, `load_state_dict`, `.to()`) or the grad mode differs."""
         if self.frozen_embedding is None:
             return self.weight
-        if self.freeze_mask.device != self.weight.device:
-            self.freeze_mask = self.freeze_mask.to(self.weight.device)
-        return torch.where(self.freeze_mask[:, None], self.frozen_embedding.weight.to(self.weight.dtype), self.weight)
+        w, f = self.weight, self.frozen_embedding.weight
+        if self.freeze_mask.device != w.device:
+            self.freeze_mask = self.freeze_mask.to(w.device)
+        key = (w._version, f._version, w.data_ptr(), f.data_ptr(), w.dtype, torch.is_grad_enabled(),
+               w.requires_grad, f.requires_grad)
+        cached = _merged_tables.get(self)  # beside the module, not on it: deepcopy / pickling of the model stay as they were
+        if cached is None or cached[0] != key:
+            cached = (key, MergeTablesFn.apply(w, f, self.freeze_mask))
+            _merged_tables[self] = cached
+        return cached[1]
 
     def forward(self, input: LongTensor) -> Tensor:
         # the reference asserts `input.max() < V` here (a host sync per call, modules.py:924-926); the kernel clamps

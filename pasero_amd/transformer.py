@@ -646,10 +646,13 @@ class _LayerBase(modules._PerCallAttrs, nn.Module):
     def _prenorm(self, x: Tensor, hook: str, norm):
         """`residual = x; x = *_prenorm(x)` of a sub-block -> (x, residual).  Pre-norm layers with the stock hook and a
         LayerNorm module: one autograd node for both uses of the input (autograd.LayerNormForkFn — the two gradients meet
-        inside the LayerNorm backward kernel instead of in an elementwise addition); the reference's hook call otherwise."""
+        inside the LayerNorm backward kernel instead of in an elementwise addition); the reference's hook call otherwise.
+        The node reads the module's parameters and does not go through its `__call__`: a norm module that carries forward /
+        pre-forward hooks (`register_forward_hook`) keeps the hook call, so those hooks fire as in the reference."""
         m = self._norm_module(norm)
         if (self.prenorm and not _NO_LN_FORK and torch.is_grad_enabled() and x.requires_grad and x.is_cuda
                 and isinstance(m, modules.LayerNorm) and getattr(m, 'weight', None) is not None
+                and not m._forward_hooks and not m._forward_pre_hooks
                 and self._hooks_are_base(hook) and not torch.is_autocast_enabled('cuda')):
             y, residual = LayerNormForkFn.apply(x, m.weight, m.bias, m.eps)
             return y, residual

@@ -104,3 +104,21 @@ def make_freeze_mask(seed: int, V: int, frac: float = 0.4) -> np.ndarray:
     """(V,) bool: which source embeddings are frozen (pasero/tasks/translation.py:141-146 builds it from a regex over the
     dictionary; here a seeded random subset)"""
     return _rs(seed, 'freeze_encoder_embed_mask').rand(V) < frac
+
+
+# the configuration fields every fixture with a `cfg` entry stores (oracle/make_golden.py::cfg_json writes exactly these, plus
+# the EXTRA_KEYS that are set): tests/test_oracle_golden.py::test_every_fixture_cfg_has_the_current_schema
+CFG_KEYS = [
+    'encoder_layers', 'decoder_layers', 'embed_dim', 'encoder_ffn_dim', 'decoder_ffn_dim',
+    'encoder_attention_heads', 'decoder_attention_heads', 'dropout', 'attention_dropout', 'activation_dropout',
+    'label_smoothing', 'activation_fn', 'encoder_prenorm', 'decoder_prenorm', 'encoder_embed_norm',
+    'decoder_embed_norm', 'encoder_positional_encoding', 'decoder_positional_encoding',
+    'positional_encoding_shift', 'scale_embed', 'encoder_max_len', 'decoder_max_len', 'shared_embeddings',
+    'tied_output_projection', 'rope_base', 'input_dim', 'conv_input_dim', 'conv_channels', 'conv_kernel_sizes',
+    'conv_strides', 'conv_activation', 'norm_eps', 'padding_idx', 'eos_idx', 'bos_idx', 'attention_key_bias',
+    'has_bias', 'rms_norm', 'norm_bias', 'scale_attn', 'prompt_loss', 'shared_norm',
+]
+
+
+EXTRA_KEYS = ['lora_rank', 'lora_alpha', 'encoder_adapter_dim', 'decoder_adapter_dim', 'adapter_zero_init',
+              'train_all_params']

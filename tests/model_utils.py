@@ -44,6 +44,8 @@ def oracle_state(g, cfg):
     P = O.to_torch_state(paramgen.make_state_dict(int(g['seed']), golden_names_shapes(g)))
     if cfg.shared_embeddings and 'encoder.embed_tokens.weight' in P:
         P['decoder.embed_tokens.weight'] = P['encoder.embed_tokens.weight']
+        if 'decoder.embed_tokens.frozen_embedding.weight' in P:
+            P['decoder.embed_tokens.frozen_embedding.weight'] = P['encoder.embed_tokens.frozen_embedding.weight']
     if 'freeze_seed' in getattr(g, 'files', g):
         P['encoder.embed_tokens.freeze_mask'] = torch.from_numpy(paramgen.make_freeze_mask(int(g['freeze_seed']), int(g['V'])))
     return P

@@ -30,7 +30,7 @@ def test_library_exports_every_header_symbol():
 
 
 @pytest.mark.parametrize('name', ['tiny_encdec_post', 'tiny_encdec_pre', 'tiny_encdec_rotary', 'tiny_encdec_swiglu', 'speech_whisper',
-                                  'speech_iwslt', 'base_c1', 'tiny_adapter', 'tiny_lora', 'tiny_hd128', 'tiny_encdec_rms', 'tiny_opts_a', 'tiny_opts_b', 'tiny_hd128_rotary', 'tiny_lora_rotary', 'tiny_freeze_embed'])
+                                  'speech_iwslt', 'base_c1', 'tiny_adapter', 'tiny_lora', 'tiny_hd128', 'tiny_encdec_rms', 'tiny_opts_a', 'tiny_opts_b', 'tiny_hd128_rotary', 'tiny_lora_rotary', 'tiny_freeze_embed', 'tiny_freeze_shared'])
 def test_parameter_names_and_shapes_match_reference(name):
     g = load_golden(name)
     _, model = build_model(g)
@@ -146,3 +146,7 @@ def test_assembly_audit_tells_loop_spills_from_spills_that_run_once(tmp_path):
     assert once.returncode == 0 and '0 problems' in once.stdout and 'runs once' in once.stdout, once.stdout
     inside = run(head + loop[:2] + [spill] + loop[2:] + tail)
     assert inside.returncode == 1 and 'spill traffic inside the K loop' in inside.stdout, inside.stdout
+    # an assembly without LLVM's loop annotations cannot be audited for in-loop spills: refused, not waved through
+    bare = [ln.split(';')[0].rstrip() if ln.startswith('.LBB') else ln for ln in loop]
+    unannotated = run(head + bare[:2] + [spill] + bare[2:] + tail)
+    assert unannotated.returncode == 1 and 'no label with a loop annotation' in unannotated.stdout, unannotated.stdout

@@ -145,6 +145,37 @@ def test_partially_frozen_source_embeddings_fp32_vs_reference():
     assert emb.frozen_embedding.weight.grad[mask].abs().max() > 0
 
 
+def test_partially_frozen_embeddings_shared_with_the_decoder_fp32_vs_reference():
+    """shared_embeddings + freeze_mask: the decoder carries the encoder's Embedding, so its lookup, its tied
+    projection AND incremental decoding read the blended table — loss / gradients / logits against the real reference, and the
+    reference's greedy tokens bit for bit (the native decoding plan holds one raw table pointer and must stand aside); the
+    three readers of a training step share ONE merge of the two tables"""
+    from pasero_amd import decode
+    from pasero_amd.modules import MergeTablesFn
+    g, cfg, model, batch = _check_encdec('tiny_freeze_shared')
+    emb = model.decoder.embed_tokens
+    assert emb is model.encoder.embed_tokens and emb.frozen_embedding is not None
+    model.eval()
+    assert decode.get_plan(model.decoder) is None
+    with torch.no_grad():
+        enc_out, enc_mask, _ = model.encoder(batch['encoder_input'], batch['encoder_input_length'])
+        tokens = _greedy(model, enc_out, enc_mask, int(g['max_output_len']))
+    assert tokens.shape == g['greedy_tokens'].shape and (tokens.cpu().numpy() == g['greedy_tokens']).all()
+    # one merge node per parameter state
+    model.train()
+    model.zero_grad(set_to_none=True)
+    loss, _ = model(**batch)
+    merges, seen, todo = 0, set(), [loss.grad_fn]
+    while todo:
+        fn = todo.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        merges += type(fn).__name__.startswith(MergeTablesFn.__name__)
+        todo += [f for f, _ in fn.next_functions]
+    assert merges == 1, merges
+
+
 def test_adapter_transformer_frozen_backbone_fp32_vs_reference():
     """adapter_transformer (pasero/models/adapters.py): bottleneck adapters after every layer, only they are trained;
     loss, every adapter gradient, logits and argmax against the real reference; frozen parameters get no gradient"""

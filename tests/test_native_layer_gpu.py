@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import paramgen
+from pasero_amd import functional as F
 from model_utils import load_paramgen
 
 pytestmark = pytest.mark.gpu
@@ -194,6 +195,52 @@ def test_prenorm_input_fork_against_autograds_addition(dtype, tol):
         a, r = g1[k].float(), g0[k].float()
         ref = g0[k.replace('bias', 'weight')].float().norm().item() if k.endswith('k_proj.bias') else r.norm().item()
         assert (a - r).norm().item() <= tol * ref + 1e-7, (k, (a - r).norm().item(), ref)
+
+
+def test_prenorm_input_fork_with_one_output_unused():
+    """the fork node does not materialise a missing output gradient as zeros — only the LayerNorm branch consumed
+    -> the LayerNorm gradient alone (no dz_extra operand); only the residual branch consumed -> the identity; both against
+    the two-use form"""
+    from pasero_amd.autograd import LayerNormForkFn, ResidualLayerNormFn
+    torch.manual_seed(3)
+    x = torch.randn(96, 512, device='cuda', dtype=torch.bfloat16, requires_grad=True)
+    g = torch.randn(512, device='cuda', dtype=torch.bfloat16, requires_grad=True)
+    b = torch.randn(512, device='cuda', dtype=torch.bfloat16, requires_grad=True)
+    w = torch.randn(96, 512, device='cuda', dtype=torch.bfloat16)
+
+    def grads(fn):
+        for t in (x, g, b):
+            t.grad = None
+        fn().backward()
+        return [None if t.grad is None else t.grad.clone() for t in (x, g, b)]
+    y_only = grads(lambda: (LayerNormForkFn.apply(x, g, b, 1e-5)[0] * w).float().sum())
+    ref = grads(lambda: (ResidualLayerNormFn.apply(x, None, g, b, 1e-5, 0.0) * w).float().sum())
+    for a, r in zip(y_only, ref):
+        assert torch.equal(a, r)
+    res_only = grads(lambda: (LayerNormForkFn.apply(x, g, b, 1e-5)[1] * w).float().sum())
+    assert torch.equal(res_only[0], w) and res_only[1] is None and res_only[2] is None
+
+
+def test_forward_split_boundary_moves_rows_by_round_off_only():
+    """functional.fwd_split gates on M (512..2048 rows), so fc2 of NLLB-1.3B (8192 -> 1024) sums 4 K-slabs at 2048
+    rows and one chain at 4096: the same rows agree to the fp32 round-off of that accumulation — at most one bf16 ulp on a
+    small fraction of the outputs — and inside the range a batch and its halves are bit for bit equal"""
+    torch.manual_seed(5)
+    K, N = 8192, 1024
+    a = (torch.randn(4096, K, device='cuda') * 0.5).bfloat16()
+    w = (torch.randn(N, K, device='cuda') * K ** -0.5).bfloat16()
+    assert F.fwd_split(4096, N, K, a.dtype) == 1 and F.fwd_split(2048, N, K, a.dtype) == 4 == F.fwd_split(1024, N, K, a.dtype)
+    whole = F.gemm(a, w, splitk=F.fwd_split(4096, N, K, a.dtype))
+    halves = torch.cat([F.gemm(a[i:i + 2048], w, splitk=4) for i in (0, 2048)])
+    quarters = torch.cat([F.gemm(a[i:i + 1024], w, splitk=4) for i in range(0, 4096, 1024)])
+    assert torch.equal(halves, quarters)
+    ref = a.double() @ w.double().t()
+    ulp = 2.0 ** (torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)  # bf16: 8 significant bits
+    d = (whole.double() - halves.double()).abs()
+    assert (d <= ulp * 1.001).all(), (d / ulp).max().item()
+    assert (d > 0).float().mean().item() < 0.05
+    for t in (whole, halves):
+        assert ((t.double() - ref).abs() <= ulp * 1.001).all()
 
 
 def test_encoder_gradient_chain_belongs_to_the_decoder_pass():

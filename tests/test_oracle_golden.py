@@ -31,6 +31,8 @@ def _run_encdec(name, full=True):
     P = {k: v.requires_grad_() for k, v in _state(g, seed).items()}
     if cfg.shared_embeddings:  # one tensor under two names (transformer.py:151-153)
         P['decoder.embed_tokens.weight'] = P['encoder.embed_tokens.weight']
+        if 'decoder.embed_tokens.frozen_embedding.weight' in P:
+            P['decoder.embed_tokens.frozen_embedding.weight'] = P['encoder.embed_tokens.frozen_embedding.weight']
     if 'freeze_seed' in g.files:  # the task's (V,) bool mask of frozen source embeddings: an input, not a parameter
         P['encoder.embed_tokens.freeze_mask'] = torch.from_numpy(paramgen.make_freeze_mask(int(g['freeze_seed']), int(g['V'])))
     prompt_cols = int(g['prompt_cols']) if 'prompt_cols' in g.files else 0
@@ -97,6 +99,28 @@ def test_tiny_encdec_rmsnorm_rotary_swiglu_no_bias():
 def test_tiny_partially_frozen_source_embeddings():
     """Embedding(freeze_mask=...) (modules.py:900-947): rows of the mask read `frozen_embedding.weight`"""
     _run_encdec('tiny_freeze_embed')
+
+
+def test_tiny_partially_frozen_embeddings_shared_with_the_decoder():
+    """shared_embeddings + freeze_mask: the decoder's lookup and tied projection blend the two tables too (the decoder IS the
+    encoder's Embedding object, transformer.py:151-153) — loss, gradients, logits, and the reference's greedy tokens through
+    the oracle's incremental decoder; with the frozen table ignored on the decoder side the tokens differ (the fixture tells)"""
+    _run_encdec('tiny_freeze_shared')
+    g = load_golden('tiny_freeze_shared')
+    cfg = golden_cfg(g)
+    P = _state(g, int(g['seed']))
+    for k in ('weight', 'frozen_embedding.weight'):
+        P['decoder.embed_tokens.' + k] = P['encoder.embed_tokens.' + k]
+    P['encoder.embed_tokens.freeze_mask'] = torch.from_numpy(paramgen.make_freeze_mask(int(g['freeze_seed']), int(g['V'])))
+    batch = paramgen.make_text_batch(int(g['seed']), int(g['B']), int(g['S']), int(g['T']), int(g['V']))
+    with torch.no_grad():
+        enc_out, enc_mask = O.encoder(P, cfg, torch.from_numpy(batch['encoder_input']),
+                                      torch.from_numpy(batch['encoder_input_length']))
+        tokens = O.greedy_decode(P, cfg, enc_out, enc_mask, int(g['max_output_len']))
+        assert (tokens.numpy() == g['greedy_tokens']).all()
+        Q = {k: v for k, v in P.items() if k != 'decoder.embed_tokens.frozen_embedding.weight'}
+        wrong = O.greedy_decode(Q, cfg, enc_out, enc_mask, int(g['max_output_len']))
+        assert wrong.shape != tokens.shape or (wrong.numpy() != g['greedy_tokens']).any()
 
 
 def test_tiny_heads_of_128_rotary():
@@ -333,3 +357,25 @@ def test_first_steps_of_the_reference_training_curve():
             for n, gr in zip(used, grads):
                 p_new, m[n], v[n] = O.adam_step(P[n].detach(), gr, m[n], v[n], step + 1, max(cur, min_lr), b1, b2, eps, wd)
                 P[n].copy_(p_new)
+
+
+def test_every_fixture_cfg_has_the_current_schema():
+    """a fixture written before a field was added to the schema would hand the model a configuration that silently lacks it
+    (conftest.golden_cfg builds the namespace from the stored JSON): every `cfg` holds exactly paramgen.CFG_KEYS plus the
+    EXTRA_KEYS that are set, and every whole-model fixture names its architecture and frozen set"""
+    import glob
+    import json
+    import os
+    from conftest import GOLDEN
+    seen = 0
+    for path in sorted(glob.glob(os.path.join(GOLDEN, '*.npz'))):
+        g = np.load(path, allow_pickle=False)
+        if 'cfg' not in g.files:
+            continue
+        seen += 1
+        keys = set(json.loads(str(g['cfg'])))
+        assert set(paramgen.CFG_KEYS) <= keys, (os.path.basename(path), sorted(set(paramgen.CFG_KEYS) - keys))
+        assert keys <= set(paramgen.CFG_KEYS) | set(paramgen.EXTRA_KEYS), (os.path.basename(path), sorted(keys))
+        if os.path.basename(path).startswith(('tiny_', 'base_')):  # gen_encdec's layout
+            assert 'arch' in g.files and 'frozen_names' in g.files, os.path.basename(path)
+    assert seen >= 20

@@ -76,6 +76,12 @@ def audit(path: str):
             pass
         pending = {}  # register -> line of the asm tr read that wrote it
         looping = False  # inside a block LLVM marks as part of a loop
+        # rule 3 tells a spill inside the loop from one that runs once by LLVM's label annotations ("Loop Header" / "in Loop"):
+        # an assembly written without them (no verbose-asm comments, another format) would turn every in-loop spill into a
+        # note — so a K loop between the markers with no annotated label at all fails the audit instead of passing it
+        if not any(re.match(r'^\.LBB\d+_\d+:.*Loop', body[k]) for k in range(b, e)):
+            problems.append(f'{name}: no label with a loop annotation between the loop markers: cannot tell in-loop spills '
+                            f'from run-once ones (assembly without verbose-asm comments?)')
         for k, in_loop in [(k, lp) for (s0, s1, lp) in spans for k in range(s0, s1)]:
             ln = body[k]
             if not in_loop:  # the B-fragment region: only rule 2
