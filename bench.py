@@ -63,6 +63,51 @@ SPEECH = ('c4_whisper', 'c4_iwslt')       # S counts input frames; the encoder l
 DEVICE_INIT = ('c5_nllb_1b3', 'c4_iwslt')  # 1.4 G parameters: created and drawn on the device (a CPU init takes a minute)
 
 
+def build_workload(workload: str, dtype, device, rank: int = 0, world: int = 1):
+    """model (random-init weights, identical on every rank), configuration and one synthetic batch of `workload` on `device`
+    -> (cfg, model, batch, wav); `wav` is the (B, 480 000) fp32 audio of the Whisper workload (its log-mel runs inside the
+    step), None otherwise.  Also used by tools/gemm_in_model.py (the GEMM census of a step)."""
+    from pasero_amd import config as C, rng
+    from pasero_amd import adapters  # noqa: F401  (registers adapter_transformer: the IWSLT recipe's architecture)
+    cfg_name, V, B, S, T = WORKLOADS[workload]
+    # dropout 0.1, label smoothing 0.1: the training configuration (the IWSLT recipe brings its own)
+    cfg = getattr(C, cfg_name)(**(IWSLT_OVERRIDES if workload == 'c4_iwslt' else {}))
+    arch = C.get_architecture(cfg)
+    dist_cfg = C.DistributedConfig(dp_size=world, dp_rank=rank)
+    if workload in DEVICE_INIT:
+        from pasero_amd import modules
+        with modules.fast_init(device, dtype):
+            model = arch(cfg, dist_cfg, C.SyntheticTask(V))
+        model = model.to(dtype).to(device)
+        gen = torch.Generator(device=device).manual_seed(1234)  # identical random-init weights on every rank
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.dim() == 1:
+                    p.fill_(1.0) if ('norm' in n and n.endswith('weight')) else p.zero_()
+                else:
+                    p.copy_(torch.randn(p.shape, generator=gen, device=device, dtype=torch.float32) * 0.02)
+    else:
+        torch.manual_seed(1234)  # identical random-init weights on every rank
+        model = arch(cfg, dist_cfg, C.SyntheticTask(V)).to(dtype).to(device)
+    if workload == 'c4_iwslt':  # cli/train.py:237-238
+        import re
+        for n, p in model.named_parameters():
+            p.requires_grad = bool(re.match(IWSLT_TRAIN_REGEX, n))
+    model.train()
+    rng.manual_seed(1 + rank)
+    batch = synthetic_batch(B, S if workload not in SPEECH else 4, T, V, seed=1 + rank, device=device)
+    wav = None
+    if workload == 'c4_whisper':  # SURVEY §8d C4: wav ~ N(0, 0.1^2) fp32, 30 s at 16 kHz
+        gen = torch.Generator().manual_seed(rank)
+        wav = (0.1 * torch.randn(B, 480000, generator=gen)).to(device)
+        batch['encoder_input_length'] = torch.full((B,), S, dtype=torch.int64, device=device)
+    if workload == 'c4_iwslt':    # SURVEY §8d C4: features ~ N(0, 1), S = 1000 frames of 1024
+        gen = torch.Generator().manual_seed(rank)
+        batch['encoder_input'] = torch.randn(B, S, cfg.input_dim, generator=gen).to(dtype).to(device)
+        batch['encoder_input_length'] = torch.full((B,), S, dtype=torch.int64, device=device)
+    return cfg, model, batch, wav
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -448,42 +493,8 @@ def run(args):
     def measure(workload: str, steps: int, warmup: int, with_ddp: bool):
         """build `workload`, run `warmup` untimed + `steps` timed steps -> (elapsed s, tokens, GemmTimer, cfg, dims, ddp)"""
         cfg_name, V, B, S, T = WORKLOADS[workload]
-        # dropout 0.1, label smoothing 0.1: the training configuration (the IWSLT recipe brings its own)
-        cfg = getattr(C, cfg_name)(**(IWSLT_OVERRIDES if workload == 'c4_iwslt' else {}))
-        arch = C.get_architecture(cfg)
-        dist_cfg = C.DistributedConfig(dp_size=world, dp_rank=rank)
-        if workload in DEVICE_INIT:
-            from pasero_amd import modules
-            with modules.fast_init(device, dtype):
-                model = arch(cfg, dist_cfg, C.SyntheticTask(V))
-            model = model.to(dtype).to(device)
-            gen = torch.Generator(device=device).manual_seed(1234)  # identical random-init weights on every rank
-            with torch.no_grad():
-                for n, p in model.named_parameters():
-                    if p.dim() == 1:
-                        p.fill_(1.0) if ('norm' in n and n.endswith('weight')) else p.zero_()
-                    else:
-                        p.copy_(torch.randn(p.shape, generator=gen, device=device, dtype=torch.float32) * 0.02)
-        else:
-            torch.manual_seed(1234)  # identical random-init weights on every rank
-            model = arch(cfg, dist_cfg, C.SyntheticTask(V)).to(dtype).to(device)
-        if workload == 'c4_iwslt':  # cli/train.py:237-238
-            import re
-            for n, p in model.named_parameters():
-                p.requires_grad = bool(re.match(IWSLT_TRAIN_REGEX, n))
-        model.train()
-        rng.manual_seed(1 + rank)
+        cfg, model, batch, wav = build_workload(workload, dtype, device, rank, world)
         ddp = DistributedDataParallel(model) if with_ddp else model
-        batch = synthetic_batch(B, S if workload not in SPEECH else 4, T, V, seed=1 + rank, device=device)
-        wav = None
-        if workload == 'c4_whisper':  # SURVEY §8d C4: wav ~ N(0, 0.1^2) fp32, 30 s at 16 kHz
-            gen = torch.Generator().manual_seed(rank)
-            wav = (0.1 * torch.randn(B, 480000, generator=gen)).to(device)
-            batch['encoder_input_length'] = torch.full((B,), S, dtype=torch.int64, device=device)
-        if workload == 'c4_iwslt':    # SURVEY §8d C4: features ~ N(0, 1), S = 1000 frames of 1024
-            gen = torch.Generator().manual_seed(rank)
-            batch['encoder_input'] = torch.randn(B, S, cfg.input_dim, generator=gen).to(dtype).to(device)
-            batch['encoder_input_length'] = torch.full((B,), S, dtype=torch.int64, device=device)
 
         def step():
             for p in model.parameters():

@@ -100,6 +100,9 @@ int pk_gemm_relu_bits(const void* A, const void* B, void* C, const void* bias, u
                       float alpha, int dtype, void* stream);
 int pk_gemm_timing_stop(void);
 int pk_gemm_timing_read(int i, int* kernel, int* a_col, int* b_col, int* splitk, int* dtype, double* flops, float* ms);
+/* the problem size of sample i (M, N, K as pk_gemm was called; 1, 1, 1 for a grouped launch, whose flops are a sum).  Kernel
+ * tag 64 = the few-rows kernel (gemm_skinny.hip).  No reference counterpart (diagnostics: tools/gemm_in_model.py). */
+int pk_gemm_timing_shape(int i, long long* M, long long* N, long long* K);
 
 /* ---- The weight gradients of one layer in ONE launch: replaces the per-nn.Linear `grad_weight = grad_output^T @ input`
  * (+ `grad_bias = grad_output.sum(0)`) that autograd issues one by one during the backward of a layer,

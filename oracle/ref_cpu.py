@@ -273,6 +273,29 @@ def _ffn(P, prefix, x, cfg):
     return linear(y, P[prefix + '.fc2.weight'], P.get(prefix + '.fc2.bias'))
 
 
+def adapter_layer(P: dict, prefix: str, x: Tensor, scaling: float = 1.0) -> Tensor:
+    """models/modules.py:248-370, AdapterLayer.forward (:338-351) as adapter_transformer configures it (adapters.py:241-249,
+    276-284: LayerNorm, biases, ReLU, residual, scaling 1):  x + up(relu(down(LayerNorm(x)))) * scaling.  nn.LayerNorm with
+    its default eps (1e-5), whatever cfg.norm_eps says (modules.py:311)."""
+    h = layer_norm(x, P[prefix + '.layer_norm.weight'], P[prefix + '.layer_norm.bias'], 1e-5)
+    h = activation('relu', linear(h, P[prefix + '.down.weight'], P.get(prefix + '.down.bias')))
+    h = linear(h, P[prefix + '.up.weight'], P.get(prefix + '.up.bias'))
+    return r16(x + (h * scaling if scaling != 1.0 else h))
+
+
+def _adapters(P: dict, prefix: str, x: Tensor) -> Tensor:
+    """adapters.py:251-263, 286-298: every adapter of `adapters_in_use`, in order, behind the layer (the oracle runs the ones
+    the state holds, in the order their parameters are registered)"""
+    head = prefix + '.adapters.'
+    uids = []
+    for k in P:
+        if k.startswith(head) and k.endswith('.down.weight'):
+            uids.append(k[len(head):-len('.down.weight')])
+    for uid in uids:
+        x = adapter_layer(P, head + uid, x)
+    return x
+
+
 def encoder_layer(P: dict, prefix: str, x: Tensor, pad_mask: Tensor, cfg) -> Tensor:
     """models/transformer.py:1056-1099 (dropout = identity)"""
     pre = cfg.encoder_prenorm
@@ -290,7 +313,7 @@ def encoder_layer(P: dict, prefix: str, x: Tensor, pad_mask: Tensor, cfg) -> Ten
     x = r16(res + _ffn(P, prefix, x, cfg))
     if not pre:
         x = _ln(P, _final_norm(cfg, prefix), x, cfg)
-    return x
+    return _adapters(P, prefix, x)
 
 
 def decoder_layer(P: dict, prefix: str, x: Tensor, enc_out: Tensor, enc_mask: Tensor, cfg,
@@ -326,7 +349,7 @@ def decoder_layer(P: dict, prefix: str, x: Tensor, enc_out: Tensor, enc_mask: Te
     x = r16(res + _ffn(P, prefix, x, cfg))
     if not pre:
         x = _ln(P, _final_norm(cfg, prefix), x, cfg)
-    return x
+    return _adapters(P, prefix, x)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -742,6 +742,7 @@ struct GemmSample {
     hipEvent_t start, stop;
     int kernel, a_col, b_col, splitk, dtype;
     double flops;
+    long long M, N, K;
 };
 struct GemmTiming {
     bool on = false;
@@ -757,6 +758,7 @@ inline GemmSample* timing_begin(int kernel, int a_col, int b_col, int splitk, in
     GemmSample* sm = &g_timing.pool[g_timing.used++];
     sm->kernel = kernel; sm->a_col = a_col; sm->b_col = b_col; sm->splitk = splitk; sm->dtype = dtype;
     sm->flops = 2.0 * (double)M * (double)N * (double)K;
+    sm->M = M; sm->N = N; sm->K = K;
     (void)hipEventRecord(sm->start, stream);
     return sm;
 }
@@ -796,7 +798,10 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         // weight is 128 KB, re-reading it per 64-row block costs nothing, while the 128-tile kernel ran it at 1.2 TB/s: 28 -> 9 us)
         if (!a_col && !b_col && (M <= 64 || (M <= 256 && N <= 8192) || (M <= 1024 && N <= 512) || N <= 64) && splitk <= 1 && !asum_out &&
             !no_skinny) {
+            GemmSample* sm = timing_begin(64, a_col, b_col, 1, dtype16, M, N, K, stream);  // (sample tag 64: the few-rows kernel)
             int rc = pk_gemm_skinny_launch(A, B, C, M, N, K, lda, ldb, ep, dtype16, stream);
+            if (rc == 1) timing_end(sm, stream);
+            else if (sm) --g_timing.used;  // not eligible (or an error): the sample slot goes back
             if (rc != 0) return rc == 1 ? 0 : rc;  // 1 = launched, 0 = not eligible, anything else = error
         }
         // short contraction (K = 512 / 256), many rows, lean epilogue: the B-stationary walk (gemmbs.hip) — no epilogue phase
@@ -1098,5 +1103,11 @@ extern "C" int pk_gemm_timing_read(int i, int* kernel, int* a_col, int* b_col, i
     if (e == hipSuccess) e = hipEventElapsedTime(ms, sm.start, sm.stop);
     if (e != hipSuccess) { pk_set_error("pk_gemm_timing_read: %s", hipGetErrorString(e)); return (int)e; }
     *kernel = sm.kernel; *a_col = sm.a_col; *b_col = sm.b_col; *splitk = sm.splitk; *dtype = sm.dtype; *flops = sm.flops;
+    return 0;
+}
+extern "C" int pk_gemm_timing_shape(int i, long long* M, long long* N, long long* K) {
+    PK_CHECK_ARG(i >= 0 && i < g_timing.used && M && N && K, "pk_gemm_timing_shape: sample %d of %d", i, g_timing.used);
+    const GemmSample& sm = g_timing.pool[i];
+    *M = sm.M; *N = sm.N; *K = sm.K;
     return 0;
 }

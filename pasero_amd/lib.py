@@ -30,6 +30,7 @@ SIGNATURES = {
     'pk_gemm_timing_start': (I, [I, I]),
     'pk_gemm_timing_stop': (I, []),
     'pk_gemm_timing_read': (I, [I, P, P, P, P, P, P, P]),
+    'pk_gemm_timing_shape': (I, [I, P, P, P]),
     'pk_gemm_wgrad_group_eligible': (I, [P, I]),
     'pk_gemm_wgrad_group_workspace': (SZ, [P, I]),
     'pk_gemm_wgrad_group': (I, [P, I, I, P, SZ, P]),

@@ -372,6 +372,30 @@ def _check_grads(got, ref, what, tol=0.05, kproj_tol=0.2):
     return checked
 
 
+def _bf16_bracket(what, loss, got, state, cfg, cpu_batch, true_loss, true, bound=1.5):
+    """the bracket of test_c2_pair_bf16_error_is_the_error_of_16_bit_storage for any layer pair — per
+    gradient, the HIP bf16 path's distance from the fp32 truth within `bound` x the distance of the oracle with bf16 module
+    boundaries (oracle/ref_cpu.py ACT_DTYPE), + 0.3 % of the gradient's norm for tensors both get almost exactly"""
+    o16_loss, _, o16 = _oracle_grads(state, cfg, cpu_batch, torch.bfloat16)
+    e_hip, e_o16 = abs(loss - true_loss) / abs(true_loss), abs(o16_loss - true_loss) / abs(true_loss)
+    assert e_hip <= bound * e_o16 + 1e-3, (what, e_hip, e_o16)
+    worst, rows = (0.0, None), []
+    for k, r in true.items():
+        if k.endswith('k_proj.bias') or k not in got:
+            continue
+        n = r.norm().item()
+        if n == 0:
+            continue
+        h, o = (got[k] - r).norm().item() / n, (o16[k] - r).norm().item() / n
+        rows.append((h / max(o, 1e-12), k, h, o))
+        if o > 0 and h / o > worst[0]:
+            worst = (h / o, k)
+    bad = [(k, round(h, 5), round(o, 5)) for ratio, k, h, o in rows if h > bound * o + 3e-3]
+    print(f'{what} bf16 error bracket: loss hip {e_hip:.2e} / oracle-bf16 {e_o16:.2e}; worst gradient ratio '
+          f'{worst[0]:.2f} ({worst[1]}); {len(rows)} gradients')
+    assert not bad, (what, bad)
+
+
 def test_c4_shape_prenorm_pair_bf16_native_layers_against_the_cpu_oracle():
     """the natively run pre-norm 16-bit layer had no oracle comparison (its rows >= 256 / d >= 256 rule
     keeps every d = 128 reference fixture off it).  The whole C4 path at its own rows with ONE encoder + ONE decoder layer:
@@ -410,6 +434,7 @@ def test_c4_shape_prenorm_pair_bf16_native_layers_against_the_cpu_oracle():
     assert logs['num_tokens'] == ref_logs['num_tokens']
     assert abs(loss.item() - ref_loss) <= 2e-2 * abs(ref_loss), (loss.item(), ref_loss)
     assert _check_grads(got, ref, 'c4') >= 40
+    _bf16_bracket('c4', loss.item(), got, state, cfg, cpu_batch, ref_loss, ref)
 
 
 def test_c5_width_prenorm_pair_bf16_native_layers_against_the_cpu_oracle():
@@ -446,6 +471,71 @@ def test_c5_width_prenorm_pair_bf16_native_layers_against_the_cpu_oracle():
     assert logs['num_tokens'] == ref_logs['num_tokens']
     assert abs(loss.item() - ref_loss) <= 2e-2 * abs(ref_loss), (loss.item(), ref_loss)
     assert _check_grads(got, ref, 'c5') >= 40
+    _bf16_bracket('c5', loss.item(), got, state, cfg, cpu_batch, ref_loss, ref)
+
+
+def test_iwslt_recipe_layer_pair_frozen_backbone_bf16_against_the_cpu_oracle(monkeypatch):
+    """the frozen-backbone per-op route of the IWSLT2023 recipe at ITS rows and width, against the
+    oracle: (32, 1000, 1024) features -> in_linear 1024 -> 80 + ReLU -> conv k5 s2 + GLU -> 500 positions = 16 000 rows of
+    d = 1024; ONE frozen pre-norm encoder layer with a trained bottleneck adapter (d -> 64 -> d) behind it, ONE frozen decoder
+    layer (T = 64: 2048 rows, f = 8192), bf16; only in_linear, the subsampler and the adapter train — so every gradient that
+    is checked has crossed the frozen decoder and encoder layers backwards.  oracle/ref_cpu.py in fp32 on the same
+    bf16-representable weights: loss 2e-2, gradients 5 % relative L2; and the routes the recipe's timed step depends on must
+    have run: the pre-norm fork node, the forward K-slabs of fc2 at 2048 rows, the few-rows kernel for the adapter's
+    16 000 x 64 down-projection."""
+    import paramgen
+    import bench
+    from pasero_amd import autograd, config as C, functional as PF
+    from pasero_amd import adapters  # noqa: F401
+    V_, B_, S_, T_ = 1000, 32, 1000, 64
+    over = {**bench.IWSLT_OVERRIDES, 'encoder_layers': 1, 'decoder_layers': 1, 'encoder_adapter_layer_ids': [0],
+            'dropout': 0.0, 'attention_dropout': 0.0}
+    cfg = C.AdapterNLLB1B3Config(**over)
+    model = C.get_architecture(cfg)(cfg, C.DistributedConfig(), C.SyntheticTask(V_))
+    names_shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    state = {k: torch.from_numpy(v).bfloat16().float() for k, v in paramgen.make_state_dict(47, names_shapes).items()}
+    if cfg.shared_embeddings:
+        state['decoder.embed_tokens.weight'] = state['encoder.embed_tokens.weight']
+    model.load_state_dict(state)
+    model = model.to(torch.bfloat16).cuda().train()
+    trained_re = r'(.*\.in_linear|.*\.subsample|.*\.adapters)'
+    import re
+    for n, p in model.named_parameters():
+        p.requires_grad = bool(re.match(trained_re, n))
+    trained = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert any('adapters.default.down.weight' in n for n in trained) and not any('.fc1.' in n for n in trained)
+    feats = torch.randn(B_, S_, 1024, generator=torch.Generator().manual_seed(8)).bfloat16().float()
+    tb = paramgen.make_text_batch(13, B_, 4, T_, V_)
+    cpu_batch = {'encoder_input': feats, 'encoder_input_length': torch.full((B_,), S_, dtype=torch.int64),
+                 'decoder_input': torch.from_numpy(tb['decoder_input']), 'prompt_mask': torch.from_numpy(tb['prompt_mask'])}
+    batch = {k: (v.bfloat16() if v.is_floating_point() else v).cuda() for k, v in cpu_batch.items()}
+    forks, splits = {'n': 0}, []
+    orig_fork, orig_split = autograd.LayerNormForkFn.forward, PF.fwd_split
+
+    def fork(*a, **k):
+        forks['n'] += 1
+        return orig_fork(*a, **k)
+    monkeypatch.setattr(autograd.LayerNormForkFn, 'forward', staticmethod(fork))
+    monkeypatch.setattr(PF, 'fwd_split', lambda M, N, K, dt: splits.append((M, N, K, orig_split(M, N, K, dt))) or splits[-1][3])
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss, logs = model(**batch)
+        loss.backward()
+        return loss, logs
+    (loss, logs), tags = _gemm_tags(step)
+    # (the encoder layer's two pre-norm sub-blocks + the decoder sub-blocks whose input carries a gradient: with a frozen
+    # embedding that is the feed-forward block, behind the cross-attention)
+    assert 3 <= forks['n'] <= 5, forks
+    assert (2048, 1024, 8192, 4) in splits, splits          # the decoder's fc2 as K-slabs
+    assert 64 in tags, tags                                 # the few-rows kernel (the adapter's down-projection)
+    got = {k: p.grad.float().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == trained, set(got) ^ trained
+    ref_loss, ref_logs, ref = _oracle_grads(state, cfg, cpu_batch)
+    ref = {k: v for k, v in ref.items() if k in trained}
+    assert logs['num_tokens'] == ref_logs['num_tokens']
+    assert abs(loss.item() - ref_loss) <= 2e-2 * abs(ref_loss), (loss.item(), ref_loss)
+    assert _check_grads(got, ref, 'iwslt') == len(trained)
 
 
 def test_c2_pair_bf16_error_is_the_error_of_16_bit_storage():

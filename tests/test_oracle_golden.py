@@ -379,3 +379,14 @@ def test_every_fixture_cfg_has_the_current_schema():
         if os.path.basename(path).startswith(('tiny_', 'base_')):  # gen_encdec's layout
             assert 'arch' in g.files and 'frozen_names' in g.files, os.path.basename(path)
     assert seen >= 20
+
+
+def test_tiny_adapter_transformer_frozen_backbone():
+    """adapter_transformer (pasero/models/adapters.py:232-301, modules.py:248-370): the oracle's bottleneck adapter behind
+    every layer against the real reference — loss, every adapter gradient (the fixture stores gradients of trained parameters
+    only), encoder output, logits, argmax"""
+    g = load_golden('tiny_adapter')
+    frozen = {str(n) for n in g['frozen_names']}
+    assert frozen and all('adapters.' in str(n) for n in g['grad_names'])
+    assert all('adapters.' not in n for n in frozen)
+    _run_encdec('tiny_adapter')
