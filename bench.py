@@ -428,7 +428,8 @@ def rehearse_cpu(args, rank: int, world: int):
                           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                           'rehearsal': 'CPU/gloo stand-in model: plumbing only, NOT a measurement',
                           'config': {'workload': 'rehearsal', 'tokens_per_rank_per_step': tokens_per_step,
-                                     'parallelism': f'dp{world}'}}))
+                                     'parallelism': f'dp{world}',
+                                     'gradient_all_reduce': ddp.describe() if hasattr(ddp, 'describe') else None}}))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -573,8 +574,9 @@ def run(args):
             'config': {'workload': f'{args.workload}: {cfg_name} V={V}, per-GPU batch (B,S,T)=({B},{S},{T}), '
                                    f'dropout {cfg.dropout}, label smoothing {cfg.label_smoothing}, full-length rows',
                        'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}',
-                       'gradient_all_reduce': (getattr(getattr(ddp, '_native', None), 'report', None)
-                                               or ('torch.distributed' if world > 1 else None)),
+                       # the reducer describing itself (transport, the schedule chosen and the measured time of each of the
+                       # three, every bucket's size in launch order): a scaling run must explain its own numbers
+                       'gradient_all_reduce': (ddp.describe() if hasattr(ddp, 'describe') else None),
                        'step': 'forward + backward' + (' + bucketed RCCL all-reduce + fused logs all-reduce' if world > 1 else ''),
                        'algorithmic_tflop_per_step_per_gpu': step_flops / 1e12,
                        'model_tflops_per_gpu': step_flops * args.steps / elapsed / 1e12,

@@ -243,6 +243,13 @@ size_t pk_embed_bwd_workspace(long long ntok, long long V, int d);
 int pk_embed_bwd(const long long* ids, const void* dout, void* dE, void* workspace, size_t ws_bytes, long long ntok,
                  int d, long long V, long long pad_idx, float scale, float drop_p, unsigned long long seed,
                  unsigned long long offset, int dtype, void* stream);
+/*   the same sums ADDED INTO a gradient that is already in dE — what autograd does with a separate (V, d) `add` when the
+ *   embedding matrix is also the tied output projection (pasero/models/transformer.py:151-153, modules.py:935-947: the
+ *   table receives the projection's dense dW and the lookups' sparse rows): every row with tokens = fp32(existing row) + its
+ *   fixed-order sum, rounded once; rows without tokens and row pad_idx are not touched (no memset, no dense pass). */
+int pk_embed_bwd_acc(const long long* ids, const void* dout, void* dE, void* workspace, size_t ws_bytes, long long ntok,
+                     int d, long long V, long long pad_idx, float scale, float drop_p, unsigned long long seed,
+                     unsigned long long offset, int dtype, void* stream);
 
 /* ---- Label-smoothed cross-entropy (K6): replaces logits.float() + 2x F.cross_entropy(ignore_index=pad,
  * reduction='sum', label_smoothing) + 3 .item() syncs, pasero/models/transformer.py:354-380.

@@ -711,6 +711,32 @@ class DropoutFn(Function):
         return F.dropout(_contig(dy), ctx.p, ctx.seed, ctx.offset), None
 
 
+# The tied table's gradient in ONE (V, d) tensor.  With `tied_output_projection` (and `shared_embeddings`) the embedding matrix
+# receives the projection's dense dW and the sparse rows of one or two lookups (pasero/models/transformer.py:151-153,
+# modules.py:935-947); as three autograd contributions that costs, per lookup, a (V, d) zero fill + a dense `add` pass over the
+# table (NLLB-1.3B: 525 MB each, 0.8 ms per step).  Instead the vocabulary loss's backward — the first node of every backward
+# pass — offers its dW as the SINK of this pass, keyed by the table it was computed for; a lookup of the same table adds its rows
+# into it in place (pk_embed_bwd_acc: touched rows only) and returns no gradient of its own.  The offer ends with the pass (an
+# engine callback).  What makes the in-place addition sound: the engine keeps the first gradient that reaches an input buffer by
+# reference (no copy), AccumulateGrad for the table runs only after every contributor has reported — a lookup that returns None
+# has — and nothing saves dW for a later backward.  PASERO_NO_GRAD_SINK=1: three contributions, as before (A/B).
+_NO_GRAD_SINK = os.environ.get('PASERO_NO_GRAD_SINK', '0') not in ('', '0')
+_grad_sinks = {}  # (data_ptr, shape, dtype) of the table -> its dense gradient of the running backward pass
+
+
+def _table_key(weight: Tensor):
+    return (weight.data_ptr(), tuple(weight.shape), weight.dtype)
+
+
+def _offer_grad_sink(key, gw: Tensor):
+    if _NO_GRAD_SINK or gw is None or not gw.is_contiguous():
+        return
+    first = not _grad_sinks
+    _grad_sinks[key] = gw
+    if first:
+        torch.autograd.Variable._execution_engine.queue_callback(_grad_sinks.clear)
+
+
 class EmbeddingFn(Function):
     """dropout(E[ids] * scale + pos[pos_start : pos_start+T])
     (pasero/models/modules.py:916-933; pasero/models/transformer.py:727-744, 866-878)"""
@@ -722,6 +748,7 @@ class EmbeddingFn(Function):
         out = F.embed_fwd(ids, weight, pos_table, scale, pos_start, p, seed, offset)
         ctx.args = (scale, pos_start, p, seed, offset, padding_idx, weight.size(0))
         ctx.pos_rows = pos_table.size(0) if pos_table is not None else 0
+        ctx.table = _table_key(weight)
         ctx.save_for_backward(ids)
         return out
 
@@ -732,7 +759,11 @@ class EmbeddingFn(Function):
         dout = _contig(dout)
         dE = dpos = None
         if ctx.needs_input_grad[1]:
-            dE = F.embed_bwd(ids, dout, V, padding_idx, scale, p, seed, offset)
+            sink = _grad_sinks.get(ctx.table)
+            if sink is not None and sink.dtype == dout.dtype and sink.shape == (V, dout.size(-1)):
+                F.embed_bwd(ids, dout, V, padding_idx, scale, p, seed, offset, into=sink)  # (dE stays None: nothing to add)
+            else:
+                dE = F.embed_bwd(ids, dout, V, padding_idx, scale, p, seed, offset)
         if ctx.needs_input_grad[2]:  # learned positions: sum over the batch of the (masked) gradient
             B, T, d = dout.shape
             dm = F.dropout(dout, p, seed, offset) if p > 0 else dout
@@ -821,6 +852,7 @@ class VocabCrossEntropyFn(Function):
                     g0 = r1
         sums = F.ce_finalize(row_loss, row_nll, tgt, padding_idx)
         ctx.x_shape = x.shape
+        ctx.table = _table_key(weight)
         if grad:
             ctx.save_for_backward(dx, dw)
         return sums
@@ -831,6 +863,7 @@ class VocabCrossEntropyFn(Function):
         g = _contig(dsums)[:1].float()  # d(total)/d(loss); nll / num_tokens are logging outputs
         gx = F.scale(dx, g).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         gw = F.scale(dw, g) if ctx.needs_input_grad[1] else None
+        _offer_grad_sink(ctx.table, gw)  # (lookups of the same table add their rows into gw: see _grad_sinks)
         return gx, gw, None, None, None
 
 

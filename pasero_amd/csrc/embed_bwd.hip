@@ -69,7 +69,21 @@ __device__ __forceinline__ void add_row_chunk(float (&a)[8], const T* __restrict
 constexpr int SHORT_RUN = 16;
 constexpr int FLAG_BEGIN = 1, FLAG_END = 2, FLAG_SPAN = 4;  // partial of a run cut at the range start / end / both
 
-template <typename T, int NB>
+// row `id` of dE (columns c0 .. c0 + 8) added to a[0..8): the accumulate form (pk_embed_bwd_acc) sums into a gradient that is
+// already there — the tied projection's dW — before the one rounding
+template <typename T>
+__device__ __forceinline__ void add_existing(float (&a)[8], const T* __restrict__ src) {
+    if constexpr (sizeof(T) == 2) {
+        Vec16<T> v = load16<T>(src);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += v.get(e);
+    } else {
+        const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+        a[0] += lo.x; a[1] += lo.y; a[2] += lo.z; a[3] += lo.w; a[4] += hi.x; a[5] += hi.y; a[6] += hi.z; a[7] += hi.w;
+    }
+}
+
+template <typename T, int NB, bool ACC>
 __global__ __launch_bounds__(256) void embed_segsum_kernel(const unsigned* __restrict__ keys,
                                                            const unsigned* __restrict__ toks,
                                                            const T* __restrict__ dout, T* __restrict__ dE,
@@ -100,6 +114,7 @@ __global__ __launch_bounds__(256) void embed_segsum_kernel(const unsigned* __res
                 const int c0 = b * 512 + lane * 8;
                 if (c0 >= d) continue;
                 T* dst = dE + (long long)id * d + c0;
+                if constexpr (ACC) add_existing<T>(a[b], dst);
                 if constexpr (sizeof(T) == 2) {
                     Vec16<T> o;
 #pragma unroll
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(256) void embed_segsum_kernel(const unsigned* __res
 
 // rows whose run crosses workgroup ranges: the workgroup in whose range the run BEGINS adds the partial sums of the
 // ranges it runs through, in range order, and writes the row (one wave per chain; lane = 8 columns per block of 512)
-template <typename T, int NB>
+template <typename T, int NB, bool ACC>
 __global__ __launch_bounds__(64) void embed_fixup_kernel(const unsigned* __restrict__ keys, const float* __restrict__ part,
                                                         const int* __restrict__ flags, T* __restrict__ dE, int nwg,
                                                         long long ntok, int d, long long pad_idx) {
@@ -217,6 +232,7 @@ __global__ __launch_bounds__(64) void embed_fixup_kernel(const unsigned* __restr
         const int c0 = b * 512 + lane * 8;
         if (c0 >= d) continue;
         T* dst = dE + (long long)id * d + c0;
+        if constexpr (ACC) add_existing<T>(a[b], dst);
         if constexpr (sizeof(T) == 2) {
             Vec16<T> o;
 #pragma unroll
@@ -255,17 +271,20 @@ extern "C" size_t pk_embed_bwd_workspace(long long ntok, long long V, int d) {
            align_up(nwg * 4) + 256;
 }
 
-// dE[V,d] = sum over tokens of dout[tok] * keep/(1-p) * scale into row ids[tok]; row pad_idx and rows without tokens 0.
-extern "C" int pk_embed_bwd(const long long* ids, const void* dout, void* dE, void* workspace, size_t ws_bytes,
-                            long long ntok, int d, long long V, long long pad_idx, float scale, float drop_p,
-                            unsigned long long seed, unsigned long long offset, int dtype, void* stream) {
+namespace {
+// dE[V,d] = sum over tokens of dout[tok] * keep/(1-p) * scale into row ids[tok]; row pad_idx and rows without tokens 0 —
+// or, `acc`: the same sums added INTO dE (rows without tokens and row pad_idx untouched, every touched row = fp32(existing)
+// + its fixed-order sum, rounded once)
+int embed_bwd_impl(const long long* ids, const void* dout, void* dE, void* workspace, size_t ws_bytes,
+                   long long ntok, int d, long long V, long long pad_idx, float scale, float drop_p,
+                   unsigned long long seed, unsigned long long offset, int dtype, void* stream, bool acc) {
     PK_CHECK_ARG(dE && (ntok == 0 || (ids && dout)), "pk_embed_bwd: null tensor");
     PK_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 4096, "pk_embed_bwd: embedding width %d (needs a multiple of 8, <= 4096)", d);
     PK_CHECK_ARG(V > 0 && V < (1ll << 31) && ntok < (1ll << 31), "pk_embed_bwd: sizes beyond 2^31");
     PK_CHECK_ARG(((uintptr_t)dout % 16) == 0 && ((uintptr_t)dE % 16) == 0, "pk_embed_bwd: operands must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const size_t esz = dtype == PK_F32 ? 4 : 2;
-    hipError_t e = hipMemsetAsync(dE, 0, (size_t)V * d * esz, s);
+    hipError_t e = acc ? hipSuccess : hipMemsetAsync(dE, 0, (size_t)V * d * esz, s);
     if (e != hipSuccess) { pk_set_error("pk_embed_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
     if (ntok == 0) return 0;
     PK_CHECK_ARG(workspace && ws_bytes >= pk_embed_bwd_workspace(ntok, V, d), "pk_embed_bwd: workspace too small");
@@ -286,12 +305,17 @@ extern "C" int pk_embed_bwd(const long long* ids, const void* dout, void* dE, vo
     const float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     const dim3 grid((unsigned)nwg);
     const int nb = (d + 511) / 512;
-#define PK_SEG(TT, NBV)                                                                                               \
+#define PK_SEG2(TT, NBV, AC)                                                                                          \
     do {                                                                                                              \
-        hipLaunchKernelGGL((embed_segsum_kernel<TT, NBV>), grid, dim3(256), 0, s, k_out, v_out, (const TT*)dout, (TT*)dE, \
-                           part, flags, ntok, d, pad_idx, scale, thr, ds, seed, offset);                             \
-        hipLaunchKernelGGL((embed_fixup_kernel<TT, NBV>), grid, dim3(64), 0, s, k_out, part, flags, (TT*)dE, nwg, ntok, d, \
-                           pad_idx);                                                                                  \
+        hipLaunchKernelGGL((embed_segsum_kernel<TT, NBV, AC>), grid, dim3(256), 0, s, k_out, v_out, (const TT*)dout,  \
+                           (TT*)dE, part, flags, ntok, d, pad_idx, scale, thr, ds, seed, offset);                     \
+        hipLaunchKernelGGL((embed_fixup_kernel<TT, NBV, AC>), grid, dim3(64), 0, s, k_out, part, flags, (TT*)dE, nwg, \
+                           ntok, d, pad_idx);                                                                         \
+    } while (0)
+#define PK_SEG(TT, NBV)                       \
+    do {                                      \
+        if (acc) PK_SEG2(TT, NBV, true);      \
+        else PK_SEG2(TT, NBV, false);         \
     } while (0)
 #define PK_SEG_NB(TT)                                      \
     do {                                                   \
@@ -306,6 +330,22 @@ extern "C" int pk_embed_bwd(const long long* ids, const void* dout, void* dE, vo
     else PK_CHECK_ARG(false, "pk_embed_bwd: dtype %d not supported", dtype);
 #undef PK_SEG_NB
 #undef PK_SEG
+#undef PK_SEG2
     PK_LAUNCH_CHECK();
     return 0;
+}
+}  // namespace
+
+extern "C" int pk_embed_bwd(const long long* ids, const void* dout, void* dE, void* workspace, size_t ws_bytes,
+                            long long ntok, int d, long long V, long long pad_idx, float scale, float drop_p,
+                            unsigned long long seed, unsigned long long offset, int dtype, void* stream) {
+    return embed_bwd_impl(ids, dout, dE, workspace, ws_bytes, ntok, d, V, pad_idx, scale, drop_p, seed, offset, dtype, stream,
+                          false);
+}
+
+extern "C" int pk_embed_bwd_acc(const long long* ids, const void* dout, void* dE, void* workspace, size_t ws_bytes,
+                                long long ntok, int d, long long V, long long pad_idx, float scale, float drop_p,
+                                unsigned long long seed, unsigned long long offset, int dtype, void* stream) {
+    return embed_bwd_impl(ids, dout, dE, workspace, ws_bytes, ntok, d, V, pad_idx, scale, drop_p, seed, offset, dtype, stream,
+                          true);
 }

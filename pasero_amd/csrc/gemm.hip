@@ -843,6 +843,14 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
             // slices, all prologue / epilogue, and 64 fp32 slabs to reduce: on 128-tiles with 32 slices the step gains
             // 1 % (19.99 -> 19.76 ms); from 12 tiles up (qkv, fc1/fc2 gradients) the 256 kernel wins (threshold 16: 14.27
             // vs 14.00 ms of GEMM time per step)
+            // an output the 128 x 256-tile form fills the chip with (80..159 256-tiles: NLLB-1.3B's N = d GEMMs at 8192 rows)
+            // is not split even where the caller allows it: two K slices of 256-tiles + the reduction launch took 103 + 17 us
+            // for the fc2 dX (8192 x 1024 x 8192) where the unsplit 128 x 256 tiles take 111 (round 5; PK_GEMM_HM_NOSPLIT=0: A/B)
+            static const bool hm_nosplit = [] { const char* e = getenv("PK_GEMM_HM_NOSPLIT"); return !e || atoi(e) != 0; }();
+            static const bool halfm_env = [] { const char* e = getenv("PK_GEMM_HALFM"); return !e || atoi(e) != 0; }();
+            const bool hm_takes_it = hm_nosplit && halfm_env && e8 && t256 < 160 && !a_col && !asum_out && lean_epi &&
+                                     ((M + 127) / 128) * ((N + 255) / 256) >= 160 && tile_pref != 256 && g_use_8p != 2;
+            if (splitk > 1 && hm_takes_it) splitk = 1;
             if (splitk > 1 && (sk_mode == 2 || t256 < sk_min_tiles)) sk = 0;
             else if (splitk > 1) {  // the caller allows split-K: re-derive the factor for 256-tiles (~1 workgroup per CU)
                 sk = (int)std::max(1LL, std::min((long long)(256 / std::max(1LL, t256)), K8 / 512));

@@ -248,6 +248,25 @@ class DistributedDataParallel(nn.Module):
         if self.world_size > 1:
             self._broadcast_state()
 
+    def describe(self) -> dict:
+        """what a scaling run needs to explain itself (bench.py prints it into its JSON line): the transport and, on the native
+        path, the all-reduce schedule in use with the time and the correctness check of EVERY schedule as `choose_schedule`
+        measured them on this node; the buckets in launch order (MiB each: the first collective of a step can start once the
+        first bucket is complete, the last one is not overlapped with backward) and how many of them are gradient arenas that
+        a natively run layer writes in place"""
+        sizes = [round(b.numel * b.flat.element_size() / (1 << 20), 3) for b in self._buckets]
+        if not self._reduce_enabled:
+            transport = 'none (one rank)'
+        elif self._native is not None:
+            transport = "RCCL C API (csrc/comm.hip) on a dedicated stream"
+        else:
+            transport = 'torch.distributed (%s)' % (dist.get_backend(self.process_group) if dist.is_initialized() else '-')
+        return {'transport': transport, 'world_size': self.world_size,
+                'schedule_trial': dict(self._native.report) if self._native is not None else None,
+                'buckets': len(sizes), 'bucket_mib': sizes, 'total_mib': round(sum(sizes), 3),
+                'largest_bucket_mib': max(sizes) if sizes else 0.0, 'last_bucket_mib': sizes[-1] if sizes else 0.0,
+                'arena_layers': len(self._arena_layers), 'find_unused_parameters': self.find_unused_parameters}
+
     # ---- setup ----
     def _native_groups(self):
         """{parameter: (layer, [its parameters in gradient-arena order])} for every layer whose backward is one native call

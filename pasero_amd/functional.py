@@ -415,17 +415,22 @@ def add_positions(x: Tensor, pos: Optional[Tensor], scale: float, pos_start: int
 
 
 def embed_bwd(ids: Tensor, dout: Tensor, V: int, pad_idx: int, scale: float, drop_p: float = 0.0, seed: int = 0,
-              offset: int = 0) -> Tensor:
-    require_gpu(ids, dout)
+              offset: int = 0, into: Optional[Tensor] = None) -> Tensor:
+    """dE (V, d) of the lookup; `into`: add the rows into that (V, d) gradient instead (pk_embed_bwd_acc: no zero fill, no
+    dense pass — the tied projection's dW that the table already received) and return it"""
+    require_gpu(ids, dout, into)
     d = dout.size(-1)
     assert dout.is_contiguous() and ids.is_contiguous() and ids.dtype == torch.int64
     assert dout.numel() == ids.numel() * d
-    dE = torch.empty(V, d, dtype=dout.dtype, device=dout.device)
+    if into is not None:
+        assert into.shape == (V, d) and into.dtype == dout.dtype and into.is_contiguous()
+    dE = into if into is not None else torch.empty(V, d, dtype=dout.dtype, device=dout.device)
     ws_bytes = lib.load().pk_embed_bwd_workspace(ids.numel(), V, d)
     ws = lib.workspace(ws_bytes, dout.device, 'embed')
     L = lib.load()
-    check(L.pk_embed_bwd(ptr(ids), ptr(dout), ptr(dE), ptr(ws), ws_bytes, ids.numel(), d, V, int(pad_idx),
-                         float(scale), float(drop_p), int(seed), int(offset), dtype_code(dout), stream_ptr()),
+    fn = L.pk_embed_bwd_acc if into is not None else L.pk_embed_bwd
+    check(fn(ptr(ids), ptr(dout), ptr(dE), ptr(ws), ws_bytes, ids.numel(), d, V, int(pad_idx),
+             float(scale), float(drop_p), int(seed), int(offset), dtype_code(dout), stream_ptr()),
           'pk_embed_bwd')
     return dE
 

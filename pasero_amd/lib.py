@@ -54,6 +54,7 @@ SIGNATURES = {
     'pk_embed_fwd': (I, [P, P, P, P, LL, I, I, LL, F, I, F, ULL, ULL, I, P]),
     'pk_embed_bwd_workspace': (SZ, [LL, LL, I]),
     'pk_embed_bwd': (I, [P, P, P, P, SZ, LL, I, LL, LL, F, F, ULL, ULL, I, P]),
+    'pk_embed_bwd_acc': (I, [P, P, P, P, SZ, LL, I, LL, LL, F, F, ULL, ULL, I, P]),
     'pk_ce_rows': (I, [P, LL, P, P, LL, P, P, P, LL, LL, LL, F, I, P]),
     'pk_ce_finalize': (I, [P, P, P, LL, LL, P, P]),
     'pk_colsum_workspace': (SZ, [LL, LL]),

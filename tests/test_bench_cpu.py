@@ -37,6 +37,11 @@ def test_bench_self_launches_two_ranks():
     assert j['value'] > 0 and 'rehearsal' in j
     # whole-job tokens: both ranks' tokens are in `value`
     assert abs(j['value'] * j['ms_per_step'] * 1e-3 - 2 * j['config']['tokens_per_rank_per_step']) < 1e-6
+    # the reducer explains itself in the line: transport, buckets in launch order and their sizes
+    ar = j['config']['gradient_all_reduce']
+    assert ar['world_size'] == 2 and 'gloo' in ar['transport'] and ar['schedule_trial'] is None
+    assert ar['buckets'] == len(ar['bucket_mib']) >= 2 and abs(sum(ar['bucket_mib']) - ar['total_mib']) < 1e-2
+    assert ar['last_bucket_mib'] == ar['bucket_mib'][-1] and ar['largest_bucket_mib'] == max(ar['bucket_mib'])
 
 
 def test_bench_single_rank_is_not_relaunched():

@@ -390,7 +390,11 @@ def _bf16_bracket(what, loss, got, state, cfg, cpu_batch, true_loss, true, bound
         rows.append((h / max(o, 1e-12), k, h, o))
         if o > 0 and h / o > worst[0]:
             worst = (h / o, k)
-    bad = [(k, round(h, 5), round(o, 5)) for ratio, k, h, o in rows if h > bound * o + 3e-3]
+    # (the cross-attention key projection's gradient is a near-total cancellation — softmax ignores a constant added to every
+    # key — over S keys: what is left of it amplifies any difference in summation order; its plain bound is 20 % where the
+    # others have 5 %, and its bracket is 2 x theirs.  Measured at the C4 pair, S = 1500: 0.84 % against the bf16 oracle's 0.34 %)
+    bad = [(k, round(h, 5), round(o, 5)) for ratio, k, h, o in rows
+           if h > (2 * bound if 'encoder_attn.k_proj' in k else bound) * o + 3e-3]
     print(f'{what} bf16 error bracket: loss hip {e_hip:.2e} / oracle-bf16 {e_o16:.2e}; worst gradient ratio '
           f'{worst[0]:.2f} ({worst[1]}); {len(rows)} gradients')
     assert not bad, (what, bad)

@@ -569,6 +569,46 @@ def test_embedding_backward_runs_across_workgroup_ranges(F, counts):
     assert a[pad].abs().max().item() == 0
 
 
+@pytest.mark.parametrize('dtype,V,d,ntok', [(torch.bfloat16, 8032, 512, 32768), (torch.float32, 1000, 1024, 3000),
+                                            (torch.float16, 300, 136, 777), (torch.bfloat16, 50, 256, 700)])
+def test_embedding_backward_added_into_an_existing_gradient(F, dtype, V, d, ntok):
+    """pk_embed_bwd_acc (the tied table: the lookup's rows added into the projection's dense dW): every row with tokens =
+    fp32(existing) + the fixed-order sum, rounded once — within one rounding of existing + pk_embed_bwd's own result —, rows
+    without tokens and the pad row bit for bit what they were, cut runs (a heavy hitter across workgroup ranges) included,
+    reproducible bit for bit, and the empty batch leaves everything alone"""
+    g = torch.Generator().manual_seed(V * 3 + d)
+    ids = torch.randint(0, V, (ntok,), generator=g)
+    ids[torch.rand(ntok, generator=g) < 0.25] = 2
+    ids[torch.rand(ntok, generator=g) < 0.05] = 1
+    dout = (torch.randn(ntok, d, generator=g) * 0.5).to(dtype).cuda()
+    base = torch.randn(V, d, generator=g).to(dtype).cuda()
+    outs = []
+    for _ in range(2):
+        acc = base.clone()
+        assert F.embed_bwd(ids.cuda(), dout, V, 1, 1.5, drop_p=0.1, seed=3, offset=9, into=acc) is acc
+        outs.append(acc)
+    assert torch.equal(outs[0], outs[1])
+    acc = base.clone()
+    F.embed_bwd(ids.cuda(), dout, V, 1, 1.5, into=acc)
+    ref = base.double().cpu()
+    keep = ids != 1
+    ref.index_add_(0, ids[keep], dout.double().cpu()[keep] * 1.5)
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    assert rel_err(acc, ref.float()) < tol
+    untouched = torch.ones(V, dtype=torch.bool)
+    untouched[ids] = False
+    untouched[1] = True
+    assert torch.equal(acc[untouched.cuda()], base[untouched.cuda()])
+    alone = F.embed_bwd(ids.cuda(), dout, V, 1, 1.5)
+    two_roundings = (base.float() + alone.float()).to(dtype)
+    ulp = 2.0 ** -23 if dtype == torch.float32 else (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11)
+    scale = torch.maximum(base.float().abs(), alone.float().abs()).clamp_min(1e-3)  # (the rounding of `alone` is the larger one)
+    assert ((acc.float() - two_roundings.float()).abs() <= 2.5 * ulp * scale).all()
+    same = base.clone()
+    F.embed_bwd(ids[:0].cuda(), dout[:0], V, 1, 1.0, into=same)
+    assert torch.equal(same, base)
+
+
 @pytest.mark.parametrize('ntok,V', [(1, 50), (2, 8032), (1000, 8032), (4097, 600), (32768, 8032), (32768, 70376), (8192, 256206),
                                     (32767, 131072), (40000, 8032)])
 def test_embedding_backward_sort_sizes(F, ntok, V):

@@ -176,6 +176,44 @@ def test_partially_frozen_embeddings_shared_with_the_decoder_fp32_vs_reference()
     assert merges == 1, merges
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_tied_table_gradient_is_one_tensor(dtype, monkeypatch):
+    """shared embeddings + tied projection (transformer.py:151-153): the table's gradient is the projection's dense dW with the
+    rows of BOTH lookups added in place (pk_embed_bwd_acc; autograd._grad_sinks) — the same gradient as three autograd
+    contributions (fp32: to summation-order round-off; bf16: one rounding instead of three), no offer left behind after the
+    pass, and a second backward pass (retained graph) gives the same result again"""
+    from pasero_amd import autograd, functional as PF
+    g = load_golden('tiny_encdec_post')
+    cfg, model = build_model(g, dtype, 'cuda')
+    assert cfg.shared_embeddings and cfg.tied_output_projection
+    model.train()
+    batch = text_batch(g, 'cuda')
+    calls = []
+    real = PF.embed_bwd
+    monkeypatch.setattr(PF, 'embed_bwd', lambda *a, into=None, **k: (calls.append(into is not None), real(*a, into=into, **k))[1])
+
+    def grads(retain=False):
+        model.zero_grad(set_to_none=True)
+        loss, _ = model(**batch)
+        loss.backward(retain_graph=retain)
+        first = model.encoder.embed_tokens.weight.grad.float().clone()
+        if retain:
+            model.zero_grad(set_to_none=True)
+            loss.backward()
+            assert torch.equal(model.encoder.embed_tokens.weight.grad.float(), first)
+        return first
+    sunk = grads(retain=True)
+    assert calls == [True, True, True, True] and not autograd._grad_sinks, calls
+    del calls[:]
+    monkeypatch.setattr(autograd, '_NO_GRAD_SINK', True)
+    plain = grads()
+    assert calls == [False, False]
+    tol = 1e-6 if dtype == torch.float32 else 1.2e-2
+    assert (sunk - plain).abs().max().item() <= tol * plain.abs().max().item()
+    if dtype == torch.float32:  # and both are the reference's gradient
+        assert rel(sunk, g['grad:encoder.embed_tokens.weight']) < 2e-4
+
+
 def test_adapter_transformer_frozen_backbone_fp32_vs_reference():
     """adapter_transformer (pasero/models/adapters.py): bottleneck adapters after every layer, only they are trained;
     loss, every adapter gradient, logits and argmax against the real reference; frozen parameters get no gradient"""
