@@ -133,6 +133,13 @@ int pk_gemm_wgrad_group(const PkWgradProblem* problems, int n, int dtype, void* 
  *     out[2 b] = problem index, out[2 b + 1] = position in that problem's slab-major (K-slab, tile) walk, both -1 for a
  *     workgroup that exits at once; at most `cap` workgroups are written.  Returns the grid size, -1 on bad arguments. */
 int pk_gemm_wgrad_group_map(const PkWgradProblem* problems, int n, int* out, int cap);
+/*   Round 5: a problem the plan cuts into exactly TWO K-slabs is finished inside the GEMM launch — of the two workgroups of a
+ *     tile the second to arrive adds the first one's fp32 partial (published write-through behind an agent-scope flag) to its
+ *     own and stores the 16-bit tile; fp32 addition commutes, so the result is bit for bit the reduction launch's whatever the
+ *     arrival order.  A group of only such problems (NLLB-1.3B's layers at 8192 rows) has no reduction launch at all.
+ *     pk_gemm_wgrad_pair: diagnostic switch, 1 / 0 = on (default; env PK_WGRAD_PAIR sets the initial value) / every split
+ *     problem through the reduction launch; negative: query only.  Returns the previous setting. */
+int pk_gemm_wgrad_pair(int on);
 
 /* ---- Linear + residual + dropout + LayerNorm in one kernel (K4 fused into K2/K5): replaces the tail of a post-norm
  * sub-block, `x = self.out_proj(x)` / `x = self.fc2(x)` followed by `x = residual + dropout(x); x = LayerNorm(x)`,

@@ -188,7 +188,7 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
                                             T* __restrict__ asum_out, long long M, long long N, long long K,
                                             long long lda, long long ldb, int kchunk, unsigned a_bytes,
                                             unsigned b_bytes, int lin, unsigned long long* stamps,
-                                            const EpiParams& ep) {
+                                            const EpiParams& ep, unsigned* pair_sync = nullptr) {
     typedef typename M16<T>::vec V;
     typedef __attribute__((address_space(3))) void lds_void;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -211,6 +211,7 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     PK_STAMP();  // tile start
     const int kslab = lin / (nt_m * nt_n);
     int t = lin % (nt_m * nt_n);
+    const int tile_id = t;  // (the tile's position in the walk of its problem: what the two workgroups of a pair share)
     const int GROUP_M = nt_n <= 2 ? 8 : 4;
     int group_size = GROUP_M * nt_n, gid = t / group_size, first_m = gid * GROUP_M;
     int gsz = min(nt_m - first_m, GROUP_M);
@@ -465,6 +466,39 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     __syncthreads();
     PK_STAMP();  // K loop done
 
+    // ---- pair mode (grouped weight gradients whose problem has exactly TWO K-slabs): no reduction launch.  The two workgroups
+    // of a tile draw a ticket; the FIRST stores its fp32 partial write-through (`sc1`) and raises the tile's flag, the SECOND
+    // waits for the flag, adds the first one's partial to its own accumulators as they pass through the staging buffer and
+    // stores the finished 16-bit tile — one slab written and read instead of two, and own + other = other + own bit for bit,
+    // so the result does not depend on who came first (and equals the reduction kernel's 0 + slab 0 + slab 1).  The hand-off
+    // is MI355X_MICROARCH.md's valid form "sc1 payload stores -> every storing wave's vmcnt(0) -> workgroup barrier -> ONE
+    // lane's relaxed agent-scope flag store" / "ONE relaxed poll -> ONE agent acquire -> vmcnt(0) -> workgroup barrier ->
+    // plain loads", correct for any placement of the two workgroups.  The second workgroup can only wait for a workgroup that
+    // is already running (it holds ticket 0), so the wait ends whatever the dispatch order; it is bounded all the same.
+    // ticket and flag: pair_sync[2 tile], [2 tile + 1], zeroed by a memset node ahead of every launch.
+    int role = 0;  // 0: not a pair, 1: first to arrive (publishes its slab), 2: second (adds and finishes)
+    unsigned* sync_w = nullptr;
+    if constexpr (A_COL && B_COL && !ANY && !TAIL && !HM) {
+        if (pair_sync) {
+            sync_w = pair_sync + 2 * tile_id;
+            unsigned* lw = reinterpret_cast<unsigned*>(smem + SMEM - 16);  // (the stages are dead; staging uses the first 66 KiB)
+            if (tid == 0) *lw = __hip_atomic_fetch_add(sync_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            role = __builtin_amdgcn_readfirstlane(*lw == 0u ? 1 : 2);
+            if (role == 2) {
+                if (tid == 0) {
+                    for (unsigned spins = 0; spins < (1u << 22); ++spins) {  // (~0.5 s: a lost partner must not hang the GPU)
+                        if (__hip_atomic_load(sync_w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+            }
+        }
+    }
+
     if constexpr (A_COL) {
         if (do_asum) {  // lanes 0..15 of every wave hold the sums of rows 128 mh + 64 wr + 16 wc + lane
             float* red = reinterpret_cast<float*>(smem);  // [256]
@@ -475,7 +509,11 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
             __syncthreads();
             if (tid < BM && m0 + tid < M) {
                 const float sum = red[tid];
-                if (asum_ws) asum_ws[(long long)kslab * M + m0 + tid] = sum;
+                if (role == 1) {  // (part of what the flag publishes)
+                    __hip_atomic_store(asum_ws + (long long)kslab * M + m0 + tid, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (role == 2) {
+                    asum_out[m0 + tid] = from_f32<T>(sum + asum_ws[(long long)(1 - kslab) * M + m0 + tid]);
+                } else if (asum_ws) asum_ws[(long long)kslab * M + m0 + tid] = sum;
                 else asum_out[m0 + tid] = from_f32<T>(sum);
             }
             __syncthreads();
@@ -500,6 +538,23 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     };
     if (pre_aux) aux_load(0);
     constexpr int NPASS = HM ? 2 : 4;
+    // pair mode, second workgroup: this thread's chunks of the first workgroup's slab, one pass ahead of their use
+    float4 oth[4][2];
+    auto other_load = [&](int p) {
+        const int col = (tid & 31) * 8, r0 = tid >> 5;
+        const long long gn = n0 + col;
+        if (gn + 8 > N) return;
+        const float* oslab = ws + (long long)(1 - kslab) * M * N;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const long long gm = m0 + p * 64 + r0 + 16 * it;
+            if (gm < M) {
+                oth[it][0] = *reinterpret_cast<const float4*>(oslab + gm * N + gn);
+                oth[it][1] = *reinterpret_cast<const float4*>(oslab + gm * N + gn + 4);
+            }
+        }
+    };
+    if (role == 2) other_load(0);
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         if (wr == (p & 1)) {  // tile rows [64p, 64p + 64) = row half p >> 1 of the waves with wr == p & 1
@@ -522,7 +577,42 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
             for (int it = 0; it < 4; ++it) av[it] = av_next[it];
             if (p + 1 < NPASS) aux_load(p + 1);
         }
-        if (ws) {  // split-K partial: raw fp32 slab [splitk][M][N]
+        if (ws && role == 2) {  // the pair's second workgroup: own partial (staging buffer) + the first one's slab -> C
+            const int col = (tid & 31) * 8, r0 = tid >> 5;
+            const long long gn = n0 + col;
+            float4 cur[4][2];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) { cur[it][0] = oth[it][0]; cur[it][1] = oth[it][1]; }
+            if (p + 1 < NPASS) other_load(p + 1);  // (one pass ahead, as the aux operand of the single GEMMs)
+            if (gn + 8 <= N) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const long long gm = mh + r0 + 16 * it;
+                    if (gm >= M) continue;
+                    const float* src = cs + (r0 + 16 * it) * CP + col;
+                    const float4 a4 = *reinterpret_cast<const float4*>(src), b4 = *reinterpret_cast<const float4*>(src + 4);
+                    float v[8] = {a4.x + cur[it][0].x, a4.y + cur[it][0].y, a4.z + cur[it][0].z, a4.w + cur[it][0].w,
+                                  b4.x + cur[it][1].x, b4.y + cur[it][1].y, b4.z + cur[it][1].z, b4.w + cur[it][1].w};
+                    store16_nt<T>(C + gm * ep.ldc + gn, vec16_pack<T>(v));
+                }
+            }
+        } else if (ws && role == 1) {  // the pair's first workgroup: its slab, write-through
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ws, 0, (int)(2 * M * N * 4), 0x00020000);
+            const int col = (tid & 31) * 8, r0 = tid >> 5;
+            const long long gn = n0 + col;
+            if (gn + 8 <= N) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const long long gm = mh + r0 + 16 * it;
+                    if (gm >= M) continue;
+                    const float* src = cs + (r0 + 16 * it) * CP + col;
+                    const unsigned off = (unsigned)((((long long)kslab * M + gm) * N + gn) * 4);
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4_t*>(src), rs, (int)off, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4_t*>(src + 4), rs, (int)(off + 16), 0, 16);
+                }
+            }
+        } else if (ws) {  // split-K partial: raw fp32 slab [splitk][M][N]
             float* slab = ws + (long long)kslab * M * N;
             const int col = (tid & 31) * 8, r0 = tid >> 5;
             const long long gn = n0 + col;
@@ -550,6 +640,11 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
             else epilogue_pass<T, PK_ACT_NONE, 2>(cs, C, ep, mh, n0, M, N, tid, av);
         }
         if (p + 1 < NPASS) __syncthreads();
+    }
+    if (role == 1) {  // publish: every storing wave drains its write-through stores, then ONE lane raises the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(sync_w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifdef PK8P_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -835,6 +930,7 @@ struct GroupProb {
     long long M, N, K, lda, ldb, ldc;
     int kchunk, wg_begin, blk_begin, nslab;
     unsigned a_bytes, b_bytes;
+    unsigned* pair_sync;  // pair mode (two K-slabs reduced inside the kernel): [tiles][2] ticket / flag words, else null
 };
 struct GroupArgs {
     GroupProb p[PK_WGRAD_MAX];
@@ -884,7 +980,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_group_kernel(GroupArgs g, Group
     ep.ldaux = 0; ep.ldc = q.ldc; ep.ldpre = 0;
     ep.act = PK_ACT_NONE; ep.mode = 0; ep.alpha = 1.f;
     gemm8p_tile<T, true, true, false, false>((const T*)q.A, (const T*)q.B, (T*)q.C, q.ws, q.asum_ws, (T*)q.asum_out, q.M,
-                                             q.N, q.K, q.lda, q.ldb, q.kchunk, q.a_bytes, q.b_bytes, lin, stamps, ep);
+                                             q.N, q.K, q.lda, q.ldb, q.kchunk, q.a_bytes, q.b_bytes, lin, stamps, ep,
+                                             q.pair_sync);
 }
 
 // C_p = sum over the K-slabs of problem p (fixed order: deterministic), 16-byte chunks; + the fused bias-gradient sums
@@ -1035,6 +1132,10 @@ struct GroupPlan {
     size_t ws_off[PK_WGRAD_MAX], asum_off[PK_WGRAD_MAX];  // in floats
     int total_wgs, total_blks;
     size_t ws_floats;
+    // pair mode: problems with exactly two K-slabs are reduced inside the kernel (gemm8p_tile, role 1 / 2) and own no blocks
+    // of the reduction launch; their ticket / flag words sit behind the slabs ([sync_off, sync_off + sync_words) floats)
+    bool pair[PK_WGRAD_MAX];
+    size_t sync_off[PK_WGRAD_MAX], sync_begin, sync_words;
 };
 
 inline long long tiles256(const PkWgradProblem& q) { return ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN); }
@@ -1061,6 +1162,10 @@ double list_makespan(double dur_long, long long n_long, double dur_short, long l
     }
     return last;
 }
+// pair mode on / off: PK_WGRAD_PAIR=0 in the environment, or pk_gemm_wgrad_pair(0) at run time (how the tests obtain the
+// reduction launch's result as the reference of the in-kernel one, in one process)
+int g_pair_on = [] { const char* e = getenv("PK_WGRAD_PAIR"); return (!e || atoi(e) != 0) ? 1 : 0; }();
+
 void plan_group_uncached(const PkWgradProblem* p, int n, GroupPlan* pl) {
     long long kmax = 0;
     for (int i = 0; i < n; ++i) kmax = std::max(kmax, p[i].K);
@@ -1117,9 +1222,12 @@ void plan_group_uncached(const PkWgradProblem* p, int n, GroupPlan* pl) {
         wg += (int)tiles256(p[i]) * sp;
         pl->blk_begin[i] = blk;
         pl->ws_off[i] = pl->asum_off[i] = 0;
+        // (PK_WGRAD_PAIR=0: every split problem through the reduction launch, as before round 5 — the A/B and the tests'
+        // reference; the slab region of a pair must be addressable through one buffer descriptor: < 2 GiB)
+        pl->pair[i] = g_pair_on && sp == 2 && 2 * p[i].M * p[i].N * 4 < (1LL << 31);
         if (sp > 1) {
             const long long chunks = p[i].M * (p[i].N / 8);
-            blk += (int)std::min(2048LL, (chunks + 255) / 256);
+            if (!pl->pair[i]) blk += (int)std::min(2048LL, (chunks + 255) / 256);
             pl->ws_off[i] = off;
             off += ((size_t)sp * p[i].M * p[i].N + 3) & ~(size_t)3;
             if (p[i].asum_out) {
@@ -1130,16 +1238,24 @@ void plan_group_uncached(const PkWgradProblem* p, int n, GroupPlan* pl) {
     }
     pl->total_wgs = wg;
     pl->total_blks = blk;
+    off = (off + 63) & ~(size_t)63;  // the sync words on 256-byte lines of their own
+    pl->sync_begin = off;
+    for (int i = 0; i < n; ++i) {
+        pl->sync_off[i] = off;
+        if (pl->pair[i]) off += ((size_t)2 * tiles256(p[i]) + 3) & ~(size_t)3;
+    }
+    pl->sync_words = off - pl->sync_begin;
     pl->ws_floats = off;
 }
 // (the plan depends on the shapes and on which problems carry a bias sum: cached — four calls per launch ask for it)
 void plan_group(const PkWgradProblem* p, int n, GroupPlan* pl) {
-    struct Key { long long v[PK_WGRAD_MAX][4]; int n; };
+    struct Key { long long v[PK_WGRAD_MAX][4]; int n, pair_on; };
     static std::mutex mu;
     static std::vector<std::pair<Key, GroupPlan>> cache;
     Key k;
     memset(&k, 0, sizeof k);
     k.n = n;
+    k.pair_on = g_pair_on;
     for (int i = 0; i < n; ++i) { k.v[i][0] = p[i].M; k.v[i][1] = p[i].N; k.v[i][2] = p[i].K; k.v[i][3] = p[i].asum_out != nullptr; }
     {
         std::lock_guard<std::mutex> g(mu);
@@ -1250,6 +1366,12 @@ int plan_map(const PkWgradProblem* p, int n, const GroupPlan& pl, GroupMap* mp) 
 }
 }  // namespace
 
+extern "C" int pk_gemm_wgrad_pair(int on) {
+    const int prev = g_pair_on;
+    if (on >= 0) g_pair_on = on ? 1 : 0;
+    return prev;
+}
+
 // 1 if the problem can ride in a grouped launch: what the dispatcher asks of a 256-tile (col,col) GEMM (gemm.hip)
 extern "C" int pk_gemm8p_group_eligible(const PkWgradProblem* q) {
     auto al = [](const void* p, long long ld) { return ((uintptr_t)p % 16) == 0 && (ld % 8) == 0; };
@@ -1309,8 +1431,13 @@ extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype,
         q.a_bytes = (unsigned)a_bytes; q.b_bytes = (unsigned)b_bytes;
         q.ws = pl.nslab[i] > 1 ? workspace + pl.ws_off[i] : nullptr;
         q.asum_ws = (pl.nslab[i] > 1 && p[i].asum_out) ? workspace + pl.asum_off[i] : nullptr;
+        q.pair_sync = pl.pair[i] ? reinterpret_cast<unsigned*>(workspace + pl.sync_off[i]) : nullptr;
     }
     for (int i = n; i < PK_WGRAD_MAX; ++i) { g.p[i].wg_begin = 0x7fffffff; g.p[i].blk_begin = 0x7fffffff; }
+    if (pl.sync_words) {  // tickets and flags start from zero in EVERY launch (the workspace is shared scratch)
+        hipError_t e = hipMemsetAsync(workspace + pl.sync_begin, 0, pl.sync_words * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) { pk_set_error("pk_gemm_wgrad_group: memset: %s", hipGetErrorString(e)); return (int)e; }
+    }
     unsigned long long* stamps = nullptr;
 #if defined(PK8P_STAMPS) || defined(PKBS_STAMPS)  /* (diagnostic builds only: the shipped library never reads the variable) */
     static unsigned long long* const stamp_buf = [] { const char* e = getenv("PK8P_STAMP_PTR"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
@@ -1335,7 +1462,7 @@ extern "C" int pk_gemm8p_group_reduce(const PkWgradProblem* p, int n, int dtype,
     for (int i = 0; i < n; ++i) {
         GroupProb& q = g.p[i];
         q.C = p[i].C; q.asum_out = p[i].asum_out; q.M = p[i].M; q.N = p[i].N; q.ldc = p[i].ldc;
-        q.nslab = pl.nslab[i];
+        q.nslab = pl.pair[i] ? 1 : pl.nslab[i];  // (a pair is finished inside the GEMM kernel)
         // a problem without slabs owns no blocks: its first block is that of the next split problem (never selected:
         // group_select takes the LAST problem whose first block is <= the block index)
         q.blk_begin = pl.blk_begin[i];

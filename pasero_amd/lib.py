@@ -35,6 +35,7 @@ SIGNATURES = {
     'pk_gemm_wgrad_group_workspace': (SZ, [P, I]),
     'pk_gemm_wgrad_group': (I, [P, I, I, P, SZ, P]),
     'pk_gemm_wgrad_group_map': (I, [P, I, P, I]),
+    'pk_gemm_wgrad_pair': (I, [I]),
     'pk_gemm_ln_eligible': (I, [LL, LL, LL, LL, LL, I]),
     'pk_gemm_ln_fwd': (I, [P] * 10 + [LL] * 6 + [F, F, ULL, ULL, I, P]),
     'pk_decoder_step_scratch': (SZ, [P, I]),

@@ -212,3 +212,71 @@ def test_random_groups(seed):
         k_in = 8 * rnd.randint(32, 160)
         entries.append((*_problem(rows, n_out, k_in, torch.bfloat16, 7 * seed + i), rnd.random() < 0.5))
     _check(entries, torch.bfloat16)
+
+
+def _pair_mode(on):
+    from pasero_amd import lib
+    return lib.load().pk_gemm_wgrad_pair(int(on))
+
+
+def _c5_layer_entries(seed, rows=8192, d=1024, f=8192, decoder=False, dtype=torch.bfloat16):
+    e = [(*_problem(rows, 3 * d, d, dtype, seed), True), (*_problem(rows, d, d, dtype, seed + 1), True),
+         (*_problem(rows, f, d, dtype, seed + 2), True), (*_problem(rows, d, f, dtype, seed + 3), True)]
+    if decoder:
+        e += [(*_problem(rows, d, d, dtype, seed + 4), True), (*_problem(rows, 2 * d, d, dtype, seed + 5), False),
+              (*_problem(rows, d, d, dtype, seed + 6), True)]
+    return e
+
+
+@pytest.mark.parametrize('decoder', [False, True])
+def test_two_slab_problems_are_reduced_inside_the_kernel(decoder):
+    """Round 5 (VERDICT r4 item 1 ii): a problem of exactly two K-slabs is finished by the second of its tile's two workgroups
+    (csrc/gemm8p.hip, pair mode) — NLLB-1.3B's layers at 8192 rows, where the plan has two slabs for q|k|v / out-proj / the
+    cross projections and none for fc1 / fc2.  Weight AND bias gradients bit for bit those of the reduction launch
+    (pk_gemm_wgrad_pair(0)), against fp64, with pad columns in the way and a ragged M."""
+    from pasero_amd import functional as F
+    entries = _c5_layer_entries(50, decoder=decoder)
+    entries.append((*_problem(8192, 1000, 1032, torch.bfloat16, 58, pad_out=8), True))  # ragged M / N / K, padded rows
+    prev = _pair_mode(1)
+    try:
+        got = F.wgrad_group(entries)
+        _pair_mode(0)
+        ref = F.wgrad_group(entries)
+    finally:
+        _pair_mode(prev)
+    for (dy, x, wb), (dw, db), (rw, rb) in zip(entries, got, ref):
+        assert torch.equal(dw, rw), (dy.shape, x.shape)
+        assert (db is None and rb is None) or torch.equal(db, rb)
+        r64 = dy.double().t() @ x.double()
+        assert (dw.double() - r64).abs().max().item() <= 2 ** -8 * r64.abs().max().item()
+    _check(entries, torch.bfloat16)
+
+
+def test_in_kernel_reduction_race_screen():
+    """the hand-off between the two workgroups of a tile (write-through slab -> flag -> acquire -> plain loads) under what
+    would expose a missing release / acquire: 45 launches over THREE different data sets in turn at the same workspace
+    addresses (a stale line of an earlier launch would be another set's numbers, not this one's), while a second stream keeps
+    the memory system busy with copies; every weight and bias gradient bitwise the reduction launch's result for that set"""
+    from pasero_amd import functional as F
+    sets = [_c5_layer_entries(100 + 10 * k, decoder=bool(k & 1)) for k in range(3)]
+    prev = _pair_mode(0)
+    try:
+        refs = [[(dw.clone(), None if db is None else db.clone()) for dw, db in F.wgrad_group(s)] for s in sets]
+        _pair_mode(1)
+        side = torch.cuda.Stream()
+        src = torch.randn(64 << 20, device='cuda')
+        dst = torch.empty_like(src)
+        stop = torch.cuda.Event()
+        for it in range(45):
+            if it % 3 != 2:  # uneven load: two launches in three run beside a 256 MiB copy
+                with torch.cuda.stream(side):
+                    dst.copy_(src)
+            k = (it * 7) % 3
+            out = F.wgrad_group(sets[k])
+            for (dw, db), (rw, rb) in zip(out, refs[k]):
+                assert torch.equal(dw, rw), (it, k)
+                assert (db is None and rb is None) or torch.equal(db, rb), (it, k)
+        stop.record()
+        torch.cuda.synchronize()
+    finally:
+        _pair_mode(prev)
