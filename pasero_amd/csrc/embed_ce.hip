@@ -67,15 +67,21 @@ __device__ __forceinline__ void online_merge(float& m, float& s, float m2, float
     m = mn;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, long long ld,
-                                                 const long long* __restrict__ target, T* __restrict__ dlogits,
-                                                 long long ldd, float* __restrict__ row_loss,
-                                                 float* __restrict__ row_nll, float* __restrict__ row_lse, long long V,
-                                                 long long pad_idx, float eps, bool vec_ok) {
-    constexpr int EPV = 16 / sizeof(T);
-    __shared__ float red_m[4], red_s[4], red_t[4];
-    __shared__ float bc[2];
+// THREADS = 256: the general two-pass kernel (eight workgroups per CU).  THREADS = 1024 with `extern` LDS padding that leaves ONE
+// workgroup per CU: rows too wide for the register-resident kernel (NLLB's 256 206 columns = 512 KB per row).  With eight
+// small workgroups per CU the rows in flight are 256 x 8 x 512 KB = 1 GB and the second pass re-reads its row from HBM;
+// with one wide workgroup per CU they are 128 MB, inside the 256 MiB Infinity Cache, and the second read stays on the die.
+template <typename T, int THREADS, int PAD_FLOATS = 0>
+__global__ __launch_bounds__(THREADS) void ce_kernel(const T* __restrict__ logits, long long ld,
+                                                     const long long* __restrict__ target, T* __restrict__ dlogits,
+                                                     long long ldd, float* __restrict__ row_loss,
+                                                     float* __restrict__ row_nll, float* __restrict__ row_lse, long long V,
+                                                     long long pad_idx, float eps, bool vec_ok) {
+    constexpr int EPV = 16 / sizeof(T), NW = THREADS / 64;
+    // (PAD_FLOATS: LDS nobody uses, declared so that fewer workgroups fit a CU — the statistics live at its start, which keeps
+    // the whole array allocated)
+    __shared__ float red_all[3 * NW + 2 + PAD_FLOATS];
+    float* red_m = red_all, *red_s = red_all + NW, *red_t = red_all + 2 * NW, *bc = red_all + 3 * NW;
     const long long row = blockIdx.x;
     const T* x = logits + row * ld;
     const long long tgt = target[row];
@@ -113,13 +119,13 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, l
             m = mn;
         };
         long long ch = tid;
-        for (; ch + 768 < nvec; ch += 1024) {
-            const Vec16<T> v0 = load16<T>(x + ch * EPV), v1 = load16<T>(x + (ch + 256) * EPV);
-            const Vec16<T> v2 = load16<T>(x + (ch + 512) * EPV), v3 = load16<T>(x + (ch + 768) * EPV);
+        for (; ch + 3 * THREADS < nvec; ch += 4 * THREADS) {
+            const Vec16<T> v0 = load16<T>(x + ch * EPV), v1 = load16<T>(x + (ch + THREADS) * EPV);
+            const Vec16<T> v2 = load16<T>(x + (ch + 2 * THREADS) * EPV), v3 = load16<T>(x + (ch + 3 * THREADS) * EPV);
             take(v0); take(v1); take(v2); take(v3);
         }
-        for (; ch < nvec; ch += 256) take(load16<T>(x + ch * EPV));
-        for (long long c = nvec * EPV + tid; c < V; c += 256) {
+        for (; ch < nvec; ch += THREADS) take(load16<T>(x + ch * EPV));
+        for (long long c = nvec * EPV + tid; c < V; c += THREADS) {
             float a = to_f32<T>(x[c]);
             tot += a;
             online_merge(m, s, a, 1.f);
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, l
         __syncthreads();
         if (tid == 0) {
             float M = red_m[0], S = red_s[0], Tt = red_t[0];
-            for (int w = 1; w < 4; ++w) { online_merge(M, S, red_m[w], red_s[w]); Tt += red_t[w]; }
+            for (int w = 1; w < NW; ++w) { online_merge(M, S, red_m[w], red_s[w]); Tt += red_t[w]; }
             bc[0] = M + __logf(S);
             bc[1] = Tt;
         }
@@ -174,18 +180,18 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ logits, l
     };
     if (active) {
         long long ch = tid;
-        for (; ch + 768 < nvec; ch += 1024) {
-            const Vec16<T> v0 = load16<T>(x + ch * EPV), v1 = load16<T>(x + (ch + 256) * EPV);
-            const Vec16<T> v2 = load16<T>(x + (ch + 512) * EPV), v3 = load16<T>(x + (ch + 768) * EPV);
-            grad(v0, ch); grad(v1, ch + 256); grad(v2, ch + 512); grad(v3, ch + 768);
+        for (; ch + 3 * THREADS < nvec; ch += 4 * THREADS) {
+            const Vec16<T> v0 = load16<T>(x + ch * EPV), v1 = load16<T>(x + (ch + THREADS) * EPV);
+            const Vec16<T> v2 = load16<T>(x + (ch + 2 * THREADS) * EPV), v3 = load16<T>(x + (ch + 3 * THREADS) * EPV);
+            grad(v0, ch); grad(v1, ch + THREADS); grad(v2, ch + 2 * THREADS); grad(v3, ch + 3 * THREADS);
         }
-        for (; ch < nvec; ch += 256) grad(load16<T>(x + ch * EPV), ch);
+        for (; ch < nvec; ch += THREADS) grad(load16<T>(x + ch * EPV), ch);
     } else {
         Vec16<T> o;
         o.raw = {0, 0, 0, 0};
-        for (long long ch = tid; ch < nvec; ch += 256) store16<T>(dx + ch * EPV, o);
+        for (long long ch = tid; ch < nvec; ch += THREADS) store16<T>(dx + ch * EPV, o);
     }
-    for (long long c = nvec * EPV + tid; c < V; c += 256) {
+    for (long long c = nvec * EPV + tid; c < V; c += THREADS) {
         float g = active ? __expf(to_f32<T>(x[c]) - lse) - uni - (c == tgt ? 1.f - eps : 0.f) : 0.f;
         dx[c] = from_f32<T>(g);
     }
@@ -522,9 +528,27 @@ extern "C" int pk_ce_rows(const void* logits, long long ld, const long long* tar
         constexpr int EPV = 16 / sizeof(T);
         bool vec_ok = is_aligned16(logits) && ld % EPV == 0 && (!dlogits || (is_aligned16(dlogits) && ldd % EPV == 0));
         if (!launch_ce_reg<T>((const T*)logits, ld, target, (T*)dlogits, ldd, row_loss, row_nll, row_lse, V, pad_idx, eps, rows,
-                              vec_ok, (hipStream_t)stream))
-            hipLaunchKernelGGL((ce_kernel<T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const T*)logits,
-                               ld, target, (T*)dlogits, ldd, row_loss, row_nll, row_lse, V, pad_idx, eps, vec_ok);
+                              vec_ok, (hipStream_t)stream)) {
+            // rows beyond the register-resident kernel's 98 304 columns, 16-bit: one 1024-thread workgroup per CU (the rows in
+            // flight then fit the Infinity Cache: see ce_kernel).  PK_CE_WIDE_LDS: bytes of LDS padding = workgroups per CU
+            // (default 84 KiB: one workgroup per CU; 0: no padding, two fit — the A/B), PK_CE_WIDE=0: the 256-thread form as before round 5.
+            static const bool wide_on = [] { const char* e = getenv("PK_CE_WIDE"); return !e || atoi(e) != 0; }();
+            static const int wide_lds = [] { const char* e = getenv("PK_CE_WIDE_LDS"); return e ? atoi(e) : 84 * 1024; }();
+            if (wide_on && sizeof(T) == 2 && vec_ok && V / EPV > 12 * 1024) {
+                if (wide_lds > 0)
+                    hipLaunchKernelGGL((ce_kernel<T, 1024, 84 * 256>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
+                                       (const T*)logits, ld, target, (T*)dlogits, ldd, row_loss, row_nll, row_lse, V, pad_idx,
+                                       eps, vec_ok);
+                else
+                    hipLaunchKernelGGL((ce_kernel<T, 1024>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
+                                       (const T*)logits, ld, target, (T*)dlogits, ldd, row_loss, row_nll, row_lse, V, pad_idx,
+                                       eps, vec_ok);
+            }
+            else
+                hipLaunchKernelGGL((ce_kernel<T, 256>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                                   (const T*)logits, ld, target, (T*)dlogits, ldd, row_loss, row_nll, row_lse, V, pad_idx, eps,
+                                   vec_ok);
+        }
     })
     PK_LAUNCH_CHECK();
     return 0;

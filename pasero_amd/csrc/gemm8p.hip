@@ -474,21 +474,27 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     // is MI355X_MICROARCH.md's valid form "sc1 payload stores -> every storing wave's vmcnt(0) -> workgroup barrier -> ONE
     // lane's relaxed agent-scope flag store" / "ONE relaxed poll -> ONE agent acquire -> vmcnt(0) -> workgroup barrier ->
     // plain loads", correct for any placement of the two workgroups.  The second workgroup can only wait for a workgroup that
-    // is already running (it holds ticket 0), so the wait ends whatever the dispatch order; it is bounded all the same.
-    // ticket and flag: pair_sync[2 tile], [2 tile + 1], zeroed by a memset node ahead of every launch.
+    // is already running (it holds the even ticket), so the wait ends whatever the dispatch order; it is bounded all the same.
+    // ticket and flag: pair_sync[2 tile], [2 tile + 1] in a buffer the library owns (zeroed once, when it is allocated).  No
+    // per-launch reset: the ticket only ever counts up, every pair takes exactly two tickets — an even one (first) and the odd one
+    // behind it (second) — and the first workgroup publishes by storing the SECOND's ticket value into the flag; the second
+    // waits until the flag equals its own ticket.  Flag values of earlier launches are smaller tickets, never this one
+    // (a memset node per launch cost 4.7 us of stream time each, more than the reduction launch it was to save).
     int role = 0;  // 0: not a pair, 1: first to arrive (publishes its slab), 2: second (adds and finishes)
     unsigned* sync_w = nullptr;
+    unsigned ticket = 0;
     if constexpr (A_COL && B_COL && !ANY && !TAIL && !HM) {
         if (pair_sync) {
             sync_w = pair_sync + 2 * tile_id;
             unsigned* lw = reinterpret_cast<unsigned*>(smem + SMEM - 16);  // (the stages are dead; staging uses the first 66 KiB)
             if (tid == 0) *lw = __hip_atomic_fetch_add(sync_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
-            role = __builtin_amdgcn_readfirstlane(*lw == 0u ? 1 : 2);
+            ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)*lw);
+            role = (ticket & 1u) ? 2 : 1;
             if (role == 2) {
                 if (tid == 0) {
                     for (unsigned spins = 0; spins < (1u << 22); ++spins) {  // (~0.5 s: a lost partner must not hang the GPU)
-                        if (__hip_atomic_load(sync_w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                        if (__hip_atomic_load(sync_w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ticket) break;
                         __builtin_amdgcn_s_sleep(4);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -644,7 +650,7 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     if (role == 1) {  // publish: every storing wave drains its write-through stores, then ONE lane raises the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(sync_w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(sync_w + 1, ticket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifdef PK8P_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1165,6 +1171,23 @@ double list_makespan(double dur_long, long long n_long, double dur_short, long l
 // pair mode on / off: PK_WGRAD_PAIR=0 in the environment, or pk_gemm_wgrad_pair(0) at run time (how the tests obtain the
 // reduction launch's result as the reference of the in-kernel one, in one process)
 int g_pair_on = [] { const char* e = getenv("PK_WGRAD_PAIR"); return (!e || atoi(e) != 0) ? 1 : 0; }();
+// the ticket / flag words of pair mode: one buffer per device, owned by the library, zeroed once; launches on ONE stream at a
+// time use it (as they do the split-K workspace the caller hands in)
+constexpr size_t PAIR_SYNC_WORDS = 64 * 1024;
+unsigned* pair_sync_buffer() {
+    static std::mutex mu;
+    static unsigned* buf[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    if (!buf[dev]) {
+        unsigned* p = nullptr;
+        if (hipMalloc((void**)&p, PAIR_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, PAIR_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        buf[dev] = p;
+    }
+    return buf[dev];
+}
 
 void plan_group_uncached(const PkWgradProblem* p, int n, GroupPlan* pl) {
     long long kmax = 0;
@@ -1238,14 +1261,33 @@ void plan_group_uncached(const PkWgradProblem* p, int n, GroupPlan* pl) {
     }
     pl->total_wgs = wg;
     pl->total_blks = blk;
-    off = (off + 63) & ~(size_t)63;  // the sync words on 256-byte lines of their own
-    pl->sync_begin = off;
-    for (int i = 0; i < n; ++i) {
-        pl->sync_off[i] = off;
-        if (pl->pair[i]) off += ((size_t)2 * tiles256(p[i]) + 3) & ~(size_t)3;
-    }
-    pl->sync_words = off - pl->sync_begin;
     pl->ws_floats = off;
+    // ticket / flag words of the pairs: offsets into the library's sync buffer (pair_sync_buffer); a group that would not
+    // fit keeps its last problems on the reduction launch
+    size_t words = 0;
+    pl->sync_begin = 0;
+    for (int i = 0; i < n; ++i) {
+        pl->sync_off[i] = words;
+        if (!pl->pair[i]) continue;
+        const size_t need = ((size_t)2 * tiles256(p[i]) + 63) & ~(size_t)63;  // (256-byte lines of its own per problem)
+        if (words + need > PAIR_SYNC_WORDS) {
+            pl->pair[i] = false;
+            pl->blk_begin[i] = -1;  // (marks: needs its blocks after all — fixed up below)
+            continue;
+        }
+        words += need;
+    }
+    pl->sync_words = words;
+    bool redo = false;
+    for (int i = 0; i < n; ++i) redo |= pl->blk_begin[i] < 0;
+    if (redo) {  // re-deal the reduction blocks now that some problems lost their pair status
+        int b = 0;
+        for (int i = 0; i < n; ++i) {
+            pl->blk_begin[i] = b;
+            if (pl->nslab[i] > 1 && !pl->pair[i]) b += (int)std::min(2048LL, (p[i].M * (p[i].N / 8) + 255) / 256);
+        }
+        pl->total_blks = b;
+    }
 }
 // (the plan depends on the shapes and on which problems carry a bias sum: cached — four calls per launch ask for it)
 void plan_group(const PkWgradProblem* p, int n, GroupPlan* pl) {
@@ -1418,6 +1460,8 @@ extern "C" int pk_gemm8p_group_map(const PkWgradProblem* p, int n, int* out, int
 extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream) {
     GroupPlan pl;
     plan_group(p, n, &pl);
+    unsigned* sync_buf = pl.sync_words ? pair_sync_buffer() : nullptr;
+    if (pl.sync_words && !sync_buf) { pk_set_error("pk_gemm_wgrad_group: no sync buffer for the in-kernel reduction"); return (int)hipErrorOutOfMemory; }
     GroupArgs g;
     g = GroupArgs{};
     g.n = n;
@@ -1431,13 +1475,9 @@ extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype,
         q.a_bytes = (unsigned)a_bytes; q.b_bytes = (unsigned)b_bytes;
         q.ws = pl.nslab[i] > 1 ? workspace + pl.ws_off[i] : nullptr;
         q.asum_ws = (pl.nslab[i] > 1 && p[i].asum_out) ? workspace + pl.asum_off[i] : nullptr;
-        q.pair_sync = pl.pair[i] ? reinterpret_cast<unsigned*>(workspace + pl.sync_off[i]) : nullptr;
+        q.pair_sync = pl.pair[i] ? sync_buf + pl.sync_off[i] : nullptr;
     }
     for (int i = n; i < PK_WGRAD_MAX; ++i) { g.p[i].wg_begin = 0x7fffffff; g.p[i].blk_begin = 0x7fffffff; }
-    if (pl.sync_words) {  // tickets and flags start from zero in EVERY launch (the workspace is shared scratch)
-        hipError_t e = hipMemsetAsync(workspace + pl.sync_begin, 0, pl.sync_words * sizeof(float), (hipStream_t)stream);
-        if (e != hipSuccess) { pk_set_error("pk_gemm_wgrad_group: memset: %s", hipGetErrorString(e)); return (int)e; }
-    }
     unsigned long long* stamps = nullptr;
 #if defined(PK8P_STAMPS) || defined(PKBS_STAMPS)  /* (diagnostic builds only: the shipped library never reads the variable) */
     static unsigned long long* const stamp_buf = [] { const char* e = getenv("PK8P_STAMP_PTR"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();

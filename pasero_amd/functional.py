@@ -156,10 +156,10 @@ def fwd_split(M: int, N: int, K: int, dtype) -> int:
     """csrc/layer.cpp: fwd_split — forward GEMMs are not split as a rule; the exception is a projection back to d from a long
     contraction at a few thousand rows (NLLB-1.3B's fc2, 8192 -> 1024, at the IWSLT recipe's 2048-row decoder batch: 32 tiles of
     256 x 256, 123 us on the 128-tile kernel, ~40 as K-slabs + reduction).  16-bit types only (fp32 is the parity path).
-    The rule gates on M: within 512..2048 rows (multiples of 256) the slab count depends on N and K alone, so a batch and its
-    halves compute the same rows bit for bit THERE; across the boundary (a 4096-row batch against its 2048-row halves, an
-    evaluation batch against a training batch) fc2's summation order differs — 4 partial sums of K / 4 added in fp32 against
-    one chain over K — and the rows agree to fp32 round-off of the accumulation, not bitwise
+    The rule gates on M, and pk_gemm re-derives its own slab count from the output's tile count: the number of partial sums of
+    a row's contraction therefore depends on the batch's row count (one chain at 4096 rows, 8 slabs of the 256-tile kernel at
+    2048, 4 of the 128-tile kernel at 1024).  The same row in batches of different sizes agrees to the fp32 round-off of the
+    accumulation — at most one ulp of the 16-bit output — never bitwise by construction
     (tests/test_native_layer_gpu.py::test_forward_split_boundary_moves_rows_by_round_off_only pins that deviation).  The
     native layer applies the same rule (the two paths stay bit for bit equal)."""
     if dtype == torch.float32:

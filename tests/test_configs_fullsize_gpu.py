@@ -154,14 +154,17 @@ def test_c4_iwslt_recipe_full_size():
              'prompt_mask': torch.from_numpy(tb['prompt_mask']).cuda()}
     cfg, model = build(dropout=0.0, attention_dropout=0.0)
     assert (cfg.encoder_layers, cfg.decoder_layers, cfg.embed_dim, cfg.conv_kernel_sizes, cfg.input_dim) == (24, 24, 1024, [5], 1024)
-    assert sorted(int(k) for k in range(24) if len(model.encoder.layers[k].adapters)) == list(range(3, 24))
+    assert [k for k in range(24) if len(getattr(model.encoder.layers[k], 'adapters', ()))] == list(range(3, 24))
     with torch.no_grad():
         enc_out, enc_mask, _ = model.encoder(batch['encoder_input'], batch['encoder_input_length'])
     assert enc_out.shape == (B, 500, 1024) and not enc_mask.any()
     watch = ['encoder.in_linear.0.weight', 'encoder.subsample.conv_layers.0.weight', 'encoder.layers.0.fc1.weight',
              'encoder.layers.2.self_attn.q_proj.weight', 'encoder.layers.3.adapters.default.down.weight',
              'encoder.layers.23.adapters.default.up.weight', 'encoder.layers.12.adapters.default.layer_norm.weight']
-    full, logs = _halves_property(model, batch, watch, B)
+    # (loss 1e-4, not 2e-5: the decoder batch is 2048 rows whole and 1024 rows halved, on two sides of functional.fwd_split's
+    # row gate — fc2's contraction is summed in another number of partial sums and single outputs move by one bf16 ulp,
+    # tests/test_native_layer_gpu.py::test_forward_split_boundary_moves_rows_by_round_off_only; measured 2.2e-5)
+    full, logs = _halves_property(model, batch, watch, B, loss_tol=1e-4)
     assert logs['num_tokens'] == int((batch['decoder_input'][:, 1:] != cfg.padding_idx).sum())
     trained = {n for n, p in model.named_parameters() if p.requires_grad}
     assert 20 < len(trained) < sum(1 for _ in model.parameters()) // 2

@@ -602,7 +602,7 @@ def test_embedding_backward_added_into_an_existing_gradient(F, dtype, V, d, ntok
     alone = F.embed_bwd(ids.cuda(), dout, V, 1, 1.5)
     two_roundings = (base.float() + alone.float()).to(dtype)
     ulp = 2.0 ** -23 if dtype == torch.float32 else (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11)
-    scale = torch.maximum(base.float().abs(), alone.float().abs()).clamp_min(1e-3)  # (the rounding of `alone` is the larger one)
+    scale = torch.maximum(torch.maximum(base.float().abs(), alone.float().abs()), acc.float().abs()).clamp_min(1e-3)
     assert ((acc.float() - two_roundings.float()).abs() <= 2.5 * ulp * scale).all()
     same = base.clone()
     F.embed_bwd(ids[:0].cuda(), dout[:0], V, 1, 1.0, into=same)
@@ -664,10 +664,11 @@ def test_cross_entropy_rows(F, dtype, eps, V):
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('V,ld', [(1000, 1000), (8192, 8192), (32000, 32000), (50004, 50008), (98304, 98304), (98312, 98312),
-                                   (256206, 256208)])
+                                   (256206, 256208), (131080, 131080), (300000, 300000)])
 def test_cross_entropy_rows_register_resident(F, dtype, V, ld):
     """16-bit rows of up to 98 304 columns stay in registers between the statistics and the gradient pass (`ce_reg_kernel`:
-    4 vectors x 256 threads, 4 / 12 vectors x 1024 threads); wider rows (NLLB's 256 206) and fp32 take the two-pass kernel.
+    4 vectors x 256 threads, 4 / 12 vectors x 1024 threads); wider rows (NLLB's 256 206) take the two-pass kernel as ONE
+    1024-thread workgroup per CU (round 5: the rows in flight then fit the Infinity Cache), fp32 the 256-thread two-pass kernel.
     Every instantiation and both sides of each boundary, a row pitch padded to 8 with a scalar tail (50 004 in rows of 50 008,
     256 206 in 256 208: the pad columns must come back as zeros), padding targets, the gradient written over the logits —
     against the oracle's label-smoothed cross-entropy in fp32 (transformer.py:324-380)."""

@@ -222,9 +222,11 @@ def test_prenorm_input_fork_with_one_output_unused():
 
 
 def test_forward_split_boundary_moves_rows_by_round_off_only():
-    """functional.fwd_split gates on M (512..2048 rows), so fc2 of NLLB-1.3B (8192 -> 1024) sums 4 K-slabs at 2048
-    rows and one chain at 4096: the same rows agree to the fp32 round-off of that accumulation — at most one bf16 ulp on a
-    small fraction of the outputs — and inside the range a batch and its halves are bit for bit equal"""
+    """functional.fwd_split gates on M (512..2048 rows) and pk_gemm re-derives its own slab count from the tile count,
+    so the number of partial sums in fc2 of NLLB-1.3B (8192 -> 1024) depends on the batch's row count: one chain at 4096 rows,
+    8 slabs of the 256-tile kernel at 2048, 4 slabs of the 128-tile kernel at 1024.  What holds, and is pinned here: the same
+    row in batches of different sizes agrees to the fp32 round-off of the accumulation — at most one bf16 ulp, on a small
+    fraction of the outputs — and every variant is within one ulp of the fp64 product."""
     torch.manual_seed(5)
     K, N = 8192, 1024
     a = (torch.randn(4096, K, device='cuda') * 0.5).bfloat16()
@@ -233,14 +235,18 @@ def test_forward_split_boundary_moves_rows_by_round_off_only():
     whole = F.gemm(a, w, splitk=F.fwd_split(4096, N, K, a.dtype))
     halves = torch.cat([F.gemm(a[i:i + 2048], w, splitk=4) for i in (0, 2048)])
     quarters = torch.cat([F.gemm(a[i:i + 1024], w, splitk=4) for i in range(0, 4096, 1024)])
-    assert torch.equal(halves, quarters)
     ref = a.double() @ w.double().t()
-    ulp = 2.0 ** (torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)  # bf16: 8 significant bits
-    d = (whole.double() - halves.double()).abs()
-    assert (d <= ulp * 1.001).all(), (d / ulp).max().item()
-    assert (d > 0).float().mean().item() < 0.05
-    for t in (whole, halves):
+    # one bf16 ulp of the exact value (8 significant bits); below 2^-6 the fp32 accumulation error of an 8192-term sum of
+    # O(0.5 x 0.01) products (~1e-5) is no longer small against an ulp of the value, so the scale stops shrinking there
+    ulp = 2.0 ** (torch.floor(torch.log2(ref.abs().clamp_min(2.0 ** -6))) - 7)
+    for other in (halves, quarters):
+        d = (whole.double() - other.double()).abs()
+        assert (d <= ulp * 1.001).all(), (d / ulp).max().item()
+        assert (d > 0).float().mean().item() < 0.05
+    for t in (whole, halves, quarters):
         assert ((t.double() - ref).abs() <= ulp * 1.001).all()
+    # the rule itself is deterministic: the same batch twice is the same bits
+    assert torch.equal(halves, torch.cat([F.gemm(a[i:i + 2048], w, splitk=4) for i in (0, 2048)]))
 
 
 def test_encoder_gradient_chain_belongs_to_the_decoder_pass():

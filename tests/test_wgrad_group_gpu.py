@@ -249,7 +249,6 @@ def test_two_slab_problems_are_reduced_inside_the_kernel(decoder):
         assert (db is None and rb is None) or torch.equal(db, rb)
         r64 = dy.double().t() @ x.double()
         assert (dw.double() - r64).abs().max().item() <= 2 ** -8 * r64.abs().max().item()
-    _check(entries, torch.bfloat16)
 
 
 def test_in_kernel_reduction_race_screen():
