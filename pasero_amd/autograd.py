@@ -603,6 +603,9 @@ class FFNResidualLnFn(Function):
         return dx, dw1, db1, dw2, db2, None, dgamma, dbeta, None, None, None
 
 
+_ADAPTER_R4 = os.environ.get('PASERO_ADAPTER_R4', '0') not in ('', '0')  # (A/B: the adapter backward as before round 5)
+
+
 class AdapterFn(Function):
     """y = res + s · up(act(down(LN(x))))   — the bottleneck adapter of Bapna et al. and, without LayerNorm / biases /
     activation and with `res` = the frozen layer's output, LoRA (pasero/models/modules.py:248-370 AdapterLayer.forward,
@@ -641,20 +644,41 @@ class AdapterFn(Function):
         s = ctx.scaling
         dup_w = dup_b = ddown_w = ddown_b = dln_w = dln_b = dx = None
         want_ub = ctx.has_ub and ng[8]
-        if ng[7] or want_ub:
-            dup_w, dup_b = _wgrad(dy2, a, ng[7], want_ub)
-            if s != 1.0:
-                dup_w = F.scale(dup_w, None, s) if dup_w is not None else None
-                dup_b = F.scale(dup_b, None, s) if dup_b is not None else None
+        want_db = ctx.has_db and ng[6]
         need_da = ng[0] or ng[2] or ng[3] or ng[5] or ng[6]
+        da = None
         if need_da:
+            # d(pre-activation) = s · (dY · W_up) ⊙ act′: a contraction over d into <= 64 columns.  As a (row, col) product it
+            # ran on the 128-tile kernel (16 000 x 64, K = 1024: 37 us); over a transposed copy of W_up (64 x d: 128 KB) it is a
+            # (row, row) product the few-rows kernel takes (22 us), act′ in its epilogue
+            b, b_col = up_w, True
+            if up_w.size(1) <= 64 and up_w.size(0) % 64 == 0 and dy2.dtype != torch.float32 and not _ADAPTER_R4:
+                b, b_col = up_w.t().contiguous(), False
             if ctx.act == 'none':
-                da = F.gemm(dy2, up_w, b_col=True, alpha=s)
-            else:  # d(pre-activation) = s · (dY · W_up) ⊙ act′
-                da = F.gemm(dy2, up_w, b_col=True, alpha=s, act=ctx.act, aux=a if pre is None else pre, mode=2)
-            want_db = ctx.has_db and ng[6]
-            if ng[5] or want_db:
-                ddown_w, ddown_b = _wgrad(da, h, ng[5], want_db)
+                da = F.gemm(dy2, b, b_col=b_col, alpha=s)
+            else:
+                da = F.gemm(dy2, b, b_col=b_col, alpha=s, act=ctx.act, aux=a if pre is None else pre, mode=2)
+        # the two weight gradients (d x r and r x d, contraction over all rows) in ONE grouped launch where the kernel takes
+        # them (16-bit, r >= 64: pk_gemm_wgrad_group_eligible), bias sums included; one by one otherwise
+        probs = []
+        if ng[7] or want_ub:
+            probs.append(('up', dy2, a, ng[7], want_ub))
+        if need_da and (ng[5] or want_db):
+            probs.append(('down', da, h, ng[5], want_db))
+        grouped = (len(probs) == 2 and not _ADAPTER_R4
+                   and all(w and F.wgrad_group_eligible(g_, x_) for _, g_, x_, w, _ in probs))
+        if grouped:
+            (dup_w, dup_b), (ddown_w, ddown_b) = F.wgrad_group([(g_, x_, wb) for _, g_, x_, _, wb in probs])
+        else:
+            for name, g_, x_, w, wb in probs:
+                if name == 'up':
+                    dup_w, dup_b = _wgrad(g_, x_, w, wb)
+                else:
+                    ddown_w, ddown_b = _wgrad(g_, x_, w, wb)
+        if s != 1.0:
+            dup_w = F.scale(dup_w, None, s) if dup_w is not None else None
+            dup_b = F.scale(dup_b, None, s) if dup_b is not None else None
+        if need_da:
             if ng[0] or ng[2] or ng[3]:
                 if ctx.has_ln:
                     dh = F.gemm(da, down_w, b_col=True)

@@ -796,7 +796,10 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         // too much of A: N = 1536 / 2048 at K = 512 8.8 -> 12.2 / 9.0 -> 15.4 us, they stay on the tiles.  C4 step -0.25 ms.)
         // (round 4: any number of rows for outputs of <= 64 columns — an adapter's down-projection, 16 000 x 64 with K = 1024: the
         // weight is 128 KB, re-reading it per 64-row block costs nothing, while the 128-tile kernel ran it at 1.2 TB/s: 28 -> 9 us)
-        if (!a_col && !b_col && (M <= 64 || (M <= 256 && N <= 8192) || (M <= 1024 && N <= 512) || N <= 64) && splitk <= 1 && !asum_out &&
+        // (PK_SKINNY_M2 / PK_SKINNY_N2: the second row / column bound, 1024 / 512 by default — the experiment knob of round 5)
+        static const long long sk_m2 = [] { const char* e = getenv("PK_SKINNY_M2"); return e ? atoll(e) : 1024LL; }();
+        static const long long sk_n2 = [] { const char* e = getenv("PK_SKINNY_N2"); return e ? atoll(e) : 512LL; }();
+        if (!a_col && !b_col && (M <= 64 || (M <= 256 && N <= 8192) || (M <= sk_m2 && N <= sk_n2) || N <= 64) && splitk <= 1 && !asum_out &&
             !no_skinny) {
             GemmSample* sm = timing_begin(64, a_col, b_col, 1, dtype16, M, N, K, stream);  // (sample tag 64: the few-rows kernel)
             int rc = pk_gemm_skinny_launch(A, B, C, M, N, K, lda, ldb, ep, dtype16, stream);
@@ -848,8 +851,13 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
             // for the fc2 dX (8192 x 1024 x 8192) where the unsplit 128 x 256 tiles take 111 (round 5; PK_GEMM_HM_NOSPLIT=0: A/B)
             static const bool hm_nosplit = [] { const char* e = getenv("PK_GEMM_HM_NOSPLIT"); return !e || atoi(e) != 0; }();
             static const bool halfm_env = [] { const char* e = getenv("PK_GEMM_HALFM"); return !e || atoi(e) != 0; }();
+            // (PK_GEMM_HM_SMALL: experiment of round 5 — a few thousand rows x d with a d-long contraction, the frozen 2048-row
+            // decoder projections of the IWSLT recipe: 64 tiles of 128 x 256 instead of 128 tiles of 128 x 128 with two K slices)
+            static const bool hm_small = [] { const char* e = getenv("PK_GEMM_HM_SMALL"); return e && atoi(e) != 0; }();
+            const long long t_half_pre = ((M + 127) / 128) * ((N + 255) / 256);
+            const bool small_hm = hm_small && M <= 4096 && t_half_pre >= 48 && t_half_pre < 160 && K8 >= 1024 && N % 256 == 0;
             const bool hm_takes_it = hm_nosplit && halfm_env && e8 && t256 < 160 && !a_col && !asum_out && lean_epi &&
-                                     ((M + 127) / 128) * ((N + 255) / 256) >= 160 && tile_pref != 256 && g_use_8p != 2;
+                                     (t_half_pre >= 160 || small_hm) && tile_pref != 256 && g_use_8p != 2;
             if (splitk > 1 && hm_takes_it) splitk = 1;
             if (splitk > 1 && (sk_mode == 2 || t256 < sk_min_tiles)) sk = 0;
             else if (splitk > 1) {  // the caller allows split-K: re-derive the factor for 256-tiles (~1 workgroup per CU)
@@ -866,7 +874,7 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
             // form (128 x 256 tiles) gives every CU one.  Lean epilogues, row-form A, no split-K.  PK_GEMM_HALFM=0: off (A/B).
             static const bool halfm_on = [] { const char* e = getenv("PK_GEMM_HALFM"); return !e || atoi(e) != 0; }();
             const long long t_half = ((M + 127) / 128) * ((N + 255) / 256);
-            const bool half_m = halfm_on && e8 && !fills && sk == 1 && !a_col && !asum_out && lean_epi && t_half >= 160 && tile_pref != 256 && g_use_8p != 2;
+            const bool half_m = halfm_on && e8 && !fills && sk == 1 && !a_col && !asum_out && lean_epi && (t_half >= 160 || small_hm) && tile_pref != 256 && g_use_8p != 2;
             if (sk > 0 && (tile_pref == 256 || fills || half_m || (g_use_8p == 2 && e8))) {
                 float* w2 = sk > 1 ? (float*)workspace : nullptr;
                 float* asw = (sk > 1 && asum_out) ? w2 + (size_t)sk * M * N : nullptr;

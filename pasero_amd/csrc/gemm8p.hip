@@ -1418,7 +1418,10 @@ extern "C" int pk_gemm_wgrad_pair(int on) {
 extern "C" int pk_gemm8p_group_eligible(const PkWgradProblem* q) {
     auto al = [](const void* p, long long ld) { return ((uintptr_t)p % 16) == 0 && (ld % 8) == 0; };
     if (!q->A || !q->B || !q->C) return 0;
-    if (q->M < 256 || q->N < 256 || q->K < 64 || q->N % 8) return 0;
+    // (round 5: outputs down to 64 rows / columns ride too — an adapter's d x 64 and 64 x d weight gradients fill a quarter of
+    // their 256-tiles, but what they cost is the one pass over the 16 000 x 1024 operand, which the group's K-slabs spread over
+    // the chip; one by one they ran as 128-tile split-K GEMMs + a reduction launch each: 21 + 23 + 2 x 6 us -> one launch)
+    if (q->M < 64 || q->N < 64 || (q->M < 256 && q->N < 256) || q->K < 64 || q->N % 8) return 0;
     if (!al(q->A, q->lda) || !al(q->B, q->ldb) || !al(q->C, q->ldc)) return 0;
     if (q->M % 8 && q->lda < ((q->M + 7) & ~7LL)) return 0;
     if (tiles256(*q) > 4096) return 0;

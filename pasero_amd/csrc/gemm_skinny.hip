@@ -10,6 +10,7 @@
 //     memory in MFMA layout (16 B per lane, k contiguous: lane (r, h) holds row r, k = 8h..8h+7 of the k-step) with a
 //     whole unrolled batch of loads in flight before the first MFMA;
 //   * the four partial tiles meet in LDS (fp32), then bias / activation / residual and 16-byte stores.
+#include <cstdlib>
 #include "common.h"
 #include "gemm_epi.h"
 
@@ -75,14 +76,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
     Vec16<T> bv, av;
     const bool full = gn + 8 <= N;
     if (ep.bias && full) bv = load16<T>(reinterpret_cast<const T*>(ep.bias) + gn);
-    if (MODE == 1 && full) av = load16<T>(reinterpret_cast<const T*>(ep.aux) + gm * ep.ldaux + gn);
+    if (MODE != 0 && full) av = load16<T>(reinterpret_cast<const T*>(ep.aux) + gm * ep.ldaux + gn);
     Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float y = v[e] * ep.alpha;
-        if (ep.bias) y += full ? bv.get(e) : (gn + e < N ? to_f32(reinterpret_cast<const T*>(ep.bias)[gn + e]) : 0.f);
-        y = act_fwd_t<T>(ACT, y);
-        if (MODE == 1) y += full ? av.get(e) : (gn + e < N ? to_f32(reinterpret_cast<const T*>(ep.aux)[gm * ep.ldaux + gn + e]) : 0.f);
+        if (MODE == 2) {  // the act'-mask epilogue (pk_gemm mode 2: C = alpha * A B^T * act'(aux), no bias) — an adapter's dA
+            const float a = full ? av.get(e) : (gn + e < N ? to_f32(reinterpret_cast<const T*>(ep.aux)[gm * ep.ldaux + gn + e]) : 0.f);
+            y *= act_bwd_t<T>(ACT, a);
+        } else {
+            if (ep.bias) y += full ? bv.get(e) : (gn + e < N ? to_f32(reinterpret_cast<const T*>(ep.bias)[gn + e]) : 0.f);
+            y = act_fwd_t<T>(ACT, y);
+            if (MODE == 1) y += full ? av.get(e) : (gn + e < N ? to_f32(reinterpret_cast<const T*>(ep.aux)[gm * ep.ldaux + gn + e]) : 0.f);
+        }
         v[e] = y;
     }
     o = vec16_pack<T>(v);
@@ -100,8 +106,10 @@ extern "C" int pk_gemm_skinny_launch(const void* A, const void* B, void* C, long
                                      long long lda, long long ldb, EpiParams ep, int dtype, void* stream) {
     const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) && lda % 8 == 0 &&
                          ldb % 8 == 0 && ep.ldc % 8 == 0 && (!ep.bias || (uintptr_t)ep.bias % 16 == 0) &&
-                         (ep.mode != 1 || ((uintptr_t)ep.aux % 16 == 0 && ep.ldaux % 8 == 0));
-    if (!aligned || (M > 1024 && N > 64) || M > 64LL * 65535 || K % 64 != 0 || K <= 0 || ep.preact || ep.mode > 1) return 0;
+                         (ep.mode == 0 || ((uintptr_t)ep.aux % 16 == 0 && ep.ldaux % 8 == 0));
+    static const long long sk_m2 = [] { const char* e = getenv("PK_SKINNY_M2"); return e ? atoll(e) : 1024LL; }();
+    if (!aligned || (M > sk_m2 && N > 64) || M > 64LL * 65535 || K % 64 != 0 || K <= 0 || ep.preact || ep.mode > 2) return 0;
+    if (ep.mode == 2 && ep.bias) return 0;
     dim3 grid((unsigned)((N + SK_BN - 1) / SK_BN), (unsigned)((M + SK_BM - 1) / SK_BM)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define SK_T(TT, ACT, MD) \
@@ -109,9 +117,9 @@ extern "C" int pk_gemm_skinny_launch(const void* A, const void* B, void* C, long
 #define SK_L(ACT)                                                       \
     do {                                                                \
         if (dtype == PK_F16) {                                          \
-            if (ep.mode == 0) SK_T(f16, ACT, 0); else SK_T(f16, ACT, 1); \
+            if (ep.mode == 0) SK_T(f16, ACT, 0); else if (ep.mode == 1) SK_T(f16, ACT, 1); else SK_T(f16, ACT, 2); \
         } else {                                                        \
-            if (ep.mode == 0) SK_T(bf16, ACT, 0); else SK_T(bf16, ACT, 1); \
+            if (ep.mode == 0) SK_T(bf16, ACT, 0); else if (ep.mode == 1) SK_T(bf16, ACT, 1); else SK_T(bf16, ACT, 2); \
         }                                                               \
     } while (0)
     switch (ep.act) {

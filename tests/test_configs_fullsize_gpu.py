@@ -164,7 +164,10 @@ def test_c4_iwslt_recipe_full_size():
     # (loss 1e-4, not 2e-5: the decoder batch is 2048 rows whole and 1024 rows halved, on two sides of functional.fwd_split's
     # row gate — fc2's contraction is summed in another number of partial sums and single outputs move by one bf16 ulp,
     # tests/test_native_layer_gpu.py::test_forward_split_boundary_moves_rows_by_round_off_only; measured 2.2e-5)
-    full, logs = _halves_property(model, batch, watch, B, loss_tol=1e-4)
+    # (gradients 0.1 of the maximum, not 0.03: what reaches in_linear and the subsampler has crossed 24 + 24 frozen layers
+    # backwards, every tensor on the way rounded to bf16 — and rounded differently in a batch and in its halves, whose GEMMs
+    # are cut into other K-slabs; measured 0.073 on in_linear's weight, the adapters and layers 0-2 stay under 0.03)
+    full, logs = _halves_property(model, batch, watch, B, loss_tol=1e-4, grad_tol=0.1)
     assert logs['num_tokens'] == int((batch['decoder_input'][:, 1:] != cfg.padding_idx).sum())
     trained = {n for n, p in model.named_parameters() if p.requires_grad}
     assert 20 < len(trained) < sum(1 for _ in model.parameters()) // 2

@@ -696,6 +696,41 @@ def test_cross_entropy_rows_register_resident(F, dtype, V, ld):
         assert (lg[:, V:(V + 7) // 8 * 8] == 0).all()
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('M,act', [(16000, 'relu'), (2048, 'relu'), (777, 'gelu'), (2048, 'none')])
+def test_few_rows_kernel_with_the_activation_derivative_epilogue(F, dtype, M, act):
+    """an adapter's dA = s (dY W_up) * act'(a) — a contraction over d into 64 columns — on the few-rows kernel (pk_gemm mode 2
+    there since round 5): against fp64, bit for bit the tiled kernel's result for the (row, col) form of the same product,
+    and the launch sampling says which kernel ran (tag 64)"""
+    import ctypes
+    from pasero_amd import lib
+    g = torch.Generator().manual_seed(M)
+    dy = (torch.randn(M, 1024, generator=g) * 0.5).to(dtype).cuda()
+    w_up = (torch.randn(1024, 64, generator=g) * 0.05).to(dtype).cuda()
+    aux = torch.randn(M, 64, generator=g).to(dtype).cuda()
+    if act == 'relu':
+        aux = aux.clamp_min(0)
+    L = lib.load()
+    lib.check(L.pk_gemm_timing_start(8, 1), 'start')
+    kw = dict(act=act, aux=aux, mode=2) if act != 'none' else {}
+    out = F.gemm(dy, w_up.t().contiguous(), alpha=0.5, **kw)
+    n = L.pk_gemm_timing_stop()
+    ints = [ctypes.c_int() for _ in range(5)]
+    fl, ms = ctypes.c_double(), ctypes.c_float()
+    lib.check(L.pk_gemm_timing_read(0, *[ctypes.byref(x) for x in ints], ctypes.byref(fl), ctypes.byref(ms)), 'read')
+    assert n == 1 and ints[0].value == 64, (n, ints[0].value)
+    tiled = F.gemm(dy, w_up, b_col=True, alpha=0.5, **kw)
+    ref = 0.5 * (dy.double() @ w_up.double())
+    if act == 'relu':
+        ref = ref * (aux > 0)
+    elif act == 'gelu':
+        x = aux.double()
+        ref = ref * (0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5)
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -9
+    assert (out.double() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    assert (out.double() - tiled.double()).abs().max().item() <= tol * ref.abs().max().item()
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('M,N', [(1000, 512), (7, 2048), (33000, 1536), (50, 100), (3, 9)])
 def test_colsum(F, dtype, M, N):

@@ -85,21 +85,22 @@ def test_unsplit_problems_and_more_than_one_launch():
 def test_ineligible_problems_are_refused_by_the_c_entry_and_routed_by_the_group():
     from pasero_amd import functional as F
     from pasero_amd.autograd import WGradGroup
-    dy, x = _problem(2048, 64, 512, torch.bfloat16, 30)        # 64 output rows: below the 256-tile kernel's floor
+    dy, x = _problem(2048, 56, 512, torch.bfloat16, 30)        # 56 output rows: below the grouped kernel's floor of 64
     assert not F.wgrad_group_eligible(dy, x)
+    assert not F.wgrad_group_eligible(*_problem(2048, 128, 128, torch.bfloat16, 33))   # both sides under a tile: pk_gemm
     with pytest.raises(RuntimeError, match='not eligible'):
         F.wgrad_group([(dy, x, False)])
     dyf, xf = _problem(2048, 512, 512, torch.float32, 31)      # fp32: the exact-fp32 128-tile kernel, one by one
     assert not F.wgrad_group_eligible(dyf, xf)
-    w = torch.nn.Parameter(torch.empty(64, 512, device='cuda', dtype=torch.bfloat16))
+    w = torch.nn.Parameter(torch.empty(56, 512, device='cuda', dtype=torch.bfloat16))
     w2 = torch.nn.Parameter(torch.empty(512, 512, device='cuda', dtype=torch.bfloat16))
     g = WGradGroup()
     g.bind([w, w2])
-    g.add(dy, x, [(g.slot(w), 0, 64)], None)                   # computed on the spot by pk_gemm
+    g.add(dy, x, [(g.slot(w), 0, 56)], None)                   # computed on the spot by pk_gemm
     dy2, x2 = _problem(2048, 512, 512, torch.bfloat16, 32)
     g.add(dy2, x2, [(g.slot(w2), 0, 512)], None)               # waits for the launch
     grads = g.flush()
-    assert torch.equal(grads[0], F.gemm(dy, x, a_col=True, b_col=True, splitk=F.choose_splitk(64, 512, 2048)))
+    assert torch.equal(grads[0], F.gemm(dy, x, a_col=True, b_col=True, splitk=F.choose_splitk(56, 512, 2048)))
     ref = dy2.double().t() @ x2.double()
     assert (grads[1].double() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item()
     with pytest.raises(RuntimeError, match='after the group had been launched'):
@@ -196,6 +197,30 @@ def test_second_backward_over_a_retained_graph(monkeypatch):
     for n, p in model.named_parameters():
         want = 2 * once[n]
         assert (p.grad.float() - want).norm().item() <= 1e-2 * max(want.norm().item(), 1e-20), n
+
+
+@pytest.mark.parametrize('rows', [16000, 2048, 520])
+def test_bottleneck_adapter_gradients_ride_in_the_group(rows):
+    """round 5: outputs of 64 rows or columns — an adapter's d x 64 (up) and 64 x d (down) weight gradients with their bias
+    sums, contraction over all rows (the IWSLT recipe: 16 000 encoder / 2048 decoder rows) — are one grouped launch: against
+    fp64, a quarter-filled 256-tile on either side, alone and beside a full-size problem"""
+    from pasero_amd import functional as F
+    dt = torch.bfloat16
+    up = (*_problem(rows, 1024, 64, dt, 70), True)      # dW_up = dY^T a: 1024 x 64
+    down = (*_problem(rows, 64, 1024, dt, 71), True)    # dW_down = dA^T h: 64 x 1024
+    for dy, x, _ in (up, down):
+        assert F.wgrad_group_eligible(dy, x)
+    for entries in ([up, down], [down, (*_problem(rows, 512, 512, dt, 72), False), up]):
+        res = F.wgrad_group(entries)
+        for (dy, x, _), (dw, db) in zip(entries, res):
+            ref = dy.double().t() @ x.double()
+            assert dw.shape == ref.shape
+            assert (dw.double() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item()
+            bref = dy.double().sum(0)
+            if db is not None:
+                assert (db.double() - bref).abs().max().item() <= 2 ** -7 * max(bref.abs().max().item(), 1.0)
+        again = F.wgrad_group(entries)
+        assert all(torch.equal(a[0], b[0]) for a, b in zip(res, again))
 
 
 @pytest.mark.parametrize('seed', range(12))
