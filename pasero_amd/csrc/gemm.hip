@@ -851,11 +851,13 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
             // for the fc2 dX (8192 x 1024 x 8192) where the unsplit 128 x 256 tiles take 111 (round 5; PK_GEMM_HM_NOSPLIT=0: A/B)
             static const bool hm_nosplit = [] { const char* e = getenv("PK_GEMM_HM_NOSPLIT"); return !e || atoi(e) != 0; }();
             static const bool halfm_env = [] { const char* e = getenv("PK_GEMM_HALFM"); return !e || atoi(e) != 0; }();
-            // (PK_GEMM_HM_SMALL: experiment of round 5 — a few thousand rows x d with a d-long contraction, the frozen 2048-row
-            // decoder projections of the IWSLT recipe: 64 tiles of 128 x 256 instead of 128 tiles of 128 x 128 with two K slices)
-            static const bool hm_small = [] { const char* e = getenv("PK_GEMM_HM_SMALL"); return e && atoi(e) != 0; }();
+            // (round 5: also a few thousand rows x d with a d-long contraction — the frozen 2048-row decoder projections of the
+            // IWSLT recipe and their dX: 64 tiles of 128 x 256 instead of 128 tiles of 128 x 128, with two K slices for the dX —
+            // 19 -> 16 us per launch, 142 launches per step: 64.26 -> 63.92 ms same box.  Longer contractions stay split (fc2,
+            // 8192 deep: 40 us as K-slabs, ~90 unsplit on 64 workgroups).  PK_GEMM_HM_SMALL=0: off)
+            static const bool hm_small = [] { const char* e = getenv("PK_GEMM_HM_SMALL"); return !e || atoi(e) != 0; }();
             const long long t_half_pre = ((M + 127) / 128) * ((N + 255) / 256);
-            const bool small_hm = hm_small && M <= 4096 && t_half_pre >= 48 && t_half_pre < 160 && K8 >= 1024 && N % 256 == 0;
+            const bool small_hm = hm_small && M <= 4096 && t_half_pre >= 48 && t_half_pre < 160 && K8 >= 1024 && K8 <= 1536 && N % 256 == 0;
             const bool hm_takes_it = hm_nosplit && halfm_env && e8 && t256 < 160 && !a_col && !asum_out && lean_epi &&
                                      (t_half_pre >= 160 || small_hm) && tile_pref != 256 && g_use_8p != 2;
             if (splitk > 1 && hm_takes_it) splitk = 1;

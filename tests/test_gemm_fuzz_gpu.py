@@ -253,11 +253,15 @@ def test_vocabulary_that_is_no_multiple_of_8_runs_on_the_256_tile_kernel(rows, V
     (8192, 1024, 1024, False, 0, 'none', True), (8192, 1024, 8192, False, 0, 'relu', True),
     (8192, 1024, 1024, True, 1, 'none', False), (8192, 1024, 3072, True, 0, 'none', False),
     (8000, 1024, 1088, True, 2, 'relu', False), (4000, 2048, 1024, False, 1, 'none', True),
-    (8192, 1024, 1000, True, 0, 'none', False)])
+    (8192, 1024, 1000, True, 0, 'none', False),
+    # round 5: a few thousand rows x d with a d-long contraction (the IWSLT recipe's 2048-row decoder projections and their dX)
+    (2048, 1024, 1024, False, 0, 'none', True), (2048, 1024, 1024, True, 1, 'none', False), (1900, 1024, 1024, True, 0, 'none', False),
+    (4096, 768, 1536, False, 0, 'relu', True)])
 def test_half_m_tiles_for_outputs_that_fill_half_the_chip(M, N, K, b_col, mode, act, bias):
     """Outputs of 80..159 256-tiles (NLLB-1.3B's 8192 x 1024 projections at C5) run on gemm8p's 128 x 256 tile form (launch
     sampling: tag bit 0x400): forward with bias / ReLU, dX with the residual-branch gradient as aux, the ReLU-masked dH form,
-    ragged M (a partial last tile), K with a partial last K-tile — against fp64."""
+    ragged M (a partial last tile), K with a partial last K-tile — against fp64.  Since round 5 also outputs of 48..159 such
+    tiles at <= 4096 rows with a contraction of 1024..1536 (the 128-tile kernel took 19 us for 2048 x 1024 x 1024, this one 16)."""
     import ctypes
     from pasero_amd import functional as F, lib
     torch.manual_seed(M + N + K)
