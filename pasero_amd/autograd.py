@@ -738,27 +738,49 @@ class DropoutFn(Function):
 # The tied table's gradient in ONE (V, d) tensor.  With `tied_output_projection` (and `shared_embeddings`) the embedding matrix
 # receives the projection's dense dW and the sparse rows of one or two lookups (pasero/models/transformer.py:151-153,
 # modules.py:935-947); as three autograd contributions that costs, per lookup, a (V, d) zero fill + a dense `add` pass over the
-# table (NLLB-1.3B: 525 MB each, 0.8 ms per step).  Instead the vocabulary loss's backward — the first node of every backward
-# pass — offers its dW as the SINK of this pass, keyed by the table it was computed for; a lookup of the same table adds its rows
-# into it in place (pk_embed_bwd_acc: touched rows only) and returns no gradient of its own.  The offer ends with the pass (an
-# engine callback).  What makes the in-place addition sound: the engine keeps the first gradient that reaches an input buffer by
-# reference (no copy), AccumulateGrad for the table runs only after every contributor has reported — a lookup that returns None
-# has — and nothing saves dW for a later backward.  PASERO_NO_GRAD_SINK=1: three contributions, as before (A/B).
+# table (NLLB-1.3B: 525 MB each, 0.8 ms per step).  Instead:
+#   * the model marks the table it hands to the vocabulary loss (`tie_table`: a tensor hook on it, registered once);
+#   * the vocabulary loss's backward — the first node of a backward pass — opens a SESSION for that table;
+#   * a lookup of a table with an open session does not compute a (V, d) gradient: it leaves (ids, dOut, arguments) in the
+#     session and returns None;
+#   * the hook fires when autograd has summed every contribution to the table's gradient (all producers have reported, the
+#     deferring lookups too) and adds the deferred rows INTO that sum (pk_embed_bwd_acc: touched rows only, one rounding).
+# Nothing depends on which tensor object the engine keeps in its input buffers: two graphs back-propagated together
+# (`(l1 + l2).backward()`) put two dense contributions and four lookups into one session, and the hook sees their sum.  The
+# session ends with the pass (an engine callback); a lookup without a session behaves as before.  PASERO_NO_GRAD_SINK=1:
+# three separate contributions, as before round 5 (A/B).
 _NO_GRAD_SINK = os.environ.get('PASERO_NO_GRAD_SINK', '0') not in ('', '0')
-_grad_sinks = {}  # (data_ptr, shape, dtype) of the table -> its dense gradient of the running backward pass
+_table_sessions = {}  # (data_ptr, shape, dtype) of a tied table -> lookups deferred in the running backward pass
 
 
 def _table_key(weight: Tensor):
     return (weight.data_ptr(), tuple(weight.shape), weight.dtype)
 
 
-def _offer_grad_sink(key, gw: Tensor):
-    if _NO_GRAD_SINK or gw is None or not gw.is_contiguous():
-        return
-    first = not _grad_sinks
-    _grad_sinks[key] = gw
-    if first:
-        torch.autograd.Variable._execution_engine.queue_callback(_grad_sinks.clear)
+def tie_table(weight: Tensor) -> Tensor:
+    """mark `weight` as a table that is both looked up and used as the vocabulary projection (see above); idempotent"""
+    if _NO_GRAD_SINK or not weight.requires_grad or not weight.is_cuda or getattr(weight, '_pk_tied_hook', None) is not None:
+        return weight
+    import weakref
+    ref = weakref.ref(weight)
+
+    def add_deferred_rows(grad):
+        w = ref()
+        items = _table_sessions.pop(_table_key(w), None) if w is not None else None
+        if not items:
+            return None
+        g = grad if grad.is_contiguous() else grad.contiguous()
+        for ids, dout, (V, pad, scale, p, seed, offset) in items:
+            F.embed_bwd(ids, dout, V, pad, scale, p, seed, offset, into=g)
+        return g
+    weight._pk_tied_hook = weight.register_hook(add_deferred_rows)
+    return weight
+
+
+def _open_table_session(key):
+    if not _table_sessions:
+        torch.autograd.Variable._execution_engine.queue_callback(_table_sessions.clear)
+    _table_sessions.setdefault(key, [])
 
 
 class EmbeddingFn(Function):
@@ -783,9 +805,9 @@ class EmbeddingFn(Function):
         dout = _contig(dout)
         dE = dpos = None
         if ctx.needs_input_grad[1]:
-            sink = _grad_sinks.get(ctx.table)
-            if sink is not None and sink.dtype == dout.dtype and sink.shape == (V, dout.size(-1)):
-                F.embed_bwd(ids, dout, V, padding_idx, scale, p, seed, offset, into=sink)  # (dE stays None: nothing to add)
+            session = _table_sessions.get(ctx.table)
+            if session is not None and dout.dtype == ctx.table[2]:
+                session.append((ids, dout, (V, padding_idx, scale, p, seed, offset)))  # (added into the table's summed gradient)
             else:
                 dE = F.embed_bwd(ids, dout, V, padding_idx, scale, p, seed, offset)
         if ctx.needs_input_grad[2]:  # learned positions: sum over the batch of the (masked) gradient
@@ -876,7 +898,8 @@ class VocabCrossEntropyFn(Function):
                     g0 = r1
         sums = F.ce_finalize(row_loss, row_nll, tgt, padding_idx)
         ctx.x_shape = x.shape
-        ctx.table = _table_key(weight)
+        tied = getattr(weight, '_pk_tied_hook', None) is not None and not _NO_GRAD_SINK
+        ctx.table = _table_key(weight) if tied else None
         if grad:
             ctx.save_for_backward(dx, dw)
         return sums
@@ -887,7 +910,8 @@ class VocabCrossEntropyFn(Function):
         g = _contig(dsums)[:1].float()  # d(total)/d(loss); nll / num_tokens are logging outputs
         gx = F.scale(dx, g).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         gw = F.scale(dw, g) if ctx.needs_input_grad[1] else None
-        _offer_grad_sink(ctx.table, gw)  # (lookups of the same table add their rows into gw: see _grad_sinks)
+        if gw is not None and ctx.table is not None:
+            _open_table_session(ctx.table)  # (lookups of this table hand their rows to the table's hook: see tie_table)
         return gx, gw, None, None, None
 
 

@@ -23,7 +23,7 @@ from torch import Tensor, LongTensor, BoolTensor
 from . import modules, native_layer
 from .profiling import block as _bench_block, region as _bench_region
 from .modules import Embedding, Identity
-from .autograd import (FFNFn, GatedFFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn,
+from .autograd import (FFNFn, GatedFFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn, tie_table,
                        AddPositionsFn, LinearFn, ResidualLink, WGradGroup, WGradSinkFn, BlockTail, FFNResidualLnFn,
                        block_tail_eligible, LayerNormForkFn)
 
@@ -313,6 +313,8 @@ class Transformer(EncoderDecoder):
         `--benchmark` log the reference's 'output_projection' and 'loss' entries are both inside this one 'loss'"""
         dec = self.decoder
         weight = dec.embed_tokens.effective_weight() if dec.output_projection is None else dec.output_projection.weight
+        if dec.output_projection is None:
+            tie_table(weight)  # (the table is looked up AND projected onto: its gradient is assembled in one tensor)
         sums = VocabCrossEntropyFn.apply(features, weight, target, self.padding_idx, self.cfg.label_smoothing or 0.0)
         return sums[0], self._logs(sums.detach(), target.size(0))
 

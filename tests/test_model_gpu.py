@@ -179,9 +179,10 @@ def test_partially_frozen_embeddings_shared_with_the_decoder_fp32_vs_reference()
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_tied_table_gradient_is_one_tensor(dtype, monkeypatch):
     """shared embeddings + tied projection (transformer.py:151-153): the table's gradient is the projection's dense dW with the
-    rows of BOTH lookups added in place (pk_embed_bwd_acc; autograd._grad_sinks) — the same gradient as three autograd
-    contributions (fp32: to summation-order round-off; bf16: one rounding instead of three), no offer left behind after the
-    pass, and a second backward pass (retained graph) gives the same result again"""
+    rows of BOTH lookups added into it by the table's hook (pk_embed_bwd_acc; autograd.tie_table) — the same gradient as three
+    autograd contributions (fp32: to summation-order round-off; bf16: one rounding instead of three), no session left behind
+    after the pass, a second backward pass (retained graph) gives the same result again, and two graphs back-propagated
+    together (`(l1 + l2).backward()`: two dense contributions, four lookups, ONE session) give the sum of their gradients"""
     from pasero_amd import autograd, functional as PF
     g = load_golden('tiny_encdec_post')
     cfg, model = build_model(g, dtype, 'cuda')
@@ -203,7 +204,7 @@ def test_tied_table_gradient_is_one_tensor(dtype, monkeypatch):
             assert torch.equal(model.encoder.embed_tokens.weight.grad.float(), first)
         return first
     sunk = grads(retain=True)
-    assert calls == [True, True, True, True] and not autograd._grad_sinks, calls
+    assert calls == [True, True, True, True] and not autograd._table_sessions, calls
     del calls[:]
     monkeypatch.setattr(autograd, '_NO_GRAD_SINK', True)
     plain = grads()
@@ -212,6 +213,18 @@ def test_tied_table_gradient_is_one_tensor(dtype, monkeypatch):
     assert (sunk - plain).abs().max().item() <= tol * plain.abs().max().item()
     if dtype == torch.float32:  # and both are the reference's gradient
         assert rel(sunk, g['grad:encoder.embed_tokens.weight']) < 2e-4
+    # two graphs in one backward pass
+    monkeypatch.setattr(autograd, '_NO_GRAD_SINK', False)
+    b2 = {k: (v.flip(0).contiguous() if v.dim() else v) for k, v in batch.items()}
+    model.zero_grad(set_to_none=True)
+    model(**b2)[0].backward()
+    other = model.encoder.embed_tokens.weight.grad.float().clone()
+    model.zero_grad(set_to_none=True)
+    del calls[:]
+    (model(**batch)[0] + model(**b2)[0]).backward()
+    both = model.encoder.embed_tokens.weight.grad.float()
+    assert calls == [True] * 4 and not autograd._table_sessions
+    assert (both - (sunk + other)).abs().max().item() <= 2 * tol * (sunk + other).abs().max().item()
 
 
 def test_adapter_transformer_frozen_backbone_fp32_vs_reference():
