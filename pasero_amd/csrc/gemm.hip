@@ -1064,6 +1064,23 @@ EpiParams relu_bits_epi(const void* bias, void* C, long long ldc, int mode, floa
 }
 }  // namespace
 
+namespace {
+// round 5: the same mask bits through the phase-interleaved kernel's lean epilogue (gemm8p.hip: epilogue_pass_bits) — the
+// d = 1024 feed-forward (K = 1024), whose dH GEMM read 134-268 MB of activations per launch for their signs.  Taken where
+// launch_gemm sends the plain GEMM of this shape to gemm8p's 256 x 256 or 128 x 256 tiles WITHOUT a split (the conditions of
+// its `fills` / `half_m` branches, restated); PK_GEMM_RELU_BITS8P=0: off (A/B)
+bool relu_bits_8p_ok(const void* A, const void* B, const void* C, const void* bias, long long M, long long N, long long K,
+                     long long lda, long long ldb, long long ldc, int b_col) {
+    static const bool on = [] { const char* e = getenv("PK_GEMM_RELU_BITS8P"); return !e || atoi(e) != 0; }();
+    if (!on || !g_use_8p || M < 256 || N < 256 || K < 64 || K % 64 || N % 32) return false;
+    auto al = [](const void* p, long long ld) { return ((uintptr_t)p % 16) == 0 && (ld % 8) == 0; };
+    if (!al(A, lda) || !al(B, ldb) || !al(C, ldc) || (bias && (uintptr_t)bias % 16)) return false;
+    if (!pk_gemm8p_eligible(M, N, K, lda, ldb, 0, b_col, 0)) return false;
+    const long long t256 = ((M + 255) / 256) * ((N + 255) / 256), t_half = ((M + 127) / 128) * ((N + 255) / 256);
+    return t256 >= 160 || t_half >= 160;
+}
+}  // namespace
+
 extern "C" int pk_gemm_relu_bits_eligible(const void* A, const void* B, const void* C, const void* bias, long long M,
                                           long long N, long long K, long long lda, long long ldb, long long ldc,
                                           long long ldbits, int b_col, int mode, int dtype) {
@@ -1071,7 +1088,8 @@ extern "C" int pk_gemm_relu_bits_eligible(const void* A, const void* B, const vo
     if (!on) return 0;
     if ((dtype != PK_BF16 && dtype != PK_F16) || (mode != 0 && mode != 2) || N % 32 || ldbits < N / 8 || ldbits % 4) return 0;
     const EpiParams ep = relu_bits_epi(bias, const_cast<void*>(C), ldc, mode, 1.f);
-    return pk_gemmbs_eligible(A, B, C, M, N, K, lda, ldb, 0, b_col, &ep);
+    if (pk_gemmbs_eligible(A, B, C, M, N, K, lda, ldb, 0, b_col, &ep)) return 1;
+    return relu_bits_8p_ok(A, B, C, bias, M, N, K, lda, ldb, ldc, b_col) ? 1 : 0;
 }
 
 extern "C" int pk_gemm_relu_bits(const void* A, const void* B, void* C, const void* bias, unsigned char* bits, long long M,
@@ -1082,8 +1100,22 @@ extern "C" int pk_gemm_relu_bits(const void* A, const void* B, void* C, const vo
                  "pk_gemm_relu_bits: M=%lld N=%lld K=%lld mode %d is not a shape of the B-stationary kernel; ask "
                  "pk_gemm_relu_bits_eligible and use pk_gemm with the activations as the mask operand", M, N, K, mode);
     EpiParams ep = relu_bits_epi(bias, C, ldc, mode, alpha);
-    ep.aux = nullptr;
     hipStream_t s = (hipStream_t)stream;
+    if (!pk_gemmbs_eligible(A, B, C, M, N, K, lda, ldb, 0, b_col, &ep)) {  // the phase-interleaved kernel (relu_bits_8p_ok held)
+        PK_CHECK_ARG(((uintptr_t)bits % 4) == 0, "pk_gemm_relu_bits: the mask rows must be 4-byte aligned");
+        ep.aux = nullptr; ep.ldaux = 0;
+        ep.bits = bits; ep.ldbits = ldbits;
+        const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
+        ep.half_m = t256 >= 160 ? 0 : 1;
+        // (sample tag: the gemm8p instantiation | 0x1000 mask as bits)
+        GemmSample* sm = timing_begin(8 | 0x1000 | (ep.half_m ? 0x400 : 0) | (mode == 2 ? 0x2000 : 0), 0, b_col, 1, dtype, M, N, K, s);
+        long long a_b = 0, b_b = 0;
+        (void)a_b; (void)b_b;
+        const int rc = pk_gemm8p_launch(A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, 0, b_col, (int)K, 1, ep, dtype, stream);
+        timing_end(sm, s);
+        return rc == 1 ? 0 : (rc == 0 ? (pk_set_error("pk_gemm_relu_bits: the phase-interleaved kernel refused the shape"), -1) : rc);
+    }
+    ep.aux = nullptr;
     GemmSample* sm = timing_begin(0x200 | (int)(K / 64) | (PK_ACT_RELU << 4) | (mode == 2 ? 0x40 : 0) | 0x80, 0, b_col, 1, dtype, M, N, K, s);
     const int rc = pk_gemmbs_launch(A, B, C, M, N, K, lda, ldb, b_col, ep, dtype, stream, bits, ldbits);
     timing_end(sm, s);

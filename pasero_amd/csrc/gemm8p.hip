@@ -119,6 +119,72 @@ __device__ __forceinline__ void epilogue_pass(const float* __restrict__ cs, T* _
     }
 }
 
+// The ReLU feed-forward's mask as ONE BIT per element (EpiParams::bits; gemmbs.hip does the same for K = 512): the d = 1024
+// dH = (dZ W2) * [h > 0] GEMM read the 134 MB of activations of a C5 layer (268 MB at C3) for their signs alone.
+//   MODE 0: C = relu(alpha v + bias) and, beside it, the byte of this thread's eight columns — from the STORED 16-bit patterns
+//           (what a later `h > 0` on the tensor would see); the four bytes of four neighbouring lanes leave as one dword store;
+//   MODE 2: C = bit ? alpha v : 0, `bw[it]` = the dword that holds this thread's byte of row `it` (loaded one pass ahead by
+//           the caller: four lanes read the same dword).
+template <typename T, int MODE>
+__device__ __forceinline__ void epilogue_pass_bits(const float* __restrict__ cs, T* __restrict__ C, const EpiParams& ep,
+                                                   long long mh, long long n0, long long M, long long N, int tid,
+                                                   const unsigned (&bw)[4]) {
+    static_assert(MODE == 0 || MODE == 2, "fc1 forward / the masked dH GEMM");
+    const int col = (tid & 31) * 8, r0 = tid >> 5;
+    const long long gn = n0 + col;
+    if (gn + 8 > N) return;  // (N % 32 == 0: the four lanes that share a mask dword leave together)
+    float b[8];
+    if (MODE == 0 && ep.bias) {
+        Vec16<T> bv = load16<T>(reinterpret_cast<const T*>(ep.bias) + gn);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = bv.get(e);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = 0.f;
+    }
+    const float alpha = ep.alpha;
+    const int sh = 8 * (tid & 3);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const long long gm = mh + r0 + 16 * it;
+        if (gm >= M) continue;
+        const float* src = cs + (r0 + 16 * it) * CP + col;
+        const float4 a4 = *reinterpret_cast<const float4*>(src), b4 = *reinterpret_cast<const float4*>(src + 4);
+        float x[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+        const unsigned mbyte = MODE == 2 ? (bw[it] >> sh) & 0xFFu : 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = x[e] * alpha;
+            if (MODE == 2) y = ((mbyte >> e) & 1u) ? y : 0.f;
+            else y = fmaxf(y + b[e], 0.f);
+            x[e] = y;
+        }
+        typedef __attribute__((ext_vector_type(8))) float f32x8;
+        f32x8 f = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
+        Vec16<T> o;
+        o.raw = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename H16<T>::vec));
+        store16_nt<T>(C + gm * ep.ldc + gn, o);
+        if (MODE == 0) {
+            // bit e = (the stored value > 0), without compares (as gemmbs.hip): after max(0, .) no 16-bit pattern has its sign
+            // set, so adding 0x7FFF carries into bit 15 / 31 exactly where a half is not zero
+            unsigned u = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {  // flags of dword w (elements 2 w, 2 w + 1) to bits 9 + 2 w and 25 + 2 w
+                const unsigned ow = (&o.raw.x)[w];
+                u |= ((ow + 0x7FFF7FFFu) >> (6 - 2 * w)) & (0x80008000u >> (6 - 2 * w));
+            }
+            const unsigned byte = ((u >> 9) | (u >> 24)) & 0xFFu;
+            // the four lanes of a quad hold the bytes of 32 consecutive columns of one row: lane 0 of the quad collects them
+            // by DPP (no LDS round trip) and stores ONE dword
+            const unsigned b1 = (unsigned)__builtin_amdgcn_mov_dpp((int)byte, 0x55, 0xF, 0xF, true);   // quad_perm: lane 1 of the quad
+            const unsigned b2 = (unsigned)__builtin_amdgcn_mov_dpp((int)byte, 0xAA, 0xF, 0xF, true);   // lane 2
+            const unsigned b3 = (unsigned)__builtin_amdgcn_mov_dpp((int)byte, 0xFF, 0xF, 0xF, true);   // lane 3
+            const unsigned wd = byte | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            if ((tid & 3) == 0) *reinterpret_cast<unsigned*>(ep.bits + gm * ep.ldbits + (gn >> 3)) = wd;
+        }
+    }
+}
+
 // The same 64-row pass for every other epilogue of pk_gemm (include/pasero_hip.h): any activation (GELU erf / tanh, SiLU:
 // the Whisper / BLOOM / Llama feed-forward layers, pasero/models/modules.py:220-228), the pre-activation as a second output
 // (`preact`: what act' needs in backward), mode 3 = act(v + bias) * aux (the SwiGLU / GEGLU gate, transformer.py:1011-1018)
@@ -530,7 +596,21 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     float* cs = reinterpret_cast<float*>(smem);
     // the aux operand of the lean mode 1 / 2 epilogues, one pass ahead of its use (aux may alias C: a chunk is read by the
     // thread that stores it, and before that store)
-    const bool pre_aux = !ws && !ANY && ep.mode != 0;
+    const bool use_bits = !ws && !ANY && ep.bits != nullptr;      // (mode 0 + ReLU writes the mask bits, mode 2 + ReLU reads them)
+    const bool pre_aux = !ws && !ANY && ep.mode != 0 && !use_bits;
+    const bool pre_bits = use_bits && ep.mode == 2;
+    unsigned bw_next[4] = {0u, 0u, 0u, 0u};
+    auto bits_load = [&](int p) {  // this thread's mask dwords of pass p (four lanes share one)
+        const int col = (tid & 31) * 8, r0 = tid >> 5;
+        const long long gn = n0 + col;
+        if (gn + 8 > N) return;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const long long gm = m0 + p * 64 + r0 + 16 * it;
+            if (gm < M) bw_next[it] = *reinterpret_cast<const unsigned*>(ep.bits + gm * ep.ldbits + ((gn >> 3) & ~3LL));
+        }
+    };
+    if (pre_bits) bits_load(0);
     Vec16<T> av_next[4];
     auto aux_load = [&](int p) {
         const int col = (tid & 31) * 8, r0 = tid >> 5;
@@ -583,6 +663,8 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
             for (int it = 0; it < 4; ++it) av[it] = av_next[it];
             if (p + 1 < NPASS) aux_load(p + 1);
         }
+        unsigned bw[4] = {bw_next[0], bw_next[1], bw_next[2], bw_next[3]};
+        if (pre_bits && p + 1 < NPASS) bits_load(p + 1);
         if (ws && role == 2) {  // the pair's second workgroup: own partial (staging buffer) + the first one's slab -> C
             const int col = (tid & 31) * 8, r0 = tid >> 5;
             const long long gn = n0 + col;
@@ -635,6 +717,9 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
             }
         } else if constexpr (ANY) {
             epilogue_pass_any<T>(cs, C, ep, mh, n0, M, N, tid);
+        } else if (use_bits) {
+            if (ep.mode == 0) epilogue_pass_bits<T, 0>(cs, C, ep, mh, n0, M, N, tid, bw);
+            else epilogue_pass_bits<T, 2>(cs, C, ep, mh, n0, M, N, tid, bw);
         } else if (ep.mode == 0) {
             if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 0>(cs, C, ep, mh, n0, M, N, tid, av);
             else epilogue_pass<T, PK_ACT_NONE, 0>(cs, C, ep, mh, n0, M, N, tid, av);
@@ -870,7 +955,21 @@ __device__ __forceinline__ void gemm8p_hm2_tile(const T* __restrict__ A, const T
 
     // ---- epilogue: two 64-row passes through the fp32 staging buffer, the aux operand one pass ahead (as gemm8p_tile) ----
     float* cs = reinterpret_cast<float*>(smem);
-    const bool pre_aux = ep.mode != 0;
+    const bool use_bits = ep.bits != nullptr;
+    const bool pre_aux = ep.mode != 0 && !use_bits;
+    const bool pre_bits = use_bits && ep.mode == 2;
+    unsigned bw_next[4] = {0u, 0u, 0u, 0u};
+    auto bits_load = [&](int p) {
+        const int col = (tid & 31) * 8, r0 = tid >> 5;
+        const long long gn = n0 + col;
+        if (gn + 8 > N) return;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const long long gm = m0 + p * 64 + r0 + 16 * it;
+            if (gm < M) bw_next[it] = *reinterpret_cast<const unsigned*>(ep.bits + gm * ep.ldbits + ((gn >> 3) & ~3LL));
+        }
+    };
+    if (pre_bits) bits_load(0);
     Vec16<T> av_next[4];
     auto aux_load = [&](int p) {
         const int col = (tid & 31) * 8, r0 = tid >> 5;
@@ -905,7 +1004,12 @@ __device__ __forceinline__ void gemm8p_hm2_tile(const T* __restrict__ A, const T
             for (int it = 0; it < 4; ++it) av[it] = av_next[it];
             if (p == 0) aux_load(1);
         }
-        if (ep.mode == 0) {
+        unsigned bw[4] = {bw_next[0], bw_next[1], bw_next[2], bw_next[3]};
+        if (pre_bits && p == 0) bits_load(1);
+        if (use_bits) {
+            if (ep.mode == 0) epilogue_pass_bits<T, 0>(cs, C, ep, mh, n0, M, N, tid, bw);
+            else epilogue_pass_bits<T, 2>(cs, C, ep, mh, n0, M, N, tid, bw);
+        } else if (ep.mode == 0) {
             if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 0>(cs, C, ep, mh, n0, M, N, tid, av);
             else epilogue_pass<T, PK_ACT_NONE, 0>(cs, C, ep, mh, n0, M, N, tid, av);
         } else if (ep.mode == 1) {

@@ -12,6 +12,11 @@ struct EpiParams {
     long long nstore = 0;   // PK_GEMM_PAD_N: columns up to `nstore` = N rounded up to 8 may be STORED (0: N) — gemm8p's lean epilogue
     int half_m = 0;         // gemm8p.hip: 128 x 256 tiles (an output of 256 x 256 tiles would fill half the chip)
     long long kb_rows = 0;  // PK_GEMM_PAD_K: the rows a col-form B really has (the K passed on is rounded up to 8; 0: K)
+    // the ReLU mask as one bit per element (pk_gemm_relu_bits): [M][ldbits] bytes, bit (n & 7) of byte n >> 3 of row m = (stored
+    // C[m][n] > 0).  mode 0 + ReLU writes it beside C, mode 2 + ReLU reads it instead of aux.  gemmbs.hip takes it as a launch
+    // argument of its own; gemm8p.hip (round 5: the d = 1024 feed-forward, K = 1024) through these fields
+    unsigned char* bits = nullptr;
+    long long ldbits = 0;
 };
 
 // One weight-gradient problem of a grouped launch (include/pasero_hip.h: PkWgradProblem): C[M,N] = A^T B, both operands

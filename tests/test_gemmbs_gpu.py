@@ -158,6 +158,42 @@ def test_relu_mask_as_bits(F, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('M,N,K', [(8192, 8192, 1024), (4096, 4096, 1024), (8192, 1024, 2048), (8200, 4096, 1024), (32768, 4096, 1024)])
+def test_relu_mask_as_bits_on_the_phase_interleaved_kernel(F, dtype, M, N, K):
+    """round 5: the same mask bits for the d = 1024 feed-forward (NLLB-1.3B at C5: 8192 x 8192 x 1024; transformer_big at C3:
+    32768 x 4096 x 1024), through gemm8p's lean epilogue on 256 x 256 and 128 x 256 tiles (`epilogue_pass_bits`): h bit for bit
+    pk_gemm's ReLU output, the bits numpy's packbits of (h > 0), the masked dH bit for bit pk_gemm mode 2 with h as the mask
+    operand; ragged rows; the launch sampling says which kernel ran (tag 0x1000)."""
+    import ctypes
+    from pasero_amd import lib
+    rs = np.random.RandomState(M + N)
+    x = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(dtype).cuda()
+    w1 = (torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32)) * 0.05).to(dtype).cuda()
+    b1 = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(dtype).cuda()
+    w2 = (torch.from_numpy(rs.standard_normal((K, N)).astype(np.float32)) * 0.05).to(dtype).cuda()
+    dy = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(dtype).cuda()
+    assert F.relu_bits_eligible(x, w1)
+    L = lib.load()
+    lib.check(L.pk_gemm_timing_start(8, 1), 'start')
+    h, bits = F.gemm_relu_bits(x, w1, b1)
+    dh = F.gemm_mask_bits(dy, w2, bits)
+    n = L.pk_gemm_timing_stop()
+    tags = []
+    for i in range(n):
+        ints = [ctypes.c_int() for _ in range(5)]
+        fl, ms = ctypes.c_double(), ctypes.c_float()
+        lib.check(L.pk_gemm_timing_read(i, *[ctypes.byref(t) for t in ints], ctypes.byref(fl), ctypes.byref(ms)), 'read')
+        tags.append(ints[0].value)
+    assert n == 2 and all(t & 0x1000 for t in tags) and (tags[1] & 0x2000), [hex(t) for t in tags]
+    h_ref = F.gemm(x, w1, bias=b1, act='relu')
+    assert torch.equal(h.view(torch.int16), h_ref.view(torch.int16))
+    want = np.packbits((h_ref.float() > 0).cpu().numpy(), axis=1, bitorder='little')
+    assert np.array_equal(bits.cpu().numpy(), want)
+    dh_ref = F.gemm(dy, w2, b_col=True, act='relu', aux=h_ref, mode=2)
+    assert torch.equal(dh.view(torch.int16), dh_ref.view(torch.int16))
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_gelu_epilogues_between_the_mfmas(F, dtype):
     """the GELU feed-forward of the speech / BERT-style configurations (pasero/models/modules.py:220-228): fc1 forward
     writes gelu(pre) AND pre, the dH GEMM multiplies by gelu'(pre).  Both must equal the tiled kernel bit for bit (the

@@ -5,7 +5,7 @@ GRBM_GUI_ACTIVE`, --kernel-trace only) -> JSON for profiles/.
                      4 SIMDs of every CU, against the cycles the CUs had work: MI355X_MICROARCH.md, counter units)
   clock_ghz        = GRBM_GUI_ACTIVE / 8 / kernel duration (sum over the 8 XCDs).  GRBM_GUI_ACTIVE keeps counting while the
                      dispatch is set up and drained, so on short dispatches the quotient exceeds what the part can clock
-                     (max 2.4 GHz): such values are not written — the row gets `clock_ghz: null` and
+                     (max 2.4 GHz): values above it are not written — the row gets `clock_ghz: null` and
                      `clock_note: "non-physical (<value>): dispatch too short for GRBM_GUI_ACTIVE / duration"` instead
 usage: tools/pmc_mfma.py <pmc_dir> <note> > profiles/rNN_mfma_util_pmc.json"""
 import collections
@@ -36,7 +36,7 @@ for k in sorted(acc, key=lambda k: -acc[k].get('SQ_BUSY_CU_CYCLES', 0.0)):
     if dur[k] and a.get('GRBM_GUI_ACTIVE'):
         e['avg_us_under_the_profiler'] = round(dur[k] / n[k] / 1e3, 1)
         ghz = a['GRBM_GUI_ACTIVE'] / 8.0 / dur[k]
-        if ghz <= 2.5:
+        if ghz <= 2.4:  # (the part's maximum clock)
             e['clock_ghz'] = round(ghz, 2)
         else:
             e['clock_ghz'] = None
