@@ -452,18 +452,33 @@ class ResidualLayerNormFn(Function):
                 dbeta if ctx.has_beta else None, None, None, None, None)
 
 
+class DropLink:
+    """Hand-over between `z = residual + dropout(x)` (ResidualDropoutFn) and the pre-norm fork that consumes z
+    (LayerNormForkFn): the fork's backward already computes dz — the LayerNorm gradient plus the residual branch's — in one
+    kernel, and that kernel can write the MASKED copy the dropout's backward needs in the same pass (pk_residual_ln_bwd's
+    dx output; what the native layer call does).  The producer leaves (p, seed, offset) here in forward; the consumer's
+    backward leaves the masked gradient and the address of dz; the producer's backward takes it if the dz it receives is
+    that very tensor (another consumer of z would make autograd hand over a sum: then it draws the mask itself)."""
+    __slots__ = ('p', 'seed', 'offset', 'masked', 'dz_ptr')
+
+    def __init__(self):
+        self.p, self.seed, self.offset, self.masked, self.dz_ptr = 0.0, 0, 0, None, 0
+
+
 class LayerNormForkFn(Function):
     """(LayerNorm(x), x) — a pre-norm sub-block reads its input twice: through the LayerNorm and, as the residual, around
     the sub-block (pasero/models/transformer.py:1070-1075: `residual = x; x = self.self_attn_prenorm(x)`).  As two
     consumers of one tensor, autograd adds their gradients in an elementwise pass of its own (141 launches per step of the
     IWSLT recipe, 2.3 % of it); as ONE node the residual branch's gradient enters the LayerNorm backward kernel as
-    `dz_extra` — what the native layer call does (csrc/layer.cpp `ln_in_bwd`), with one rounding instead of two."""
+    `dz_extra` — what the native layer call does (csrc/layer.cpp `ln_in_bwd`), with one rounding instead of two.
+    `drop`: the DropLink of the `residual + dropout(.)` that produced x, if any (round 5)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float):
+    def forward(ctx, x, gamma, beta, eps: float, drop=None):
         xc = _contig(x)
         y, _, mean, rstd = F.residual_ln_fwd(xc, None, gamma, beta, eps, want_z=False)
         ctx.has_beta = beta is not None
+        ctx.drop = drop if (drop is not None and drop.p > 0 and xc.dtype != torch.float32) else None
         ctx.save_for_backward(xc, gamma, mean, rstd)
         # an output nobody consumed arrives as None in backward, not as a tensor of zeros allocated for the occasion
         ctx.set_materialize_grads(False)
@@ -473,13 +488,17 @@ class LayerNormForkFn(Function):
     def backward(ctx, dy, dres):
         x, gamma, mean, rstd = ctx.saved_tensors
         if dy is None:  # only the residual branch was used: the identity
-            return (dres if ctx.needs_input_grad[0] else None), None, None, None
+            return (dres if ctx.needs_input_grad[0] else None), None, None, None, None
         want_pg = ctx.needs_input_grad[1] or (ctx.has_beta and ctx.needs_input_grad[2])
         extra = _contig(dres) if dres is not None else None  # None: only the LayerNorm branch was used
-        dx, _, dgamma, dbeta = F.residual_ln_bwd(_contig(dy), extra, x, gamma, mean, rstd, want_dres=True, want_dx=False,
-                                                 want_param_grads=want_pg, has_beta=ctx.has_beta)
+        d = ctx.drop if ctx.needs_input_grad[0] else None
+        dx, masked, dgamma, dbeta = F.residual_ln_bwd(
+            _contig(dy), extra, x, gamma, mean, rstd, want_dres=True, want_dx=d is not None, want_param_grads=want_pg,
+            has_beta=ctx.has_beta, drop_p=d.p if d else 0.0, seed=d.seed if d else 0, offset=d.offset if d else 0)
+        if d is not None:
+            d.masked, d.dz_ptr = masked, dx.data_ptr()
         return (dx if ctx.needs_input_grad[0] else None, dgamma if ctx.needs_input_grad[1] else None,
-                dbeta if (ctx.has_beta and ctx.needs_input_grad[2]) else None, None)
+                dbeta if (ctx.has_beta and ctx.needs_input_grad[2]) else None, None, None)
 
 
 class BlockTail:
@@ -702,14 +721,18 @@ class AdapterFn(Function):
 
 
 class ResidualDropoutFn(Function):
-    """z = residual + dropout(x)   (pre-norm blocks: pasero/models/transformer.py:1043-1044,1049-1050)"""
+    """z = residual + dropout(x)   (pre-norm blocks: pasero/models/transformer.py:1043-1044,1049-1050).
+    `link`: a DropLink the caller will hand to the fork that consumes z — its backward then supplies the masked gradient."""
 
     @staticmethod
-    def forward(ctx, x, residual, p: float):
+    def forward(ctx, x, residual, p: float, link=None):
         x, residual = _contig(x), _contig(residual)
         seed, offset = rng.next_offset() if p > 0 else (0, 0)
         _, z, _, _ = F.residual_ln_fwd(x, residual, None, None, 0.0, p, seed, offset)
         ctx.p, ctx.seed, ctx.offset = p, seed, offset
+        ctx.link = link
+        if link is not None:
+            link.p, link.seed, link.offset = p, seed, offset
         return z
 
     @staticmethod
@@ -717,8 +740,14 @@ class ResidualDropoutFn(Function):
         dz = _contig(dz)
         dx = dz
         if ctx.p > 0 and ctx.needs_input_grad[0]:
-            dx = F.dropout(dz, ctx.p, ctx.seed, ctx.offset)
-        return dx, dz, None
+            link = ctx.link
+            if link is not None and link.masked is not None and link.dz_ptr == dz.data_ptr() and link.masked.shape == dz.shape:
+                dx = link.masked  # (written by the consumer's LayerNorm backward kernel in the pass that made dz)
+            else:
+                dx = F.dropout(dz, ctx.p, ctx.seed, ctx.offset)
+        if ctx.link is not None:
+            ctx.link.masked = None
+        return dx, dz, None, None
 
 
 class DropoutFn(Function):

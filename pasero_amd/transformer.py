@@ -25,7 +25,7 @@ from .profiling import block as _bench_block, region as _bench_region
 from .modules import Embedding, Identity
 from .autograd import (FFNFn, GatedFFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn, tie_table,
                        AddPositionsFn, LinearFn, ResidualLink, WGradGroup, WGradSinkFn, BlockTail, FFNResidualLnFn,
-                       block_tail_eligible, LayerNormForkFn)
+                       block_tail_eligible, LayerNormForkFn, DropLink)
 
 from .config import register_model  # also enters the reference's registry when `pasero` is importable
 
@@ -36,6 +36,7 @@ _NO_WGRAD_GROUP = bool(int(os.environ.get('PASERO_NO_WGRAD_GROUP', '0') or 0))
 _NO_FUSED_TAIL = bool(int(os.environ.get('PASERO_NO_FUSED_TAIL', '0') or 0))
 # diagnostic: pre-norm sub-blocks call their LayerNorm hook and leave the sum of the two input gradients to autograd
 _NO_LN_FORK = bool(int(os.environ.get('PASERO_NO_LN_FORK', '0') or 0))
+_NO_DROP_LINK = bool(int(os.environ.get('PASERO_NO_DROP_LINK', '0') or 0))  # (A/B: stand-alone dropout masks in the pre-norm backward)
 # diagnostic: read the step's sums at the end of the forward pass, as the reference does (A/B of the deferred read)
 _EAGER_LOGS = bool(int(os.environ.get('PASERO_EAGER_LOGS', '0') or 0))
 LN2 = math.log(2)
@@ -639,7 +640,14 @@ class _LayerBase(modules._PerCallAttrs, nn.Module):
         self._ffn_group = None
 
     def _residual(self, x: Tensor, residual: Tensor) -> Tensor:
-        return ResidualDropoutFn.apply(x, residual, self.dropout.p if self.training else 0.0)
+        p = self.dropout.p if self.training else 0.0
+        if p > 0 and self.prenorm and not _NO_LN_FORK and not _NO_DROP_LINK and torch.is_grad_enabled() and x.dtype != torch.float32:
+            # (the fork that reads z next writes the masked gradient for this dropout in its own backward pass: autograd.DropLink)
+            link = DropLink()
+            z = ResidualDropoutFn.apply(x, residual, p, link)
+            z._pk_drop_link = link
+            return z
+        return ResidualDropoutFn.apply(x, residual, p)
 
     def _norm_module(self, norm):
         """`final_layer_norm` is a lambda when --shared-norm (:977-980)"""
@@ -656,7 +664,7 @@ class _LayerBase(modules._PerCallAttrs, nn.Module):
                 and isinstance(m, modules.LayerNorm) and getattr(m, 'weight', None) is not None
                 and not m._forward_hooks and not m._forward_pre_hooks
                 and self._hooks_are_base(hook) and not torch.is_autocast_enabled('cuda')):
-            y, residual = LayerNormForkFn.apply(x, m.weight, m.bias, m.eps)
+            y, residual = LayerNormForkFn.apply(x, m.weight, m.bias, m.eps, getattr(x, '_pk_drop_link', None))
             return y, residual
         return getattr(self, hook)(x), x
 

@@ -175,20 +175,30 @@ def test_prenorm_input_fork_against_autograds_addition(dtype, tol):
     batch = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(4, 24, 40, 36, V, ragged=True).items()}
     calls = {'n': 0}
     orig = autograd.LayerNormForkFn.backward
+    drops = []
+    real_dropout = F.dropout
 
     def counted(*a, **k):
         calls['n'] += 1
         return orig(*a, **k)
     autograd.LayerNormForkFn.backward = staticmethod(counted)
+    F.dropout = lambda *a, **k: (drops.append(1), real_dropout(*a, **k))[1]
     try:
         l1, n1, g1, c1 = _step(model, batch, native=False)
-        forks = calls['n']
+        forks, drops_fork = calls['n'], len(drops)
         transformer._NO_LN_FORK = True
+        del drops[:]
         l0, n0, g0, c0 = _step(model, batch, native=False)
+        drops_plain = len(drops)
     finally:
         transformer._NO_LN_FORK = False
         autograd.LayerNormForkFn.backward = staticmethod(orig)
+        F.dropout = real_dropout
     assert c1 == 0 and c0 == 0 and forks == 2 * 2 + 2 * 3 and calls['n'] == forks, (c1, c0, forks, calls)
+    # round 5: a `residual + dropout(.)` whose output goes straight into the next fork gets its masked gradient from that fork's
+    # LayerNorm backward kernel (autograd.DropLink): 2 x 1 encoder + 2 x 2 decoder stand-alone dropout launches fewer
+    # (16-bit only: fp32 is the parity path and keeps the stand-alone mask)
+    assert drops_plain - drops_fork == (2 * 1 + 2 * 2 if dtype != torch.float32 else 0), (drops_plain, drops_fork)
     assert n1 == n0 and l1 == l0, (l1, l0)
     assert set(g1) == set(g0)
     for k in g0:
