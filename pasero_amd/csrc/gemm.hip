@@ -876,7 +876,18 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
             // form (128 x 256 tiles) gives every CU one.  Lean epilogues, row-form A, no split-K.  PK_GEMM_HALFM=0: off (A/B).
             static const bool halfm_on = [] { const char* e = getenv("PK_GEMM_HALFM"); return !e || atoi(e) != 0; }();
             const long long t_half = ((M + 127) / 128) * ((N + 255) / 256);
-            const bool half_m = halfm_on && e8 && !fills && sk == 1 && !a_col && !asum_out && lean_epi && (t_half >= 160 || small_hm) && tile_pref != 256 && g_use_8p != 2;
+            // (round 5, PK_GEMM_HM_ROUNDS: an output whose 256-tiles leave the last round of the chip half empty while its
+            // 128 x 256 tiles make whole rounds — NLLB-1.3B's q|k|v projection at 8192 rows: 384 tiles = 1.5 rounds against 768 =
+            // 3 — by the per-tile costs of the two schedules, K / 64 x 1.45 + 6.5 us against K / 64 x 0.72 + 5.5)
+            // (C5's q|k|v forward 64.5 -> 59.2 us, the step 72.93 -> 72.75 ms same box; =0: off)
+            static const bool hm_rounds = [] { const char* e = getenv("PK_GEMM_HM_ROUNDS"); return !e || atoi(e) != 0; }();
+            bool by_rounds = false;
+            if (hm_rounds && fills && sk == 1 && t256 < 1024) {
+                const double kt = (double)((K8 + 63) / 64);
+                const double c256 = (double)((t256 + 255) / 256) * (kt * 1.45 + 6.5), chalf = (double)((t_half + 255) / 256) * (kt * 0.72 + 5.5);
+                by_rounds = chalf < 0.92 * c256;
+            }
+            const bool half_m = halfm_on && e8 && (!fills || by_rounds) && sk == 1 && !a_col && !asum_out && lean_epi && (t_half >= 160 || small_hm) && tile_pref != 256 && g_use_8p != 2;
             if (sk > 0 && (tile_pref == 256 || fills || half_m || (g_use_8p == 2 && e8))) {
                 float* w2 = sk > 1 ? (float*)workspace : nullptr;
                 float* asw = (sk > 1 && asum_out) ? w2 + (size_t)sk * M * N : nullptr;

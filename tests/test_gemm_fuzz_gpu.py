@@ -256,7 +256,9 @@ def test_vocabulary_that_is_no_multiple_of_8_runs_on_the_256_tile_kernel(rows, V
     (8192, 1024, 1000, True, 0, 'none', False),
     # round 5: a few thousand rows x d with a d-long contraction (the IWSLT recipe's 2048-row decoder projections and their dX)
     (2048, 1024, 1024, False, 0, 'none', True), (2048, 1024, 1024, True, 1, 'none', False), (1900, 1024, 1024, True, 0, 'none', False),
-    (4096, 768, 1536, False, 0, 'relu', True)])
+    (4096, 768, 1536, False, 0, 'relu', True),
+    # round 5: 384 256-tiles = 1.5 rounds of the chip against 768 half-tiles = 3 (NLLB-1.3B's q|k|v projection at 8192 rows)
+    (8192, 3072, 1024, False, 0, 'none', True)])
 def test_half_m_tiles_for_outputs_that_fill_half_the_chip(M, N, K, b_col, mode, act, bias):
     """Outputs of 80..159 256-tiles (NLLB-1.3B's 8192 x 1024 projections at C5) run on gemm8p's 128 x 256 tile form (launch
     sampling: tag bit 0x400): forward with bias / ReLU, dX with the residual-branch gradient as aux, the ReLU-masked dH form,
