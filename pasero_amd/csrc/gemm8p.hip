@@ -248,7 +248,7 @@ __device__ __noinline__ void epilogue_pass_any(const float* __restrict__ cs, T* 
 // issued against an empty descriptor (so every counted wait still counts the same instructions), its fragment reads, its
 // two quadrant MFMA sections and its two epilogue passes are compiled out.  Not the schedule one would design for this tile
 // (two of four phases only synchronise), but every hazard distance of the full schedule holds a fortiori.
-template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL, bool HM = false>
+template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL, bool HM = false, bool BITS = false>
 __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
                                             float* __restrict__ ws, float* __restrict__ asum_ws,
                                             T* __restrict__ asum_out, long long M, long long N, long long K,
@@ -596,9 +596,12 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     float* cs = reinterpret_cast<float*>(smem);
     // the aux operand of the lean mode 1 / 2 epilogues, one pass ahead of its use (aux may alias C: a chunk is read by the
     // thread that stores it, and before that store)
-    const bool use_bits = !ws && !ANY && ep.bits != nullptr;      // (mode 0 + ReLU writes the mask bits, mode 2 + ReLU reads them)
+    // (BITS: an instantiation of its own — mode 0 + ReLU writes the mask bits, mode 2 + ReLU reads them; as a run-time branch in
+    // the common instantiations it cost the d = 512 dX GEMMs 2 us per launch)
+    static_assert(!BITS || (!A_COL && !ANY && !TAIL), "the mask bits ride on the lean row-form instantiations");
+    constexpr bool use_bits = BITS;
     const bool pre_aux = !ws && !ANY && ep.mode != 0 && !use_bits;
-    const bool pre_bits = use_bits && ep.mode == 2;
+    const bool pre_bits = use_bits && !ws && ep.mode == 2;
     unsigned bw_next[4] = {0u, 0u, 0u, 0u};
     auto bits_load = [&](int p) {  // this thread's mask dwords of pass p (four lanes share one)
         const int col = (tid & 31) * 8, r0 = tid >> 5;
@@ -664,7 +667,9 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
             if (p + 1 < NPASS) aux_load(p + 1);
         }
         unsigned bw[4] = {bw_next[0], bw_next[1], bw_next[2], bw_next[3]};
-        if (pre_bits && p + 1 < NPASS) bits_load(p + 1);
+        if constexpr (BITS) {
+            if (pre_bits && p + 1 < NPASS) bits_load(p + 1);
+        }
         if (ws && role == 2) {  // the pair's second workgroup: own partial (staging buffer) + the first one's slab -> C
             const int col = (tid & 31) * 8, r0 = tid >> 5;
             const long long gn = n0 + col;
@@ -717,7 +722,7 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
             }
         } else if constexpr (ANY) {
             epilogue_pass_any<T>(cs, C, ep, mh, n0, M, N, tid);
-        } else if (use_bits) {
+        } else if constexpr (BITS) {
             if (ep.mode == 0) epilogue_pass_bits<T, 0>(cs, C, ep, mh, n0, M, N, tid, bw);
             else epilogue_pass_bits<T, 2>(cs, C, ep, mh, n0, M, N, tid, bw);
         } else if (ep.mode == 0) {
@@ -744,7 +749,7 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
 #undef PK_STAMP
 }
 
-template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL, bool HM = false>
+template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL, bool HM = false, bool BITS = false>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A, const T* __restrict__ B,
                                                        T* __restrict__ C, float* __restrict__ ws,
                                                        float* __restrict__ asum_ws, T* __restrict__ asum_out,
@@ -752,8 +757,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const T* __restrict__ A,
                                                        long long ldb, int kchunk, unsigned a_bytes, unsigned b_bytes,
                                                        int total, unsigned long long* stamps, EpiParams ep) {
     // slab-major (K-slab, tile) walk over the XCD-contiguous remap: an XCD owns whole K-slabs
-    gemm8p_tile<T, A_COL, B_COL, ANY, TAIL, HM>(A, B, C, ws, asum_ws, asum_out, M, N, K, lda, ldb, kchunk, a_bytes, b_bytes,
-                                                xcd_remap(blockIdx.x, gridDim.x), stamps, ep);
+    gemm8p_tile<T, A_COL, B_COL, ANY, TAIL, HM, BITS>(A, B, C, ws, asum_ws, asum_out, M, N, K, lda, ldb, kchunk, a_bytes, b_bytes,
+                                                      xcd_remap(blockIdx.x, gridDim.x), stamps, ep);
 }
 
 // ---- 128 x 256 tiles with a schedule of their own (round 4) ----
@@ -777,7 +782,7 @@ constexpr int HSTAGE = 3 * HALF, HSMEM = 3 * HSTAGE;
 constexpr int S_A = 0, S_B0 = 1, S_B1 = 2;
 }  // namespace hm2
 
-template <typename T, bool B_COL, bool TAIL>
+template <typename T, bool B_COL, bool TAIL, bool BITS = false>
 __device__ __forceinline__ void gemm8p_hm2_tile(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
                                                 long long M, long long N, long long K, long long lda, long long ldb,
                                                 unsigned a_bytes, unsigned b_bytes, int lin, const EpiParams& ep) {
@@ -955,7 +960,7 @@ __device__ __forceinline__ void gemm8p_hm2_tile(const T* __restrict__ A, const T
 
     // ---- epilogue: two 64-row passes through the fp32 staging buffer, the aux operand one pass ahead (as gemm8p_tile) ----
     float* cs = reinterpret_cast<float*>(smem);
-    const bool use_bits = ep.bits != nullptr;
+    constexpr bool use_bits = BITS;  // (an instantiation of its own, as in gemm8p_tile)
     const bool pre_aux = ep.mode != 0 && !use_bits;
     const bool pre_bits = use_bits && ep.mode == 2;
     unsigned bw_next[4] = {0u, 0u, 0u, 0u};
@@ -1005,8 +1010,10 @@ __device__ __forceinline__ void gemm8p_hm2_tile(const T* __restrict__ A, const T
             if (p == 0) aux_load(1);
         }
         unsigned bw[4] = {bw_next[0], bw_next[1], bw_next[2], bw_next[3]};
-        if (pre_bits && p == 0) bits_load(1);
-        if (use_bits) {
+        if constexpr (BITS) {
+            if (pre_bits && p == 0) bits_load(1);
+        }
+        if constexpr (BITS) {
             if (ep.mode == 0) epilogue_pass_bits<T, 0>(cs, C, ep, mh, n0, M, N, tid, bw);
             else epilogue_pass_bits<T, 2>(cs, C, ep, mh, n0, M, N, tid, bw);
         } else if (ep.mode == 0) {
@@ -1023,11 +1030,11 @@ __device__ __forceinline__ void gemm8p_hm2_tile(const T* __restrict__ A, const T
     }
 }
 
-template <typename T, bool B_COL, bool TAIL>
+template <typename T, bool B_COL, bool TAIL, bool BITS = false>
 __global__ __launch_bounds__(512, 2) void gemm8p_hm2_kernel(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
                                                            long long M, long long N, long long K, long long lda,
                                                            long long ldb, unsigned a_bytes, unsigned b_bytes, EpiParams ep) {
-    gemm8p_hm2_tile<T, B_COL, TAIL>(A, B, C, M, N, K, lda, ldb, a_bytes, b_bytes, xcd_remap(blockIdx.x, gridDim.x), ep);
+    gemm8p_hm2_tile<T, B_COL, TAIL, BITS>(A, B, C, M, N, K, lda, ldb, a_bytes, b_bytes, xcd_remap(blockIdx.x, gridDim.x), ep);
 }
 
 // ---- grouped weight gradients: up to PK_WGRAD_MAX (col,col) problems C_p = A_p^T B_p in ONE launch ----
@@ -1209,6 +1216,25 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
                                (unsigned)b_bytes, total, stamps, ep);                                                    \
     } while (0)
     static const bool hm2_on = [] { const char* e = getenv("PK_GEMM_HM2"); return !e || atoi(e) != 0; }();  // (A/B: 0 = the switched-off form)
+    if (ep.bits) {  // the ReLU mask as bits (pk_gemm_relu_bits): instantiations of their own, lean epilogue, whole K-tiles, no split
+        if (a_col || any || tail || splitk != 1 || ws) return 0;
+#define PK_B8(TT, BC) hipLaunchKernelGGL((gemm8p_kernel<TT, false, BC, false, false, false, true>), grid, block, 0, s, (const TT*)A, \
+                                         (const TT*)B, (TT*)C, ws, asum_ws, (TT*)asum_out, M, N, K, lda, ldb, kchunk,             \
+                                         (unsigned)a_bytes, (unsigned)b_bytes, total, stamps, ep)
+#define PK_BH(TT, BC) hipLaunchKernelGGL((gemm8p_hm2_kernel<TT, BC, false, true>), grid, block, 0, s, (const TT*)A, (const TT*)B,  \
+                                         (TT*)C, M, N, K, lda, ldb, (unsigned)a_bytes, (unsigned)b_bytes, ep)
+        if (hm) {
+            if (dtype == PK_F16) { if (b_col) PK_BH(f16, true); else PK_BH(f16, false); }
+            else { if (b_col) PK_BH(bf16, true); else PK_BH(bf16, false); }
+        } else {
+            if (dtype == PK_F16) { if (b_col) PK_B8(f16, true); else PK_B8(f16, false); }
+            else { if (b_col) PK_B8(bf16, true); else PK_B8(bf16, false); }
+        }
+#undef PK_B8
+#undef PK_BH
+        PK_LAUNCH_CHECK();
+        return 1;
+    }
     if (hm && hm2_on && splitk == 1 && !ws) {  // the 128 x 256 tile with its own two-phase schedule
 #define PK_H2(TT, BC, TL)                                                                                               \
     hipLaunchKernelGGL((gemm8p_hm2_kernel<TT, BC, TL>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, M, N, K, lda, \
