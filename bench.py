@@ -223,9 +223,17 @@ class GemmTimer:
             return 'gemm8p_group_kernel<%s>' % t
         if kernel == (8 | 0x80):  # Linear + residual + dropout + LayerNorm (pk_gemm_ln_fwd)
             return 'gemm8p_ln_kernel<%s, %d>' % (t, a_col)  # (a_col: the epilogue specialisation, see pk_gemm_ln_fwd)
-        if kernel & 0xF == 8 and (kernel & ~0x400) < 256:  # gemm8p instantiation: <T, A_COL, B_COL, ANY epilogue, TAIL K-tile, half-M tile>
-            return 'gemm8p_kernel<%s, %s, %s, %s, %s, %s>' % (t, tf[a_col], tf[b_col], tf[(kernel >> 4) & 1], tf[(kernel >> 5) & 1],
-                                                              tf[(kernel >> 10) & 1])
+        if kernel == 64:  # the few-rows kernel (gemm_skinny.hip; its activation / mode template arguments are not in the sample)
+            return 'gemm_skinny_kernel<%s, ...>' % t
+        if kernel & 0xF == 8 and (kernel & ~0x3400) < 256:
+            # gemm8p.hip: 0x10 general epilogue, 0x20 partial last K-tile, 0x400 the 128 x 256 tile (a kernel of its own since
+            # round 4: <T, B_COL, TAIL, BITS>), 0x1000 the ReLU mask as bits (round 5; 0x2000: the dH GEMM that reads them);
+            # gemm8p_kernel<T, A_COL, B_COL, ANY epilogue, TAIL K-tile, half-M form, BITS> — the names rocprofv3 prints
+            bits = tf[(kernel >> 12) & 1]
+            if kernel & 0x400:
+                return 'gemm8p_hm2_kernel<%s, %s, %s, %s>' % (t, tf[b_col], tf[(kernel >> 5) & 1], bits)
+            return 'gemm8p_kernel<%s, %s, %s, %s, %s, false, %s>' % (t, tf[a_col], tf[b_col], tf[(kernel >> 4) & 1],
+                                                                       tf[(kernel >> 5) & 1], bits)
         if kernel & 0x200:  # the B-stationary kernel (gemmbs.hip): <T, B_COL, K-tiles, activation, act'-mask, mask as bits, preact>
             return 'gemmbs_kernel<%s, %s, %d, %d, %s, %s, %s>' % (t, tf[b_col], kernel & 0xF, (kernel >> 4) & 3, tf[(kernel >> 6) & 1],
                                                                 tf[(kernel >> 7) & 1], tf[(kernel >> 8) & 1])
