@@ -96,6 +96,37 @@ __global__ __launch_bounds__(256) void col2im1d_kernel(const T* __restrict__ dA,
     }
 }
 
+// the same for 16-byte chunks of channels (C a multiple of the chunk width, 16-byte aligned rows): the scalar kernel above moved
+// Whisper's second conv gradient (16 x 3000 x 512) at 1 TB/s — two-byte accesses and two integer divisions per element
+template <typename T>
+__global__ __launch_bounds__(256) void col2im1d_vec_kernel(const T* __restrict__ dA, T* __restrict__ dx, int B, int L,
+                                                           int C, int R, int Lout, int ksize, int stride, int pad) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int cpr = C / EPV;
+    const long long total = (long long)B * L * cpr;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % cpr);
+        const long long t = i / cpr;
+        const int l = (int)(t % L), b = (int)(t / L);
+        float s[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) s[e] = 0.f;
+        for (int j = 0; j < ksize; ++j) {  // (the same order of additions as the scalar kernel: bit for bit its result)
+            const int num = l + pad - j;
+            if (num < 0 || num % stride) continue;
+            const int r = num / stride;
+            if (r >= Lout) continue;
+            const Vec16<T> v = load16<T>(dA + ((long long)b * R + r) * ksize * C + (long long)j * C + ch * EPV);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) s[e] += v.get(e);
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) o.set(e, s[e]);
+        store16<T>(dx + i * EPV, o);
+    }
+}
+
 // rotary position embedding on the first `ncols` columns of each row (heads of 64: q|k of a packed projection):
 //   y[i] = x[i] cos_i - x[i+32] sin_i ;  y[i+32] = x[i+32] cos_i + x[i] sin_i       (i < 32, angle = pos * inv_freq_i)
 // inverse = 1 rotates by -angle (the backward pass).  cos/sin: fp32 tables [max_pos][head_dim / 2].
@@ -191,8 +222,13 @@ extern "C" int pk_col2im1d(const void* dA, void* dx, int B, int L, int C, int R,
     PK_CHECK_ARG(dA && dx && stride > 0 && ksize > 0, "pk_col2im1d: bad arguments");
     if ((long long)B * L * C == 0) return 0;
     PK_DTYPE_SWITCH(dtype, "pk_col2im1d", {
-        hipLaunchKernelGGL((col2im1d_kernel<T>), dim3(grid_for((long long)B * L * C, 1024)), dim3(256), 0,
-                           (hipStream_t)stream, (const T*)dA, (T*)dx, B, L, C, R, Lout, ksize, stride, pad);
+        constexpr int EPV = 16 / sizeof(T);
+        if (C % EPV == 0 && ((uintptr_t)dA % 16) == 0 && ((uintptr_t)dx % 16) == 0)
+            hipLaunchKernelGGL((col2im1d_vec_kernel<T>), dim3(grid_for((long long)B * L * (C / EPV), 2048)), dim3(256), 0,
+                               (hipStream_t)stream, (const T*)dA, (T*)dx, B, L, C, R, Lout, ksize, stride, pad);
+        else
+            hipLaunchKernelGGL((col2im1d_kernel<T>), dim3(grid_for((long long)B * L * C, 1024)), dim3(256), 0,
+                               (hipStream_t)stream, (const T*)dA, (T*)dx, B, L, C, R, Lout, ksize, stride, pad);
     })
     PK_LAUNCH_CHECK();
     return 0;

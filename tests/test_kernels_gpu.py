@@ -732,6 +732,27 @@ def test_few_rows_kernel_with_the_activation_derivative_epilogue(F, dtype, M, ac
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,L,C,k,stride', [(3, 50, 64, 3, 2), (2, 301, 512, 3, 1), (2, 100, 40, 5, 2), (1, 37, 12, 5, 2), (4, 64, 6, 3, 2)])
+def test_col2im1d(F, dtype, B, L, C, k, stride):
+    """pk_col2im1d (the input gradient of the channels-last Conv1d, pasero/models/modules.py:793-799 backward): the 16-byte
+    chunk kernel (C a multiple of 8 / 4) and the scalar one (C = 12 in bf16, 6) against an explicit scatter of the windows in fp64"""
+    pad = k // 2
+    Lout = (L + 2 * pad - k) // stride + 1
+    R = -(-(L + 2 * pad) // stride)
+    g = torch.Generator().manual_seed(B * L + C)
+    dA = torch.randn(B * R, k * C, generator=g).to(dtype)
+    ref = torch.zeros(B, L + 2 * pad + stride * R, C, dtype=torch.float64)
+    for r in range(Lout):
+        for j in range(k):
+            ref[:, r * stride + j] += dA.view(B, R, k, C)[:, r, j].double()
+    ref = ref[:, pad:pad + L]
+    out = F.col2im1d(dA.cuda(), B, L, C, R, Lout, k, stride, pad)
+    assert out.shape == (B, L, C)
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert (out.double().cpu() - ref).abs().max().item() <= tol * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('M,N', [(1000, 512), (7, 2048), (33000, 1536), (50, 100), (3, 9)])
 def test_colsum(F, dtype, M, N):
     x = rnd((M, N), 60, dtype)
