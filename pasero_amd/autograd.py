@@ -330,6 +330,17 @@ class PackedLinearFn(Function):
         group = None
         if params and isinstance(params[-1], WGradGroup):
             group, params = params[-1], params[:-1]
+        # `link` may also be the decoder pass's encoder-gradient chain (native_layer.DencChain, round 5: the per-op path's
+        # cross-attention k|v projections join it): every decoder layer reads the same encoder output, and their dX GEMMs
+        # add into ONE tensor (epilogue mode 1, in place) instead of autograd adding 23 (rows, d) tensors of the IWSLT recipe
+        ctx.chain = None
+        if link is not None and hasattr(link, 'buf'):
+            chain, link = link, None
+            if (ctx.needs_input_grad[0] and any(wants_grad(ctx)[:1])
+                    and chain.key == (x.data_ptr(), tuple(x.shape), x.dtype) and x.is_contiguous()):
+                ctx.chain = chain
+                chain.n += 1
+                chain.left = chain.n
         ctx.link = link.attach() if (link is not None and ctx.needs_input_grad[0]) else None
         ctx.group, ctx.params = group, (params if group is not None else None)
         x2 = _2d(_contig(x))
@@ -345,7 +356,19 @@ class PackedLinearFn(Function):
         n = ctx.n
         dy2 = _2d(_contig(dy))
         dx = None
-        if ctx.needs_input_grad[0]:
+        chain = ctx.chain
+        if ctx.needs_input_grad[0] and chain is not None and chain.n > 1:
+            sk = F.choose_splitk(dy2.size(0), w_flat.size(1), w_flat.size(0))
+            if chain.left == chain.n:                     # the first of the chain in this backward pass writes the tally,
+                chain.buf = torch.empty(*dy.shape[:-1], w_flat.size(1), dtype=dy2.dtype, device=dy2.device)
+                torch.autograd.Variable._execution_engine.queue_callback(chain.check)
+                F.gemm(dy2, w_flat, b_col=True, out=_2d(chain.buf), splitk=sk)
+            else:                                         # the others add theirs to it, in place,
+                F.gemm(dy2, w_flat, b_col=True, aux=_2d(chain.buf), mode=1, out=_2d(chain.buf), splitk=sk)
+            chain.left -= 1
+            if chain.left == 0:                           # and the last one hands the sum to autograd
+                dx, chain.buf, chain.left = chain.buf, None, chain.n
+        elif ctx.needs_input_grad[0]:
             dx = _dx_gemm(dy2, w_flat, ctx.link).view(*dy.shape[:-1], w_flat.size(1))
         D = w_flat.size(0) // n
         grads = [None] * (2 * n + (1 if ctx.group is not None else 0))

@@ -700,7 +700,9 @@ class MultiheadAttention(_PerCallAttrs, nn.Module):
             attn = AttentionFn.apply(qkv, None, None, attn_mask, H, self.causal and T > 1, scale, drop, fold)
         elif key is value:
             q = LinearFn.apply(query, q_w, q_b, 'none', link, group)
-            kv = PackedLinearFn.apply(key, w[D:], None if b is None else b[D:], 2, None, k_w, v_w, k_b, v_b, *gp)
+            # (the decoder pass's encoder-gradient chain, if one is open: native_layer.open_chain / PackedLinearFn)
+            from . import native_layer
+            kv = PackedLinearFn.apply(key, w[D:], None if b is None else b[D:], 2, native_layer._chain, k_w, v_w, k_b, v_b, *gp)
             attn = AttentionFn.apply(q, kv, None, attn_mask, H, self.causal and T > 1, scale, drop)
         else:
             q = LinearFn.apply(query, q_w, q_b, 'none', link, group)
