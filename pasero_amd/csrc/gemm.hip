@@ -834,7 +834,13 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
         const bool simple = epi_ok && (lean_epi || (e8 && splitk <= 1)) &&  // (the split-K reduce kernel has its own epilogue)
                             (e8 || (N % 8 == 0 && !pad_k));  // (only gemm8p.hip knows the padded forms)
         const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        if (simple && addr_ok && k_ok && tile_pref != 128 && M >= 256 && N >= 256) {
+        // (round 5: a general epilogue — GELU with its pre-activation output — behind a contraction of a few K-tiles is an
+        // elementwise pass, not a GEMM: Whisper's first conv, 48 032 x 512 x 240, took 99 us on the 256-tile kernel's general
+        // epilogue call; the 128-tile kernel's straight-line GELU path with two workgroups per CU takes it.  PK_GEMM_ANY_SHORTK=0: off)
+        static const bool any_shortk = [] { const char* e = getenv("PK_GEMM_ANY_SHORTK"); return !e || atoi(e) != 0; }();
+        const bool general_epi = ep.preact || ep.mode == 3 || (ep.act != PK_ACT_NONE && ep.act != PK_ACT_RELU);
+        const bool short_any = any_shortk && general_epi && K8 <= 256 && ep.act == PK_ACT_GELU && ep.mode != 1 && ep.mode != 3;
+        if (simple && addr_ok && k_ok && tile_pref != 128 && M >= 256 && N >= 256 && !short_any) {
             int sk = 1;
             long long per = K8;
             // split-K (weight-gradient) GEMMs: the 256 kernel re-derives its own split factor (~1 workgroup per CU).
