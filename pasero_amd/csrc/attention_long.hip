@@ -528,6 +528,13 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_long_kernel(const T* __restri
         qoff[i] = (unsigned)row * q_rsb + 16 * ch;
         dooff[i] = (unsigned)row * do_rsb + 16 * ch;
     }
+    unsigned raddr[2];  // row reads of an image (row_frag<DUAL>): this lane's row, chunks 2 kk + h for even / odd kk (kk >> 1 adds 512)
+    {
+        typedef __attribute__((address_space(3))) char lds_char;
+        const unsigned base = (unsigned)(unsigned long)(lds_char*)ring;
+        raddr[0] = base + lds_off<DUAL>(lane & 31, lane >> 5);
+        raddr[1] = base + lds_off<DUAL>(lane & 31, 2 + (lane >> 5));
+    }
     unsigned taddr[2];  // transposed reads of an image: rows 4 h + q and + 8 of d-tile 0 (see the forward kernel)
     {
         typedef __attribute__((address_space(3))) char lds_char;
@@ -554,20 +561,38 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_long_kernel(const T* __restri
         }
     };
     // thread tid < 64: the row constants of row tid of a tile; every thread: dword tid & 3 of the keep bits of row tid >> 2
+    // (round 5: the loads are RAW and unconditional — rows past T read row T - 1 — and the sign, the scale and the select are
+    // applied where the registers are consumed, a tile later.  Written `l_n = t < T ? -lse[..] * inv_scale : -inf`, hipcc
+    // waited for each load where the product stood: two serial trips to memory per tile on wave 0, in front of the DMA request,
+    // with the other three waves waiting at the next barrier.)
     float l_n = 0.f, d_n = 0.f;
     unsigned m_n = 0u;
     auto rows_g2r = [&](int tile) {
         const int t0 = tile * KT;
         if (tid < KT) {
-            const int t = t0 + tid;
-            l_n = t < p.T ? -lse[row0 + t] * inv_scale : -INFINITY;  // -inf -> p = 0 for rows past T
-            d_n = t < p.T ? -delta[row0 + t] : 0.f;
+            const long long t = row0 + min(t0 + tid, p.T - 1);
+            l_n = lse[t];
+            d_n = delta[t];
         }
         if constexpr (DROP) {
             const int t = t0 + (tid >> 2);
             const long long byte0 = (long long)blk * 16 + (tid & 3) * 4;
-            m_n = (t >= p.T || byte0 + 4 > p.mask_pitch) ? 0u
-                                                        : *reinterpret_cast<const unsigned*>(p.drop_mask + (row0 + t) * p.mask_pitch + byte0);
+            const bool okw = t < p.T && byte0 + 4 <= p.mask_pitch;
+            m_n = *reinterpret_cast<const unsigned*>(p.drop_mask + (row0 + (okw ? t : 0)) * p.mask_pitch + (okw ? byte0 : 0));
+        }
+    };
+    // the registers of `rows_g2r(tile)` into stage st of the LDS rows
+    auto rows_r2s = [&](int tile, int st) {
+        const int t0 = tile * KT;
+        if (tid < KT) {
+            const bool in = t0 + tid < p.T;
+            rowc[st][0][tid] = in ? -l_n * inv_scale : -INFINITY;  // -inf -> p = 0 for rows past T
+            rowc[st][1][tid] = in ? -d_n : 0.f;
+        }
+        if constexpr (DROP) {
+            const int t = t0 + (tid >> 2);
+            const long long byte0 = (long long)blk * 16 + (tid & 3) * 4;
+            m_lds[st * KT * 4 + tid] = (t < p.T && byte0 + 4 <= p.mask_pitch) ? m_n : 0u;
         }
     };
 
@@ -579,6 +604,24 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_long_kernel(const T* __restri
         const bool check = p.causal && ws0 + 31 > t0 + off;   // some pairs are masked
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+            // Row fragments of the Q and dO images in inline asm as well (round 5): hipcc's wait-count pass drains vmcnt before a
+            // `ds_read` that may alias an LDS-DMA in flight — here the NEXT tile's pieces, requested a few instructions earlier:
+            // the prefetch was waited for in front of the first fragment read of every tile (an asm read carries no memory
+            // operand; the forward and dQ kernels escape the drain only because theirs lose it in a branch fold).
+            bf16x8_t qr[NF], dr[NF];
+            {
+                const unsigned r0 = raddr[0] + (unsigned)(q_lds - ring), r1 = raddr[1] + (unsigned)(q_lds - ring);
+#pragma unroll
+                for (int kk = 0; kk < NF; ++kk) {
+                    if (kk & 1) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qr[kk]) : "v"(r1), "i"(4096 * qb + 512 * (kk >> 1)));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dr[kk]) : "v"(r1), "i"(8192 + 4096 * qb + 512 * (kk >> 1)));
+                    } else {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qr[kk]) : "v"(r0), "i"(4096 * qb + 512 * (kk >> 1)));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dr[kk]) : "v"(r0), "i"(8192 + 4096 * qb + 512 * (kk >> 1)));
+                    }
+                }
+            }
             f32x16 sc, dp;
             float4 d4[4];
 #pragma unroll
@@ -592,10 +635,12 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_long_kernel(const T* __restri
                     dp[4 * g + j] = DROP ? 0.f : (&d4[g].x)[j];
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(qr[0]), "+v"(qr[1]), "+v"(qr[2]), "+v"(qr[3]), "+v"(dr[0]), "+v"(dr[1]), "+v"(dr[2]), "+v"(dr[3]));
 #pragma unroll
             for (int kk = 0; kk < NF; ++kk) {
-                sc = mm<T>(row_frag<DUAL>(q_lds, qb * 32, kk, lane), kf[kk], sc);
-                dp = mm<T>(row_frag<DUAL>(do_lds, qb * 32, kk, lane), vf[kk], dp);
+                sc = mm<T>(qr[kk], kf[kk], sc);
+                dp = mm<T>(dr[kk], vf[kk], dp);
             }
             if (check) {  // wave-uniform: the causal boundary crosses this (tile, wave) block
                 int sq = s - off - t0 - qb * 32 - 4 * (lane >> 5);  // key s is visible to query index (in the block) >= sq
@@ -661,8 +706,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_long_kernel(const T* __restri
     for (int tile = tile0; tile < ntiles; ++tile) {
         const int st = tile & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the tile and the row constants behind them
-        if (tid < KT) { rowc[st][0][tid] = l_n; rowc[st][1][tid] = d_n; }
-        if constexpr (DROP) m_lds[st * KT * 4 + tid] = m_n;
+        rows_r2s(tile, st);
         __syncthreads();                                   // everyone's pieces and rows; the other stage is free
         if (tile + 1 < ntiles) {
             rows_g2r(tile + 1);
