@@ -15,7 +15,7 @@ for B, H, T, S, causal, drop in [(16, 8, 1500, 1500, False, 0.0), (8, 16, 500, 5
         lens = torch.randint(S // 2, S + 1, (B,), device='cuda'); pad = torch.arange(S, device='cuda')[None] >= lens[:, None]
     do = torch.randn(B, T, D, device='cuda').bfloat16()
     ref = None
-    for it in range(40):
+    for it in range(int(os.environ.get("PK_DET_ITERS", "40"))):
         if drop:
             o, lse, mask = F.attn_fwd(q, k, v, H, pad, causal, 0.125, drop, 7, 3)
             g = F.attn_bwd(q, k, v, o, do, lse, H, pad, causal, 0.125, drop_p=drop, drop_mask=mask)
