@@ -5,6 +5,7 @@ on the hot path.
 import math
 import os
 import threading
+import weakref
 from typing import Optional
 
 import torch
@@ -480,12 +481,27 @@ class DropLink:
     (LayerNormForkFn): the fork's backward already computes dz — the LayerNorm gradient plus the residual branch's — in one
     kernel, and that kernel can write the MASKED copy the dropout's backward needs in the same pass (pk_residual_ln_bwd's
     dx output; what the native layer call does).  The producer leaves (p, seed, offset) here in forward; the consumer's
-    backward leaves the masked gradient and the address of dz; the producer's backward takes it if the dz it receives is
-    that very tensor (another consumer of z would make autograd hand over a sum: then it draws the mask itself)."""
-    __slots__ = ('p', 'seed', 'offset', 'masked', 'dz_ptr')
+    backward `offer`s the masked gradient together with the dz it belongs to; the producer's backward `take`s it only if
+    the dz it receives is that very tensor, untouched.  Another consumer of z makes autograd hand over a SUM — and its input
+    buffer adds in place when it holds the last reference, so the sum can sit at dz's address: the link keeps
+    a reference to dz until the hand-over (the engine then adds out of place, into a new tensor) and also compares the
+    tensor's version counter; in either case the producer draws the mask itself."""
+    __slots__ = ('p', 'seed', 'offset', 'masked', 'dz', 'dz_version')
 
     def __init__(self):
-        self.p, self.seed, self.offset, self.masked, self.dz_ptr = 0.0, 0, 0, None, 0
+        self.p, self.seed, self.offset, self.masked, self.dz, self.dz_version = 0.0, 0, 0, None, None, 0
+
+    def offer(self, masked, dz) -> None:
+        self.masked, self.dz, self.dz_version = masked, dz, dz._version
+
+    def take(self, dz):
+        """the masked gradient offered for exactly this `dz`, or None; the offer is consumed either way"""
+        masked, mine, version = self.masked, self.dz, self.dz_version
+        self.masked = self.dz = None
+        if (masked is None or mine is None or dz.data_ptr() != mine.data_ptr() or dz._version != version
+                or dz.shape != masked.shape or dz.dtype != mine.dtype):
+            return None
+        return masked
 
 
 class LayerNormForkFn(Function):
@@ -519,7 +535,7 @@ class LayerNormForkFn(Function):
             _contig(dy), extra, x, gamma, mean, rstd, want_dres=True, want_dx=d is not None, want_param_grads=want_pg,
             has_beta=ctx.has_beta, drop_p=d.p if d else 0.0, seed=d.seed if d else 0, offset=d.offset if d else 0)
         if d is not None:
-            d.masked, d.dz_ptr = masked, dx.data_ptr()
+            d.offer(masked, dx)
         return (dx if ctx.needs_input_grad[0] else None, dgamma if ctx.needs_input_grad[1] else None,
                 dbeta if (ctx.has_beta and ctx.needs_input_grad[2]) else None, None, None)
 
@@ -763,13 +779,11 @@ class ResidualDropoutFn(Function):
         dz = _contig(dz)
         dx = dz
         if ctx.p > 0 and ctx.needs_input_grad[0]:
-            link = ctx.link
-            if link is not None and link.masked is not None and link.dz_ptr == dz.data_ptr() and link.masked.shape == dz.shape:
-                dx = link.masked  # (written by the consumer's LayerNorm backward kernel in the pass that made dz)
-            else:
-                dx = F.dropout(dz, ctx.p, ctx.seed, ctx.offset)
-        if ctx.link is not None:
-            ctx.link.masked = None
+            masked = ctx.link.take(dz) if ctx.link is not None else None
+            # (masked: written by the consumer's LayerNorm backward kernel in the pass that made dz)
+            dx = masked if masked is not None else F.dropout(dz, ctx.p, ctx.seed, ctx.offset)
+        elif ctx.link is not None:
+            ctx.link.take(dz)
         return dx, dz, None, None
 
 
@@ -813,7 +827,6 @@ def tie_table(weight: Tensor) -> Tensor:
     """mark `weight` as a table that is both looked up and used as the vocabulary projection (see above); idempotent"""
     if _NO_GRAD_SINK or not weight.requires_grad or not weight.is_cuda or getattr(weight, '_pk_tied_hook', None) is not None:
         return weight
-    import weakref
     ref = weakref.ref(weight)
 
     def add_deferred_rows(grad):
@@ -821,6 +834,8 @@ def tie_table(weight: Tensor) -> Tensor:
         items = _table_sessions.pop(_table_key(w), None) if w is not None else None
         if not items:
             return None
+        if grad is None:  # an undefined sum (a nested / reentrant pass whose dense contribution never came): start from zeros
+            grad = torch.zeros_like(w)
         g = grad if grad.is_contiguous() else grad.contiguous()
         for ids, dout, (V, pad, scale, p, seed, offset) in items:
             F.embed_bwd(ids, dout, V, pad, scale, p, seed, offset, into=g)
@@ -846,7 +861,10 @@ class EmbeddingFn(Function):
         out = F.embed_fwd(ids, weight, pos_table, scale, pos_start, p, seed, offset)
         ctx.args = (scale, pos_start, p, seed, offset, padding_idx, weight.size(0))
         ctx.pos_rows = pos_table.size(0) if pos_table is not None else 0
-        ctx.table = _table_key(weight)
+        # rows are deferred only for the tensor `tie_table` marked — the one whose hook will add them; another autograd
+        # tensor over the same storage (a view, a detached copy that requires grad) has a gradient of its own
+        # (checked in backward: the model ties the table when it reaches the loss, after the lookups of the same pass)
+        ctx.table, ctx.table_ref = _table_key(weight), weakref.ref(weight)
         ctx.save_for_backward(ids)
         return out
 
@@ -857,7 +875,9 @@ class EmbeddingFn(Function):
         dout = _contig(dout)
         dE = dpos = None
         if ctx.needs_input_grad[1]:
-            session = _table_sessions.get(ctx.table)
+            w = ctx.table_ref()
+            tied = w is not None and getattr(w, '_pk_tied_hook', None) is not None
+            session = _table_sessions.get(ctx.table) if tied else None
             if session is not None and dout.dtype == ctx.table[2]:
                 session.append((ids, dout, (V, padding_idx, scale, p, seed, offset)))  # (added into the table's summed gradient)
             else:

@@ -137,6 +137,9 @@ class Adam(torch.optim.Optimizer):
                                float(max_norm), float(group['lr']), float(b1), float(b2), float(group['eps']),
                                float(group['weight_decay']), 0, base + offs[i][1], dtype_code(params[0]),
                                stream_ptr()), 'pk_mt_adam')
+            # the kernel wrote the parameters through raw pointers: tell autograd, as an in-place op would (anything keyed
+            # on `_version` — Embedding.effective_weight's merged table — must see the step)
+            torch._C._increment_version(params)
         self._keepalive = table  # the launches read it asynchronously
         return gnorm
 

@@ -94,3 +94,64 @@ def test_sinusoidal_table_vs_reference(d):
     np.testing.assert_allclose(table[2:42], g[f'd{d}'], rtol=0, atol=1e-5)
     np.testing.assert_allclose(table[19:22], g[f'd{d}_off'], rtol=0, atol=1e-5)
     np.testing.assert_allclose(table[[0, 1, 2, 150, 301]], g[f'd{d}_rows'], rtol=0, atol=5e-5)
+
+
+def test_merged_embedding_table_follows_the_fused_optimizer_step():
+    """`Embedding.effective_weight` caches where(freeze_mask, frozen, weight) keyed on the tables'
+    `_version`; `optim.Adam.fused_step` writes the parameters through raw pointers (pk_mt_adam), so it has to bump the
+    versions itself — otherwise every training forward after the first step reads the step-0 table
+    (pasero/models/modules.py:929-946 gathers from the live tables each call)."""
+    from pasero_amd.modules import Embedding
+    from pasero_amd.optim import Adam
+    torch.manual_seed(3)
+    V, d = 40, 64
+    mask = torch.zeros(V, dtype=torch.bool)
+    mask[::3] = True
+    e = Embedding(V, d, 1, freeze_mask=mask).cuda()
+    mask = mask.cuda()
+    opt = Adam(list(e.parameters()), lr=0.1, weight_decay=0.0)
+    ids = torch.randint(2, V, (4, 9), device='cuda')
+    for step in range(3):
+        E = e.effective_weight()
+        assert torch.equal(E, torch.where(mask[:, None], e.frozen_embedding.weight, e.weight)), step
+        before = e.weight.detach().clone()
+        e(ids).square().sum().backward()
+        v0 = e.weight._version
+        opt.fused_step(1.0, 0.0)
+        torch.cuda.synchronize()
+        assert e.weight._version > v0
+        assert not torch.equal(before, e.weight)  # the step moved the trainable table ...
+        E2 = e.effective_weight()
+        assert E2 is not E  # ... and the merged table was rebuilt, inside grad mode as well as outside
+        assert torch.equal(E2, torch.where(mask[:, None], e.frozen_embedding.weight, e.weight))
+        with torch.no_grad():
+            assert torch.equal(e.effective_weight(), E2.detach())
+        opt.zero_grad(set_to_none=True)
+
+
+def test_lookup_through_an_alias_of_a_tied_table_keeps_its_own_gradient():
+    """rows are deferred to the tied table's hook only by lookups of the tensor `tie_table` marked; a second
+    autograd tensor over the same storage has its own gradient, and the table's gradient is then the dense dW alone"""
+    from pasero_amd import autograd
+    from pasero_amd.autograd import EmbeddingFn, VocabCrossEntropyFn, tie_table
+    torch.manual_seed(5)
+    V, d, B, T = 48, 64, 3, 7
+    w = torch.nn.Parameter(torch.randn(V, d, device='cuda') * 0.1)
+    tie_table(w)
+    alias = w.detach().requires_grad_()
+    assert alias.data_ptr() == w.data_ptr()
+    x = torch.randn(B, T, d, device='cuda', requires_grad=True)
+    tgt = torch.randint(2, V, (B, T), device='cuda')
+    ids = torch.randint(2, V, (B, T), device='cuda')
+
+    def run(table):
+        for t in (w, alias, x):
+            t.grad = None
+        sums = VocabCrossEntropyFn.apply(x, w, tgt, 1, 0.1)
+        (sums[0] + EmbeddingFn.apply(ids, table, None, 1.0, 0, 0.0, 1).square().sum()).backward()
+        assert not autograd._table_sessions
+        return w.grad.clone(), (None if alias.grad is None else alias.grad.clone())
+    both, none = run(w)  # the marked tensor itself: one gradient holding the dense dW and the lookup's rows
+    assert none is None
+    dense, rows = run(alias)
+    assert rows is not None and rel(dense + rows, both) < 1e-5 and rows.abs().sum() > 0
