@@ -206,10 +206,11 @@ class GemmTimer:
 
     def __init__(self):
         self.samples = 0
+        self.launches_per_step = 0
 
-    def start(self, max_samples: int):
+    def start(self, max_samples: int, stride: int = 0):
         from pasero_amd import lib
-        lib.check(lib.load().pk_gemm_timing_start(int(max_samples), self.STRIDE), 'pk_gemm_timing_start')
+        lib.check(lib.load().pk_gemm_timing_start(int(max_samples), stride or self.STRIDE), 'pk_gemm_timing_start')
 
     def stop(self):
         from pasero_amd import lib
@@ -522,7 +523,15 @@ def run(args):
             step()
         fence()
         if not args.no_roofline:
-            timer.start(400 * steps // GemmTimer.STRIDE + 64)
+            # the sample buffer is sized from a COUNTED step (one more untimed step with every GEMM call sampled): a fixed
+            # guess of 400 launches per step filled up at 54-69 % of the timed region of C5 (586) and the IWSLT recipe (759),
+            # so their per-kernel averages and `gemm_share_of_step` came from the first part of it only
+            timer.start(4096, stride=1)
+            step()
+            fence()
+            timer.stop()
+            timer.launches_per_step = timer.samples
+            timer.start(timer.launches_per_step * steps // GemmTimer.STRIDE + 64)
         # five sub-windows of the timed region, cut by events on the launch stream (no synchronisation inside the region):
         # one short sample per round cannot show the 3-5 % the boxes differ by, the spread inside a run can
         nwin = 5 if steps >= 10 else 1
@@ -590,15 +599,18 @@ def run(args):
                        'model_tflops_per_gpu': step_flops * args.steps / elapsed / 1e12,
                        'mfma_peak_fraction_whole_step': step_flops * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS},
         }
+        out['config']['sclk_mhz_median'] = timer.sclk['median'] if timer.sclk else None
+        roofline = None
         if not args.no_roofline and timer.samples:
             summ = timer.summary()
             dom = max(summ, key=lambda k: summ[k]['total_ms'])
             d = summ[dom]
-            out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': d['tflops'], 'peak': PEAK_BF16_TFLOPS,
+            roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': d['tflops'], 'peak': PEAK_BF16_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': d['tflops'] / PEAK_BF16_TFLOPS, 'traffic': None,
                                'avg_launch_us': d['avg_us'], 'sampled_launches': d['launches'],
                                'sampling': f'HIP events around the kernel of every {GemmTimer.STRIDE}th pk_gemm call, on its stream',
                                'flops_per_launch': d['flops_per_launch'],
+                               'gemm_launches_per_step': timer.launches_per_step,
                                'gemm_share_of_step': GemmTimer.STRIDE * sum(v['total_ms'] for v in summ.values()) / (1e3 * elapsed),
                                'all_gemm_kernels': {k: {'tflops': round(v['tflops'], 1), 'avg_us': round(v['avg_us'], 1),
                                                         'sampled_launches': v['launches']} for k, v in summ.items()}}
@@ -606,16 +618,19 @@ def run(args):
                 live_pmc_traffic(dom, args.workload, args.dtype)
             if traffic is None:
                 traffic, how = committed_pmc_traffic(dom), f'committed profiles/ ({how})'
-            out['roofline']['traffic'] = traffic
-            out['roofline']['traffic_source'] = how
+            roofline['traffic'] = traffic
+            roofline['traffic_source'] = how
             if traffic:  # the same kernel against the memory roof: L2 <-> fabric bytes per launch / its duration
                 gbps = traffic / (d['avg_us'] * 1e-6) / 1e9
-                out['roofline']['hbm'] = {'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBPS}
+                roofline['hbm'] = {'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBPS}
         if world == 1 and not args.no_extra_workloads and args.workload == 'c2_base_bf16':
             # the other BASELINE configurations that fit one GPU, timed by THIS run after the headline region (same
             # process, same protocol, a few steps each): d = 1024 is where north_star states its 40 % target
             del ddp
             out['extra_workloads'] = {}
+            # the same numbers, compact, INSIDE `config` (the driver keeps `config` whole but only a tail of the line: C3's
+            # record was cut out of BENCH_r04 / r05): name -> [ms per step, whole-step fraction of 2.5 PFLOP/s, sclk MHz]
+            out['config']['extras'] = {}
             for name in ('c3_big', 'c4_whisper', 'c5_nllb_1b3', 'c4_iwslt'):
                 torch.cuda.empty_cache()
                 e_steps = args.extra_steps if name not in DEVICE_INIT else max(1, args.extra_steps // 2)  # (80-100 ms steps)
@@ -635,12 +650,22 @@ def run(args):
                 if not args.no_roofline and e_timer.samples:
                     es = e_timer.summary()
                     edom = max(es, key=lambda k: es[k]['total_ms'])
+                    top = sorted(es, key=lambda k: -es[k]['total_ms'])[:4]  # (the full tables: profiles/rNN_<workload>_*)
                     rec.update({'dominant_kernel': edom, 'achieved_tflops': es[edom]['tflops'],
                                 'frac': es[edom]['tflops'] / PEAK_BF16_TFLOPS, 'avg_launch_us': es[edom]['avg_us'],
                                 'sampled_launches': es[edom]['launches'],
-                                'all_gemm_kernels': {k: {'tflops': round(v['tflops'], 1), 'avg_us': round(v['avg_us'], 1),
-                                                         'sampled_launches': v['launches']} for k, v in es.items()}})
+                                'gemm_launches_per_step': e_timer.launches_per_step,
+                                'gemm_share_of_step': GemmTimer.STRIDE * sum(v['total_ms'] for v in es.values()) / (1e3 * e_el),
+                                'top_gemm_kernels': {k: {'tflops': round(es[k]['tflops'], 1), 'avg_us': round(es[k]['avg_us'], 1),
+                                                         'sampled_launches': es[k]['launches']} for k in top}})
                 out['extra_workloads'][name] = rec
+                frac = round(rec['mfma_peak_fraction_whole_step'], 4)
+                sclk = round(e_timer.sclk['median']) if e_timer.sclk else None
+                out['config']['extras'][name] = [round(rec['ms_per_step'], 3), frac, sclk]
+                out['config'][name + '_ms_per_step'] = round(rec['ms_per_step'], 3)  # (flat copies: scalars survive any parser)
+                out['config'][name + '_mfma_frac_whole_step'] = frac
+        if roofline is not None:  # (after the extras: the line's longest table last but one)
+            out['roofline'] = roofline
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         _JSON_LINE.append(json.dumps(out))

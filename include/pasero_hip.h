@@ -137,8 +137,14 @@ int pk_gemm_wgrad_group_map(const PkWgradProblem* problems, int n, int* out, int
  *     tile the second to arrive adds the first one's fp32 partial (published write-through behind an agent-scope flag) to its
  *     own and stores the 16-bit tile; fp32 addition commutes, so the result is bit for bit the reduction launch's whatever the
  *     arrival order.  A group of only such problems (NLLB-1.3B's layers at 8192 rows) has no reduction launch at all.
+ *     Round 6: the hand-off fails LOUDLY and is stream-safe.  The ticket / flag words are per (device, stream) — grouped
+ *     launches running at once on two streams never see each other's tickets; a stream beyond the library's 32 buffers takes
+ *     the reduction launch.  A second workgroup whose bounded wait ends without its partner's flag stores NaN for its tile
+ *     and raises a sticky error word in host-visible memory: the NEXT pk_gemm_wgrad_group call on any stream returns an error
+ *     (pk_last_error names the tile) after re-zeroing every ticket buffer — a wrong weight gradient is never silent.
  *     pk_gemm_wgrad_pair: diagnostic switch, 1 / 0 = on (default; env PK_WGRAD_PAIR sets the initial value) / every split
- *     problem through the reduction launch; negative: query only.  Returns the previous setting. */
+ *     problem through the reduction launch; 2 = on AND the first workgroup's publish dropped, the second's wait shortened
+ *     (tests of the error path only); negative: query only.  Returns the previous setting. */
 int pk_gemm_wgrad_pair(int on);
 
 /* ---- Linear + residual + dropout + LayerNorm in one kernel (K4 fused into K2/K5): replaces the tail of a post-norm

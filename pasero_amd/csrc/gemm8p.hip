@@ -248,13 +248,22 @@ __device__ __noinline__ void epilogue_pass_any(const float* __restrict__ cs, T* 
 // issued against an empty descriptor (so every counted wait still counts the same instructions), its fragment reads, its
 // two quadrant MFMA sections and its two epilogue passes are compiled out.  Not the schedule one would design for this tile
 // (two of four phases only synchronise), but every hazard distance of the full schedule holds a fortiori.
+// pair mode's control words (grouped weight gradients; see "pair mode" in gemm8p_tile): where a lost hand-off is reported,
+// how long the second workgroup waits, and the diagnostic that makes it wait in vain (tests)
+struct PairCtl {
+    unsigned* err;        // sticky error word in host-visible memory (the host reads it before the next grouped launch)
+    unsigned spin_limit;  // polls of the partner's flag before the second workgroup gives up
+    int drop_publish;     // diagnostic: the first workgroup does NOT raise its flag
+};
+
 template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL, bool HM = false, bool BITS = false>
 __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
                                             float* __restrict__ ws, float* __restrict__ asum_ws,
                                             T* __restrict__ asum_out, long long M, long long N, long long K,
                                             long long lda, long long ldb, int kchunk, unsigned a_bytes,
                                             unsigned b_bytes, int lin, unsigned long long* stamps,
-                                            const EpiParams& ep, unsigned* pair_sync = nullptr) {
+                                            const EpiParams& ep, unsigned* pair_sync = nullptr,
+                                            const PairCtl pctl = PairCtl{nullptr, 0u, 0}) {
     typedef typename M16<T>::vec V;
     typedef __attribute__((address_space(3))) void lds_void;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -546,7 +555,12 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     // behind it (second) — and the first workgroup publishes by storing the SECOND's ticket value into the flag; the second
     // waits until the flag equals its own ticket.  Flag values of earlier launches are smaller tickets, never this one
     // (a memset node per launch cost 4.7 us of stream time each, more than the reduction launch it was to save).
+    // A wait that ends WITHOUT the flag (a partner that died, tickets of another stream mixed in — neither can happen
+    // while the buffer is used as the host code uses it) must not become a silently wrong weight gradient: the second
+    // workgroup then writes the tile's id into a sticky error word the host reads before its next grouped launch
+    // (pk_gemm8p_group_launch: RuntimeError through pk_last_error, tickets re-zeroed) and stores NaN instead of sums.
     int role = 0;  // 0: not a pair, 1: first to arrive (publishes its slab), 2: second (adds and finishes)
+    bool lost = false;  // role 2 only: the partner's flag never came
     unsigned* sync_w = nullptr;
     unsigned ticket = 0;
     if constexpr (A_COL && B_COL && !ANY && !TAIL && !HM) {
@@ -559,14 +573,19 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
             role = (ticket & 1u) ? 2 : 1;
             if (role == 2) {
                 if (tid == 0) {
-                    for (unsigned spins = 0; spins < (1u << 22); ++spins) {  // (~0.5 s: a lost partner must not hang the GPU)
-                        if (__hip_atomic_load(sync_w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ticket) break;
+                    unsigned got = 0u;
+                    for (unsigned spins = 0; spins < pctl.spin_limit; ++spins) {  // (2^22: ~0.5 s — a lost partner must not hang the GPU)
+                        if (__hip_atomic_load(sync_w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ticket) { got = 1u; break; }
                         __builtin_amdgcn_s_sleep(4);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    lw[1] = got;
+                    if (!got && pctl.err)
+                        __hip_atomic_store(pctl.err, 0x80000000u | (unsigned)tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 __syncthreads();
+                lost = __builtin_amdgcn_readfirstlane((int)lw[1]) == 0;
             }
         }
     }
@@ -584,7 +603,8 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
                 if (role == 1) {  // (part of what the flag publishes)
                     __hip_atomic_store(asum_ws + (long long)kslab * M + m0 + tid, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else if (role == 2) {
-                    asum_out[m0 + tid] = from_f32<T>(sum + asum_ws[(long long)(1 - kslab) * M + m0 + tid]);
+                    const float other = lost ? __builtin_nanf("") : asum_ws[(long long)(1 - kslab) * M + m0 + tid];
+                    asum_out[m0 + tid] = from_f32<T>(sum + other);
                 } else if (asum_ws) asum_ws[(long long)kslab * M + m0 + tid] = sum;
                 else asum_out[m0 + tid] = from_f32<T>(sum);
             }
@@ -676,6 +696,11 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
             float4 cur[4][2];
 #pragma unroll
             for (int it = 0; it < 4; ++it) { cur[it][0] = oth[it][0]; cur[it][1] = oth[it][1]; }
+            if (lost) {  // (wave-uniform; never taken in a healthy launch)
+                const float nan = __builtin_nanf("");
+#pragma unroll
+                for (int it = 0; it < 4; ++it) { cur[it][0] = float4{nan, nan, nan, nan}; cur[it][1] = cur[it][0]; }
+            }
             if (p + 1 < NPASS) other_load(p + 1);  // (one pass ahead, as the aux operand of the single GEMMs)
             if (gn + 8 <= N) {
 #pragma unroll
@@ -740,7 +765,8 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     if (role == 1) {  // publish: every storing wave drains its write-through stores, then ONE lane raises the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(sync_w + 1, ticket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && !pctl.drop_publish)
+            __hip_atomic_store(sync_w + 1, ticket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifdef PK8P_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1052,6 +1078,7 @@ struct GroupProb {
 struct GroupArgs {
     GroupProb p[PK_WGRAD_MAX];
     int n;
+    PairCtl pair;
 };
 
 __device__ __forceinline__ GroupProb group_select(const GroupArgs& g, int first_field_of, int pos) {
@@ -1098,7 +1125,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_group_kernel(GroupArgs g, Group
     ep.act = PK_ACT_NONE; ep.mode = 0; ep.alpha = 1.f;
     gemm8p_tile<T, true, true, false, false>((const T*)q.A, (const T*)q.B, (T*)q.C, q.ws, q.asum_ws, (T*)q.asum_out, q.M,
                                              q.N, q.K, q.lda, q.ldb, q.kchunk, q.a_bytes, q.b_bytes, lin, stamps, ep,
-                                             q.pair_sync);
+                                             q.pair_sync, g.pair);
 }
 
 // C_p = sum over the K-slabs of problem p (fixed order: deterministic), 16-byte chunks; + the fused bias-gradient sums
@@ -1299,27 +1326,65 @@ double list_makespan(double dur_long, long long n_long, double dur_short, long l
     return last;
 }
 // pair mode on / off: PK_WGRAD_PAIR=0 in the environment, or pk_gemm_wgrad_pair(0) at run time (how the tests obtain the
-// reduction launch's result as the reference of the in-kernel one, in one process)
+// reduction launch's result as the reference of the in-kernel one, in one process).  2 = on + the diagnostic that drops the
+// first workgroup's publish and shortens the second's wait (tests of the error path; never set in production).
 int g_pair_on = [] { const char* e = getenv("PK_WGRAD_PAIR"); return (!e || atoi(e) != 0) ? 1 : 0; }();
-// the ticket / flag words of pair mode: one buffer per device, owned by the library, zeroed once; launches on ONE stream at a
-// time use it (as they do the split-K workspace the caller hands in)
+// The ticket / flag words of pair mode: ONE BUFFER PER (device, stream), owned by the library, zeroed when it is allocated.
+// Tickets of one buffer only mean something in launch order, and launches are ordered within a stream only: two grouped
+// launches running at once on two streams would interleave their tickets in a shared buffer and mis-pair.
+// A stream beyond the table's capacity gets no buffer and its launches take the reduction launch instead.
 constexpr size_t PAIR_SYNC_WORDS = 64 * 1024;
-unsigned* pair_sync_buffer() {
-    static std::mutex mu;
-    static unsigned* buf[64] = {nullptr};
+constexpr int PAIR_SYNC_STREAMS = 32;
+struct PairSyncEntry { int dev; hipStream_t stream; unsigned* words; };
+std::mutex g_pair_mu;
+PairSyncEntry g_pair_bufs[PAIR_SYNC_STREAMS];
+int g_pair_nbufs = 0;
+unsigned* g_pair_err_host = nullptr;  // sticky error word: pinned host memory the kernels write (PairCtl::err)
+unsigned* g_pair_err_dev = nullptr;
+
+unsigned* pair_sync_buffer(hipStream_t s, bool allocate) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> g(mu);
-    if (!buf[dev]) {
-        unsigned* p = nullptr;
-        if (hipMalloc((void**)&p, PAIR_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, PAIR_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return nullptr; }
-        buf[dev] = p;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(g_pair_mu);
+    for (int i = 0; i < g_pair_nbufs; ++i)
+        if (g_pair_bufs[i].dev == dev && g_pair_bufs[i].stream == s) return g_pair_bufs[i].words;
+    if (!allocate || g_pair_nbufs >= PAIR_SYNC_STREAMS) return nullptr;
+    if (!g_pair_err_host) {
+        unsigned* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc((void**)&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        *h = 0u;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return nullptr; }
+        g_pair_err_host = h;
+        g_pair_err_dev = (unsigned*)d;
     }
-    return buf[dev];
+    unsigned* p = nullptr;
+    if (hipMalloc((void**)&p, PAIR_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemset(p, 0, PAIR_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+    g_pair_bufs[g_pair_nbufs++] = PairSyncEntry{dev, s, p};
+    return p;
 }
 
-void plan_group_uncached(const PkWgradProblem* p, int n, GroupPlan* pl) {
+// A kernel of an EARLIER grouped launch reported a lost hand-off (its tile holds NaN): returns the word and clears it; every
+// ticket buffer is re-zeroed behind a device synchronisation (an odd ticket left behind would mis-pair all later launches).
+unsigned pair_error_take() {
+    if (!g_pair_err_host) return 0u;
+    const unsigned e = *(volatile unsigned*)g_pair_err_host;
+    if (!e) return 0u;
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> g(g_pair_mu);
+    for (int i = 0; i < g_pair_nbufs; ++i) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (g_pair_bufs[i].dev != dev) (void)hipSetDevice(g_pair_bufs[i].dev);
+        (void)hipMemset(g_pair_bufs[i].words, 0, PAIR_SYNC_WORDS * sizeof(unsigned));
+        if (g_pair_bufs[i].dev != dev) (void)hipSetDevice(dev);
+    }
+    *(volatile unsigned*)g_pair_err_host = 0u;
+    return e;
+}
+
+void plan_group_uncached(const PkWgradProblem* p, int n, GroupPlan* pl, bool pair_on) {
     long long kmax = 0;
     for (int i = 0; i < n; ++i) kmax = std::max(kmax, p[i].K);
     double best = 1e30;
@@ -1377,7 +1442,7 @@ void plan_group_uncached(const PkWgradProblem* p, int n, GroupPlan* pl) {
         pl->ws_off[i] = pl->asum_off[i] = 0;
         // (PK_WGRAD_PAIR=0: every split problem through the reduction launch, as before round 5 — the A/B and the tests'
         // reference; the slab region of a pair must be addressable through one buffer descriptor: < 2 GiB)
-        pl->pair[i] = g_pair_on && sp == 2 && 2 * p[i].M * p[i].N * 4 < (1LL << 31);
+        pl->pair[i] = pair_on && sp == 2 && 2 * p[i].M * p[i].N * 4 < (1LL << 31);
         if (sp > 1) {
             const long long chunks = p[i].M * (p[i].N / 8);
             if (!pl->pair[i]) blk += (int)std::min(2048LL, (chunks + 255) / 256);
@@ -1420,21 +1485,21 @@ void plan_group_uncached(const PkWgradProblem* p, int n, GroupPlan* pl) {
     }
 }
 // (the plan depends on the shapes and on which problems carry a bias sum: cached — four calls per launch ask for it)
-void plan_group(const PkWgradProblem* p, int n, GroupPlan* pl) {
+void plan_group(const PkWgradProblem* p, int n, GroupPlan* pl, bool pair_on = g_pair_on != 0) {
     struct Key { long long v[PK_WGRAD_MAX][4]; int n, pair_on; };
     static std::mutex mu;
     static std::vector<std::pair<Key, GroupPlan>> cache;
     Key k;
     memset(&k, 0, sizeof k);
     k.n = n;
-    k.pair_on = g_pair_on;
+    k.pair_on = pair_on ? 1 : 0;
     for (int i = 0; i < n; ++i) { k.v[i][0] = p[i].M; k.v[i][1] = p[i].N; k.v[i][2] = p[i].K; k.v[i][3] = p[i].asum_out != nullptr; }
     {
         std::lock_guard<std::mutex> g(mu);
         for (const auto& e : cache)
             if (memcmp(&e.first, &k, sizeof k) == 0) { *pl = e.second; return; }
     }
-    plan_group_uncached(p, n, pl);
+    plan_group_uncached(p, n, pl, pair_on);
     std::lock_guard<std::mutex> g(mu);
     if (cache.size() >= 64) cache.erase(cache.begin());
     cache.emplace_back(k, *pl);
@@ -1540,7 +1605,7 @@ int plan_map(const PkWgradProblem* p, int n, const GroupPlan& pl, GroupMap* mp) 
 
 extern "C" int pk_gemm_wgrad_pair(int on) {
     const int prev = g_pair_on;
-    if (on >= 0) g_pair_on = on ? 1 : 0;
+    if (on >= 0) g_pair_on = on == 2 ? 2 : (on ? 1 : 0);
     return prev;
 }
 
@@ -1591,13 +1656,21 @@ extern "C" int pk_gemm8p_group_map(const PkWgradProblem* p, int n, int* out, int
 // Returns 1 if launched, a hip error code otherwise.  The caller (gemm.hip: pk_gemm_wgrad_group) has checked eligibility
 // and the workspace size.
 extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (const unsigned e = pair_error_take()) {
+        pk_set_error("pk_gemm_wgrad_group: an earlier grouped launch lost a hand-off of its in-kernel two-slab reduction "
+                     "(tile %u of a problem: its weight gradient was poisoned with NaN); the ticket words were reset",
+                     e & 0x7fffffffu);
+        return (int)hipErrorUnknown;
+    }
     GroupPlan pl;
     plan_group(p, n, &pl);
-    unsigned* sync_buf = pl.sync_words ? pair_sync_buffer() : nullptr;
-    if (pl.sync_words && !sync_buf) { pk_set_error("pk_gemm_wgrad_group: no sync buffer for the in-kernel reduction"); return (int)hipErrorOutOfMemory; }
+    unsigned* sync_buf = pl.sync_words ? pair_sync_buffer(s, true) : nullptr;
+    if (pl.sync_words && !sync_buf) plan_group(p, n, &pl, false);  // no ticket words for this stream: the reduction launch
     GroupArgs g;
     g = GroupArgs{};
     g.n = n;
+    g.pair = PairCtl{g_pair_err_dev, g_pair_on == 2 ? (1u << 10) : (1u << 22), g_pair_on == 2 ? 1 : 0};
     for (int i = 0; i < n; ++i) {
         GroupProb& q = g.p[i];
         long long a_bytes, b_bytes;
@@ -1616,7 +1689,6 @@ extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype,
     static unsigned long long* const stamp_buf = [] { const char* e = getenv("PK8P_STAMP_PTR"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
     stamps = stamp_buf;
 #endif
-    hipStream_t s = (hipStream_t)stream;
     GroupMap mp;
     const int grid = plan_map(p, n, pl, &mp);
     if (dtype == PK_F16) hipLaunchKernelGGL((gemm8p_group_kernel<f16>), dim3(grid), dim3(512), 0, s, g, mp, stamps);
@@ -1628,6 +1700,8 @@ extern "C" int pk_gemm8p_group_launch(const PkWgradProblem* p, int n, int dtype,
 extern "C" int pk_gemm8p_group_reduce(const PkWgradProblem* p, int n, int dtype, float* workspace, void* stream) {
     GroupPlan pl;
     plan_group(p, n, &pl);
+    // (the plan the launch before this call used: without ticket words for this stream it ran every problem unpaired)
+    if (pl.sync_words && !pair_sync_buffer((hipStream_t)stream, false)) plan_group(p, n, &pl, false);
     if (pl.total_blks == 0) return 1;
     GroupArgs g;
     g = GroupArgs{};
