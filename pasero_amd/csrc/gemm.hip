@@ -33,6 +33,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 extern "C" int pk_gemm256_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
                                  long long M, long long N, long long K, long long lda, long long ldb, int a_col,
                                  int b_col, int kchunk, int splitk, EpiParams ep, int dtype, void* stream);
+extern "C" int pk_gemm8p_is_pw(long long M, long long N, long long K, long long lda, long long ldb, int a_col, int b_col,
+                               int splitk, int has_ws, int has_asum, const EpiParams* ep);
 extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
                                 long long M, long long N, long long K, long long lda, long long ldb, int a_col,
                                 int b_col, int kchunk, int splitk, EpiParams ep, int dtype, void* stream);
@@ -901,12 +903,16 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
                 // operands beyond 4 GiB).  PK_GEMM_8P=0 switches it off (A/B inside one process: tools/gemm_bench.py)
                 // (sample tag of the gemm8p instantiation: 8 | 0x10 general epilogue | 0x20 partial last K-tile)
                 const bool any_epi = ep.preact || ep.mode == 3 || (ep.act != PK_ACT_NONE && ep.act != PK_ACT_RELU);
-                const int tag8 = 8 | (any_epi ? 0x10 : 0) | (K8 % 64 ? 0x20 : 0) | (half_m ? 0x400 : 0);
-                GemmSample* sm = timing_begin(e8 ? tag8 : 256, a_col, b_col, std::max(sk, 1), dtype16, M, N, K, stream);
                 EpiParams ep8 = ep;
                 if (e8 && pad_n) ep8.nstore = (N + 7) & ~7LL;
                 if (e8 && pad_k) ep8.kb_rows = K;
                 ep8.half_m = half_m ? 1 : 0;
+                float* w2pre = sk > 1 ? (float*)workspace : nullptr;
+                // (0x800: the persistent 128 x 256-tile kernel, gemmpw.hip — whatever tile the rules above chose)
+                const bool pw = e8 && pk_gemm8p_is_pw(M, N, K8, lda, ldb, a_col, b_col, std::max(sk, 1), w2pre != nullptr,
+                                                      asum_out != nullptr, &ep8);
+                const int tag8 = pw ? (8 | 0x800) : (8 | (any_epi ? 0x10 : 0) | (K8 % 64 ? 0x20 : 0) | (half_m ? 0x400 : 0));
+                GemmSample* sm = timing_begin(e8 ? tag8 : 256, a_col, b_col, std::max(sk, 1), dtype16, M, N, K, stream);
                 int rc = (e8 ? pk_gemm8p_launch : pk_gemm256_launch)(A, B, C, w2, asw, asum_out, M, N, e8 ? K8 : K, lda, ldb,
                                                                     a_col, b_col, (int)per, std::max(sk, 1), ep8, dtype16, stream);
                 timing_end(sm, stream);
@@ -1125,9 +1131,8 @@ extern "C" int pk_gemm_relu_bits(const void* A, const void* B, void* C, const vo
         const long long t256 = ((M + 255) / 256) * ((N + 255) / 256);
         ep.half_m = t256 >= 160 ? 0 : 1;
         // (sample tag: the gemm8p instantiation | 0x1000 mask as bits)
-        GemmSample* sm = timing_begin(8 | 0x1000 | (ep.half_m ? 0x400 : 0) | (mode == 2 ? 0x2000 : 0), 0, b_col, 1, dtype, M, N, K, s);
-        long long a_b = 0, b_b = 0;
-        (void)a_b; (void)b_b;
+        const bool pw = pk_gemm8p_is_pw(M, N, K, lda, ldb, 0, b_col, 1, 0, 0, &ep) != 0;  // (0x800: gemmpw.hip's persistent kernel)
+        GemmSample* sm = timing_begin(8 | 0x1000 | (pw ? 0x800 : (ep.half_m ? 0x400 : 0)) | (mode == 2 ? 0x2000 : 0), 0, b_col, 1, dtype, M, N, K, s);
         const int rc = pk_gemm8p_launch(A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, 0, b_col, (int)K, 1, ep, dtype, stream);
         timing_end(sm, s);
         return rc == 1 ? 0 : (rc == 0 ? (pk_set_error("pk_gemm_relu_bits: the phase-interleaved kernel refused the shape"), -1) : rc);

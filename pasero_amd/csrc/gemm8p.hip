@@ -1191,6 +1191,19 @@ extern "C" int pk_gemm8p_eligible(long long M, long long N, long long K, long lo
     return a_bytes <= lim && b_bytes <= lim;
 }
 
+// The persistent 128 x 256-tile kernel (gemmpw.hip, round 6): row-form A, whole K-tiles, many rounds of tiles, lean epilogue.
+extern "C" int pk_gemmpw_eligible(long long M, long long N, long long K, long long lda, long long ldb, long long ldc, int b_col,
+                                  const EpiParams* ep);
+extern "C" int pk_gemmpw_launch(const void* A, const void* B, void* C, long long M, long long N, long long K, long long lda,
+                                long long ldb, unsigned a_bytes, unsigned b_bytes, int b_col, EpiParams ep, int dtype,
+                                void* stream);
+// 1 if pk_gemm8p_launch sends this call to it (the dispatcher asks for the timing sample's tag)
+extern "C" int pk_gemm8p_is_pw(long long M, long long N, long long K, long long lda, long long ldb, int a_col, int b_col,
+                               int splitk, int has_ws, int has_asum, const EpiParams* ep) {
+    if (a_col || splitk != 1 || has_ws || has_asum || ep->kb_rows > 0 || ep->mode == 3) return 0;
+    return pk_gemmpw_eligible(M, N, K, lda, ldb, ep->ldc, b_col, ep);
+}
+
 // Returns 1 if the GEMM was launched, 0 if it is not eligible, or a hip error code.
 extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
                                 long long M, long long N, long long K, long long lda, long long ldb, int a_col,
@@ -1202,6 +1215,8 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
         long long unused;
         operand_bytes(M, N, ep.kb_rows, lda, ldb, a_col, b_col, &unused, &b_bytes);
     }
+    if (pk_gemm8p_is_pw(M, N, K, lda, ldb, a_col, b_col, splitk, ws != nullptr, asum_ws || asum_out, &ep))
+        return pk_gemmpw_launch(A, B, C, M, N, K, lda, ldb, (unsigned)a_bytes, (unsigned)b_bytes, b_col, ep, dtype, stream);
     const bool hm = ep.half_m && !a_col && !(ep.preact || ep.mode == 3 || (ep.act != PK_ACT_NONE && ep.act != PK_ACT_RELU));
     const int tm = hm ? BM / 2 : BM;
     const int total = (int)(((M + tm - 1) / tm) * ((N + BN - 1) / BN) * splitk);

@@ -25,6 +25,7 @@ SIGNATURES = {
     'pk_gemm_ex': (I, [P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, SZ, P, I, P]),
     'pk_gemm_use_8p': (I, [I]),
     'pk_gemm_use_bs': (I, [I]),
+    'pk_gemm_use_pw': (I, [I]),
     'pk_gemm_relu_bits_eligible': (I, [P, P, P, P, LL, LL, LL, LL, LL, LL, LL, I, I, I]),
     'pk_gemm_relu_bits': (I, [P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, I, I, F, I, P]),
     'pk_gemm_timing_start': (I, [I, I]),

@@ -8,6 +8,9 @@ by __graft_entry__.build() and the CPU tests:
   2. the transposed LDS reads are inline asm, so the compiler neither waits for them nor knows when their destination
      registers become valid: from each `ds_read_b64_tr_b16` to the next `s_waitcnt lgkmcnt(0)` nothing else may read or
      write those registers (a compiler copy there would move stale data);
+  2b. the same for inline-asm `buffer_load_dword*` to registers (gemmpw.hip's side operands: the hardware does not interlock
+     a register with a load in flight): from the load to the next `s_waitcnt vmcnt(..)` nothing may touch its destination
+     (checked over the whole kernel body, in program order);
   3. no scratch (spill) traffic inside the K loop's blocks (spills in the prologue / epilogue, or between the markers
      but outside every loop block — executed once — are reported, not refused).
 The smallest counted wait a kernel places in its loop is 6 unless the kernel says otherwise with a `; PK8P_MIN_VMCNT n`
@@ -43,7 +46,7 @@ def audit(path: str):
     notes = []
     i = 0
     while i < len(lines):
-        m = re.match(r'^(_ZN[^:]*(?:gemm8p_(?:group_|ln_|hm2_)?|gemmbs_)kernel[^:]*):', lines[i])
+        m = re.match(r'^(_ZN[^:]*(?:gemm8p_(?:group_|ln_|hm2_|pw_)?|gemmbs_)kernel[^:]*):', lines[i])
         if not m:
             i += 1
             continue
@@ -74,6 +77,36 @@ def audit(path: str):
                           next(k for k, ln in enumerate(body) if 'PKBS_BFRAG_END' in ln), False))
         except StopIteration:
             pass
+        # rule 2b: asm buffer loads (between ;;#ASMSTART / ;;#ASMEND) over the whole body
+        in_asm, vpend = False, {}
+        for k, ln in enumerate(body):
+            if 'ASMSTART' in ln:
+                in_asm = True
+                continue
+            if 'ASMEND' in ln:
+                in_asm = False
+                continue
+            op, ops = operands(ln)
+            if not op or op.endswith(':') or op.startswith('.') or op.startswith(';'):
+                continue
+            if op == 's_waitcnt' and 'vmcnt' in ln:
+                vpend.clear()
+                continue
+            if op in ('s_branch', 's_endpgm', 's_setpc_b64'):
+                vpend.clear()
+                continue
+            if in_asm and op.startswith('buffer_load_dword') and ops and 'lds' not in ln:
+                for r in regs(ops[0]):
+                    vpend[r] = k
+                continue
+            if vpend and ops:
+                touched = set().union(*[regs(t) for t in ops])
+                bad = touched & set(vpend)
+                if bad:
+                    problems.append(f'{name}: line {k}: `{ln.strip()}` touches v{sorted(bad)} before a vmcnt wait covers the asm '
+                                    f'load at line {vpend[sorted(bad)[0]]}')
+                    for r in bad:
+                        del vpend[r]
         pending = {}  # register -> line of the asm tr read that wrote it
         looping = False  # inside a block LLVM marks as part of a loop
         # rule 3 tells a spill inside the loop from one that runs once by LLVM's label annotations ("Loop Header" / "in Loop"):
