@@ -1419,29 +1419,36 @@ void plan_group_uncached(const PkWgradProblem* p, int n, GroupPlan* pl, bool pai
         if (cost < best) { best = cost; bestL = L; }
         if (L <= 512) break;
     }
-    // the mixed plans: problems of at most `cut` tiles at half the length (PK_WGRAD_MIXED=0: off, A/B)
+    // the mixed plans: problems of at most `cut` tiles at a FRACTION of the length (PK_WGRAD_MIXED=0: off, A/B).  Round 4 knew
+    // L / 2 only; round 6 adds L / 3 and L / 4 (PK_WGRAD_MIXED_DIV=2: as before): NLLB-1.3B's ENCODER layer at 8192 rows is
+    // fc1 / fc2 unsplit (256 workgroups of 128 K-tiles = one round of the chip) + q|k|v and out-proj (64 tiles) — at L / 2
+    // those are 128 workgroups of 64 K-tiles on half the CUs (makespan 192 K-tiles where the work is 160 per CU), at L / 4
+    // 256 workgroups of 32: every CU runs one long and one short workgroup.
     static const bool mixed_on = [] { const char* e = getenv("PK_WGRAD_MIXED"); return !e || atoi(e) != 0; }();
+    static const int mixed_div = [] { const char* e = getenv("PK_WGRAD_MIXED_DIV"); return e ? std::max(2, std::min(4, atoi(e))) : 4; }();
     long long mixL = 0, mixLs = 0, mixcut = -1;
     double mixbest = 0.95 * best;
-    prevL = -1;
-    for (int s = 1; mixed_on && s <= 16; ++s) {
-        const long long L = ((kmax + s - 1) / s + BK - 1) / BK * BK, Ls = (L / 2 + BK - 1) / BK * BK;
-        if (L == prevL || Ls < 512) continue;
-        prevL = L;
-        for (int c = 0; c < n; ++c) {
-            const long long cut = tiles256(p[c]);
-            long long nl = 0, ns = 0, split_wgs = 0;
-            bool any_big = false;
-            for (int i = 0; i < n; ++i) {
-                const bool small = tiles256(p[i]) <= cut;
-                const long long sp = (p[i].K + (small ? Ls : L) - 1) / (small ? Ls : L);
-                (small ? ns : nl) += tiles256(p[i]) * sp;
-                if (sp > 1) split_wgs += tiles256(p[i]) * sp;
-                any_big |= !small;
+    for (int div = 2; mixed_on && div <= mixed_div; ++div) {
+        prevL = -1;
+        for (int s = 1; s <= 16; ++s) {
+            const long long L = ((kmax + s - 1) / s + BK - 1) / BK * BK, Ls = (L / div + BK - 1) / BK * BK;
+            if (L == prevL || Ls < 512) continue;
+            prevL = L;
+            for (int c = 0; c < n; ++c) {
+                const long long cut = tiles256(p[c]);
+                long long nl = 0, ns = 0, split_wgs = 0;
+                bool any_big = false;
+                for (int i = 0; i < n; ++i) {
+                    const bool small = tiles256(p[i]) <= cut;
+                    const long long sp = (p[i].K + (small ? Ls : L) - 1) / (small ? Ls : L);
+                    (small ? ns : nl) += tiles256(p[i]) * sp;
+                    if (sp > 1) split_wgs += tiles256(p[i]) * sp;
+                    any_big |= !small;
+                }
+                if (!any_big || nl + ns > 4096) continue;
+                const double cost = list_makespan(wg_us(L), nl, wg_us(Ls), ns) + (double)split_wgs * 0.105 + (split_wgs ? 4.0 : 0.0);
+                if (cost < mixbest) { mixbest = cost; mixL = L; mixLs = Ls; mixcut = cut; }
             }
-            if (!any_big || nl + ns > 4096) continue;
-            const double cost = list_makespan(wg_us(L), nl, wg_us(Ls), ns) + (double)split_wgs * 0.105 + (split_wgs ? 4.0 : 0.0);
-            if (cost < mixbest) { mixbest = cost; mixL = L; mixLs = Ls; mixcut = cut; }
         }
     }
     int wg = 0, blk = 0;
