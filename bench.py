@@ -226,6 +226,10 @@ class GemmTimer:
             return 'gemm8p_ln_kernel<%s, %d>' % (t, a_col)  # (a_col: the epilogue specialisation, see pk_gemm_ln_fwd)
         if kernel == 64:  # the few-rows kernel (gemm_skinny.hip; its activation / mode template arguments are not in the sample)
             return 'gemm_skinny_kernel<%s, ...>' % t
+        if kernel & 0x4000:  # the persistent walk of 256 x 256 tiles (round 6): <T, B_COL, BITS>
+            return 'gemm8p_pt_kernel<%s, %s, %s>' % (t, tf[b_col], tf[(kernel >> 12) & 1 or (kernel >> 13) & 1])
+        if kernel & 0x800:   # gemmpw.hip (off by default): <T, B_COL, EPI>
+            return 'gemm8p_pw_kernel<%s, %s, %d>' % (t, tf[b_col], 2 if kernel & 0x2000 else (1 if kernel & 0x1000 else 0))
         if kernel & 0xF == 8 and (kernel & ~0x3400) < 256:
             # gemm8p.hip: 0x10 general epilogue, 0x20 partial last K-tile, 0x400 the 128 x 256 tile (a kernel of its own since
             # round 4: <T, B_COL, TAIL, BITS>), 0x1000 the ReLU mask as bits (round 5; 0x2000: the dH GEMM that reads them);

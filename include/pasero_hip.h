@@ -85,15 +85,17 @@ int pk_gemm_use_8p(int on);
  * one).  Sample tag in pk_gemm_timing_read: 0x200 | number of K-tiles | activation << 4 | 0x40 the act'-mask epilogue
  * (mode 2) | 0x80 the mask as bits | 0x100 the pre-activation as second output. */
 int pk_gemm_use_bs(int on);
-/* diagnostic: 1 / 0 lets pk_gemm / pk_gemm_relu_bits send row-form GEMMs of many tile rounds and a short contraction (at
- * least two rounds of 128 x 256 tiles over the chip, 10..32 whole K-tiles: the d = 1024 projections, fc1 forward, masked dH
- * GEMM and vocabulary logits — pasero/models/modules.py:92-96, transformer.py:999-1019) to the PERSISTENT kernel
- * (gemmpw.hip, round 6: one workgroup per CU walks its tiles, the K-tiles of consecutive tiles form one stream through the
- * LDS ring, a finished tile leaves from a second register set during the next tile's first K-tiles: no prologue, no
- * epilogue phase) / keeps them on gemm8p.hip's one-tile workgroups (the DEFAULT: the persistent kernel is bit for bit equal
- * and measured 20-30 % slower — an experiment kept behind this switch, docs/experiments.md); negative: query only.  Returns
- * the previous setting (env PK_GEMM_PW=1 sets the initial one).
- * Sample tag in pk_gemm_timing_read: 8 | 0x800 (| 0x1000 the mask bits written, | 0x2000 read). */
+/* diagnostic: a MASK of two persistent GEMM kernels for row-form A (round 6; negative: query only; returns the previous mask;
+ * env PK_GEMM_PW sets the initial one, default 2).  Both keep the summation order of the tiled kernels: results bit for bit equal.
+ *   bit 1 (ON by default): the persistent WALK of gemm8p.hip's 256 x 256 tiles (gemm8p_pt_kernel) — one workgroup per CU runs
+ *     its tiles one after the other and requests the next tile's first K-tile behind the current tile's last, so a tile's
+ *     epilogue runs with its successor's operands on their way; an even number >= 4 of whole K-tiles, at least two rounds of
+ *     tiles over the chip, mode 0 (bias, none / ReLU) or the mask-bit epilogues of pk_gemm_relu_bits.  Worth 0.4 % of the C3 /
+ *     C5 steps (the vocabulary logits + 4 %): the one-tile launch already overlaps a tile's store drain with the next
+ *     workgroup's prologue.  Sample tag in pk_gemm_timing_read: 8 | 0x4000 (| 0x1000 / 0x2000 the mask bits written / read).
+ *   bit 0 (off): the persistent 128 x 256-tile kernel with a second accumulator set (gemmpw.hip: a finished tile leaves from
+ *     registers during the next tile's first K-tiles: no prologue, no epilogue phase; 10..32 whole K-tiles) — measured 20-30 %
+ *     SLOWER than the tiled kernels, kept as an experiment (docs/experiments.md).  Sample tag 8 | 0x800. */
 int pk_gemm_use_pw(int on);
 /* The ReLU feed-forward's mask as ONE BIT per element (fc1 forward / fc2 dX of pasero/models/transformer.py:999-1019 at
  * K = 512): `bits` [M][ldbits] bytes, bit (n & 7) of byte n >> 3 of row m = (C[m][n] > 0) of the forward call.

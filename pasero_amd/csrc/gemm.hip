@@ -35,6 +35,8 @@ extern "C" int pk_gemm256_launch(const void* A, const void* B, void* C, float* w
                                  int b_col, int kchunk, int splitk, EpiParams ep, int dtype, void* stream);
 extern "C" int pk_gemm8p_is_pw(long long M, long long N, long long K, long long lda, long long ldb, int a_col, int b_col,
                                int splitk, int has_ws, int has_asum, const EpiParams* ep);
+extern "C" int pk_gemm8p_is_pt(long long M, long long N, long long K, long long lda, long long ldb, int a_col, int b_col,
+                               int splitk, int has_ws, int has_asum, const EpiParams* ep);
 extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws, float* asum_ws, void* asum_out,
                                 long long M, long long N, long long K, long long lda, long long ldb, int a_col,
                                 int b_col, int kchunk, int splitk, EpiParams ep, int dtype, void* stream);
@@ -911,7 +913,10 @@ int launch_gemm(const void* A, const void* B, void* C, long long M, long long N,
                 // (0x800: the persistent 128 x 256-tile kernel, gemmpw.hip — whatever tile the rules above chose)
                 const bool pw = e8 && pk_gemm8p_is_pw(M, N, K8, lda, ldb, a_col, b_col, std::max(sk, 1), w2pre != nullptr,
                                                       asum_out != nullptr, &ep8);
-                const int tag8 = pw ? (8 | 0x800) : (8 | (any_epi ? 0x10 : 0) | (K8 % 64 ? 0x20 : 0) | (half_m ? 0x400 : 0));
+                // (0x4000: the persistent walk of 256 x 256 tiles, gemm8p_pt_kernel)
+                const bool pt = e8 && !pw && pk_gemm8p_is_pt(M, N, K8, lda, ldb, a_col, b_col, std::max(sk, 1), w2pre != nullptr,
+                                                             asum_out != nullptr, &ep8);
+                const int tag8 = pw ? (8 | 0x800) : pt ? (8 | 0x4000) : (8 | (any_epi ? 0x10 : 0) | (K8 % 64 ? 0x20 : 0) | (half_m ? 0x400 : 0));
                 GemmSample* sm = timing_begin(e8 ? tag8 : 256, a_col, b_col, std::max(sk, 1), dtype16, M, N, K, stream);
                 int rc = (e8 ? pk_gemm8p_launch : pk_gemm256_launch)(A, B, C, w2, asw, asum_out, M, N, e8 ? K8 : K, lda, ldb,
                                                                     a_col, b_col, (int)per, std::max(sk, 1), ep8, dtype16, stream);
@@ -1132,7 +1137,8 @@ extern "C" int pk_gemm_relu_bits(const void* A, const void* B, void* C, const vo
         ep.half_m = t256 >= 160 ? 0 : 1;
         // (sample tag: the gemm8p instantiation | 0x1000 mask as bits)
         const bool pw = pk_gemm8p_is_pw(M, N, K, lda, ldb, 0, b_col, 1, 0, 0, &ep) != 0;  // (0x800: gemmpw.hip's persistent kernel)
-        GemmSample* sm = timing_begin(8 | 0x1000 | (pw ? 0x800 : (ep.half_m ? 0x400 : 0)) | (mode == 2 ? 0x2000 : 0), 0, b_col, 1, dtype, M, N, K, s);
+        const bool pt = !pw && pk_gemm8p_is_pt(M, N, K, lda, ldb, 0, b_col, 1, 0, 0, &ep) != 0;  // (0x4000: the persistent walk of 256 x 256 tiles)
+        GemmSample* sm = timing_begin(8 | 0x1000 | (pw ? 0x800 : pt ? 0x4000 : (ep.half_m ? 0x400 : 0)) | (mode == 2 ? 0x2000 : 0), 0, b_col, 1, dtype, M, N, K, s);
         const int rc = pk_gemm8p_launch(A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, 0, b_col, (int)K, 1, ep, dtype, stream);
         timing_end(sm, s);
         return rc == 1 ? 0 : (rc == 0 ? (pk_set_error("pk_gemm_relu_bits: the phase-interleaved kernel refused the shape"), -1) : rc);

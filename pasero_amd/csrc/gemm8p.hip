@@ -256,17 +256,26 @@ struct PairCtl {
     int drop_publish;     // diagnostic: the first workgroup does NOT raise its flag
 };
 
-template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL, bool HM = false, bool BITS = false>
+// PW ("persistent walk", round 6): ONE workgroup per CU runs the tiles xcd_remap(blockIdx + j * gridDim) one after the other —
+// row-form A, whole and an EVEN number of K-tiles, lean / mask-bit epilogues, no split — and the K-tile ring does not stop at a
+// tile's end: the requests that the one-tile kernel issues against an empty descriptor behind its last K-tile fetch the NEXT
+// tile's K-tile 0 (the same four half-tiles, the same stage: what the prologue would ask for), so a tile's epilogue runs with
+// its successor's first operands on their way and the successor has no prologue; the epilogue stages through the OTHER stage
+// (+ 1 KiB behind it).  Everything tile-dependent of the operand streams is an SGPR offset (the per-lane offsets are those of
+// tile (0, 0); rows past M / N read as zeros through the descriptor's range check).
+template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL, bool HM = false, bool BITS = false, bool PW = false>
 __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
                                             float* __restrict__ ws, float* __restrict__ asum_ws,
                                             T* __restrict__ asum_out, long long M, long long N, long long K,
                                             long long lda, long long ldb, int kchunk, unsigned a_bytes,
                                             unsigned b_bytes, int lin, unsigned long long* stamps,
                                             const EpiParams& ep, unsigned* pair_sync = nullptr,
-                                            const PairCtl pctl = PairCtl{nullptr, 0u, 0}) {
+                                            const PairCtl pctl = PairCtl{nullptr, 0u, 0}, int pw_total = 0) {
     typedef typename M16<T>::vec V;
     typedef __attribute__((address_space(3))) void lds_void;
-    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    static_assert(!PW || (!A_COL && !ANY && !TAIL && !HM), "the persistent walk: row-form A, lean epilogues, whole K-tiles");
+    constexpr int SMEM_T = PW ? SMEM + 1024 : SMEM;  // (PW: the epilogue's staging buffer = stage 1 + 1 KiB)
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_T];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -283,15 +292,33 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
 #else
 #define PK_STAMP() do { } while (0)
 #endif
+    int vb = lin;  // PW: the position in this workgroup's walk (blockIdx.x + j * gridDim.x); its tile: xcd_remap(vb, pw_total)
+    bool pw_first = true;
+    do {  // (one pass unless PW)
+    const int lin_t = PW ? xcd_remap(vb, pw_total) : lin;
     PK_STAMP();  // tile start
-    const int kslab = lin / (nt_m * nt_n);
-    int t = lin % (nt_m * nt_n);
+    const int kslab = lin_t / (nt_m * nt_n);
+    int t = lin_t % (nt_m * nt_n);
     const int tile_id = t;  // (the tile's position in the walk of its problem: what the two workgroups of a pair share)
     const int GROUP_M = nt_n <= 2 ? 8 : 4;
     int group_size = GROUP_M * nt_n, gid = t / group_size, first_m = gid * GROUP_M;
     int gsz = min(nt_m - first_m, GROUP_M);
     int tile_m = first_m + (t % group_size) % gsz, tile_n = (t % group_size) / gsz;
     const long long m0 = (long long)tile_m * TM, n0 = (long long)tile_n * BN;
+    // PW: the next tile of the walk (its K-tile 0 is requested behind this tile's last K-tile)
+    bool pw_has_next = false;
+    unsigned pw_a_cur = 0u, pw_b_cur = 0u, pw_a_nxt = 0u, pw_b_nxt = 0u;  // byte offsets of the tiles' operand panels (SGPR operands)
+    if constexpr (PW) {
+        const int vn = vb + (int)gridDim.x;
+        pw_has_next = vn < pw_total;
+        const int ln = xcd_remap(pw_has_next ? vn : 0, pw_total);
+        const int gid_n = ln / group_size, first_n = gid_n * GROUP_M, gsz_n = min(nt_m - first_n, GROUP_M);
+        const int tm_n = first_n + (ln % group_size) % gsz_n, tn_n = (ln % group_size) / gsz_n;
+        pw_a_cur = (unsigned)(m0 * lda * 2);
+        pw_a_nxt = (unsigned)((long long)tm_n * TM * lda * 2);
+        pw_b_cur = B_COL ? (unsigned)(n0 * 2) : (unsigned)(n0 * ldb * 2);
+        pw_b_nxt = B_COL ? (unsigned)((long long)tn_n * BN * 2) : (unsigned)((long long)tn_n * BN * ldb * 2);
+    }
     const long long kbeg = (long long)kslab * kchunk;
     const long long kend = min(K, kbeg + (long long)kchunk);
     // K-tiles of this slab; the last one may be partial (K % 8 == 0): col-form rows k >= K lie past the end of their
@@ -306,8 +333,13 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             // (col form with M % 8 != 0: the host only sends it here when the rows are padded, lda >= M rounded up to 8)
-            offa[h][i] = src_offset<A_COL>(wave * 2 + i, lane, lda, m0 + 128 * h, A_COL ? ((M + 7) & ~7LL) : M);
-            offb[h][i] = src_offset<B_COL>(wave * 2 + i, lane, ldb, n0 + 128 * h, N);
+            if constexpr (PW) {  // (those of tile (0, 0), no clamp: the tile is an SGPR offset, what lies past the edge reads as zeros)
+                offa[h][i] = src_offset<A_COL>(wave * 2 + i, lane, lda, 128 * h, 1LL << 40);
+                offb[h][i] = src_offset<B_COL>(wave * 2 + i, lane, ldb, 128 * h, 1LL << 40);
+            } else {
+                offa[h][i] = src_offset<A_COL>(wave * 2 + i, lane, lda, m0 + 128 * h, A_COL ? ((M + 7) & ~7LL) : M);
+                offb[h][i] = src_offset<B_COL>(wave * 2 + i, lane, ldb, n0 + 128 * h, N);
+            }
         }
     // row form, last K-tile: this lane's 16 bytes of piece i are columns k = 8 * chunk ... (the same chunk in both
     // halves and both operands: rows 8 * (2 wave + i) + (lane >> 3), swizzle (row >> 1) & 7)
@@ -330,20 +362,21 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
 #ifdef PK8P_ABL_NODMA
         const bool live = kt < 0;  // ablation build: every DMA empty (the MFMAs chew on whatever LDS holds)
 #else
-        const bool live = kt < nk;
+        const bool pw_nx = PW && kt >= nk;  // (PW: behind the last K-tile — the next tile's K-tile 0, nothing beyond it)
+        const bool live = pw_nx ? (pw_has_next && kt == nk) : kt < nk;
 #endif
         const bool tail = TAIL && kt == nk - 1 && kvalid < BK;
         if (slot < 2) {
             const bool live_a = live && !(HM && slot == SLOT_A1);  // (half-M: the second row half is never fetched)
             __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, live_a ? (int)a_bytes : 0, 0x00020000);
-            const unsigned so = kbase_a + (unsigned)kt * kstep_a;
+            const unsigned so = PW ? (pw_nx ? pw_a_nxt : pw_a_cur + (unsigned)kt * kstep_a) : kbase_a + (unsigned)kt * kstep_a;
             unsigned v0 = offa[slot][0], v1 = offa[slot][1];
             if (TAIL && !A_COL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, v0, so, 0, PK8P_AUX_A);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, v1, so, 0, PK8P_AUX_A);
         } else {
             __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, live ? (int)b_bytes : 0, 0x00020000);
-            const unsigned so = kbase_b + (unsigned)kt * kstep_b;
+            const unsigned so = PW ? (pw_nx ? pw_b_nxt : pw_b_cur + (unsigned)kt * kstep_b) : kbase_b + (unsigned)kt * kstep_b;
             unsigned v0 = offb[slot - 2][0], v1 = offb[slot - 2][1];
             if (TAIL && !B_COL && tail) { v0 = tail_ok[0] ? v0 : DEAD_OFF; v1 = tail_ok[1] ? v1 : DEAD_OFF; }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, v0, so, 0, PK8P_AUX_B);
@@ -483,6 +516,11 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    // RELAX (PW, the first two phases of a tile that is not the workgroup's first): everything these phases and the next ones
+    // read landed before the previous tile's epilogue began; what sits in the queue in front of this tile's first requests are
+    // that epilogue's stores (16 per thread or more), which the steady-state count would wait for
+    bool pw_relax = false;  // (set at the start of a later tile, cleared behind its second phase: a scalar branch, not a second copy
+    // of the loop body — that copy cost the persistent instantiations their last registers: 70-140 bytes of spills in the loop)
     auto phase = [&](auto p_c, auto s_c, int dma_kt, int dma_slot) {
         constexpr int P = decltype(p_c)::value, S = decltype(s_c)::value;
         using SN = std::integral_constant<int, S ^ 1>;
@@ -490,7 +528,13 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
         if constexpr (P == 1) load_b(s_c, I3{}, fb1);             // B1
         if constexpr (P == 2 && !HM) load_a(s_c, I1{});           // A1
         if constexpr (P == 3) load_b(SN{}, I2{}, fb0[S ^ 1]);     // B0 of the NEXT K-tile (other stage)
-        PK_WAIT(6);  // all but the three youngest half-tiles have landed (what the NEXT phase reads is among them)
+        if constexpr (PW && S == 0 && P < 2) {
+            if (pw_relax) PK_WAIT(22);
+            else PK_WAIT(6);
+            if constexpr (P == 1) pw_relax = false;
+        } else {
+            PK_WAIT(6);  // all but the three youngest half-tiles have landed (what the NEXT phase reads is among them)
+        }
         dma(dma_kt, dma_slot);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -512,15 +556,17 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     static_assert(SLOT_A0 == 0 && SLOT_A1 == 1 && SLOT_B0 == 2 && SLOT_B1 == 3, "slot constants used above");
 
     if (nk > 0) {
-        // ---- prologue: K-tile 0 whole, K-tile 1's A0 B0 ----
-        dma(0, SLOT_B0); dma(0, SLOT_A0); dma(0, SLOT_B1); dma(0, SLOT_A1);
+        // ---- prologue: K-tile 0 whole (PW, not the first tile: requested behind the previous tile's last K-tile and landed
+        // before its epilogue began), K-tile 1's A0 B0 ----
+        if (!PW || pw_first) { dma(0, SLOT_B0); dma(0, SLOT_A0); dma(0, SLOT_B1); dma(0, SLOT_A1); }
         dma(1, SLOT_B0); dma(1, SLOT_A0);
-        PK_WAIT(8);  // B0, A0 of tile 0
+        if (!PW || pw_first) PK_WAIT(8);  // B0, A0 of tile 0 (PW, later tiles: landed long ago; the queue holds the last epilogue's stores)
         PK_STAMP();  // first K-tile landed
         asm volatile("; PK8P_LOOP_BEGIN" ::: "memory");
         __builtin_amdgcn_s_barrier();
         load_b(I0{}, I2{}, fb0[0]);  // B0 of K-tile 0 (every later one is read a phase ahead, inside the loop)
         if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave of every SIMD runs one barrier behind the first
+        pw_relax = PW && !pw_first;
         for (int kt = 0; kt < nk; kt += 2) {
             phase(I0{}, I0{}, kt + 1, SLOT_B1);
             phase(I1{}, I0{}, kt + 1, SLOT_A1);
@@ -613,14 +659,14 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     }
 
     // ---- epilogue: four 64-row passes of the accumulators through the fp32 staging buffer (all stages are free) ----
-    float* cs = reinterpret_cast<float*>(smem);
+    float* cs = reinterpret_cast<float*>(smem + (PW ? STAGE : 0));  // (PW: stage 0 holds the next tile's K-tile 0)
     // the aux operand of the lean mode 1 / 2 epilogues, one pass ahead of its use (aux may alias C: a chunk is read by the
     // thread that stores it, and before that store)
     // (BITS: an instantiation of its own — mode 0 + ReLU writes the mask bits, mode 2 + ReLU reads them; as a run-time branch in
     // the common instantiations it cost the d = 512 dX GEMMs 2 us per launch)
     static_assert(!BITS || (!A_COL && !ANY && !TAIL), "the mask bits ride on the lean row-form instantiations");
     constexpr bool use_bits = BITS;
-    const bool pre_aux = !ws && !ANY && ep.mode != 0 && !use_bits;
+    const bool pre_aux = !PW && !ws && !ANY && ep.mode != 0 && !use_bits;  // (PW: mode 0 or the mask bits only)
     const bool pre_bits = use_bits && !ws && ep.mode == 2;
     unsigned bw_next[4] = {0u, 0u, 0u, 0u};
     auto bits_load = [&](int p) {  // this thread's mask dwords of pass p (four lanes share one)
@@ -750,7 +796,7 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
         } else if constexpr (BITS) {
             if (ep.mode == 0) epilogue_pass_bits<T, 0>(cs, C, ep, mh, n0, M, N, tid, bw);
             else epilogue_pass_bits<T, 2>(cs, C, ep, mh, n0, M, N, tid, bw);
-        } else if (ep.mode == 0) {
+        } else if (PW || ep.mode == 0) {
             if (ep.act == PK_ACT_RELU) epilogue_pass<T, PK_ACT_RELU, 0>(cs, C, ep, mh, n0, M, N, tid, av);
             else epilogue_pass<T, PK_ACT_NONE, 0>(cs, C, ep, mh, n0, M, N, tid, av);
         } else if (ep.mode == 1) {
@@ -772,7 +818,24 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PK_STAMP();  // epilogue stores acknowledged
 #endif
+    if constexpr (PW) {
+        vb += (int)gridDim.x;
+        pw_first = false;
+        if (vb < pw_total) __syncthreads();  // the staging buffer (stage 1) has been read: the next tile's requests may overwrite it
+    }
+    } while (PW && vb < pw_total);
 #undef PK_STAMP
+}
+
+// the persistent walk of the 256 x 256 tile (gemm8p_tile's PW form): lean and mask-bit epilogues, row-form A
+template <typename T, bool B_COL, bool BITS>
+__global__ __launch_bounds__(512, 2) void gemm8p_pt_kernel(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
+                                                          long long M, long long N, long long K, long long lda, long long ldb,
+                                                          unsigned a_bytes, unsigned b_bytes, int total,
+                                                          unsigned long long* stamps, EpiParams ep) {
+    gemm8p_tile<T, false, B_COL, false, false, false, BITS, true>(A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, (int)K, a_bytes,
+                                                                  b_bytes, (int)blockIdx.x, stamps, ep, nullptr,
+                                                                  PairCtl{nullptr, 0u, 0}, total);
 }
 
 template <typename T, bool A_COL, bool B_COL, bool ANY, bool TAIL, bool HM = false, bool BITS = false>
@@ -1197,9 +1260,25 @@ extern "C" int pk_gemmpw_eligible(long long M, long long N, long long K, long lo
 extern "C" int pk_gemmpw_launch(const void* A, const void* B, void* C, long long M, long long N, long long K, long long lda,
                                 long long ldb, unsigned a_bytes, unsigned b_bytes, int b_col, EpiParams ep, int dtype,
                                 void* stream);
+extern "C" int pk_gemm_use_pw(int on);
+// 1 if pk_gemm8p_launch runs this call as the persistent walk of 256 x 256 tiles (gemm8p_tile's PW form, gemm8p_pt_kernel):
+// row-form A, an even number (>= 4) of whole K-tiles, no split, a lean or mask-bit epilogue, at least `PK_GEMM_PT_MIN_TILES`
+// (default 512: two rounds of the chip) tiles.  Bit 1 of pk_gemm_use_pw (default on; env PK_GEMM_PW sets the mask).
+extern "C" int pk_gemm8p_is_pt(long long M, long long N, long long K, long long lda, long long ldb, int a_col, int b_col,
+                               int splitk, int has_ws, int has_asum, const EpiParams* ep) {
+    static const int min_tiles = [] { const char* e = getenv("PK_GEMM_PT_MIN_TILES"); return e ? atoi(e) : 512; }();
+    if (!(pk_gemm_use_pw(-1) & 2)) return 0;
+    if (a_col || splitk != 1 || has_ws || has_asum || ep->kb_rows > 0) return 0;
+    if (ep->preact || ep->mode == 3 || (ep->act != PK_ACT_NONE && ep->act != PK_ACT_RELU)) return 0;
+    if (ep->bits ? (ep->act != PK_ACT_RELU || (ep->mode != 0 && ep->mode != 2)) : ep->mode != 0) return 0;
+    if (K % (2 * BK) || K / BK < 4) return 0;
+    const long long t256 = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    return t256 >= min_tiles && t256 < (1LL << 24);
+}
 // 1 if pk_gemm8p_launch sends this call to it (the dispatcher asks for the timing sample's tag)
 extern "C" int pk_gemm8p_is_pw(long long M, long long N, long long K, long long lda, long long ldb, int a_col, int b_col,
                                int splitk, int has_ws, int has_asum, const EpiParams* ep) {
+    if (!(pk_gemm_use_pw(-1) & 1)) return 0;
     if (a_col || splitk != 1 || has_ws || has_asum || ep->kb_rows > 0 || ep->mode == 3) return 0;
     return pk_gemmpw_eligible(M, N, K, lda, ldb, ep->ldc, b_col, ep);
 }
@@ -1217,6 +1296,29 @@ extern "C" int pk_gemm8p_launch(const void* A, const void* B, void* C, float* ws
     }
     if (pk_gemm8p_is_pw(M, N, K, lda, ldb, a_col, b_col, splitk, ws != nullptr, asum_ws || asum_out, &ep))
         return pk_gemmpw_launch(A, B, C, M, N, K, lda, ldb, (unsigned)a_bytes, (unsigned)b_bytes, b_col, ep, dtype, stream);
+    if (pk_gemm8p_is_pt(M, N, K, lda, ldb, a_col, b_col, splitk, ws != nullptr, asum_ws || asum_out, &ep)) {
+        const int total = (int)(((M + BM - 1) / BM) * ((N + BN - 1) / BN));
+        static const int wgs = [] {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            return std::max(8, cus / 8 * 8);
+        }();
+        dim3 grid((unsigned)std::min(wgs, total / 8 * 8)), block(512);
+        hipStream_t s = (hipStream_t)stream;
+        unsigned long long* stamps = nullptr;
+#define PK_PT(TT, BC, BT) hipLaunchKernelGGL((gemm8p_pt_kernel<TT, BC, BT>), grid, block, 0, s, (const TT*)A, (const TT*)B, (TT*)C, M, N, K, \
+                                             lda, ldb, (unsigned)a_bytes, (unsigned)b_bytes, total, stamps, ep)
+        if (dtype == PK_F16) {
+            if (ep.bits) { if (b_col) PK_PT(f16, true, true); else PK_PT(f16, false, true); }
+            else { if (b_col) PK_PT(f16, true, false); else PK_PT(f16, false, false); }
+        } else {
+            if (ep.bits) { if (b_col) PK_PT(bf16, true, true); else PK_PT(bf16, false, true); }
+            else { if (b_col) PK_PT(bf16, true, false); else PK_PT(bf16, false, false); }
+        }
+#undef PK_PT
+        PK_LAUNCH_CHECK();
+        return 1;
+    }
     const bool hm = ep.half_m && !a_col && !(ep.preact || ep.mode == 3 || (ep.act != PK_ACT_NONE && ep.act != PK_ACT_RELU));
     const int tm = hm ? BM / 2 : BM;
     const int total = (int)(((M + tm - 1) / tm) * ((N + BN - 1) / BN) * splitk);

@@ -590,11 +590,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_pw_kernel(PwArgs g) {
 namespace {
 // OFF by default (PK_GEMM_PW=1 / pk_gemm_use_pw(1) turn it on): correct — bit for bit the tiled kernels — but measured SLOWER
 // than them (see the note at the top of the file and docs/experiments.md, "Round 6: the persistent GEMM").
-int g_use_pw = [] { const char* e = getenv("PK_GEMM_PW"); return (e && atoi(e) != 0) ? 1 : 0; }();
+// (a mask: bit 0 = this file's kernel, bit 1 = the persistent walk of 256 x 256 tiles in gemm8p.hip; default 2)
+int g_use_pw = [] { const char* e = getenv("PK_GEMM_PW"); return e ? (atoi(e) & 3) : 2; }();
 }
 extern "C" int pk_gemm_use_pw(int on) {
     const int old = g_use_pw;
-    if (on >= 0) g_use_pw = on ? 1 : 0;
+    if (on >= 0) g_use_pw = on & 3;
     return old;
 }
 
@@ -605,7 +606,7 @@ extern "C" int pk_gemmpw_eligible(long long M, long long N, long long K, long lo
                                   const EpiParams* ep) {
     static const int min_tiles = [] { const char* e = getenv("PK_GEMM_PW_MIN_TILES"); return e ? atoi(e) : 512; }();
     static const int max_nk = [] { const char* e = getenv("PK_GEMM_PW_MAX_NK"); return e ? atoi(e) : 32; }();
-    if (!g_use_pw) return 0;
+    if (!(g_use_pw & 1)) return 0;
     if (K % BK || K / BK < 10 || K / BK > max_nk) return 0;
     // (N % 8 != 0: pk_gemm_ex's padded rows — `nstore` columns may be stored; rows of a row-form B past N read as zeros)
     if ((N % 8 && (b_col || !ep->nstore)) || (lda % 8) || (ldb % 8) || (ldc % 8)) return 0;

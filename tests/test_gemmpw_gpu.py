@@ -78,7 +78,7 @@ def test_lean_epilogue_bitwise_the_tiled_kernels(M, N, K, b_col, bias, dtype):
         assert tags and all(t & 0x800 for t in tags), [hex(t) for t in tags]  # the persistent kernel took it
         _pw(0)
         ref, tags0 = _took_pw(lambda: F.gemm(a, b, b_col=b_col, bias=bv))
-        assert not any(t & 0x800 for t in tags0)
+        assert not any(t & 0x4800 for t in tags0)
     finally:
         _pw(prev)
     assert torch.equal(got, ref)
@@ -192,5 +192,105 @@ def test_shapes_it_does_not_take_stay_on_the_tiled_kernels():
             a, b = _rand((M, K), torch.bfloat16, 50, 0.5), _rand((N, K), torch.bfloat16, 51, 0.5)
             _, tags = _took_pw(lambda: F.gemm(a, b, **kw))
             assert tags and not any(t & 0x800 for t in tags), (M, N, K, [hex(t) for t in tags])
+    finally:
+        _pw(prev)
+
+
+# ---- the persistent walk of 256 x 256 tiles (gemm8p_tile's PW form, gemm8p_pt_kernel): bit 1 of pk_gemm_use_pw, ON by default ----
+PT_CASES = [
+    # M, N, K, b_col, bias, act
+    (8192, 8192, 1024, False, True, 'none'),     # C5 fc1-sized: 1024 tiles = 4 per workgroup
+    (8192, 8192, 1024, True, False, 'none'),     # col-form B (a dX GEMM's operand form)
+    (8192, 8192, 256, False, True, 'relu'),      # four K-tiles (the minimum), ReLU without the mask bits
+    (16000, 8192, 1024, False, True, 'none'),    # ragged M (62.5 tile rows): the IWSLT recipe's encoder rows; 2016 tiles
+    (6000, 24000, 384, True, True, 'none'),      # ragged M and N (93.75 tile columns), six K-tiles, col-form B; 2256 tiles
+    (32768, 4096, 4096, False, False, 'none'),   # a long contraction (64 K-tiles)
+    (8200, 16384, 128 * 5, False, True, 'none'),  # ten K-tiles; workgroups with 8 and with 9 tiles
+]
+
+
+@pytest.mark.parametrize('M,N,K,b_col,bias,act', PT_CASES)
+def test_persistent_walk_bitwise_the_one_tile_kernel(M, N, K, b_col, bias, act):
+    """Same tile, same K loop, same epilogue code: every output bit for bit the one-tile-per-workgroup kernel's; the walk only
+    changes which workgroup computes a tile and when its operands are requested (the next tile's K-tile 0 behind this tile's
+    last K-tile; per-lane offsets of tile (0, 0) + an SGPR offset; rows past M / N as zeros through the range check)."""
+    from pasero_amd import functional as F
+    a = _rand((M, K), torch.bfloat16, 1, 0.5)
+    b = _rand((K, N) if b_col else (N, K), torch.bfloat16, 2, 0.5)
+    bv = _rand((N,), torch.bfloat16, 3) if bias else None
+    prev = _pw(2)
+    try:
+        got, tags = _took_pw(lambda: F.gemm(a, b, b_col=b_col, bias=bv, act=act))
+        assert tags and all(t & 0x4000 for t in tags), [hex(t) for t in tags]
+        _pw(0)
+        ref, tags0 = _took_pw(lambda: F.gemm(a, b, b_col=b_col, bias=bv, act=act))
+        assert not any(t & 0x4800 for t in tags0)
+    finally:
+        _pw(prev)
+    assert torch.equal(got, ref)
+    if M * N * K <= 8192 * 8192 * 1024:  # (the fp64 product of the largest cases takes seconds: the bitwise check carries them)
+        r64 = a.double() @ (b.double() if b_col else b.double().t())
+        if bias:
+            r64 += bv.double()
+        if act == 'relu':
+            r64.clamp_(min=0)
+        assert (got.double() - r64).abs().max().item() <= 2 ** -8 * r64.abs().max().item()
+
+
+def test_persistent_walk_mask_bits_padded_rows_and_what_it_leaves_alone():
+    from pasero_amd import functional as F
+    prev = _pw(2)
+    try:
+        # the ReLU feed-forward with the mask as bits, both directions (pk_gemm_relu_bits)
+        M, f, d = 8192, 8192, 1024
+        x, w1, b1 = _rand((M, d), torch.bfloat16, 11, 0.5), _rand((f, d), torch.bfloat16, 12, 0.1), _rand((f,), torch.bfloat16, 13, 0.2)
+        dz, w2 = _rand((M, d), torch.bfloat16, 14, 0.5), _rand((d, f), torch.bfloat16, 15, 0.1)
+        (h, bits), t1 = _took_pw(lambda: F.gemm_relu_bits(x, w1, b1))
+        dh, t2 = _took_pw(lambda: F.gemm_mask_bits(dz, w2, bits))
+        assert all(t & 0x4000 for t in t1 + t2), [hex(t) for t in t1 + t2]
+        # a padded vocabulary (pk_gemm_ex PAD_N): 2048 x 256 206, the C5 logits chunk
+        V = 256206
+        xl, wl = _rand((2048, 1024), torch.bfloat16, 16, 0.5), _rand((V, 1024), torch.bfloat16, 17, 0.05)
+        ldp = (V + 15) // 16 * 16
+        lg = [torch.zeros(2048, ldp, dtype=torch.bfloat16, device='cuda') for _ in range(2)]
+        _, t3 = _took_pw(lambda: F.gemm(xl, wl, out=lg[0][:, :V], pad_n=True))
+        assert all(t & 0x4000 for t in t3), [hex(t) for t in t3]
+        # not its shapes: fewer than two rounds of tiles, an odd number of K-tiles, an aux operand
+        for Ms, Ns, Ks, kw in [(8192, 3072, 1024, {}), (8192, 8192, 192, {}),
+                               (8192, 8192, 1024, {'aux': _rand((8192, 8192), torch.bfloat16, 18), 'mode': 1})]:
+            a, b = _rand((Ms, Ks), torch.bfloat16, 19, 0.5), _rand((Ns, Ks), torch.bfloat16, 20, 0.5)
+            _, tg = _took_pw(lambda: F.gemm(a, b, **kw))
+            assert tg and not any(t & 0x4000 for t in tg), (Ms, Ns, Ks, [hex(t) for t in tg])
+        _pw(0)
+        h0, bits0 = F.gemm_relu_bits(x, w1, b1)
+        dh0 = F.gemm_mask_bits(dz, w2, bits0)
+        F.gemm(xl, wl, out=lg[1][:, :V], pad_n=True)
+    finally:
+        _pw(prev)
+    assert torch.equal(h, h0) and torch.equal(bits, bits0) and torch.equal(dh, dh0)
+    assert torch.equal(lg[0][:, :V], lg[1][:, :V])
+
+
+def test_persistent_walk_race_screen():
+    """the next tile's K-tile 0 lands in stage 0 while the epilogue stages through stage 1, and a later tile's first two waits
+    are relaxed past the epilogue's stores: 60 launches over two data sets beside a copy stream, every one bit for bit the first"""
+    from pasero_amd import functional as F
+    sets = [(_rand((8192, 1024), torch.bfloat16, 60 + k, 0.5), _rand((8192, 1024), torch.bfloat16, 70 + k, 0.5),
+             _rand((8192,), torch.bfloat16, 80 + k)) for k in range(2)]
+    prev = _pw(2)
+    try:
+        first = [F.gemm(a, b, bias=bv).clone() for a, b, bv in sets]
+        side = torch.cuda.Stream()
+        src = torch.randn(32 << 20, device='cuda')
+        dst = torch.empty_like(src)
+        bad = torch.zeros((), dtype=torch.int64, device='cuda')
+        for it in range(60):
+            if it % 3 != 2:
+                with torch.cuda.stream(side):
+                    dst.copy_(src)
+            a, b, bv = sets[it & 1]
+            bad += (F.gemm(a, b, bias=bv) != first[it & 1]).any()
+        torch.cuda.synchronize()
+        assert int(bad) == 0
     finally:
         _pw(prev)

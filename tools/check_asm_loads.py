@@ -46,7 +46,7 @@ def audit(path: str):
     notes = []
     i = 0
     while i < len(lines):
-        m = re.match(r'^(_ZN[^:]*(?:gemm8p_(?:group_|ln_|hm2_|pw_)?|gemmbs_)kernel[^:]*):', lines[i])
+        m = re.match(r'^(_ZN[^:]*(?:gemm8p_(?:group_|ln_|hm2_|pw_|pt_)?|gemmbs_)kernel[^:]*):', lines[i])
         if not m:
             i += 1
             continue

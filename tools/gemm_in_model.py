@@ -7,7 +7,7 @@ see which launches lose time to their context.
 
 Kernel tags: 128 = gemm_kernel (128 x 128 tiles), 64 = the few-rows kernel, 256 = gemm256, 8 | flags = gemm8p (0x10 general
 epilogue, 0x20 partial last K-tile, 0x400 the 128 x 256 tile, 0x40 the grouped weight gradients, 0x80 GEMM + LayerNorm,
-0x800 the small-problem group), 0x200 | ... = the B-stationary kernel."""
+0x800 gemmpw.hip's persistent 128 x 256 kernel, 0x4000 the persistent walk of 256 x 256 tiles), 0x200 | ... = the B-stationary kernel."""
 import argparse
 import collections
 import ctypes
