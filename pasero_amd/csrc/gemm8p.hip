@@ -292,6 +292,9 @@ __device__ __forceinline__ void gemm8p_tile(const T* __restrict__ A, const T* __
 #else
 #define PK_STAMP() do { } while (0)
 #endif
+    // (tried: the workgroups of the odd XCDs started 4 / 8 / 12 us late, so that one half's epilogue stores meet the other
+    // half's K loops — 8192 x 8192 x 1024 122.5 / 125.8 / 129.7 us against 122.6 without, the vocabulary logits 915-930 against
+    // 925-931: nothing; the epilogue is not only the chip's write burst)
     int vb = lin;  // PW: the position in this workgroup's walk (blockIdx.x + j * gridDim.x); its tile: xcd_remap(vb, pw_total)
     bool pw_first = true;
     do {  // (one pass unless PW)
