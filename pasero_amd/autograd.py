@@ -1064,6 +1064,105 @@ class Conv1dChannelsLastFn(Function):
         return dx, dw, db, None, None, None
 
 
+class ConvStackFn(Function):
+    """A stack of Conv1d + activation (Whisper's subsampler: k3 s1 GELU, k3 s2 GELU; pasero/models/modules.py:819-834 without the
+    GLU) as ONE node: the same implicit GEMMs as `Conv1dChannelsLastFn`, conv by conv, minus the copies between them.  With R_i
+    rows per batch out of conv i and Lp_{i+1} = R_{i+1} * stride_{i+1} rows per batch in the zero-padded input of conv i + 1:
+    where R_i == Lp_{i+1} (every stride-1 'same' conv in front of anything) GEMM row b R_i + r IS row b Lp_{i+1} + r of that
+    buffer, so the GEMM of conv i writes its activations straight into the padded input of conv i + 1, `padding` rows down —
+    no compaction of the R_i - Lout_i rows past the end (they land on padding rows and are zeroed: B x 2 rows instead of a pass
+    over the tensor), no zero fill, no copy into the padded layout; on the way back `pk_col2im1d` writes the input gradient of
+    conv i + 1 over R_i rows per batch, which is the (B, R_i, C) layout the backward of conv i contracts.  Per Whisper step (16 x
+    3000 x 512 between the convs): two 49 MB copies, a 49 MB clone and two 49 MB zero fills less."""
+
+    @staticmethod
+    def forward(ctx, x, act: str, geoms, *wb):
+        n = len(geoms)
+        B, L, C = x.shape
+        plan = []
+        for i, (stride, padding) in enumerate(geoms):
+            O, Cw, k = wb[2 * i].shape
+            assert Cw == C, (Cw, C)
+            Lout = (L + 2 * padding - k) // stride + 1
+            R = -(-(L + 2 * padding) // stride)
+            plan.append((L, C, O, k, stride, padding, Lout, R))
+            L, C = Lout, O
+        need_pre = act != 'none' and any(wants_grad(ctx))
+        saved, direct = [], []
+        # the padded input of conv 0
+        L0, C0, _, k0, s0, p0, _, R0 = plan[0]
+        xp = x.new_zeros(B * R0 * s0 + k0, C0)  # + k rows: the windows of the last (discarded) rows stay in bounds
+        xp[:B * R0 * s0].view(B, R0 * s0, C0)[:, p0:p0 + L0] = x
+        y = None
+        for i, (Li, Ci, O, k, stride, padding, Lout, R) in enumerate(plan):
+            A = torch.as_strided(xp, (B * R, k * Ci), (stride * Ci, 1))
+            wr = wb[2 * i].permute(0, 2, 1).reshape(O, k * Ci).contiguous()  # [o][(j, c)]
+            pre = torch.empty(B * R, O, dtype=x.dtype, device=x.device) if need_pre else None
+            nxt = plan[i + 1] if i + 1 < n else None
+            straight = nxt is not None and R == nxt[7] * nxt[4] and nxt[5] <= nxt[3]
+            direct.append(straight)
+            if straight:
+                _, _, _, kn, sn, pn, _, Rn = nxt
+                Lpn = Rn * sn
+                xn = torch.empty(B * Lpn + kn, O, dtype=x.dtype, device=x.device)
+                F.gemm(A, wr, bias=wb[2 * i + 1], act=act, preact=pre, out=xn[pn:pn + B * R])
+                xn[:pn].zero_()
+                xn[pn + B * R:].zero_()
+                # rows Lout .. R - 1 of every batch (windows past the end) sit on the padding rows between the batches
+                torch.as_strided(xn, (B, R - Lout, O), (Lpn * O, O, 1), (pn + Lout) * O).zero_()
+            else:
+                y = F.gemm(A, wr, bias=wb[2 * i + 1], act=act, preact=pre).view(B, R, O)[:, :Lout]
+                if nxt is not None:
+                    _, _, _, kn, sn, pn, _, Rn = nxt
+                    xn = x.new_zeros(B * Rn * sn + kn, O)
+                    xn[:B * Rn * sn].view(B, Rn * sn, O)[:, pn:pn + Lout] = y
+            saved += [xp, wr, pre]
+            if nxt is not None:
+                xp = xn
+        ctx.plan, ctx.direct, ctx.act, ctx.B = plan, direct, act, B
+        ctx.nsaved = [t is not None for t in saved]
+        ctx.save_for_backward(*[t for t in saved if t is not None])
+        return y.contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        it = iter(ctx.saved_tensors)
+        saved = [next(it) if has else None for has in ctx.nsaved]
+        plan, B, n = ctx.plan, ctx.B, len(ctx.plan)
+        grads = [None] * (2 * n)
+        dx = None
+        dyf = None  # (B, R_i, O_i): the output gradient of conv i in the GEMM's row layout, zero past Lout_i
+        for i in range(n - 1, -1, -1):
+            Li, Ci, O, k, stride, padding, Lout, R = plan[i]
+            xp, wr, pre = saved[3 * i:3 * i + 3]
+            if dyf is None:
+                dyf = dy.new_zeros(B, R, O)
+                dyf[:, :Lout] = dy
+            dz = dyf.view(B * R, O)
+            if ctx.act != 'none':
+                dz = F.act_bwd(dz, pre, ctx.act)
+            A = torch.as_strided(xp, (B * R, k * Ci), (stride * Ci, 1))
+            dyf = None
+            if i > 0 or ctx.needs_input_grad[0]:
+                dA = F.gemm(dz, wr, b_col=True)
+                if i > 0 and ctx.direct[i - 1]:
+                    Rp = plan[i - 1][7]
+                    dyf = F.col2im1d(dA, B, Rp, Ci, R, Lout, k, stride, padding)
+                    if (Lout - 1) * stride + k - 1 - padding >= Li:  # a window reaches past the input's end: not this conv's to keep
+                        dyf[:, Li:].zero_()
+                else:
+                    dxi = F.col2im1d(dA, B, Li, Ci, R, Lout, k, stride, padding)
+                    if i > 0:
+                        dy = dxi
+                    else:
+                        dx = dxi
+            dwr, db = _wgrad(dz, A, ctx.needs_input_grad[3 + 2 * i], ctx.needs_input_grad[3 + 2 * i + 1])
+            if dwr is not None:
+                grads[2 * i] = dwr.view(O, k, Ci).permute(0, 2, 1).contiguous()
+            grads[2 * i + 1] = db
+        return (dx, None, None, *grads)
+
+
 class AddPositionsFn(Function):
     """dropout(x * scale + pos[pos_start : pos_start+T]) for dense (speech) encoder inputs
     (pasero/models/transformer.py:739-744)"""

@@ -48,6 +48,7 @@ struct Consts {  // device-resident, built once per device
     int* hi;         // [80] last bin (inclusive)
     float* fbc;      // [nfbc] the weights fb[lo[m] .. hi[m]][m], filter after filter
     int* off;        // [80] first weight of filter m in fbc
+    int* meta;       // [80][3] lo | number of taps | off, one run: staged in LDS with the weights
     int nfbc;
 };
 
@@ -101,7 +102,9 @@ int get_consts(Consts& out) {
         auto up = [&](void** d, const void* h, size_t n) {
             return hipMalloc(d, n) == hipSuccess && hipMemcpy(*d, h, n, hipMemcpyHostToDevice) == hipSuccess;
         };
-        bool ok = up((void**)&c.tw_cos, tc.data(), NFFT * 4) && up((void**)&c.tw_sin, ts.data(), NFFT * 4) &&
+        std::vector<int> meta(3 * NMEL);
+        for (int m = 0; m < NMEL; ++m) { meta[3 * m] = lo[m]; meta[3 * m + 1] = hi[m] - lo[m] + 1; meta[3 * m + 2] = off[m]; }
+        bool ok = up((void**)&c.meta, meta.data(), meta.size() * 4) && up((void**)&c.tw_cos, tc.data(), NFFT * 4) && up((void**)&c.tw_sin, ts.data(), NFFT * 4) &&
                   up((void**)&c.hann, hw.data(), NFFT * 4) && up((void**)&c.fb, fb.data(), fb.size() * 4) &&
                   up((void**)&c.lo, lo.data(), NMEL * 4) && up((void**)&c.hi, hi.data(), NMEL * 4) &&
                   up((void**)&c.fbc, fbc.data(), fbc.size() * 4) && up((void**)&c.off, off.data(), NMEL * 4);
@@ -148,8 +151,12 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict_
             const float v = x[ok ? j : 0];
             return ok ? v : 0.f;
         };
+#ifdef LM_ABL_NOSTAGE
+        const float xa = 0.25f * n, xb = 0.5f, xc = 0.125f * f, xe = 1.f;
+#else
         const float xa = fetch(n, n <= 100), xb = fetch(NFFT - n, n >= 1 && n <= 100);
         const float xc = fetch(200 - n, n <= 99), xe = fetch(200 + n, n >= 1 && n <= 99);
+#endif
         const float w = n <= 100 ? cst.hann[n] : 0.f, wc = 1.f - w;
         const float sn = (xa + xb) * w, dn = (xa - xb) * w, sm = (xc + xe) * wc, dm = (xc - xe) * wc;
         const float vm = n >= 1 ? 1.f : 0.f;
@@ -175,7 +182,11 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict_
         step[t] = (2 * b) % NFFT;                          // n advances by 2 per k-step
     }
     const float* arow = a_t + frame_l * APITCH + kh;
+#ifdef LM_ABL_NODFT
+    for (int s = 0; s < 1; ++s) {
+#else
     for (int s = 0; s < NFOLD / 2; ++s) {
+#endif
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const float u = arow[t * NFOLD + 2 * s], v = arow[(2 + t) * NFOLD + 2 * s];
@@ -192,7 +203,8 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict_
     // packed filter by filter, into the part of the dead input tile behind it
     float* m_t = a_t + FT * PPITCH;          // [80][33] log-mel values of the workgroup (transposed: both accesses conflict-free)
     float* fb_t = m_t + NMEL * 33;           // [<= FBC_MAX] packed weights
-    static_assert(FT * PPITCH + NMEL * 33 + FBC_MAX <= FT * APITCH, "mel staging fits the dead input tile");
+    int* meta_t = reinterpret_cast<int*>(fb_t + FBC_MAX);  // [80][3] first bin | taps | first weight of every filter
+    static_assert(FT * PPITCH + NMEL * 33 + FBC_MAX + 3 * NMEL <= FT * APITCH, "mel staging fits the dead input tile");
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         if (bin[t] >= NBIN) continue;
@@ -203,6 +215,7 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict_
         }
     }
     for (int j = tid; j < cst.nfbc; j += 256) fb_t[j] = cst.fbc[j];
+    if (tid < 3 * NMEL) meta_t[tid] = cst.meta[tid];
     __syncthreads();
 
     // sparse mel projection + log10.  A (frame, mel) pair per thread with the FRAME on the lane: the 64 lanes of a wave work on two
@@ -212,11 +225,16 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict_
     float mx = -INFINITY;
     const int f = tid & 31;
     for (int m = tid >> 5; m < NMEL; m += 8) {
-        const int lo = cst.lo[m], len = cst.hi[m] - lo + 1;
+        // (from LDS: read from global memory here, the three were a dependent L2 round trip in front of every filter)
+        const int lo = meta_t[3 * m], len = meta_t[3 * m + 1];
         const float* pw = p_t + f * PPITCH + lo;
-        const float* fw = fb_t + cst.off[m];
+        const float* fw = fb_t + meta_t[3 * m + 2];
         float acc = 0.f;
+#ifdef LM_ABL_NOMEL
+        acc = pw[0] * fw[0];
+#else
         for (int j = 0; j < len; ++j) acc += pw[j] * fw[j];
+#endif
         const float lg = log10f(fmaxf(acc, 1e-10f));
         m_t[m * 33 + f] = lg;
         if (f0 + f < NFRAME) mx = fmaxf(mx, lg);

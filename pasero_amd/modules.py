@@ -722,6 +722,9 @@ class MultiheadAttention(_PerCallAttrs, nn.Module):
 # ------------------------------------------------------------------------------------------------------------
 # speech frontend
 # ------------------------------------------------------------------------------------------------------------
+_NO_CONV_STACK = bool(os.environ.get('PASERO_NO_CONV_STACK'))  # diagnostic: every conv a node of its own
+
+
 class ConvolutionSubsampler(nn.Module):
     """Conv1d (+GLU | GELU) stack (modules.py:774-834) computed channels-last as implicit GEMMs on the MFMA kernel:
     a (k*C_in)-wide window of the zero-padded (B, L, C_in) input IS a contiguous row of the im2col matrix, so the
@@ -748,7 +751,12 @@ class ConvolutionSubsampler(nn.Module):
         return length
 
     def forward(self, x: Tensor, length: LongTensor):
-        from .autograd import Conv1dChannelsLastFn
+        from .autograd import Conv1dChannelsLastFn, ConvStackFn
+        if self.activation_name != 'glu' and len(self.conv_layers) > 1 and not _NO_CONV_STACK:
+            # (one node for the whole stack: conv i writes into the padded input of conv i + 1 — autograd.ConvStackFn)
+            wb = [t for conv in self.conv_layers for t in (conv.weight, conv.bias)]
+            geoms = tuple((conv.stride[0], conv.padding[0]) for conv in self.conv_layers)
+            return ConvStackFn.apply(x, 'gelu', geoms, *wb), self.get_new_length(length)
         for conv in self.conv_layers:
             act = 'gelu' if self.activation_name != 'glu' else 'none'
             x = Conv1dChannelsLastFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], act)

@@ -753,6 +753,52 @@ def test_col2im1d(F, dtype, B, L, C, k, stride):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,L,C,chans,ks,strides', [
+    (3, 300, 80, (96, 64), (3, 3), (1, 2)),        # Whisper's stack: conv 0 writes straight into the padded input of conv 1
+    (2, 301, 40, (64, 64), (3, 3), (1, 2)),        # odd length
+    (2, 120, 32, (48, 40), (3, 5), (1, 1)),        # the second conv's windows reach past the end of its input (k 5, stride 1)
+    (2, 100, 32, (48, 40, 24), (3, 3, 3), (1, 1, 2)),
+    (2, 90, 32, (48, 40), (3, 3), (2, 2)),         # no straight write (stride 2 in front): the copies stay
+])
+def test_conv_stack_is_the_chain_of_convs_bit_for_bit(dtype, B, L, C, chans, ks, strides):
+    """autograd.ConvStackFn (one node: conv i's GEMM writes into the padded input of conv i + 1, pk_col2im1d writes the gradient in
+    the row layout the conv below contracts) against the chain of Conv1dChannelsLastFn nodes it replaces: the same GEMMs on the
+    same operands, so outputs and every gradient are equal bit for bit — and against torch's conv1d in fp64"""
+    from pasero_amd.autograd import Conv1dChannelsLastFn, ConvStackFn
+    g = torch.Generator().manual_seed(L + C)
+    x0 = torch.randn(B, L, C, generator=g).to(dtype).cuda()
+    ws, bs, cin = [], [], C
+    for O, k in zip(chans, ks):
+        ws.append((torch.randn(O, cin, k, generator=g) / (cin * k) ** 0.5).to(dtype).cuda())
+        bs.append((0.1 * torch.randn(O, generator=g)).to(dtype).cuda())
+        cin = O
+    outs = []
+    for stack in (True, False):
+        x = x0.clone().requires_grad_()
+        w = [t.clone().requires_grad_() for t in ws]
+        b = [t.clone().requires_grad_() for t in bs]
+        if stack:
+            y = ConvStackFn.apply(x, 'gelu', tuple((s, k // 2) for s, k in zip(strides, ks)), *[t for p in zip(w, b) for t in p])
+        else:
+            y = x
+            for wi, bi, s, k in zip(w, b, strides, ks):
+                y = Conv1dChannelsLastFn.apply(y, wi, bi, s, k // 2, 'gelu')
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(dtype).cuda()
+        y.backward(dy)
+        outs.append([y.detach(), x.grad] + [t.grad for t in w] + [t.grad for t in b])
+    for a, r in zip(*outs):
+        assert a.shape == r.shape and torch.equal(a, r)
+    x = x0.double().cpu().transpose(1, 2).requires_grad_()
+    y = x
+    for wi, bi, s, k in zip(ws, bs, strides, ks):
+        y = torch.nn.functional.gelu(torch.nn.functional.conv1d(y, wi.double().cpu(), bi.double().cpu(), stride=s, padding=k // 2))
+    y.transpose(1, 2).backward(dy.double().cpu())
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert rel_err(outs[0][0], y.transpose(1, 2)) < tol
+    assert rel_err(outs[0][1], x.grad.transpose(1, 2)) < tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('M,N', [(1000, 512), (7, 2048), (33000, 1536), (50, 100), (3, 9)])
 def test_colsum(F, dtype, M, N):
     x = rnd((M, N), 60, dtype)
