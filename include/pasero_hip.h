@@ -473,6 +473,14 @@ typedef struct {
     void *dx, *denc;                                    /* backward: gradients of x and (decoder) enc */
     const void* denc_prev;                              /* decoder: NULL, or the enc gradient accumulated so far by the layers
                                                           * above (may be denc itself): denc = this layer's + denc_prev */
+    /* pre-norm layers with dropout, backward — the hand-over of a masked gradient between stacked layers (autograd.DropLink):
+     * dy_masked: NULL, or dy already pushed through THIS layer's feed-forward dropout mask (written by the consumer of the
+     *   layer's output: the layer above): the layer does not draw that mask again;
+     * dx_masked: NULL, or room for [B*T][d]: the layer's last LayerNorm backward also writes dx through the dropout mask
+     *   (drop_p, seed, dx_mask_offset) — the feed-forward block end of the layer BELOW, whose dy_masked it becomes. */
+    const void* dy_masked;
+    void* dx_masked;
+    unsigned long long dx_mask_offset;
     void *scratch, *ws;
     size_t scratch_bytes, ws_bytes;
     void* stream;

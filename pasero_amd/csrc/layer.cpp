@@ -337,8 +337,10 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
         };
         const void* in_f = L.is_decoder ? L.cross.z : L.self.z;
         // feed-forward
-        PK_TRY(undrop(L.dy, b.dsub_f, L.ffn.drop_offset));
-        const void* do_f = drop ? b.dsub_f : L.dy;
+        // (L.dy_masked: the layer above has written dy through this mask already, in its last LayerNorm backward)
+        const bool handed = drop && L.dy_masked;
+        if (!handed) PK_TRY(undrop(L.dy, b.dsub_f, L.ffn.drop_offset));
+        const void* do_f = handed ? L.dy_masked : drop ? b.dsub_f : L.dy;
         if (L.ffn.bits)
             PK_TRY(pk_gemm_relu_bits(do_f, L.ffn.w2, b.dh, nullptr, L.ffn.bits, rows, f, d, d, f, f, f / 8, 1, 2, 1.f, dt, L.stream));
         else if (L.act == PK_ACT_NONE)
@@ -379,7 +381,9 @@ extern "C" int pk_layer_bwd(const PkLayer* lp) {
                            (long long)L.T * d, d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d, (long long)L.T * 3 * d, 3 * d,
                            L.is_decoder && L.T > 1, L.attn_scale, 0.f, nullptr, dt, L.stream));
         PK_TRY(dx_gemm(b.dproj, L.self.w_in, b.dln, nullptr, rows, d, 3 * d, true));
-        PK_TRY(ln_in_bwd(b.dln, dz, L.x, L.self.ln_g, L.self.mean, L.self.rstd, L.dx, L.self.dln_g, L.self.dln_b, nullptr, 0));
+        // (L.dx_masked: the layer below is a pre-norm layer with the same dropout: its feed-forward mask applied here)
+        PK_TRY(ln_in_bwd(b.dln, dz, L.x, L.self.ln_g, L.self.mean, L.self.rstd, L.dx, L.self.dln_g, L.self.dln_b, L.dx_masked,
+                         L.dx_mask_offset));
         PK_TRY(ln_finish());
         return pk_gemm_wgrad_group(pr, n, dt, ws, b.ws_group, L.stream);
     }

@@ -114,7 +114,8 @@ class PkLayer(ctypes.Structure):
     _fields_ = ([(n, I) for n in ('dtype', 'is_decoder', 'fused_tail', 'act', 'B', 'T', 'S', 'd', 'f', 'heads', 'prenorm')] +
                 [('eps', F), ('drop_p', F), ('attn_scale', F), ('seed', ULL), ('x', P), ('enc', P), ('self_pad', P),
                  ('cross_pad', P), ('self_', PkAttnBlock), ('cross', PkAttnBlock), ('ffn', PkFfnBlock), ('dy', P), ('dx', P),
-                 ('denc', P), ('denc_prev', P), ('scratch', P), ('ws', P), ('scratch_bytes', SZ), ('ws_bytes', SZ), ('stream', P)])
+                 ('denc', P), ('denc_prev', P), ('dy_masked', P), ('dx_masked', P), ('dx_mask_offset', ULL), ('scratch', P),
+                 ('ws', P), ('scratch_bytes', SZ), ('ws_bytes', SZ), ('stream', P)])
 
 
 _lib = None

@@ -24,6 +24,7 @@ from .lib import ACT, PkLayer, check, dtype_code
 _OFF = os.environ.get('PASERO_NO_NATIVE_LAYER', '0') not in ('', '0')
 _NO_FUSED_TAIL = os.environ.get('PASERO_NO_FUSED_TAIL', '0') not in ('', '0')
 _NO_DENC_CHAIN = os.environ.get('PASERO_NO_DENC_CHAIN', '0') not in ('', '0')  # (A/B: every decoder layer returns its own encoder gradient)
+_NO_DROP_LINK = os.environ.get('PASERO_NO_DROP_LINK', '0') not in ('', '0')  # (A/B: every pre-norm layer draws its feed-forward mask itself in backward)
 _sizes = {}  # (is_decoder, fused, prenorm, act, mask bits, B, T, S, d, f, heads, dtype, drop) -> (scratch_bytes, ws_bytes)
 
 
@@ -209,7 +210,7 @@ class NativeLayerFn(Function):
     """y = layer(x [, encoder_out]) — forward: pk_layer_fwd; backward: pk_layer_bwd (one C call each)"""
 
     @staticmethod
-    def forward(ctx, x, enc, self_pad, cross_pad, layer, is_decoder, *params):
+    def forward(ctx, x, enc, self_pad, cross_pad, layer, is_decoder, links, *params):
         L = lib.load()
         a_self = layer.self_attn
         B, T, d = x.shape
@@ -305,6 +306,16 @@ class NativeLayerFn(Function):
         if p > 0:
             seed, fb.drop_offset = rng.next_offset()
         lay.seed = seed
+        # masked-gradient hand-over between stacked pre-norm layers (autograd.DropLink): `link_out` tells the consumer of this
+        # layer's output which mask the feed-forward block end drew; `link_in` is the same note from the producer of x
+        link_in, link_out = links
+        if link_out is not None and prenorm and p > 0:
+            link_out.p, link_out.seed, link_out.offset = p, seed, fb.drop_offset
+        else:
+            link_out = None
+        if not (link_in is not None and prenorm and p > 0 and link_in.p == p and link_in.seed == seed):
+            link_in = None
+        ctx.links = (link_in, link_out)
         lay.stream = lib.stream_ptr()
         # a few-rows fc2 with a long contraction (NLLB's 8192 -> 1024 at a 2048-row decoder batch: 32 of 256 CUs as it stands)
         # runs split-K in the forward pass too when the layer brings a workspace (pk_layer_fwd_ws: 0 when no GEMM asks)
@@ -332,8 +343,13 @@ class NativeLayerFn(Function):
         x, enc, _, _, a16, a32, params = ctx.keep
         B, T, S, d, f, H = ctx.dims
         dt, dev = x.dtype, x.device
+        link_in, link_out = ctx.links
+        handed = link_out.take(dy) if link_out is not None else None  # (dy through this layer's feed-forward mask, or None)
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dx = torch.empty_like(x)
+        masked = torch.empty_like(x) if link_in is not None else None
+        lay.dy_masked = handed.data_ptr() if handed is not None else None
+        lay.dx_masked, lay.dx_mask_offset = (masked.data_ptr(), link_in.offset) if masked is not None else (None, 0)
         denc = denc_ret = None
         lay.denc_prev = None
         if is_decoder:
@@ -383,8 +399,10 @@ class NativeLayerFn(Function):
         lay.scratch, lay.scratch_bytes, lay.ws, lay.ws_bytes = scratch.data_ptr(), scratch.numel(), ws.data_ptr(), ws.numel()
         lay.stream = lib.stream_ptr()
         check(L.pk_layer_bwd(ctypes.byref(lay)), 'pk_layer_bwd')
+        if masked is not None:
+            link_in.offer(masked, dx)
         grads = grads_in_param_order(wd, w2, vec, wrows, vsz, nblk, params)
-        return (dx, denc_ret, None, None, None, None, *grads)
+        return (dx, denc_ret, None, None, None, None, None, *grads)
 
 
 def run(layer, x, enc, self_pad, cross_pad, is_decoder: bool):
@@ -392,5 +410,13 @@ def run(layer, x, enc, self_pad, cross_pad, is_decoder: bool):
         self_pad = self_pad.contiguous()
     if cross_pad is not None and not cross_pad.is_contiguous():
         cross_pad = cross_pad.contiguous()
-    return NativeLayerFn.apply(x, enc if is_decoder else None, self_pad, cross_pad, layer, is_decoder,
-                               *layer_params(layer, is_decoder))
+    link_out = None
+    if layer.prenorm and layer.training and layer.dropout.p > 0 and torch.is_grad_enabled() and not _NO_DROP_LINK:
+        from .autograd import DropLink
+        link_out = DropLink()
+    y = NativeLayerFn.apply(x, enc if is_decoder else None, self_pad, cross_pad, layer, is_decoder,
+                            (getattr(x, '_pk_drop_link', None) if link_out is not None else None, link_out),
+                            *layer_params(layer, is_decoder))
+    if link_out is not None and link_out.p > 0:
+        y._pk_drop_link = link_out
+    return y

@@ -151,3 +151,30 @@ def test_assembly_audit_tells_loop_spills_from_spills_that_run_once(tmp_path):
     bare = [ln.split(';')[0].rstrip() if ln.startswith('.LBB') else ln for ln in loop]
     unannotated = run(head + bare[:2] + [spill] + bare[2:] + tail)
     assert unannotated.returncode == 1 and 'no label with a loop annotation' in unannotated.stdout, unannotated.stdout
+
+
+def test_ctypes_structures_have_the_layout_of_the_header(tmp_path):
+    """the structs that cross the C ABI by pointer (PkLayer and its blocks, PkWgradProblem, the decoder plan) are declared twice —
+    include/pasero_hip.h and the ctypes mirrors in lib.py / decode.py: compiled from the header by gcc, every field must sit at
+    the offset ctypes gives it (a field added on one side only shifts everything behind it silently)"""
+    import ctypes
+    import subprocess
+    from pasero_amd import lib, decode
+    mirrors = {'PkWgradProblem': lib.PkWgradProblem, 'PkAttnBlock': lib.PkAttnBlock, 'PkFfnBlock': lib.PkFfnBlock,
+               'PkLayer': lib.PkLayer, 'PkDecoderLayerWeights': decode.PkDecoderLayerWeights, 'PkDecoderPlan': decode.PkDecoderPlan}
+    rename = {'self_': 'self'}  # (`self` is spelled `self_` on the Python side)
+    lines = []
+    for name, cls in mirrors.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for field, _ in cls._fields_:
+            c = rename.get(field, field)
+            lines.append(f'printf("{name}.{field} %zu\\n", offsetof({name}, {c}));')
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pasero_hip.h"\nint main(void) {\n' + '\n'.join(lines) + '\nreturn 0; }\n')
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, cls in mirrors.items():
+        assert int(got[name]) == ctypes.sizeof(cls), (name, got[name], ctypes.sizeof(cls))
+        for field, _ in cls._fields_:
+            assert int(got[f'{name}.{field}']) == getattr(cls, field).offset, (name, field)

@@ -162,6 +162,39 @@ def test_native_prenorm_layer_against_the_per_op_path(over, B, S, T):
     assert l2 == l1 and all(torch.equal(g2[k], g1[k]) for k in g1)
 
 
+def test_stacked_prenorm_layers_hand_the_masked_gradient_down(monkeypatch):
+    """pre-norm layers with dropout, stacked: the last LayerNorm backward of layer l + 1 writes the gradient of its input a second
+    time, through the feed-forward dropout mask of layer l (PkLayer.dx_masked -> dy_masked, autograd.DropLink), and layer l
+    does not draw that mask again.  Same forward (equal loss); the masked copy is rounded once instead of twice, so gradients
+    agree to bf16 round-off; the hand-over must actually happen between every pair of stacked layers and nowhere else."""
+    from pasero_amd import native_layer, autograd
+    V = 800
+    model = _model(V, dropout=0.1, encoder_layers=3, decoder_layers=3, encoder_prenorm=True, decoder_prenorm=True)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in paramgen.make_text_batch(4, 24, 30, 28, V, ragged=True).items()}
+    hits = {'n': 0}
+    orig = autograd.DropLink.take
+
+    def counted(self, dz):
+        m = orig(self, dz)
+        hits['n'] += m is not None
+        return m
+    monkeypatch.setattr(autograd.DropLink, 'take', counted)
+    l1, _, g1, c1 = _step(model, batch, native=True)
+    assert c1 == 6 and hits['n'] == 4, (c1, hits)
+    hits['n'] = 0
+    monkeypatch.setattr(native_layer, '_NO_DROP_LINK', True)
+    l0, _, g0, _ = _step(model, batch, native=True)
+    assert hits['n'] == 0
+    assert l1 == l0
+    for k in g0:
+        a, r = g1[k].float(), g0[k].float()
+        ref = g0[k.replace('bias', 'weight')].float().norm().item() if k.endswith('k_proj.bias') else r.norm().item()
+        assert (a - r).norm().item() <= 2e-2 * ref + 1e-6, (k, (a - r).norm().item(), ref)
+    monkeypatch.setattr(native_layer, '_NO_DROP_LINK', False)
+    l2, _, g2, _ = _step(model, batch, native=True)
+    assert l2 == l1 and all(torch.equal(g2[k], g1[k]) for k in g1)
+
+
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-5), (torch.bfloat16, 2.5e-2)])
 def test_prenorm_input_fork_against_autograds_addition(dtype, tol):
     """per-op path, pre-norm layers: `residual = x; x = *_prenorm(x)` as ONE autograd node (autograd.LayerNormForkFn — the
