@@ -631,7 +631,13 @@ class _LayerBase(modules._PerCallAttrs, nn.Module):
         for a in attns:
             a._wgroup = group
         self._ffn_group = group
-        return WGradSinkFn.apply(x, group, *params)
+        y = WGradSinkFn.apply(x, group, *params)
+        # (the sink is an identity whose backward passes the gradient through untouched: the note of the dropout that produced x
+        # — autograd.DropLink, left by the layer below — stays valid on its output)
+        link = getattr(x, '_pk_drop_link', None)
+        if link is not None:
+            y._pk_drop_link = link
+        return y
 
     def _wgrad_close(self, attns) -> None:
         """(a hook that skipped its sub-block must not leave the group behind for a later call)"""
