@@ -672,7 +672,10 @@ class AdapterFn(Function):
     gradients into the weight-gradient GEMMs and the residual-branch gradient into the LayerNorm backward."""
 
     @staticmethod
-    def forward(ctx, x, res, ln_w, ln_b, eps: float, down_w, down_b, up_w, up_b, act: str, scaling: float):
+    def forward(ctx, x, res, ln_w, ln_b, eps: float, down_w, down_b, up_w, up_b, act: str, scaling: float, drop=None):
+        # `drop`: the DropLink of the `residual + dropout(.)` that produced x (a pre-norm layer's last block end), when x is also the
+        # adapter's residual: the LayerNorm backward below then computes the WHOLE gradient of x and can write it through that mask
+        ctx.drop = drop if (drop is not None and drop.p > 0 and res is x and ln_w is not None and x.dtype != torch.float32) else None
         x2 = _2d(_contig(x))
         grad = any(wants_grad(ctx))
         if ln_w is not None:
@@ -741,9 +744,14 @@ class AdapterFn(Function):
                 if ctx.has_ln:
                     dh = F.gemm(da, down_w, b_col=True)
                     want_pg = ng[2] or (ctx.has_ln_b and ng[3])
-                    dx, _, dln_w, dln_b = F.residual_ln_bwd(dh, dy2 if ctx.res_is_x else None, x2, ln_w, mean, rstd,
-                                                            want_dres=True, want_dx=False, want_param_grads=want_pg,
-                                                            has_beta=ctx.has_ln_b)
+                    d = ctx.drop if (ctx.res_is_x and ng[0]) else None
+                    dx, masked, dln_w, dln_b = F.residual_ln_bwd(dh, dy2 if ctx.res_is_x else None, x2, ln_w, mean, rstd,
+                                                                 want_dres=True, want_dx=d is not None, want_param_grads=want_pg,
+                                                                 has_beta=ctx.has_ln_b, drop_p=d.p if d else 0.0,
+                                                                 seed=d.seed if d else 0, offset=d.offset if d else 0)
+                    if d is not None:
+                        dx = dx.view(*dy.shape[:-1], x2.size(1))
+                        d.offer(masked.view(dx.shape), dx)
                 elif ctx.res_is_x:
                     dx = F.gemm(da, down_w, b_col=True, aux=dy2, mode=1)  # residual branch folded into the epilogue
                 else:
@@ -756,7 +764,7 @@ class AdapterFn(Function):
         if dx is not None:
             dx = dx.view(*dy.shape[:-1], x2.size(1)) if dx.dim() == 2 else dx
         return (dx if ng[0] else None, dres, dln_w if ng[2] else None, dln_b if (ctx.has_ln_b and ng[3]) else None, None,
-                ddown_w, ddown_b, dup_w, dup_b, None, None)
+                ddown_w, ddown_b, dup_w, dup_b, None, None, None)
 
 
 class ResidualDropoutFn(Function):

@@ -231,7 +231,7 @@ class AdapterLayer(nn.Module):
             residual = x
         return AdapterFn.apply(x, residual, getattr(norm, 'weight', None), getattr(norm, 'bias', None),
                                getattr(norm, 'eps', 1e-5), self.down.weight, self.down.bias, self.up.weight,
-                               self.up.bias, self.act_name, float(self.scaling))
+                               self.up.bias, self.act_name, float(self.scaling), getattr(x, '_pk_drop_link', None))
 
     def _load_from_state_dict(self, state_dict, prefix: str, *args, **kwargs) -> None:
         """inference-time conveniences of the reference loader (modules.py:349-370); training loads strictly"""

@@ -162,6 +162,45 @@ def test_native_prenorm_layer_against_the_per_op_path(over, B, S, T):
     assert l2 == l1 and all(torch.equal(g2[k], g1[k]) for k in g1)
 
 
+def test_adapter_behind_a_prenorm_layer_offers_the_masked_gradient(monkeypatch):
+    """the bottleneck adapter that follows a pre-norm layer (`adapter_transformer`: x = layer(x); x = adapter(x)) reads the
+    layer's output twice — through its LayerNorm and as its residual — and its LayerNorm backward produces the whole gradient
+    of that tensor: with the layer's DropLink it writes the gradient through the layer's last dropout mask too, and
+    ResidualDropoutFn takes it instead of drawing the mask again.  Same forward; gradients to bf16 round-off."""
+    from pasero_amd import autograd, rng
+    from pasero_amd.autograd import AdapterFn, ResidualDropoutFn, DropLink
+    B, T, d, r = 8, 40, 512, 64
+    gen = torch.Generator().manual_seed(5)
+
+    def mk(*shape, scale=1.0):
+        return (scale * torch.randn(*shape, generator=gen)).bfloat16().cuda()
+    x0, r0, dy = mk(B, T, d), mk(B, T, d), mk(B, T, d)
+    ws = [mk(d).abs() + 0.5, mk(d, scale=0.1), mk(r, d, scale=d ** -0.5), mk(r, scale=0.1), mk(d, r, scale=r ** -0.5), mk(d, scale=0.1)]
+    hits = {'n': 0}
+    orig_take = DropLink.take
+
+    def counted(self, dz):
+        m = orig_take(self, dz)
+        hits['n'] += m is not None
+        return m
+    monkeypatch.setattr(DropLink, 'take', counted)
+    outs = []
+    for linked in (True, False):
+        rng.manual_seed(3)
+        hits['n'] = 0
+        x, res = x0.clone().requires_grad_(), r0.clone().requires_grad_()
+        w = [t.clone().requires_grad_() for t in ws]
+        link = DropLink() if linked else None
+        z = ResidualDropoutFn.apply(x, res, 0.1, link)
+        y = AdapterFn.apply(z, z, w[0], w[1], 1e-5, w[2], w[3], w[4], w[5], 'relu', 1.0, link)
+        y.backward(dy)
+        outs.append([y.detach(), x.grad, res.grad] + [t.grad for t in w])
+        assert hits['n'] == (1 if linked else 0)
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert (a.float() - b.float()).norm().item() <= 1e-2 * b.float().norm().item() + 1e-6
+
+
 @pytest.mark.parametrize('per_op_layer', [0, 1])
 def test_masked_gradient_hand_over_between_a_native_and_a_per_op_layer(monkeypatch, per_op_layer):
     """the same note travels between the two kinds of layer: a natively run pre-norm layer under a per-op one (whose
