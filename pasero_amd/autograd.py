@@ -795,6 +795,44 @@ class ResidualDropoutFn(Function):
         return dx, dz, None, None
 
 
+class ResidualDropoutLnFn(Function):
+    """z = residual + dropout(x) at the end of a pre-norm sub-block AND y = LayerNorm(z) at the head of the next one, as ONE node
+    -> (y, z)   (pasero/models/transformer.py:1043-1044 followed by :1070-1075 of the next block).  Forward: one launch of
+    pk_residual_ln_fwd with both outputs (the statistics are taken on the rounded z, as a separate pass over z takes them: bit for
+    bit ResidualDropoutFn + LayerNormForkFn) — what the native layer call does between its blocks (csrc/layer.cpp,
+    `end_and_next_norm`).  Backward: the one kernel call those two nodes share through their DropLink — the LayerNorm gradient plus
+    the residual branch's (`dz_extra`), and the same sum written once more through the dropout mask for x."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p: float, gamma, beta, eps: float):
+        x, residual = _contig(x), _contig(residual)
+        seed, offset = rng.next_offset() if p > 0 else (0, 0)
+        y, z, mean, rstd = F.residual_ln_fwd(x, residual, gamma, beta, eps, p, seed, offset)
+        ctx.p, ctx.seed, ctx.offset, ctx.has_beta = p, seed, offset, beta is not None
+        ctx.save_for_backward(z, gamma, mean, rstd)
+        ctx.set_materialize_grads(False)  # (an output nobody consumed arrives as None, not as zeros)
+        return y, z
+
+    @staticmethod
+    def backward(ctx, dy, dz):
+        z, gamma, mean, rstd = ctx.saved_tensors
+        ng = ctx.needs_input_grad
+        if dy is None:  # only z was used: the plain residual + dropout
+            if dz is None:
+                return None, None, None, None, None, None
+            dz = _contig(dz)
+            dx = F.dropout(dz, ctx.p, ctx.seed, ctx.offset) if (ctx.p > 0 and ng[0]) else dz
+            return (dx if ng[0] else None), (dz if ng[1] else None), None, None, None, None
+        want_pg = ng[3] or (ctx.has_beta and ng[4])
+        extra = _contig(dz) if dz is not None else None
+        dres, masked, dgamma, dbeta = F.residual_ln_bwd(
+            _contig(dy), extra, z, gamma, mean, rstd, want_dres=True, want_dx=ctx.p > 0 and ng[0], want_param_grads=want_pg,
+            has_beta=ctx.has_beta, drop_p=ctx.p, seed=ctx.seed, offset=ctx.offset)
+        dx = masked if ctx.p > 0 else dres
+        return (dx if ng[0] else None, dres if ng[1] else None, None, dgamma if ng[3] else None,
+                dbeta if (ctx.has_beta and ng[4]) else None, None)
+
+
 class DropoutFn(Function):
     """nn.Dropout with a regenerable Philox mask"""
 

@@ -25,7 +25,7 @@ from .profiling import block as _bench_block, region as _bench_region
 from .modules import Embedding, Identity
 from .autograd import (FFNFn, GatedFFNFn, ResidualLayerNormFn, ResidualDropoutFn, VocabCrossEntropyFn, CrossEntropyFn, tie_table,
                        AddPositionsFn, LinearFn, ResidualLink, WGradGroup, WGradSinkFn, BlockTail, FFNResidualLnFn,
-                       block_tail_eligible, LayerNormForkFn, DropLink)
+                       block_tail_eligible, LayerNormForkFn, DropLink, ResidualDropoutLnFn)
 
 from .config import register_model  # also enters the reference's registry when `pasero` is importable
 
@@ -37,6 +37,7 @@ _NO_FUSED_TAIL = bool(int(os.environ.get('PASERO_NO_FUSED_TAIL', '0') or 0))
 # diagnostic: pre-norm sub-blocks call their LayerNorm hook and leave the sum of the two input gradients to autograd
 _NO_LN_FORK = bool(int(os.environ.get('PASERO_NO_LN_FORK', '0') or 0))
 _NO_DROP_LINK = bool(int(os.environ.get('PASERO_NO_DROP_LINK', '0') or 0))  # (A/B: stand-alone dropout masks in the pre-norm backward)
+_NO_END_NORM = bool(int(os.environ.get('PASERO_NO_END_NORM', '0') or 0))  # (A/B: a pre-norm block end and the next block's LayerNorm as two launches)
 # diagnostic: read the step's sums at the end of the forward pass, as the reference does (A/B of the deferred read)
 _EAGER_LOGS = bool(int(os.environ.get('PASERO_EAGER_LOGS', '0') or 0))
 LN2 = math.log(2)
@@ -666,6 +667,9 @@ class _LayerBase(modules._PerCallAttrs, nn.Module):
         The node reads the module's parameters and does not go through its `__call__`: a norm module that carries forward /
         pre-forward hooks (`register_forward_hook`) keeps the hook call, so those hooks fire as in the reference."""
         m = self._norm_module(norm)
+        pre = x.__dict__.pop('_pk_prenormed', None) if isinstance(x, Tensor) else None
+        if pre is not None and pre[0] is m and self._hooks_are_base(hook):
+            return pre[1], x  # (LayerNorm(x) came with x: the block end in front of this block wrote both — `_block_end`)
         if (self.prenorm and not _NO_LN_FORK and torch.is_grad_enabled() and x.requires_grad and x.is_cuda
                 and isinstance(m, modules.LayerNorm) and getattr(m, 'weight', None) is not None
                 and not m._forward_hooks and not m._forward_pre_hooks
@@ -729,7 +733,7 @@ class _LayerBase(modules._PerCallAttrs, nn.Module):
         return self._block_end(x, residual, self.final_layer_norm, 'ffn_residual', 'ffn_postnorm', link)
 
     def _block_end(self, x: Tensor, residual: Tensor, norm, residual_hook: str, postnorm_hook: str,
-                   link=None, tail=None) -> Tensor:
+                   link=None, tail=None, next_norm=None, next_hook: str = None) -> Tensor:
         """`x = *_residual(x, residual); x = *_postnorm(x)` — one fused kernel for post-norm layers whose hooks are not
         overridden by a subclass, the reference's two hook calls otherwise; nothing at all if the sub-block's last GEMM
         has already done it (`tail.done`)"""
@@ -739,8 +743,23 @@ class _LayerBase(modules._PerCallAttrs, nn.Module):
         if self._hooks_are_base(residual_hook, postnorm_hook) and not self.prenorm and isinstance(norm, modules.LayerNorm):
             return ResidualLayerNormFn.apply(x, residual, norm.weight, norm.bias, norm.eps,
                                              self.dropout.p if self.training else 0.0, link)
+        if next_norm is not None and self._end_and_next_norm_ok(x, residual_hook, postnorm_hook, next_hook, next_norm):
+            # pre-norm: z = residual + dropout(x) and the LayerNorm that opens the NEXT block of this layer in one launch (and one
+            # autograd node: autograd.ResidualDropoutLnFn); `_prenorm` of that block finds LayerNorm(z) on z
+            m = self._norm_module(next_norm)
+            y, z = ResidualDropoutLnFn.apply(x, residual, self.dropout.p if self.training else 0.0, m.weight, m.bias, m.eps)
+            z._pk_prenormed = (m, y)
+            return z
         x = getattr(self, residual_hook)(x, residual)
         return getattr(self, postnorm_hook)(x)
+
+    def _end_and_next_norm_ok(self, x: Tensor, residual_hook: str, postnorm_hook: str, next_hook: str, next_norm) -> bool:
+        m = self._norm_module(next_norm)
+        return (self.prenorm and not _NO_END_NORM and not _NO_LN_FORK and torch.is_grad_enabled() and x.requires_grad and x.is_cuda
+                and x.dtype in (torch.bfloat16, torch.float16) and isinstance(m, modules.LayerNorm)
+                and getattr(m, 'weight', None) is not None and m.weight.dtype == x.dtype
+                and not m._forward_hooks and not m._forward_pre_hooks
+                and self._hooks_are_base(residual_hook, postnorm_hook, next_hook) and not torch.is_autocast_enabled('cuda'))
 
 
 class TransformerEncoderLayer(_LayerBase):
@@ -807,7 +826,7 @@ class TransformerEncoderLayer(_LayerBase):
         x = self.self_attention(x, residual, padding_mask)
         self.self_attn._tail = None
         x = self._block_end(x, residual, self.self_attn_layer_norm, 'self_attn_residual', 'self_attn_postnorm', link,
-                            tail)
+                            tail, self.final_layer_norm, 'ffn_prenorm')
         residual = x
         link = self._linked(('ffn', 'ffn_prenorm'), 'ffn_residual', 'ffn_postnorm', self.final_layer_norm, self,
                             '_ffn_link')
@@ -921,7 +940,7 @@ class TransformerDecoderLayer(_LayerBase):
         x = self.self_attention(x, residual, padding_mask, self_attn_mask=self_attn_mask, state=state)
         self.self_attn._tail = None
         x = self._block_end(x, residual, self.self_attn_layer_norm, 'self_attn_residual', 'self_attn_postnorm', link,
-                            tail)
+                            tail, self.encoder_attn_layer_norm if state is None else None, 'cross_attn_prenorm')
         residual = x
         link = self._linked(('cross_attention', 'cross_attn_prenorm'), 'cross_attn_residual', 'cross_attn_postnorm',
                             self.encoder_attn_layer_norm, self.encoder_attn, '_residual_link')
@@ -931,7 +950,7 @@ class TransformerDecoderLayer(_LayerBase):
         x = self.cross_attention(x, residual, encoder_out, encoder_mask)
         self.encoder_attn._tail = None
         x = self._block_end(x, residual, self.encoder_attn_layer_norm, 'cross_attn_residual', 'cross_attn_postnorm',
-                            link, tail)
+                            link, tail, self.final_layer_norm if state is None else None, 'ffn_prenorm')
         residual = x
         link = self._linked(('ffn', 'ffn_prenorm'), 'ffn_residual', 'ffn_postnorm', self.final_layer_norm, self,
                             '_ffn_link')

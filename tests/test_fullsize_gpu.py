@@ -520,6 +520,12 @@ def test_iwslt_recipe_layer_pair_frozen_backbone_bf16_against_the_cpu_oracle(mon
         forks['n'] += 1
         return orig_fork(*a, **k)
     monkeypatch.setattr(autograd.LayerNormForkFn, 'forward', staticmethod(fork))
+    orig_end = autograd.ResidualDropoutLnFn.forward  # (round 6: inside a layer, block end + the next block's LayerNorm as one node)
+
+    def end(*a, **k):
+        forks['n'] += 1
+        return orig_end(*a, **k)
+    monkeypatch.setattr(autograd.ResidualDropoutLnFn, 'forward', staticmethod(end))
     monkeypatch.setattr(PF, 'fwd_split', lambda M, N, K, dt: splits.append((M, N, K, orig_split(M, N, K, dt))) or splits[-1][3])
 
     def step():
